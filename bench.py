@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DEM tiles/sec of the full ESRGAN training iteration (D-step + G-step: generator and
+discriminator forward + backward + Adam) at batch 64 per GPU, fp32, 12 RRDB -- BASELINE.json `metric`,
+config "1xMI355X full ESRGAN ... batch 64, fp32" (the reference has no VGG/perceptual branch: SURVEY.md section 0).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One rank per GPU; per-GPU work is fixed (weak scaling): rank r trains on its own 64 synthetic tiles
+(np.random.RandomState(42 + r).rand, the reference's fixture recipe, srgan_train.py:1101-1105) and gradients are
+summed with one RCCL all-reduce per optimizer step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BATCH_PER_GPU = 64
+N_RRDB = 12
+
+
+def synthetic_batch(n, seed):
+    r = lambda *s: np.random.RandomState(seed=seed).rand(*s).astype(np.float32)  # noqa: E731
+    return {"X": r(n, 1, 11, 11), "W1": r(n, 1, 110, 110), "W2": r(n, 2, 22, 22), "W3": r(n, 1, 11, 11),
+            "Y": r(n, 1, 36, 36)}
+
+
+def cpu_baseline(sample_tiles=2):
+    """The oracle (NumPy restatement of the Chainer CPU path: im2col + BLAS sgemm) on this box's host cores, on a
+    bounded sample of the same workload: one full D-step + G-step at batch `sample_tiles`, 12 RRDB."""
+    from oracle import model as omodel
+    from oracle import train as otrain
+
+    arrays = synthetic_batch(sample_tiles, 42)
+    og = omodel.GeneratorModel(num_residual_blocks=N_RRDB, seed=1)
+    od = omodel.DiscriminatorModel(seed=2)
+    g_opt = otrain.Adam(og.params, alpha=1.6e-4)
+    d_opt = otrain.Adam(od.params, alpha=1.6e-4)
+    t0 = time.perf_counter()
+    otrain.train_eval_discriminator(arrays, og, od, d_opt)
+    otrain.train_eval_generator(arrays, og, od, g_opt)
+    dt = time.perf_counter() - t0
+    return {"value": sample_tiles / dt, "unit": "tiles/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 full D-step+G-step (fwd+bwd+Adam) at batch {sample_tiles}, 12 RRDB, NumPy/BLAS oracle, "
+                      f"{dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="tiles per GPU (BASELINE: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import deepbedmap_amd as dbm
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    comm = dbm.DataParallel() if world > 1 else None
+    ctx = dbm.Context(local_rank)
+    dbm._lib._default_ctx = ctx
+    # libdbm enqueues on torch's current stream: torch.cuda.synchronize() covers it, RCCL is ordered by stream events
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if comm is not None:
+        comm._shared_stream.add(id(ctx))
+
+    np.random.seed(1234)  # identical initial weights on every rank (and broadcast below for good measure)
+    g, g_opt, d, d_opt = dbm.compile_srgan_model(num_residual_blocks=N_RRDB, residual_scaling=0.1,
+                                                 learning_rate=1.6e-4)
+    if comm is not None:
+        comm.broadcast_params(g)
+        comm.broadcast_params(d)
+    batch = dbm.device_batch(synthetic_batch(args.batch, 42 + rank), ctx)  # inputs resident in HBM before timing
+
+    def step():
+        dbm.train_eval_discriminator(batch, g, d, d_opt, comm=comm)
+        dbm.train_eval_generator(batch, g, d, g_opt, comm=comm)
+
+    for _ in range(args.warmup):
+        step()
+    if comm is not None:
+        comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if comm is not None:
+        comm.barrier()
+    dt = time.perf_counter() - t0
+    if comm is not None:
+        dt = comm.max_over_ranks(dt)
+
+    # ---- roofline leg (outside the timed region): hipEvent-bracketed launches of the dominant kernel ----
+    lib = dbm._lib.lib()
+    prof = (C.c_double * 8)()
+    dbm._lib.check(lib.dbm_profile_begin(ctx.handle), ctx.handle)
+    step()
+    dbm._lib.check(lib.dbm_profile_end(ctx.handle, prof), ctx.handle)
+    ig_ms, ig_flop, ig_n, wg_ms, wg_flop, wg_n = [prof[i] for i in range(6)]
+
+    if rank == 0:
+        tiles = args.batch * world * args.steps
+        achieved = ig_flop / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
+        out = {
+            "metric": "DEM tiles/sec (fwd+bwd, gen+disc) at batch 64",
+            "value": tiles / dt,
+            "unit": "tiles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "full ESRGAN training iteration (D-step + G-step, fwd+bwd+Adam), 12 RRDB, "
+                                   "11x11 -> 36x36 tiles, fp32",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}"},
+            "roofline": {
+                "bound": "mfma", "kernel": "igemm_conv_kernel (conv forward + data gradient, v_mfma_f32_32x32x2_f32)",
+                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "launches_per_step": int(ig_n), "avg_launch_us": 1e3 * ig_ms / max(ig_n, 1),
+                "algorithmic_gflop_per_launch": ig_flop / max(ig_n, 1) / 1e9,
+                "second_kernel": {"kernel": "wgrad_kernel", "achieved": (wg_flop / (wg_ms * 1e-3) / 1e12) if wg_ms > 0 else 0.0,
+                                  "launches_per_step": int(wg_n), "avg_launch_us": 1e3 * wg_ms / max(wg_n, 1)},
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+
+
+if __name__ == "__main__":
+    main()

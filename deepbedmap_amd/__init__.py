@@ -1,0 +1,17 @@
+"""deepbedmap_amd -- MI355X-native (gfx950 HIP) drop-in for the ESRGAN hot path of weiji14/deepbedmap.
+
+Mirrors the hot-path interface of the reference's srgan_train.py; every numeric call goes through
+libdbm.so (C ABI: include/dbm.h).  There is no CPU fallback: without the built library and an
+MI355X the first model/context creation raises.
+"""
+from ._lib import DbmError, Context, default_context, build  # noqa: F401
+from .srgan import (  # noqa: F401
+    Adam, DeepbedmapInputBlock, DeviceArray, DiscriminatorModel, GeneratorModel, ResidualDenseBlock,
+    ResInResDenseBlock, Variable, calculate_discriminator_loss, calculate_generator_loss, config, global_config,
+    load_npz, optimizers, psnr, save_npz, serializers, ssim_loss_func, to_device, using_config,
+)
+from .training import (  # noqa: F401
+    SerialIterator, compile_srgan_model, concat_examples, device_batch, save_model_weights_and_architecture,
+    train_eval_discriminator, train_eval_generator, trainer,
+)
+from .parallel import DataParallel, shard_batch, shard_slice  # noqa: F401

@@ -1,0 +1,152 @@
+"""ctypes binding of libdbm.so (C ABI in include/dbm.h).
+
+The HIP library is the ONLY compute path of this package: if it is missing or no MI355X is
+visible, importing the symbols works (so CPU-only tooling can inspect the ABI) but creating a
+context raises -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdbm.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+DEVICE_PTRS = 1
+KEEP_GRAPH = 2
+BN_TRAIN = 4
+
+c_float_p = C.POINTER(C.c_float)
+c_void_pp = C.POINTER(C.c_void_p)
+
+# name -> (argtypes) ; every function returns int except dbm_last_error
+SIGNATURES = {
+    "dbm_init": [C.c_int, c_void_pp],
+    "dbm_shutdown": [C.c_void_p],
+    "dbm_set_stream": [C.c_void_p, C.c_void_p],
+    "dbm_synchronize": [C.c_void_p],
+    "dbm_profile_begin": [C.c_void_p],
+    "dbm_profile_end": [C.c_void_p, C.POINTER(C.c_double)],
+    "dbm_malloc": [C.c_void_p, C.c_size_t, c_void_pp],
+    "dbm_free": [C.c_void_p, C.c_void_p],
+    "dbm_memcpy_h2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "dbm_memcpy_d2h": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "dbm_gen_create": [C.c_void_p, C.c_int, C.c_float, C.c_int, c_void_pp],
+    "dbm_disc_create": [C.c_void_p, c_void_pp],
+    "dbm_model_destroy": [C.c_void_p],
+    "dbm_model_num_tensors": [C.c_void_p, C.POINTER(C.c_int)],
+    "dbm_model_tensor_info": [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int64),
+                              C.POINTER(C.c_int)],
+    "dbm_model_set_tensor": [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t],
+    "dbm_model_get_tensor": [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t],
+    "dbm_model_get_grad": [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t],
+    "dbm_model_count_params": [C.c_void_p, C.POINTER(C.c_int64)],
+    "dbm_model_cleargrads": [C.c_void_p],
+    "dbm_model_param_arena": [C.c_void_p, c_void_pp, C.POINTER(C.c_size_t)],
+    "dbm_model_grad_arena": [C.c_void_p, c_void_pp, C.POINTER(C.c_size_t)],
+    "dbm_model_params_changed": [C.c_void_p],
+    "dbm_gen_forward": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                        C.c_void_p, C.c_int],
+    "dbm_gen_backward": [C.c_void_p, C.c_void_p, C.c_int],
+    "dbm_disc_forward": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int],
+    "dbm_disc_backward": [C.c_void_p, C.c_int, C.c_void_p, C.c_int],
+    "dbm_discriminator_loss": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_int],
+    "dbm_generator_loss": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                           C.c_int, c_float_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int],
+    "dbm_psnr": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.c_int],
+    "dbm_ssim": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int],
+    "dbm_adam_setup": [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double],
+    "dbm_adam_update": [C.c_void_p, C.c_double],
+    "dbm_discriminator_step": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    "dbm_generator_step": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_void_p],
+    "dbm_op_conv2d": [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int] * 10,
+    "dbm_op_conv2d_backward": [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int] * 9,
+    "dbm_op_deform_conv2d": [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int] * 5,
+    "dbm_op_deform_conv2d_backward": [C.c_void_p] + [C.c_void_p] * 8 + [C.c_int] * 5,
+}
+
+_lib = None
+
+
+class DbmError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libdbm.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    jobs = str(min(8, os.cpu_count() or 1))
+    res = subprocess.run(["make", "-C", CSRC, "-j", jobs], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise DbmError("building libdbm.so failed")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with argtypes set.  Raises if libdbm.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DbmError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C deepbedmap_amd/csrc).  deepbedmap_amd has no CPU fallback."
+            )
+        l = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        l.dbm_last_error.argtypes = [C.c_void_p]
+        l.dbm_last_error.restype = C.c_char_p
+        _lib = l
+    return _lib
+
+
+def check(rc, ctx=None):
+    if rc != 0:
+        msg = lib().dbm_last_error(ctx)
+        raise DbmError(f"libdbm error {rc}: {msg.decode() if msg else '?'}")
+
+
+_default_ctx = None
+
+
+class Context:
+    """One GPU + one HIP stream (dbm_ctx)."""
+
+    def __init__(self, device=None):
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.handle = C.c_void_p()
+        l = lib()
+        rc = l.dbm_init(int(device), C.byref(self.handle))
+        if rc != 0:
+            msg = l.dbm_last_error(None)
+            raise DbmError(f"dbm_init failed ({rc}): {msg.decode() if msg else '?'}")
+        self.device = int(device)
+
+    def set_stream(self, stream_ptr):
+        check(lib().dbm_set_stream(self.handle, C.c_void_p(stream_ptr)), self.handle)
+
+    def synchronize(self):
+        check(lib().dbm_synchronize(self.handle), self.handle)
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        check(lib().dbm_malloc(self.handle, nbytes, C.byref(p)), self.handle)
+        return p.value
+
+    def free(self, ptr):
+        check(lib().dbm_free(self.handle, C.c_void_p(ptr)), self.handle)
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx

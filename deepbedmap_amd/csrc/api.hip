@@ -1,0 +1,654 @@
+// extern "C" surface of libdbm.so (include/dbm.h).  No exception crosses the boundary.
+#include "model.h"
+#include <cmath>
+
+static thread_local std::string g_last_error;
+
+#define DBM_API_BEGIN(ctxptr) \
+  dbm_ctx* _ectx = (ctxptr);  \
+  try {
+#define DBM_API_END                                   \
+  return 0;                                           \
+  }                                                   \
+  catch (const DbmError& e) {                         \
+    g_last_error = e.what();                          \
+    if (_ectx) _ectx->err = e.what();                 \
+    return e.code;                                    \
+  }                                                   \
+  catch (const std::exception& e) {                   \
+    g_last_error = e.what();                          \
+    if (_ectx) _ectx->err = e.what();                 \
+    return 3;                                         \
+  }
+
+// metrics finalisation -----------------------------------------------------------------------------
+__global__ void gen_metrics_kernel(const float* sums, const float* adv, float* out, float nhw, float npool, float nwin,
+                                   float cw, float aw, float tw, float sw) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float content = sums[0] / nhw;
+  const float topo = sums[1] / npool;
+  const float ssim = sums[2] / nwin;
+  const float mse = sums[3] / nhw;
+  out[0] = ((cw * content + aw * adv[0]) + tw * topo) + sw * (1.f - ssim);
+  out[1] = 20.f * log10f(4294967296.f / sqrtf(mse));  // psnr, data_range = 2**32 (srgan_train.py:906-928)
+  out[2] = ssim;
+}
+
+static void gaussian9(float* w, double sigma) {
+  double g[9], s = 0;
+  for (int i = 0; i < 9; ++i) { g[i] = exp(-((i - 4) * (i - 4)) / (2.0 * sigma * sigma)); s += g[i]; }
+  for (int i = 0; i < 9; ++i) w[i] = (float)(g[i] / s);
+}
+
+// staging helpers for the host-pointer forms ---------------------------------------------------------
+static const float* stage_in(dbm_ctx* c, int slot, const float* host, size_t n, int flags) {
+  if (flags & DBM_DEVICE_PTRS) return host;
+  if (!host) return nullptr;
+  c->stage[slot].ensure(n);
+  DBM_HIP(hipMemcpyAsync(c->stage[slot].p, host, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  return c->stage[slot].p;
+}
+static float* stage_out(dbm_ctx* c, int slot, float* host, size_t n, int flags) {
+  if (flags & DBM_DEVICE_PTRS) return host;
+  if (!host) return nullptr;
+  c->stage[slot].ensure(n);
+  return c->stage[slot].p;
+}
+static void finish_out(dbm_ctx* c, int slot, float* host, size_t n, int flags) {
+  if ((flags & DBM_DEVICE_PTRS) || !host) return;
+  DBM_HIP(hipMemcpyAsync(host, c->stage[slot].p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+}
+static void finish_sync(dbm_ctx* c, int flags) {
+  if (!(flags & DBM_DEVICE_PTRS)) DBM_HIP(hipStreamSynchronize(c->stream));
+}
+
+extern "C" {
+
+const char* dbm_last_error(dbm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int dbm_init(int hip_device, dbm_ctx** out) {
+  DBM_API_BEGIN(nullptr)
+  DBM_CHECK(out != nullptr, "dbm_init: out is NULL");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    throw DbmError(4, "dbm_init: no HIP device visible -- libdbm has no CPU fallback (the product path requires an MI355X)");
+  DBM_CHECK(hip_device >= 0 && hip_device < count, "dbm_init: bad device index");
+  DBM_HIP(hipSetDevice(hip_device));
+  hipDeviceProp_t prop;
+  DBM_HIP(hipGetDeviceProperties(&prop, hip_device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    throw DbmError(4, std::string("dbm_init: libdbm is built for gfx950 only, device is ") + prop.gcnArchName);
+  dbm_ctx* c = new dbm_ctx();
+  c->device = hip_device;
+  DBM_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  DBM_HIP(hipMalloc((void**)&c->zeros, 256));
+  DBM_HIP(hipMemset(c->zeros, 0, 256));
+  float w[9];
+  gaussian9(w, 1.5);
+  DBM_HIP(hipMalloc((void**)&c->ssim_win[0], sizeof(w)));
+  DBM_HIP(hipMemcpy(c->ssim_win[0], w, sizeof(w), hipMemcpyHostToDevice));
+  for (int i = 0; i < 9; ++i) w[i] = (float)(1.0 / 9.0);
+  DBM_HIP(hipMalloc((void**)&c->ssim_win[1], sizeof(w)));
+  DBM_HIP(hipMemcpy(c->ssim_win[1], w, sizeof(w), hipMemcpyHostToDevice));
+  *out = c;
+  DBM_API_END
+}
+
+int dbm_shutdown(dbm_ctx* ctx) {
+  DBM_API_BEGIN(nullptr)
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(ctx->zeros);
+  (void)hipFree(ctx->ssim_win[0]);
+  (void)hipFree(ctx->ssim_win[1]);
+  ctx->loss_tmp.release();
+  for (auto& b : ctx->stage) b.release();
+  (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  DBM_API_END
+}
+
+int dbm_set_stream(dbm_ctx* ctx, void* hip_stream) {
+  DBM_API_BEGIN(ctx)
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  DBM_API_END
+}
+
+int dbm_synchronize(dbm_ctx* ctx) {
+  DBM_API_BEGIN(ctx)
+  DBM_HIP(hipStreamSynchronize(ctx->stream));
+  DBM_API_END
+}
+
+int dbm_profile_begin(dbm_ctx* ctx) {
+  DBM_API_BEGIN(ctx)
+  DBM_HIP(hipStreamSynchronize(ctx->stream));
+  double junk[8];
+  g_profiler.collect(junk);
+  g_profiler.enabled = true;
+  DBM_API_END
+}
+
+int dbm_profile_end(dbm_ctx* ctx, double out[8]) {
+  DBM_API_BEGIN(ctx)
+  g_profiler.enabled = false;
+  DBM_HIP(hipStreamSynchronize(ctx->stream));
+  g_profiler.collect(out);
+  DBM_API_END
+}
+
+int dbm_malloc(dbm_ctx* ctx, size_t bytes, void** dptr) {
+  DBM_API_BEGIN(ctx)
+  DBM_HIP(hipMalloc(dptr, bytes ? bytes : 4));
+  DBM_API_END
+}
+int dbm_free(dbm_ctx* ctx, void* dptr) {
+  DBM_API_BEGIN(ctx)
+  DBM_HIP(hipStreamSynchronize(ctx->stream));
+  DBM_HIP(hipFree(dptr));
+  DBM_API_END
+}
+int dbm_memcpy_h2d(dbm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  DBM_API_BEGIN(ctx)
+  DBM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  DBM_HIP(hipStreamSynchronize(ctx->stream));
+  DBM_API_END
+}
+int dbm_memcpy_d2h(dbm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  DBM_API_BEGIN(ctx)
+  DBM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DBM_HIP(hipStreamSynchronize(ctx->stream));
+  DBM_API_END
+}
+
+// ---- models ----
+int dbm_gen_create(dbm_ctx* ctx, int n, float rs, int oc, dbm_model** out) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(ctx && out, "dbm_gen_create: NULL argument");
+  *out = new Generator(ctx, n, rs, oc);
+  DBM_API_END
+}
+int dbm_disc_create(dbm_ctx* ctx, dbm_model** out) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(ctx && out, "dbm_disc_create: NULL argument");
+  *out = new Discriminator(ctx);
+  DBM_API_END
+}
+int dbm_model_destroy(dbm_model* m) {
+  DBM_API_BEGIN(m ? m->ctx : nullptr)
+  if (m) {
+    (void)hipStreamSynchronize(m->ctx->stream);
+    delete m;
+  }
+  DBM_API_END
+}
+int dbm_model_num_tensors(dbm_model* m, int* n) {
+  DBM_API_BEGIN(m->ctx)
+  *n = (int)m->tensors.size();
+  DBM_API_END
+}
+int dbm_model_tensor_info(dbm_model* m, int i, const char** key, int* ndim, int64_t shape[4], int* kind) {
+  DBM_API_BEGIN(m->ctx)
+  DBM_CHECK(i >= 0 && i < (int)m->tensors.size(), "tensor index out of range");
+  const Tensor& t = m->tensors[i];
+  *key = t.key.c_str();
+  *ndim = t.ndim;
+  for (int k = 0; k < 4; ++k) shape[k] = t.shape[k];
+  *kind = t.kind;
+  DBM_API_END
+}
+static float* tensor_ptr(dbm_model* m, const Tensor& t, bool grad) {
+  if (t.kind == DBM_KIND_PARAM) return (grad ? m->grads : m->params) + t.off;
+  DBM_CHECK(!grad, "persistent values have no gradient");
+  return m->pers + t.off;
+}
+int dbm_model_set_tensor(dbm_model* m, const char* key, const float* host, size_t n) {
+  DBM_API_BEGIN(m->ctx)
+  const Tensor& t = m->tensors[m->tid(key)];
+  DBM_CHECK(n == t.n, std::string("size mismatch for ") + key);
+  DBM_HIP(hipMemcpyAsync(tensor_ptr(m, t, false), host, n * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+  DBM_HIP(hipStreamSynchronize(m->ctx->stream));
+  m->packed_dirty = true;
+  DBM_API_END
+}
+int dbm_model_get_tensor(dbm_model* m, const char* key, float* host, size_t n) {
+  DBM_API_BEGIN(m->ctx)
+  const Tensor& t = m->tensors[m->tid(key)];
+  DBM_CHECK(n == t.n, std::string("size mismatch for ") + key);
+  DBM_HIP(hipMemcpyAsync(host, tensor_ptr(m, t, false), n * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
+  DBM_HIP(hipStreamSynchronize(m->ctx->stream));
+  DBM_API_END
+}
+int dbm_model_get_grad(dbm_model* m, const char* key, float* host, size_t n) {
+  DBM_API_BEGIN(m->ctx)
+  const Tensor& t = m->tensors[m->tid(key)];
+  DBM_CHECK(n == t.n, std::string("size mismatch for ") + key);
+  DBM_HIP(hipMemcpyAsync(host, tensor_ptr(m, t, true), n * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
+  DBM_HIP(hipStreamSynchronize(m->ctx->stream));
+  DBM_API_END
+}
+int dbm_model_count_params(dbm_model* m, int64_t* n) {
+  DBM_API_BEGIN(m->ctx)
+  *n = (int64_t)m->nparam;
+  DBM_API_END
+}
+int dbm_model_cleargrads(dbm_model* m) {
+  DBM_API_BEGIN(m->ctx)
+  DBM_HIP(hipMemsetAsync(m->grads, 0, m->nparam * sizeof(float), m->ctx->stream));
+  DBM_API_END
+}
+int dbm_model_param_arena(dbm_model* m, void** dptr, size_t* n) {
+  DBM_API_BEGIN(m->ctx)
+  *dptr = m->params;
+  *n = m->nparam;
+  DBM_API_END
+}
+int dbm_model_grad_arena(dbm_model* m, void** dptr, size_t* n) {
+  DBM_API_BEGIN(m->ctx)
+  *dptr = m->grads;
+  *n = m->nparam;
+  DBM_API_END
+}
+int dbm_model_params_changed(dbm_model* m) {
+  DBM_API_BEGIN(m->ctx)
+  m->packed_dirty = true;
+  DBM_API_END
+}
+
+// ---- forward / backward ----
+int dbm_gen_forward(dbm_model* gm, int N, int H, int W, const float* x, const float* w1, const float* w2,
+                    const float* w3, float* y, int flags) {
+  DBM_API_BEGIN(gm->ctx)
+  DBM_CHECK(gm->type == 0, "dbm_gen_forward: not a generator");
+  DBM_CHECK(N >= 1 && x && w1 && w2 && w3 && y, "dbm_gen_forward: bad arguments");
+  Generator* g = static_cast<Generator*>(gm);
+  const bool keep = flags & DBM_KEEP_GRAPH;
+  const size_t n = (size_t)N, hw = (size_t)H * W, P4 = 16 * (size_t)(H - 2) * (W - 2);
+  if (flags & DBM_DEVICE_PTRS) {
+    g->forward(N, H, W, x, w1, w2, w3, y, keep);
+  } else {
+    g->ensure_ws(N, H, W, keep);
+    hipStream_t s = g->ctx->stream;
+    DBM_HIP(hipMemcpyAsync(g->in_x.p, x, n * hw * 4, hipMemcpyHostToDevice, s));
+    DBM_HIP(hipMemcpyAsync(g->in_w1.p, w1, n * 100 * hw * 4, hipMemcpyHostToDevice, s));
+    DBM_HIP(hipMemcpyAsync(g->in_w2.p, w2, n * 8 * hw * 4, hipMemcpyHostToDevice, s));
+    DBM_HIP(hipMemcpyAsync(g->in_w3.p, w3, n * hw * 4, hipMemcpyHostToDevice, s));
+    g->forward(N, H, W, g->in_x.p, g->in_w1.p, g->in_w2.p, g->in_w3.p, g->yout.p, keep);
+    DBM_HIP(hipMemcpyAsync(y, g->yout.p, n * P4 * 4, hipMemcpyDeviceToHost, s));
+    DBM_HIP(hipStreamSynchronize(s));
+  }
+  DBM_API_END
+}
+
+int dbm_gen_backward(dbm_model* gm, const float* gy, int flags) {
+  DBM_API_BEGIN(gm->ctx)
+  DBM_CHECK(gm->type == 0, "dbm_gen_backward: not a generator");
+  Generator* g = static_cast<Generator*>(gm);
+  if (flags & DBM_DEVICE_PTRS) {
+    g->backward(gy);
+  } else {
+    DBM_CHECK(g->have_graph, "generator backward without a retained forward (DBM_KEEP_GRAPH)");
+    const size_t cnt = (size_t)g->wsN * 16 * (g->wsH - 2) * (g->wsW - 2);
+    DBM_HIP(hipMemcpyAsync(g->g_y.p, gy, cnt * 4, hipMemcpyHostToDevice, g->ctx->stream));
+    g->backward(g->g_y.p);
+    DBM_HIP(hipStreamSynchronize(g->ctx->stream));
+  }
+  DBM_API_END
+}
+
+int dbm_disc_forward(dbm_model* dm, int N, int H, int W, const float* img, float* logits, int flags, int slot) {
+  DBM_API_BEGIN(dm->ctx)
+  DBM_CHECK(dm->type == 1, "dbm_disc_forward: not a discriminator");
+  Discriminator* d = static_cast<Discriminator*>(dm);
+  dbm_ctx* c = d->ctx;
+  const size_t n = (size_t)N;
+  // the image is retained by pointer for the backward pass: host input goes to a per-slot staging buffer
+  const float* dimg = stage_in(c, 4 + slot, img, n * H * W, flags);
+  float* dlog = stage_out(c, 6 + slot, logits, n, flags);
+  d->forward(N, H, W, dimg, dlog, flags & DBM_BN_TRAIN, flags & DBM_KEEP_GRAPH, slot);
+  finish_out(c, 6 + slot, logits, n, flags);
+  finish_sync(c, flags);
+  DBM_API_END
+}
+
+int dbm_disc_backward(dbm_model* dm, int slot, const float* glogits, int flags) {
+  DBM_API_BEGIN(dm->ctx)
+  DBM_CHECK(dm->type == 1, "dbm_disc_backward: not a discriminator");
+  Discriminator* d = static_cast<Discriminator*>(dm);
+  DBM_CHECK(slot == 0 || slot == 1, "bad slot");
+  const float* g = stage_in(d->ctx, 0, glogits, (size_t)d->cache[slot].N, flags);
+  d->backward(slot, g);
+  finish_sync(d->ctx, flags);
+  DBM_API_END
+}
+
+// ---- losses ----
+int dbm_discriminator_loss(dbm_ctx* ctx, const float* real, const float* fake, int N, int t_rf, int t_fr, float* out2,
+                           float* g_real, float* g_fake, int flags) {
+  DBM_API_BEGIN(ctx)
+  const float* dr = stage_in(ctx, 0, real, N, flags);
+  const float* df = stage_in(ctx, 1, fake, N, flags);
+  float* dout = stage_out(ctx, 2, out2, 2, flags);
+  float* dgr = stage_out(ctx, 3, g_real, N, flags);
+  float* dgf = stage_out(ctx, 4, g_fake, N, flags);
+  launch_ragan_loss(dr, df, N, t_rf, t_fr, dout, dgr, dgf, ctx->stream);
+  finish_out(ctx, 2, out2, 2, flags);
+  finish_out(ctx, 3, g_real, N, flags);
+  finish_out(ctx, 4, g_fake, N, flags);
+  finish_sync(ctx, flags);
+  DBM_API_END
+}
+
+// device-side generator loss; all pointers are device pointers.  out3: [g_loss, psnr, ssim].
+static void gen_loss_device(dbm_ctx* ctx, const float* y, const float* t, const float* X, const float* real_logits,
+                            const float* fake_logits, int N, int H, int W, const float w[4], int t_rf, int t_fr,
+                            int win, float* out3, float* gy) {
+  DBM_CHECK(win == 0 || win == 1, "ssim_window must be 0 (gaussian) or 1 (uniform)");
+  hipStream_t s = ctx->stream;
+  ctx->loss_tmp.ensure(16 + (size_t)N);
+  float* sums = ctx->loss_tmp.p;       // [0..4]
+  float* adv = ctx->loss_tmp.p + 8;    // [8..9]
+  float* ones = ctx->loss_tmp.p + 16;  // N
+  DBM_HIP(hipMemsetAsync(sums, 0, 16 * sizeof(float), s));
+  if (!real_logits) {
+    launch_fill(ones, N, 1.f, s);
+    real_logits = ones;
+  }
+  // adversarial term: calculate_discriminator_loss(real=ones, fake=D(fake) detached, targets swapped) (:874-879, :1233-1237)
+  launch_ragan_loss(real_logits, fake_logits, N, t_rf, t_fr, adv, nullptr, nullptr, s);
+  launch_gen_loss(y, t, X, N, H, W, w[0], w[2], w[3], ctx->ssim_win[win], sums, gy, s);
+  const float nhw = (float)N * H * W, npool = (float)N * (H / 4) * (W / 4), nwin = (float)N * (H - 8) * (W - 8);
+  hipLaunchKernelGGL(gen_metrics_kernel, dim3(1), dim3(64), 0, s, sums, adv, out3, nhw, npool, nwin, w[0], w[1], w[2], w[3]);
+  DBM_HIP(hipGetLastError());
+}
+
+int dbm_generator_loss(dbm_ctx* ctx, const float* y_pred, const float* y_true, const float* x, const float* real_logits,
+                       const float* fake_logits, int N, int H, int W, const float weights[4], int t_rf, int t_fr,
+                       int ssim_window, float* out3, float* gy, int flags) {
+  DBM_API_BEGIN(ctx)
+  const size_t n = (size_t)N, hw = (size_t)H * W, xhw = (size_t)(H / 4 + 2) * (W / 4 + 2);
+  const float* dy = stage_in(ctx, 0, y_pred, n * hw, flags);
+  const float* dt = stage_in(ctx, 1, y_true, n * hw, flags);
+  const float* dx = stage_in(ctx, 2, x, n * xhw, flags);
+  const float* dl = stage_in(ctx, 3, fake_logits, n, flags);
+  const float* dr = stage_in(ctx, 6, real_logits, n, flags);
+  float* dout = stage_out(ctx, 4, out3, 3, flags);
+  float* dgy = stage_out(ctx, 5, gy, n * hw, flags);
+  gen_loss_device(ctx, dy, dt, dx, dr, dl, N, H, W, weights, t_rf, t_fr, ssim_window, dout, dgy);
+  finish_out(ctx, 4, out3, 3, flags);
+  finish_out(ctx, 5, gy, n * hw, flags);
+  finish_sync(ctx, flags);
+  DBM_API_END
+}
+
+__global__ void psnr_finish_kernel(float* acc, float n, float range) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) acc[1] = 20.f * log10f(range / sqrtf(acc[0] / n));
+}
+__global__ void ssim_finish_kernel(const float* sums, float nwin, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = sums[2] / nwin;
+}
+
+int dbm_psnr(dbm_ctx* ctx, const float* y_pred, const float* y_true, size_t n, double data_range, float* out, int flags) {
+  DBM_API_BEGIN(ctx)
+  const float* a = stage_in(ctx, 0, y_pred, n, flags);
+  const float* b = stage_in(ctx, 1, y_true, n, flags);
+  ctx->loss_tmp.ensure(32);
+  float* acc = ctx->loss_tmp.p;
+  DBM_HIP(hipMemsetAsync(acc, 0, 8 * sizeof(float), ctx->stream));
+  launch_sqdiff(a, b, (long)n, acc, ctx->stream);
+  hipLaunchKernelGGL(psnr_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, acc, (float)n, (float)data_range);
+  if (flags & DBM_DEVICE_PTRS) {
+    DBM_HIP(hipMemcpyAsync(out, acc + 1, sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    DBM_HIP(hipMemcpyAsync(out, acc + 1, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    DBM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  DBM_API_END
+}
+
+int dbm_ssim(dbm_ctx* ctx, const float* y_pred, const float* y_true, int N, int H, int W, int ssim_window, float* out,
+             int flags) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(ssim_window == 0 || ssim_window == 1, "ssim_window must be 0 (gaussian) or 1 (uniform)");
+  const size_t cnt = (size_t)N * H * W;
+  const float* a = stage_in(ctx, 0, y_pred, cnt, flags);
+  const float* b = stage_in(ctx, 1, y_true, cnt, flags);
+  float* dout = stage_out(ctx, 2, out, 1, flags);
+  ctx->loss_tmp.ensure(32);
+  float* sums = ctx->loss_tmp.p;
+  DBM_HIP(hipMemsetAsync(sums, 0, 8 * sizeof(float), ctx->stream));
+  launch_gen_loss(a, b, nullptr, N, H, W, 0.f, 0.f, 0.f, ctx->ssim_win[ssim_window], sums, nullptr, ctx->stream);
+  hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, sums, (float)N * (H - 8) * (W - 8), dout);
+  finish_out(ctx, 2, out, 1, flags);
+  finish_sync(ctx, flags);
+  DBM_API_END
+}
+
+// ---- optimizer ----
+int dbm_adam_setup(dbm_model* m, double alpha, double beta1, double beta2, double eps) {
+  DBM_API_BEGIN(m->ctx)
+  m->alpha = alpha; m->beta1 = beta1; m->beta2 = beta2; m->eps = eps;
+  m->adam_t = 0;
+  m->adam_ready = true;
+  DBM_HIP(hipMemsetAsync(m->adam_m, 0, m->nparam * sizeof(float), m->ctx->stream));
+  DBM_HIP(hipMemsetAsync(m->adam_v, 0, m->nparam * sizeof(float), m->ctx->stream));
+  DBM_API_END
+}
+
+int dbm_adam_update(dbm_model* m, double grad_scale) {
+  DBM_API_BEGIN(m->ctx)
+  DBM_CHECK(m->adam_ready, "dbm_adam_update before dbm_adam_setup");
+  m->adam_t += 1;
+  const double fix1 = 1.0 - std::pow(m->beta1, (double)m->adam_t);
+  const double fix2 = 1.0 - std::pow(m->beta2, (double)m->adam_t);
+  const double alpha_t = m->alpha * std::sqrt(fix2) / fix1;  // AdamRule.alpha_t
+  launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (long)m->nparam, (float)alpha_t, (float)(1.0 - m->beta1),
+              (float)(1.0 - m->beta2), (float)m->eps, (float)grad_scale, m->ctx->stream);
+  m->packed_dirty = true;
+  DBM_API_END
+}
+
+// ---- fused steps ----
+int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const float* X, const float* W1,
+                           const float* W2, const float* W3, const float* Y, int train, float* metrics) {
+  DBM_API_BEGIN(gm->ctx)
+  DBM_CHECK(gm->type == 0 && dm->type == 1, "dbm_discriminator_step: (generator, discriminator) expected");
+  Generator* g = static_cast<Generator*>(gm);
+  Discriminator* d = static_cast<Discriminator*>(dm);
+  dbm_ctx* c = g->ctx;
+  hipStream_t s = c->stream;
+  const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
+  g->ensure_ws(N, H, W, false);
+  // fake images under enable_backprop=False (:1131-1137)
+  g->forward(N, H, W, X, W1, W2, W3, g->yout.p, false);
+  d->g_out.ensure(4 * (size_t)N);
+  float* lr = d->g_out.p;
+  float* lf = lr + N;
+  float* gr = lf + N;
+  float* gf = gr + N;
+  d->forward(N, H4, W4, Y, lr, train, train, 0);           // real batch (:1145)
+  d->forward(N, H4, W4, g->yout.p, lf, train, train, 1);   // fake batch (:1146) -- separate BatchNorm statistics
+  launch_ragan_loss(lr, lf, N, 1, 0, metrics, train ? gr : nullptr, train ? gf : nullptr, s);
+  if (train) {
+    DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));  // cleargrads (:1162)
+    d->backward(0, gr);                                                  // d_loss.backward() (:1163)
+    d->backward(1, gf);
+  }
+  DBM_API_END
+}
+
+int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const float* X, const float* W1,
+                       const float* W2, const float* W3, const float* Y, const float weights[4], int ssim_window,
+                       int train, float* metrics) {
+  DBM_API_BEGIN(gm->ctx)
+  DBM_CHECK(gm->type == 0 && dm->type == 1, "dbm_generator_step: (generator, discriminator) expected");
+  Generator* g = static_cast<Generator*>(gm);
+  Discriminator* d = static_cast<Discriminator*>(dm);
+  dbm_ctx* c = g->ctx;
+  hipStream_t s = c->stream;
+  const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
+  g->ensure_ws(N, H, W, train != 0);
+  g->forward(N, H, W, X, W1, W2, W3, g->yout.p, train != 0);  // (:1222-1227)
+  d->g_out.ensure(4 * (size_t)N);
+  float* lf = d->g_out.p;
+  d->forward(N, H4, W4, g->yout.p, lf, false, false, 1);  // eval-mode BatchNorm, detached (:1228-1229)
+  gen_loss_device(c, g->yout.p, Y, X, nullptr, lf, N, H4, W4, weights, 0, 1, ssim_window, metrics + 2,
+                  train ? g->g_y.p : nullptr);
+  if (train) {
+    DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), s));  // cleargrads (:1255)
+    g->backward(g->g_y.p);                                               // g_loss.backward() (:1256)
+  }
+  DBM_API_END
+}
+
+// ---- op-level entry points ----
+static IgLayer make_temp_layer(dbm_ctx* ctx, const float* w, int O, int C, int k, int stride, int pad, dbm_model& holder) {
+  // a throw-away single-layer "model" whose param arena aliases the caller's weights
+  holder.ctx = ctx;
+  holder.add_tensor("op/W", {O, C, k, k}, DBM_KIND_PARAM);
+  holder.add_tensor("op/b", {O}, DBM_KIND_PARAM);
+  holder.alloc_arenas();
+  DBM_HIP(hipMemcpyAsync(holder.params, w, sizeof(float) * (size_t)O * C * k * k, hipMemcpyDeviceToDevice, ctx->stream));
+  holder.add_iglayer("op", O, C, k, stride, pad, true);
+  holder.ensure_packed();
+  return holder.layers[0];
+}
+
+int dbm_op_conv2d(dbm_ctx* ctx, const float* x, const float* w, const float* b, float* y, int N, int C, int H, int W,
+                  int O, int k, int stride, int pad, int ups, int lrelu) {
+  DBM_API_BEGIN(ctx)
+  if (C % 32 != 0) {
+    DBM_CHECK(!ups, "few-channel conv has no fused upsample");
+    SmallConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = x; d.xsn = (long)C * H * W; d.Cin = C; d.Hin = H; d.Win = W; d.w = w; d.bias = b;
+    d.OH = (H + 2 * pad - k) / stride + 1; d.OW = (W + 2 * pad - k) / stride + 1;
+    d.y = y; d.ysn = (long)O * d.OH * d.OW; d.Cout = O; d.KH = d.KW = k; d.stride = stride; d.pad = pad; d.N = N;
+    d.act = lrelu; d.slope = 0.2f;
+    launch_smallcin_conv_fwd(d, ctx->stream);
+  } else {
+    dbm_model holder;
+    IgLayer L = make_temp_layer(ctx, w, O, C, k, stride, pad, holder);
+    if (b) DBM_HIP(hipMemcpyAsync(holder.P(L.bi), b, sizeof(float) * O, hipMemcpyDeviceToDevice, ctx->stream));
+    const int Hl = H << ups, Wl = W << ups;
+    const int OH = (Hl + 2 * pad - k) / stride + 1, OW = (Wl + 2 * pad - k) / stride + 1;
+    ConvDesc d = holder.fwd_desc(L, x, (long)C * H * W, H, W, ups, y, (long)O * OH * OW, N);
+    d.act = lrelu;
+    launch_igemm_conv(d, ctx->stream);
+    DBM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  DBM_API_END
+}
+
+int dbm_op_conv2d_backward(dbm_ctx* ctx, const float* x, const float* w, const float* gy, float* gx, float* gw,
+                           float* gb, int N, int C, int H, int W, int O, int k, int stride, int pad, int ups) {
+  DBM_API_BEGIN(ctx)
+  const int Hl = H << ups, Wl = W << ups;
+  const int OH = (Hl + 2 * pad - k) / stride + 1, OW = (Wl + 2 * pad - k) / stride + 1;
+  if (C % 32 != 0) {
+    DBM_CHECK(!ups && gx == nullptr, "few-channel conv: only the weight gradient exists on the hot path");
+    SmallConvDesc q;
+    memset(&q, 0, sizeof(q));
+    q.x = x; q.xsn = (long)C * H * W; q.Cin = C; q.Hin = H; q.Win = W; q.Cout = O; q.OH = OH; q.OW = OW;
+    q.KH = q.KW = k; q.stride = stride; q.pad = pad; q.N = N;
+    launch_smallcin_conv_wgrad(q, gy, (long)O * OH * OW, gw, gb, ctx->stream);
+  } else {
+    DBM_CHECK(O % 32 == 0 || gx == nullptr, "op dgrad needs O % 32 == 0 (pad the gradient channels)");
+    dbm_model holder;
+    IgLayer L = make_temp_layer(ctx, w, O, C, k, stride, pad, holder);
+    if (gw) {
+      WgradDesc wd;
+      memset(&wd, 0, sizeof(wd));
+      wd.x = x; wd.xsn = (long)C * H * W; wd.xsc = H * W; wd.Cin = C; wd.Hin = H; wd.Win = W; wd.ups = ups;
+      wd.dy = gy; wd.dysn = (long)O * OH * OW; wd.dysc = OH * OW; wd.Cout = O; wd.OH = OH; wd.OW = OW;
+      wd.KH = wd.KW = k; wd.stride = stride; wd.pad = pad; wd.N = N; wd.scale = 1.f; wd.gW = gw; wd.gb = gb;
+      launch_wgrad(wd, ctx->stream);
+    }
+    if (gx) {
+      ConvDesc d;
+      memset(&d, 0, sizeof(d));
+      d.x = gy; d.xsn = (long)O * OH * OW; d.N = N;
+      d.y = gx; d.ysn = (long)C * Hl * Wl; d.s1 = 1.f; d.s2 = 1.f;
+      holder.run_dgrad(L, d, Hl, Wl);  // gradient w.r.t. the (upsampled) conv input
+    }
+    DBM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  DBM_API_END
+}
+
+int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y,
+                         int N, int C, int H, int W, int O) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(C % 32 == 0, "deform conv op: C % 32 == 0");
+  DevBuf col;
+  col.ensure((size_t)N * C * 9 * H * W);
+  launch_deform_sample(x, off, col.p, N, C, H, W, 18L * H * W, ctx->stream);
+  if (O == 1) {
+    launch_gemv_cols(col.p, w, b, y, N, C * 9, H * W, ctx->stream);
+  } else {
+    dbm_model holder;
+    holder.ctx = ctx;
+    holder.add_tensor("op/W", {O, C, 3, 3}, DBM_KIND_PARAM);
+    holder.add_tensor("op/b", {O}, DBM_KIND_PARAM);
+    holder.alloc_arenas();
+    DBM_HIP(hipMemcpyAsync(holder.params, w, sizeof(float) * (size_t)O * C * 9, hipMemcpyDeviceToDevice, ctx->stream));
+    if (b) DBM_HIP(hipMemcpyAsync(holder.params + (size_t)O * C * 9, b, sizeof(float) * O, hipMemcpyDeviceToDevice, ctx->stream));
+    holder.add_iglayer("op", O, C, 3, 1, 0, true, true);
+    holder.ensure_packed();
+    ConvDesc d = holder.fwd_desc(holder.layers[0], col.p, (long)C * 9 * H * W, H, W, 0, y, (long)O * H * W, N);
+    launch_igemm_conv(d, ctx->stream);
+    DBM_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  DBM_HIP(hipStreamSynchronize(ctx->stream));
+  col.release();
+  DBM_API_END
+}
+
+int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* gy,
+                                  float* gx, float* goff, float* gw, float* gb, int N, int C, int H, int W, int O) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(C % 32 == 0, "deform conv op: C % 32 == 0");
+  hipStream_t s = ctx->stream;
+  const long P = (long)H * W;
+  DevBuf col, gcol;
+  col.ensure((size_t)N * C * 9 * P);
+  launch_deform_sample(x, off, col.p, N, C, H, W, 18 * P, s);
+  DBM_HIP(hipMemsetAsync(gx, 0, sizeof(float) * N * C * P, s));
+  if (O == 1) {
+    launch_deform_backward(x, off, nullptr, w, gy, gx, goff, N, C, H, W, 18 * P, s);
+    launch_gemv_cols_wgrad(col.p, gy, gw, gb, N, C * 9, (int)P, s);
+  } else {
+    DBM_CHECK(O % 32 == 0, "deform conv op backward: O == 1 or O % 32 == 0");
+    dbm_model holder;
+    holder.ctx = ctx;
+    holder.add_tensor("op/W", {O, C, 3, 3}, DBM_KIND_PARAM);
+    holder.add_tensor("op/b", {O}, DBM_KIND_PARAM);
+    holder.alloc_arenas();
+    DBM_HIP(hipMemcpyAsync(holder.params, w, sizeof(float) * (size_t)O * C * 9, hipMemcpyDeviceToDevice, s));
+    holder.add_iglayer("op", O, C, 3, 1, 0, true, true);
+    holder.ensure_packed();
+    const IgLayer& L = holder.layers[0];
+    gcol.ensure((size_t)N * C * 9 * P);
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = gy; d.xsn = O * P; d.N = N; d.y = gcol.p; d.ysn = C * 9 * P; d.s1 = 1.f; d.s2 = 1.f;
+    holder.run_dgrad(L, d, H, W);
+    launch_deform_backward(x, off, gcol.p, nullptr, nullptr, gx, goff, N, C, H, W, 18 * P, s);
+    WgradDesc wd;
+    memset(&wd, 0, sizeof(wd));
+    wd.x = col.p; wd.xsn = C * 9 * P; wd.xsc = (int)P; wd.Cin = C * 9; wd.Hin = H; wd.Win = W;
+    wd.dy = gy; wd.dysn = O * P; wd.dysc = (int)P; wd.Cout = O; wd.OH = H; wd.OW = W;
+    wd.KH = wd.KW = 1; wd.stride = 1; wd.pad = 0; wd.N = N; wd.scale = 1.f; wd.gW = gw; wd.gb = gb;
+    launch_wgrad(wd, s);
+    DBM_HIP(hipStreamSynchronize(s));
+  }
+  DBM_HIP(hipStreamSynchronize(s));
+  col.release();
+  gcol.release();
+  DBM_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// Internal declarations shared by the HIP translation units of libdbm.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include <stdexcept>
+
+#define DBM_MAX_TAPS 16
+
+struct DbmError : std::runtime_error {
+  int code;
+  DbmError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define DBM_HIP(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      throw DbmError(2, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + \
+                            ":" + std::to_string(__LINE__));                              \
+  } while (0)
+
+#define DBM_CHECK(cond, msg)                                                   \
+  do {                                                                         \
+    if (!(cond)) throw DbmError(1, std::string(msg) + " (" #cond ") @" + __FILE__ + ":" + \
+                                       std::to_string(__LINE__));              \
+  } while (0)
+
+// ----------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution descriptor (igemm.hip).  One launch computes, for every logical output
+// position (n, a, b), a in [0,OHl), b in [0,OWl), and every output channel c < Cout:
+//   acc = sum_t sum_ci  wp[t][ci][c] * x[n][ci][(a*sin + dy[t]) >> ups][(b*sin + dx[t]) >> ups]
+// (terms whose logical input coordinate falls outside [0, Hin<<ups) x [0, Win<<ups) are zero), then
+//   v = s1*(acc + bias[c]) + (c < r1_nch ? r1s*r1 : 0);  if (r2) v = s2*v + r2;  if (accumulate) v += y;
+//   if (act) v = lrelu(v);  if (mask && c >= mask_c0) v *= lrelu'(mask)
+// and stores v at y[n][c][(a*so+oy0)*OWp + (b*so+ox0)].
+// r1, r2, mask are addressed like y (channel stride ysc, same spatial index).
+// ----------------------------------------------------------------------------------------------
+struct ConvDesc {
+  const float* x;
+  long xsn;       // elements between images of x
+  int xsc;        // elements between channels of x (Hin*Win)
+  int Cin;        // multiple of 32
+  int Hin, Win;   // physical input dims
+  int ups;        // 0/1: nearest x2 upsample folded into the gather
+  int N, OHl, OWl;
+  int sin;
+  int T;
+  signed char dy[DBM_MAX_TAPS];
+  signed char dx[DBM_MAX_TAPS];
+  const float* wp;  // packed [T][Cin][CoutP]
+  int CoutP;        // multiple of 32
+  int Cout;
+  const float* bias;
+  float* y;
+  long ysn;
+  int ysc;
+  int OWp, so, oy0, ox0;
+  float s1;
+  const float* r1;
+  long r1sn;
+  int r1_nch;
+  float r1s;
+  const float* r2;
+  long r2sn;
+  float s2;
+  int accumulate;
+  int act;
+  float slope;
+  const float* mask;
+  long masksn;
+  int mask_c0;
+  const float* zeros;  // >= 4 bytes of device zeros
+};
+
+void launch_igemm_conv(const ConvDesc& d, hipStream_t s);
+
+// Per-kernel-family timing with HIP events on the launch stream (bench.py's roofline leg).
+// family 0 = igemm_conv_kernel (forward + data gradient), 1 = wgrad_kernel.
+struct KernelProfiler {
+  bool enabled = false;
+  struct Rec { hipEvent_t a, b; double flops; int family; };
+  std::vector<Rec> recs;
+  void begin(hipStream_t s, int family, double flops);
+  void end(hipStream_t s);
+  void collect(double out[8]);  // [ms, flops, launches] per family, then clears
+};
+extern KernelProfiler g_profiler;
+
+// weight packing (pack.hip): dst[t][k][mP] with (k,m) = (cin,cout) (transpose=0) or (cout,cin) (transpose=1);
+// tap t reads OIHW element (ky[t], kx[t]).  Rows m >= M are zero-filled; k in [K, KP) zero-filled.
+void launch_pack_weights(const float* w_oihw, int O, int C, int KH, int KW, int T, const signed char* ky,
+                         const signed char* kx, int transpose, int KP, int MP, float* dst, hipStream_t s);
+
+// wgrad (wgrad.hip): gW[o][c][ky][kx] (+)= scale * sum_{n,a,b} dy[n][o][a][b] * x[n][c][(a*stride+ky-pad)>>ups][...]
+struct WgradDesc {
+  const float* x;   // input activations
+  long xsn; int xsc; int Cin; int Hin, Win; int ups;
+  const float* dy;  // output gradients
+  long dysn; int dysc; int Cout; int OH, OW;
+  int KH, KW, stride, pad;
+  int N;
+  float scale;
+  float* gW;        // canonical OIHW, accumulated with atomicAdd
+  float* gb;        // may be null; accumulated with atomicAdd
+};
+void launch_wgrad(const WgradDesc& d, hipStream_t s);

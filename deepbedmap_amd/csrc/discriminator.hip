@@ -1,0 +1,142 @@
+// DiscriminatorModel (reference srgan_train.py:591-699): parameter table, forward, backward.
+#include "model.h"
+
+static const float SLOPE = 0.2f;
+static const int DC_O[10] = {64, 64, 128, 128, 128, 256, 256, 512, 512, 512};
+static const int DC_C[10] = {1, 64, 64, 128, 128, 128, 256, 256, 512, 512};
+static const int DC_K[10] = {3, 4, 3, 4, 3, 4, 3, 4, 3, 4};
+static const int DC_S[10] = {1, 2, 1, 2, 1, 2, 1, 2, 1, 2};
+
+Discriminator::Discriminator(dbm_ctx* c) {
+  ctx = c;
+  type = 1;
+  // conv_layer0 has a bias, conv_layer1..9 are nobias=True (:617-634)
+  for (int i = 0; i < 10; ++i) {
+    const std::string name = "conv_layer" + std::to_string(i);
+    add_tensor(name + "/W", {DC_O[i], DC_C[i], DC_K[i], DC_K[i]}, DBM_KIND_PARAM);
+    if (i == 0) add_tensor(name + "/b", {DC_O[i]}, DBM_KIND_PARAM);
+  }
+  T_c0W = tid("conv_layer0/W");
+  T_c0b = tid("conv_layer0/b");
+  for (int i = 1; i < 10; ++i) {  // :636-644
+    const std::string name = "batch_norm" + std::to_string(i);
+    T_bn[i][0] = add_tensor(name + "/gamma", {DC_O[i]}, DBM_KIND_PARAM);
+    T_bn[i][1] = add_tensor(name + "/beta", {DC_O[i]}, DBM_KIND_PARAM);
+  }
+  T_l1W = add_tensor("linear_1/W", {100, 512}, DBM_KIND_PARAM);  // :646
+  T_l1b = add_tensor("linear_1/b", {100}, DBM_KIND_PARAM);
+  T_l2W = add_tensor("linear_2/W", {1, 100}, DBM_KIND_PARAM);  // :647
+  T_l2b = add_tensor("linear_2/b", {1}, DBM_KIND_PARAM);
+  for (int i = 1; i < 10; ++i) {
+    const std::string name = "batch_norm" + std::to_string(i);
+    T_bn[i][2] = add_tensor(name + "/avg_mean", {DC_O[i]}, DBM_KIND_PERSISTENT);
+    T_bn[i][3] = add_tensor(name + "/avg_var", {DC_O[i]}, DBM_KIND_PERSISTENT);
+    T_bn[i][4] = add_tensor(name + "/N", {}, DBM_KIND_PERSISTENT);
+  }
+  for (int i = 1; i < 10; ++i)
+    L_conv[i] = add_iglayer("conv_layer" + std::to_string(i), DC_O[i], DC_C[i], DC_K[i], DC_S[i], 1, false);
+  alloc_arenas();
+  // Chainer initial state: gamma = 1, avg_var = 1 (beta, avg_mean, N = 0)
+  for (int i = 1; i < 10; ++i) {
+    launch_fill(P(T_bn[i][0]), DC_O[i], 1.f, ctx->stream);
+    launch_fill(S(T_bn[i][3]), DC_O[i], 1.f, ctx->stream);
+  }
+}
+
+static void layer_dims(int H, int W, int hs[11], int ws[11]) {
+  hs[0] = H; ws[0] = W;  // conv0 keeps the size
+  hs[1] = H; ws[1] = W;  // h0
+  for (int i = 1; i < 10; ++i) {
+    hs[i + 1] = (hs[i] + 2 - DC_K[i]) / DC_S[i] + 1;
+    ws[i + 1] = (ws[i] + 2 - DC_K[i]) / DC_S[i] + 1;
+  }
+}
+
+void Discriminator::forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot) {
+  DBM_CHECK(slot == 0 || slot == 1, "discriminator cache slot must be 0 or 1");
+  int hs[11], ws[11];
+  layer_dims(H, W, hs, ws);  // hs[i+1] = spatial size of h_i
+  DBM_CHECK(hs[10] == 1 && ws[10] == 1, "discriminator input must reduce to 1x1 (linear_1 expects 512 features)");
+  ensure_packed();
+  hipStream_t s = ctx->stream;
+  Cache& c = cache[slot];
+  const size_t n = (size_t)N;
+  c.h[0].ensure(n * 64 * H * W);
+  {  // conv_layer0 + LeakyReLU  (:658-659)
+    SmallConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = img; d.xsn = (long)H * W; d.Cin = 1; d.Hin = H; d.Win = W;
+    d.w = P(T_c0W); d.bias = P(T_c0b);
+    d.y = c.h[0].p; d.ysn = 64L * H * W; d.Cout = 64; d.OH = H; d.OW = W;
+    d.KH = d.KW = 3; d.stride = 1; d.pad = 1; d.N = N; d.act = 1; d.slope = SLOPE;
+    launch_smallcin_conv_fwd(d, s);
+  }
+  for (int i = 1; i < 10; ++i) {  // conv -> BatchNorm -> LeakyReLU  (:663-689)
+    const IgLayer& L = layers[L_conv[i]];
+    const int hin = hs[i], win = ws[i], ho = hs[i + 1], wo = ws[i + 1];
+    const size_t cnt = n * DC_O[i] * ho * wo;
+    c.z[i].ensure(cnt);
+    c.h[i].ensure(cnt);
+    c.mean[i].ensure(DC_O[i]);
+    c.istd[i].ensure(DC_O[i]);
+    ConvDesc d = fwd_desc(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, c.z[i].p, (long)DC_O[i] * ho * wo, N);
+    launch_igemm_conv(d, s);
+    if (bn_train)
+      launch_bn_train_fwd(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, S(T_bn[i][2]),
+                          S(T_bn[i][3]), N, DC_O[i], ho * wo, 1e-5f, 0.9f, SLOPE, s);
+    else
+      launch_bn_eval_fwd(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), S(T_bn[i][2]), S(T_bn[i][3]), N, DC_O[i],
+                         ho * wo, 1e-5f, SLOPE, s);
+  }
+  c.l1.ensure(n * 100);
+  launch_linear_fwd(c.h[9].p, P(T_l1W), P(T_l1b), c.l1.p, N, 512, 100, 1, SLOPE, s);  // :693-695
+  launch_linear_fwd(c.l1.p, P(T_l2W), P(T_l2b), logits, N, 100, 1, 0, SLOPE, s);       // :696
+  c.N = N; c.H = H; c.W = W;
+  c.valid = keep && bn_train;
+  if (c.valid) {  // conv_layer0's weight gradient needs the input image: keep a private copy
+    c.img.ensure(n * H * W);
+    DBM_HIP(hipMemcpyAsync(c.img.p, img, n * H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+}
+
+void Discriminator::backward(int slot, const float* glogits) {
+  Cache& c = cache[slot];
+  DBM_CHECK(c.valid, "discriminator backward without a retained training-mode forward");
+  hipStream_t s = ctx->stream;
+  const int N = c.N;
+  int hs[11], ws[11];
+  layer_dims(c.H, c.W, hs, ws);
+  const size_t n = (size_t)N;
+  g_l1.ensure(n * 100);
+  g_h[0].ensure(n * 64 * c.H * c.W);
+  g_h[1].ensure(n * 64 * c.H * c.W);
+  g_z.ensure(n * 64 * c.H * c.W);
+  // linear_2, then linear_1 (through its LeakyReLU)
+  launch_linear_bwd(c.l1.p, P(T_l2W), glogits, nullptr, g_l1.p, G(T_l2W), G(T_l2b), N, 100, 1, SLOPE, s);
+  float* gh = g_h[0].p;
+  float* gh_next = g_h[1].p;
+  launch_linear_bwd(c.h[9].p, P(T_l1W), g_l1.p, c.l1.p, gh, G(T_l1W), G(T_l1b), N, 512, 100, SLOPE, s);
+  for (int i = 9; i >= 1; --i) {
+    const IgLayer& L = layers[L_conv[i]];
+    const int hin = hs[i], win = ws[i], ho = hs[i + 1], wo = ws[i + 1];
+    launch_bn_train_bwd(c.z[i].p, gh, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, g_z.p, G(T_bn[i][0]),
+                        G(T_bn[i][1]), nullptr, N, DC_O[i], ho * wo, SLOPE, s);
+    run_wgrad(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, g_z.p, (long)DC_O[i] * ho * wo, ho, wo, N, 1.f);
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = g_z.p; d.xsn = (long)DC_O[i] * ho * wo; d.N = N;
+    d.y = gh_next; d.ysn = (long)DC_C[i] * hin * win; d.s1 = 1.f; d.s2 = 1.f;
+    if (i == 1) {  // through conv_layer0's LeakyReLU
+      d.mask = c.h[0].p; d.masksn = 64L * c.H * c.W; d.mask_c0 = 0;
+    }
+    run_dgrad(L, d, hin, win);
+    float* t = gh; gh = gh_next; gh_next = t;
+  }
+  {  // conv_layer0 weight / bias gradient
+    SmallConvDesc q;
+    memset(&q, 0, sizeof(q));
+    q.x = c.img.p; q.xsn = (long)c.H * c.W; q.Cin = 1; q.Hin = c.H; q.Win = c.W;
+    q.Cout = 64; q.OH = c.H; q.OW = c.W; q.KH = q.KW = 3; q.stride = 1; q.pad = 1; q.N = N;
+    launch_smallcin_conv_wgrad(q, gh, 64L * c.H * c.W, G(T_c0W), G(T_c0b), s);
+  }
+}

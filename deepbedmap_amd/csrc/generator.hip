@@ -1,0 +1,334 @@
+// GeneratorModel (reference srgan_train.py:421-576): parameter table, forward, backward.
+#include "model.h"
+
+static const float SLOPE = 0.2f;
+
+Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
+  ctx = c;
+  type = 0;
+  n_rrdb = n;
+  rs = r;
+  out_ch = oc;
+  DBM_CHECK(n >= 1, "num_residual_blocks must be >= 1");
+  DBM_CHECK(oc == 1, "only out_channels == 1 (the reference's value) is implemented");
+  auto conv = [&](const std::string& name, int O, int C, int KH, int KW) {
+    add_tensor(name + "/W", {O, C, KH, KW}, DBM_KIND_PARAM);
+    add_tensor(name + "/b", {O}, DBM_KIND_PARAM);
+  };
+  // DeepbedmapInputBlock  srgan_train.py:223-254
+  const char* in_names[4] = {"input_block/conv_on_X", "input_block/conv_on_W1", "input_block/conv_on_W2",
+                             "input_block/conv_on_W3"};
+  conv(in_names[0], 32, 1, 3, 3);
+  conv(in_names[1], 32, 1, 30, 30);
+  conv(in_names[2], 32, 2, 6, 6);
+  conv(in_names[3], 32, 1, 3, 3);
+  for (int i = 0; i < 4; ++i) {
+    T_in[i][0] = tid(std::string(in_names[i]) + "/W");
+    T_in[i][1] = tid(std::string(in_names[i]) + "/b");
+  }
+  conv("pre_residual_conv_layer", 64, 128, 3, 3);  // :467-474
+  L_pre = add_iglayer("pre_residual_conv_layer", 64, 128, 3, 1, 1, true);
+  const int cin[5] = {64, 96, 128, 160, 192}, cout[5] = {32, 32, 32, 32, 64};
+  for (int i = 0; i < n; ++i)      // .repeat(n) -> Sequential children "0".."n-1"  :475-477
+    for (int d = 1; d <= 3; ++d)   // ResInResDenseBlock  :383-391
+      for (int k = 1; k <= 5; ++k) {  // ResidualDenseBlock  :292-331
+        const std::string name = "residual_network/" + std::to_string(i) + "/residual_dense_block" + std::to_string(d) +
+                                 "/conv_layer" + std::to_string(k);
+        conv(name, cout[k - 1], cin[k - 1], 3, 3);
+        L_rdb.push_back(add_iglayer(name, cout[k - 1], cin[k - 1], 3, 1, 1, true));
+      }
+  conv("post_residual_conv_layer", 64, 64, 3, 3);  // :478-485
+  L_post = add_iglayer("post_residual_conv_layer", 64, 64, 3, 1, 1, true);
+  conv("post_upsample_conv_layer_1", 64, 64, 3, 3);  // :488-495
+  L_up1 = add_iglayer("post_upsample_conv_layer_1", 64, 64, 3, 1, 1, true);
+  conv("post_upsample_conv_layer_2", 64, 64, 3, 3);  // :496-503
+  L_up2 = add_iglayer("post_upsample_conv_layer_2", 64, 64, 3, 1, 1, true);
+  conv("final_conv_layer1/offset_conv", 18, 64, 3, 3);  // :506-514
+  L_off1 = add_iglayer("final_conv_layer1/offset_conv", 18, 64, 3, 1, 1, true);
+  conv("final_conv_layer1/deform_conv", 64, 64, 3, 3);
+  L_def1 = add_iglayer("final_conv_layer1/deform_conv", 64, 64, 3, 1, 0, true, /*as_1x1=*/true);
+  conv("final_conv_layer2/offset_conv", 18, 64, 3, 3);  // :515-523
+  L_off2 = add_iglayer("final_conv_layer2/offset_conv", 18, 64, 3, 1, 1, true);
+  conv("final_conv_layer2/deform_conv", oc, 64, 3, 3);
+  T_def2W = tid("final_conv_layer2/deform_conv/W");
+  T_def2b = tid("final_conv_layer2/deform_conv/b");
+  alloc_arenas();
+}
+
+void Generator::ensure_ws(int N, int H, int W, bool train) {
+  const bool same = (N == wsN && H == wsH && W == wsW);
+  if (same && (wsTrain || !train)) return;
+  DBM_CHECK(H >= 3 && W >= 3, "input tile must be at least 3x3");
+  const size_t hw = (size_t)(H - 2) * (W - 2), n = (size_t)N;
+  const int nrdb = 3 * n_rrdb;
+  const bool tr = train || (same && wsTrain);
+  in_x.ensure(n * H * W);
+  in_w1.ensure(n * 100 * H * W);
+  in_w2.ensure(n * 2 * 4 * H * W);
+  in_w3.ensure(n * H * W);
+  a0.ensure(n * 128 * hw);
+  const int ncat = tr ? nrdb + 1 : 5;
+  if ((int)cat.size() < ncat) cat.resize(ncat);
+  for (int i = 0; i < ncat; ++i) cat[i].ensure(n * 192 * hw);
+  a3.ensure(n * 64 * hw);
+  a41.ensure(n * 64 * 4 * hw);
+  a42.ensure(n * 64 * 16 * hw);
+  off1.ensure(n * 32 * 16 * hw);
+  off2.ensure(n * 32 * 16 * hw);
+  col1.ensure(n * 576 * 16 * hw);
+  a51.ensure(n * 64 * 16 * hw);
+  yout.ensure(n * 16 * hw);
+  if (tr) {
+    col2.ensure(n * 576 * 16 * hw);
+    if ((int)dA.size() < nrdb + 1) dA.resize(nrdb + 1);
+    for (int i = 0; i <= nrdb; ++i) dA[i].ensure(n * (i == nrdb ? 64 : 192) * hw);
+    g_a0.ensure(n * 128 * hw);
+    g_a3.ensure(n * 64 * hw);
+    g_u1.ensure(n * 64 * 4 * hw);
+    g_z41.ensure(n * 64 * 4 * hw);
+    g_u2.ensure(n * 64 * 16 * hw);
+    g_a42.ensure(n * 64 * 16 * hw);
+    goff1.ensure(n * 32 * 16 * hw);
+    goff2.ensure(n * 32 * 16 * hw);
+    gcol.ensure(n * 576 * 16 * hw);
+    g_a51.ensure(n * 64 * 16 * hw);
+    g_y.ensure(n * 16 * hw);
+  }
+  if (!same) {
+    // the 14 padding channels of the offset tensors must read as zero in the new layout
+    hipStream_t s = ctx->stream;
+    DBM_HIP(hipMemsetAsync(off1.p, 0, sizeof(float) * n * 32 * 16 * hw, s));
+    DBM_HIP(hipMemsetAsync(off2.p, 0, sizeof(float) * n * 32 * 16 * hw, s));
+    if (tr) {
+      DBM_HIP(hipMemsetAsync(goff1.p, 0, sizeof(float) * n * 32 * 16 * hw, s));
+      DBM_HIP(hipMemsetAsync(goff2.p, 0, sizeof(float) * n * 32 * 16 * hw, s));
+    }
+    have_graph = false;
+  }
+  wsN = N; wsH = H; wsW = W; wsTrain = tr;
+}
+
+void Generator::forward(int N, int H, int W, const float* x, const float* w1, const float* w2, const float* w3,
+                        float* y, bool keep) {
+  ensure_ws(N, H, W, keep);
+  ensure_packed();
+  hipStream_t s = ctx->stream;
+  const int h = H - 2, w = W - 2;
+  const long hw = (long)h * w;
+  const int nrdb = 3 * n_rrdb;
+  // ---- input block: four valid convolutions written straight into the 128-channel concat (:256-266) ----
+  {
+    struct { const float* in; int Cin, Hin, Win, K, stride; } br[4] = {
+        {x, 1, H, W, 3, 1}, {w1, 1, 10 * H, 10 * W, 30, 10}, {w2, 2, 2 * H, 2 * W, 6, 2}, {w3, 1, H, W, 3, 1}};
+    for (int i = 0; i < 4; ++i) {
+      SmallConvDesc d;
+      memset(&d, 0, sizeof(d));
+      d.x = br[i].in; d.xsn = (long)br[i].Cin * br[i].Hin * br[i].Win; d.Cin = br[i].Cin; d.Hin = br[i].Hin; d.Win = br[i].Win;
+      d.w = P(T_in[i][0]); d.bias = P(T_in[i][1]);
+      d.y = a0.p + (long)i * 32 * hw; d.ysn = 128 * hw; d.Cout = 32; d.OH = h; d.OW = w;
+      d.KH = d.KW = br[i].K; d.stride = br[i].stride; d.pad = 0; d.N = N; d.act = 0; d.slope = SLOPE;
+      DBM_CHECK((br[i].Hin - br[i].K) / br[i].stride + 1 == h && (br[i].Win - br[i].K) / br[i].stride + 1 == w,
+                "input block branch does not produce the (H-2, W-2) grid");
+      launch_smallcin_conv_fwd(d, s);
+    }
+  }
+  // ---- pre-residual conv + LeakyReLU -> cat[0][:, :64]  (:541-542) ----
+  {
+    ConvDesc d = fwd_desc(layers[L_pre], a0.p, 128 * hw, h, w, 0, cat[0].p, 192 * hw, N);
+    d.act = 1;
+    launch_igemm_conv(d, s);
+  }
+  // ---- RRDB trunk (:546; RDB :333-360, RRDB :393-404) ----
+  for (int j = 0; j < nrdb; ++j) {
+    float* C = cat[slot(j)].p;
+    float* Cn = cat[slot(j + 1)].p;
+    for (int k = 0; k < 4; ++k) {
+      const int cin = 64 + 32 * k;
+      ConvDesc d = fwd_desc(layers[L_rdb[j * 5 + k]], C, 192 * hw, h, w, 0, C + (long)cin * hw, 192 * hw, N);
+      d.act = 1;
+      launch_igemm_conv(d, s);
+    }
+    ConvDesc d = fwd_desc(layers[L_rdb[j * 5 + 4]], C, 192 * hw, h, w, 0, Cn, 192 * hw, N);
+    d.s1 = rs; d.r1 = C; d.r1sn = 192 * hw; d.r1_nch = 64; d.r1s = 1.f;  // a6 = a5*rs + a0  (:358)
+    if (j % 3 == 2) {  // a4 = a3*rs + x  (:402)
+      d.r2 = cat[slot(j - 2)].p; d.r2sn = 192 * hw; d.s2 = rs;
+    }
+    launch_igemm_conv(d, s);
+  }
+  // ---- post-residual conv, a3 = a1 + conv(a2)  (:550-551) ----
+  {
+    ConvDesc d = fwd_desc(layers[L_post], cat[slot(nrdb)].p, 192 * hw, h, w, 0, a3.p, 64 * hw, N);
+    d.r1 = cat[0].p; d.r1sn = 192 * hw; d.r1_nch = 64;
+    launch_igemm_conv(d, s);
+  }
+  // ---- nearest x2 + conv + LeakyReLU, twice; the resize is folded into the conv's gather (:556-568) ----
+  {
+    ConvDesc d = fwd_desc(layers[L_up1], a3.p, 64 * hw, h, w, 1, a41.p, 64 * 4 * hw, N);
+    d.act = 1;
+    launch_igemm_conv(d, s);
+    ConvDesc e = fwd_desc(layers[L_up2], a41.p, 64 * 4 * hw, 2 * h, 2 * w, 1, a42.p, 64 * 16 * hw, N);
+    e.act = 1;
+    launch_igemm_conv(e, s);
+  }
+  // ---- deformable conv 1 + LeakyReLU (:572-573): offset conv, sampler -> col, GEMM over 576 columns ----
+  const int H4 = 4 * h, W4 = 4 * w;
+  const long P4 = 16 * hw;
+  {
+    ConvDesc d = fwd_desc(layers[L_off1], a42.p, 64 * P4, H4, W4, 0, off1.p, 32 * P4, N);
+    launch_igemm_conv(d, s);
+    launch_deform_sample(a42.p, off1.p, col1.p, N, 64, H4, W4, 32 * P4, s);
+    ConvDesc g = fwd_desc(layers[L_def1], col1.p, 576 * P4, H4, W4, 0, a51.p, 64 * P4, N);
+    g.act = 1;
+    launch_igemm_conv(g, s);
+  }
+  // ---- deformable conv 2 (:574) ----
+  {
+    float* col = keep ? col2.p : col1.p;
+    ConvDesc d = fwd_desc(layers[L_off2], a51.p, 64 * P4, H4, W4, 0, off2.p, 32 * P4, N);
+    launch_igemm_conv(d, s);
+    launch_deform_sample(a51.p, off2.p, col, N, 64, H4, W4, 32 * P4, s);
+    launch_gemv_cols(col, P(T_def2W), P(T_def2b), y, N, 576, (int)P4, s);
+  }
+  bw_in[0] = x; bw_in[1] = w1; bw_in[2] = w2; bw_in[3] = w3;
+  have_graph = keep;
+}
+
+void Generator::backward(const float* gy) {
+  DBM_CHECK(have_graph && wsTrain, "generator backward without a retained forward (DBM_KEEP_GRAPH)");
+  hipStream_t s = ctx->stream;
+  const int N = wsN, H = wsH, W = wsW, h = H - 2, w = W - 2;
+  const long hw = (long)h * w, P4 = 16 * hw;
+  const int H4 = 4 * h, W4 = 4 * w, nrdb = 3 * n_rrdb;
+  // ---- final_conv_layer2 (deformable, 64 -> 1) ----
+  DBM_HIP(hipMemsetAsync(g_a51.p, 0, sizeof(float) * N * 64 * P4, s));
+  launch_deform_backward(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, goff2.p, N, 64, H4, W4, 32 * P4, s);
+  launch_gemv_cols_wgrad(col2.p, gy, G(T_def2W), G(T_def2b), N, 576, (int)P4, s);
+  {
+    const IgLayer& L = layers[L_off2];
+    run_wgrad(L, a51.p, 64 * P4, H4, W4, 0, goff2.p, 32 * P4, H4, W4, N, 1.f);
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = goff2.p; d.xsn = 32 * P4; d.N = N;
+    d.y = g_a51.p; d.ysn = 64 * P4; d.accumulate = 1; d.s1 = 1.f; d.s2 = 1.f;
+    d.mask = a51.p; d.masksn = 64 * P4; d.mask_c0 = 0;  // through F.leaky_relu (:573)
+    run_dgrad(L, d, H4, W4);
+  }
+  // ---- final_conv_layer1 (deformable, 64 -> 64): g_a51 now holds d loss / d (pre-activation) ----
+  {
+    const IgLayer& L = layers[L_def1];
+    run_wgrad(L, col1.p, 576 * P4, H4, W4, 0, g_a51.p, 64 * P4, H4, W4, N, 1.f);
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = g_a51.p; d.xsn = 64 * P4; d.N = N;
+    d.y = gcol.p; d.ysn = 576 * P4; d.s1 = 1.f; d.s2 = 1.f;
+    run_dgrad(L, d, H4, W4);
+    DBM_HIP(hipMemsetAsync(g_a42.p, 0, sizeof(float) * N * 64 * P4, s));
+    launch_deform_backward(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, goff1.p, N, 64, H4, W4, 32 * P4, s);
+  }
+  {
+    const IgLayer& L = layers[L_off1];
+    run_wgrad(L, a42.p, 64 * P4, H4, W4, 0, goff1.p, 32 * P4, H4, W4, N, 1.f);
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = goff1.p; d.xsn = 32 * P4; d.N = N;
+    d.y = g_a42.p; d.ysn = 64 * P4; d.accumulate = 1; d.s1 = 1.f; d.s2 = 1.f;
+    d.mask = a42.p; d.masksn = 64 * P4; d.mask_c0 = 0;  // through F.leaky_relu (:568)
+    run_dgrad(L, d, H4, W4);
+  }
+  // ---- post_upsample_conv_layer_2 on resize(a41) ----
+  {
+    const IgLayer& L = layers[L_up2];
+    run_wgrad(L, a41.p, 64 * 4 * hw, 2 * h, 2 * w, 1, g_a42.p, 64 * P4, H4, W4, N, 1.f);
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = g_a42.p; d.xsn = 64 * P4; d.N = N;
+    d.y = g_u2.p; d.ysn = 64 * P4; d.s1 = 1.f; d.s2 = 1.f;
+    run_dgrad(L, d, H4, W4);
+    launch_sumpool2(g_u2.p, a41.p, g_z41.p, (long)N * 64, 2 * h, 2 * w, SLOPE, s);  // resize bwd + lrelu' (:560)
+  }
+  // ---- post_upsample_conv_layer_1 on resize(a3) ----
+  {
+    const IgLayer& L = layers[L_up1];
+    run_wgrad(L, a3.p, 64 * hw, h, w, 1, g_z41.p, 64 * 4 * hw, 2 * h, 2 * w, N, 1.f);
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = g_z41.p; d.xsn = 64 * 4 * hw; d.N = N;
+    d.y = g_u1.p; d.ysn = 64 * 4 * hw; d.s1 = 1.f; d.s2 = 1.f;
+    run_dgrad(L, d, 2 * h, 2 * w);
+    launch_sumpool2(g_u1.p, nullptr, g_a3.p, (long)N * 64, h, w, SLOPE, s);
+  }
+  // ---- post_residual_conv_layer: a3 = a1 + conv(a2) ----
+  {
+    const IgLayer& L = layers[L_post];
+    run_wgrad(L, cat[nrdb].p, 192 * hw, h, w, 0, g_a3.p, 64 * hw, h, w, N, 1.f);
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = g_a3.p; d.xsn = 64 * hw; d.N = N;
+    d.y = dA[nrdb].p; d.ysn = 64 * hw; d.s1 = 1.f; d.s2 = 1.f;
+    run_dgrad(L, d, h, w);
+  }
+  // ---- trunk, last dense block first ----
+  for (int j = nrdb - 1; j >= 0; --j) {
+    const float* Gout = dA[j + 1].p;
+    const long gsn = (j + 1 == nrdb) ? 64 * hw : 192 * hw;
+    const bool third = (j % 3 == 2), first = (j % 3 == 0);
+    const float sc = third ? rs * rs : rs;  // d(out)/d(a5), including the RRDB scaling for the third block
+    float* D = dA[j].p;
+    const float* C = cat[j].p;
+    {  // conv_layer5: out = a5*rs + a0
+      const IgLayer& L = layers[L_rdb[j * 5 + 4]];
+      run_wgrad(L, C, 192 * hw, h, w, 0, Gout, gsn, h, w, N, sc);
+      ConvDesc d;
+      memset(&d, 0, sizeof(d));
+      d.x = Gout; d.xsn = gsn; d.N = N;
+      d.y = D; d.ysn = 192 * hw;
+      d.s1 = sc; d.s2 = 1.f;
+      d.r1 = Gout; d.r1sn = gsn; d.r1_nch = 64; d.r1s = third ? rs : 1.f;
+      d.mask = C; d.masksn = 192 * hw; d.mask_c0 = 160;
+      run_dgrad(L, d, h, w);
+    }
+    for (int k = 3; k >= 0; --k) {  // conv_layer4 .. conv_layer1
+      const int lo = 64 + 32 * k;   // channel offset of a_{k+1} = number of input channels of this conv
+      const IgLayer& L = layers[L_rdb[j * 5 + k]];
+      run_wgrad(L, C, 192 * hw, h, w, 0, D + (long)lo * hw, 192 * hw, h, w, N, 1.f);
+      ConvDesc d;
+      memset(&d, 0, sizeof(d));
+      d.x = D + (long)lo * hw; d.xsn = 192 * hw; d.N = N;
+      d.y = D; d.ysn = 192 * hw; d.accumulate = 1; d.s1 = 1.f; d.s2 = 1.f;
+      if (k > 0) {
+        d.mask = C; d.masksn = 192 * hw; d.mask_c0 = lo - 32;
+      } else {
+        if (first) {  // the RRDB skip: d loss / d x += d loss / d (RRDB output)
+          d.r1 = dA[j + 3].p; d.r1sn = (j + 3 == nrdb) ? 64 * hw : 192 * hw; d.r1_nch = 64; d.r1s = 1.f;
+        }
+        if (j == 0) {  // a3 = a1 + ...: add g_a3, then through the pre-residual LeakyReLU (:542)
+          d.r2 = g_a3.p; d.r2sn = 64 * hw; d.s2 = 1.f;
+          d.mask = cat[0].p; d.masksn = 192 * hw; d.mask_c0 = 0;
+        }
+      }
+      run_dgrad(L, d, h, w);
+    }
+  }
+  // ---- pre_residual_conv_layer and the input block ----
+  {
+    const IgLayer& L = layers[L_pre];
+    run_wgrad(L, a0.p, 128 * hw, h, w, 0, dA[0].p, 192 * hw, h, w, N, 1.f);
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.x = dA[0].p; d.xsn = 192 * hw; d.N = N;
+    d.y = g_a0.p; d.ysn = 128 * hw; d.s1 = 1.f; d.s2 = 1.f;
+    run_dgrad(L, d, h, w);
+    struct { const float* in; int Cin, Hin, Win, K, stride; } br[4] = {{in_x.p, 1, H, W, 3, 1},
+                                                                    {in_w1.p, 1, 10 * H, 10 * W, 30, 10},
+                                                                    {in_w2.p, 2, 2 * H, 2 * W, 6, 2},
+                                                                    {in_w3.p, 1, H, W, 3, 1}};
+    for (int i = 0; i < 4; ++i) {
+      SmallConvDesc q;
+      memset(&q, 0, sizeof(q));
+      q.x = bw_in[i] ? bw_in[i] : br[i].in;
+      q.xsn = (long)br[i].Cin * br[i].Hin * br[i].Win; q.Cin = br[i].Cin; q.Hin = br[i].Hin; q.Win = br[i].Win;
+      q.Cout = 32; q.OH = h; q.OW = w; q.KH = q.KW = br[i].K; q.stride = br[i].stride; q.pad = 0; q.N = N;
+      launch_smallcin_conv_wgrad(q, g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), s);
+    }
+  }
+}

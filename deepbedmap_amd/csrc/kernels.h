@@ -1,0 +1,60 @@
+// Launchers of the non-GEMM kernels (misc.hip, norm_loss.hip).
+#pragma once
+#include "dbm_internal.h"
+
+struct SmallConvDesc {
+  const float* x; long xsn; int Cin, Hin, Win;
+  const float* w;     // canonical OIHW
+  const float* bias;  // may be null
+  float* y; long ysn; int Cout, OH, OW;
+  int KH, KW, stride, pad;
+  int N;
+  int act; float slope;
+};
+void launch_smallcin_conv_fwd(const SmallConvDesc& d, hipStream_t s);
+void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dysn, float* gW, float* gb, hipStream_t s);
+
+void launch_deform_sample(const float* x, const float* off, float* col, int N, int C, int H, int W, long offsn, hipStream_t s);
+void launch_deform_backward(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy,
+                            float* gx, float* goff, int N, int C, int H, int W, long offsn, hipStream_t s);
+void launch_gemv_cols(const float* col, const float* w, const float* bias, float* y, int N, int K, int plane, hipStream_t s);
+void launch_gemv_cols_wgrad(const float* col, const float* gy, float* gw, float* gb, int N, int K, int plane, hipStream_t s);
+void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int H, int W, float slope, hipStream_t s);
+void launch_lrelu_bwd(const float* g, const float* mask, float* out, long total, float slope, hipStream_t s);
+
+// ---- norm_loss.hip ----
+// BatchNorm (training): per-channel batch statistics of z [N,C,plane]; writes mean/inv_std, updates running stats,
+// then y = lrelu(gamma*(z-mean)*inv_std + beta).
+void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* inv_std,
+                         float* avg_mean, float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
+                         hipStream_t s);
+void launch_bn_eval_fwd(const float* z, float* y, const float* gamma, const float* beta, const float* avg_mean,
+                        const float* avg_var, int N, int C, int plane, float eps, float slope, hipStream_t s);
+// backward through lrelu + BN(train): gz = d loss/d z ; ggamma/gbeta accumulated (+=)
+void launch_bn_train_bwd(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
+                         const float* inv_std, float* gz, float* ggamma, float* gbeta, float* scratch, int N, int C,
+                         int plane, float slope, hipStream_t s);
+// Linear layers of the discriminator head (tiny): y[n][o] = act(b[o] + sum_k W[o][k] x[n][k])
+void launch_linear_fwd(const float* x, const float* W, const float* b, float* y, int N, int K, int O, int act,
+                       float slope, hipStream_t s);
+// gx[n][k] = sum_o gyz[n][o] W[o][k]; gW[o][k] += sum_n gyz[n][o] x[n][k]; gb[o] += sum_n gyz[n][o]
+// where gyz = gy * lrelu'(y) if y_act != null else gy
+void launch_linear_bwd(const float* x, const float* W, const float* gy, const float* y_act, float* gx, float* gW,
+                       float* gb, int N, int K, int O, float slope, hipStream_t s);
+
+// RaGAN discriminator loss (srgan_train.py:960-1009) on N real + N fake logits.
+// out[0] = loss, out[1] = binary accuracy (train_eval_discriminator :1156-1158); g_real/g_fake may be null.
+void launch_ragan_loss(const float* real, const float* fake, int N, int real_target, int fake_target, float* out,
+                       float* g_real, float* g_fake, hipStream_t s);
+
+// Generator loss terms on y_pred vs y_true [N,1,H,W] and x_topo = X[:, :, 1:-1, 1:-1] (srgan_train.py:841-902).
+// sums[0..4] = sum|y-t|, sum|pool4(y)-x|, sum ssim_map, sum (y-t)^2, (unused); gy (may be null) receives
+// cw*dL1 + tw*dTopo - sw*dSSIM.  X is the full [N,1,H/4+2,W/4+2] input tile.
+void launch_gen_loss(const float* y, const float* t, const float* X, int N, int H, int W, float cw, float tw, float sw,
+                     const float* win1d, float* sums, float* gy, hipStream_t s);
+
+// Adam (Chainer form, srgan_train.py:1043-1048): one fused pass over the flat arenas.
+void launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha_t, float one_minus_beta1,
+                 float one_minus_beta2, float eps, float gscale, hipStream_t s);
+void launch_fill(float* p, long n, float v, hipStream_t s);
+void launch_sqdiff(const float* a, const float* b, long n, float* out, hipStream_t s);

@@ -1,0 +1,326 @@
+// Non-GEMM kernels of the hot path: few-input-channel convolutions (input block, D conv0),
+// deformable-convolution sampler (forward / backward), 2x2 sum-pool (backward of the nearest
+// upsample), small dense layers.  All are HBM/L2-bound VALU kernels: one position per lane,
+// coalesced along the innermost (x) axis of the NCHW fp32 tensors.
+#include "dbm_internal.h"
+#include "kernels.h"
+
+// ----------------------------------------------------------------------------------------------
+// Convolution with 1 or 2 input channels (reference srgan_train.py:223-254 input block, :617-625
+// discriminator conv_layer0).  Each thread owns one output position and 8 output channels.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void smallcin_conv_fwd_kernel(const SmallConvDesc d) {
+  const int plane = d.OH * d.OW;
+  const long P = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int cg = threadIdx.x >> 6;  // wave-uniform: 8-channel group within the 32 handled per block
+  const int co0 = blockIdx.y * 32 + cg * 8;
+  if (P >= (long)d.N * plane || co0 >= d.Cout) return;
+  const int n = (int)(P / plane);
+  const int r = (int)(P - (long)n * plane);
+  const int a = r / d.OW, b = r - a * d.OW;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = d.bias ? d.bias[co0 + i] : 0.f;
+  const int K = d.Cin * d.KH * d.KW;
+  for (int c = 0; c < d.Cin; ++c) {
+    const float* xc = d.x + (long)n * d.xsn + (long)c * d.Hin * d.Win;
+    for (int ky = 0; ky < d.KH; ++ky) {
+      const int iy = a * d.stride - d.pad + ky;
+      if ((unsigned)iy >= (unsigned)d.Hin) continue;
+      const float* xr = xc + (long)iy * d.Win;
+      const float* wr = d.w + (long)co0 * K + (c * d.KH + ky) * d.KW;
+      for (int kx = 0; kx < d.KW; ++kx) {
+        const int ix = b * d.stride - d.pad + kx;
+        const float v = ((unsigned)ix < (unsigned)d.Win) ? xr[ix] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(wr[(long)i * K + kx], v, acc[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = acc[i];
+    if (d.act) v = v >= 0.f ? v : d.slope * v;
+    d.y[(long)n * d.ysn + (long)(co0 + i) * plane + r] = v;
+  }
+}
+
+void launch_smallcin_conv_fwd(const SmallConvDesc& d, hipStream_t s) {
+  DBM_CHECK(d.Cout % 8 == 0, "smallcin conv: Cout must be a multiple of 8");
+  const long total = (long)d.N * d.OH * d.OW;
+  dim3 grid((unsigned)((total + 63) / 64), (unsigned)((d.Cout + 31) / 32));
+  hipLaunchKernelGGL(smallcin_conv_fwd_kernel, grid, dim3(256), 0, s, d);
+  DBM_HIP(hipGetLastError());
+}
+
+// gW[o][c][ky][kx] += sum_{n,a,b} dy[n][o][a][b] * x[n][c][a*s-p+ky][b*s-p+kx];  gb[o] += sum dy.
+// One thread per (o, c, ky, kx); positions are split over gridDim.y workgroups; fp32 atomics.
+__global__ __launch_bounds__(256) void smallcin_conv_wgrad_kernel(const SmallConvDesc d, const float* __restrict__ dy,
+                                                                  long dysn, float* gW, float* gb) {
+  const int K = d.Cin * d.KH * d.KW;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int plane = d.OH * d.OW;
+  const long total = (long)d.N * plane;
+  const long chunk = (total + gridDim.y - 1) / gridDim.y;
+  const long p0 = blockIdx.y * chunk, p1 = (p0 + chunk < total) ? p0 + chunk : total;
+  if (e < d.Cout * K) {
+    const int o = e / K, k = e - o * K;
+    const int c = k / (d.KH * d.KW), kr = k - c * d.KH * d.KW;
+    const int ky = kr / d.KW, kx = kr - ky * d.KW;
+    float acc = 0.f;
+    for (long P = p0; P < p1; ++P) {
+      const int n = (int)(P / plane);
+      const int r = (int)(P - (long)n * plane);
+      const int a = r / d.OW, b = r - a * d.OW;
+      const int iy = a * d.stride - d.pad + ky, ix = b * d.stride - d.pad + kx;
+      if ((unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
+        acc = fmaf(dy[(long)n * dysn + (long)o * plane + r],
+                   d.x[(long)n * d.xsn + (long)c * d.Hin * d.Win + (long)iy * d.Win + ix], acc);
+    }
+    atomicAdd(gW + e, acc);
+  }
+  if (gb && blockIdx.x == 0 && threadIdx.x < d.Cout) {
+    float acc = 0.f;
+    for (long P = p0; P < p1; ++P) {
+      const int n = (int)(P / plane);
+      const int r = (int)(P - (long)n * plane);
+      acc += dy[(long)n * dysn + (long)threadIdx.x * plane + r];
+    }
+    atomicAdd(gb + threadIdx.x, acc);
+  }
+}
+
+void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dysn, float* gW, float* gb,
+                                hipStream_t s) {
+  DBM_CHECK(d.Cout <= 256, "smallcin wgrad: Cout <= 256");
+  const int K = d.Cin * d.KH * d.KW;
+  const int nb = (d.Cout * K + 255) / 256;
+  long total = (long)d.N * d.OH * d.OW;
+  int split = (int)((2048 + nb - 1) / nb);
+  if (split > total / 16) split = (int)(total / 16);
+  if (split < 1) split = 1;
+  hipLaunchKernelGGL(smallcin_conv_wgrad_kernel, dim3(nb, split), dim3(256), 0, s, d, dy, dysn, gW, gb);
+  DBM_HIP(hipGetLastError());
+}
+
+// ----------------------------------------------------------------------------------------------
+// Deformable convolution sampler (reference srgan_train.py:506-523, :572-574; Chainer
+// deformable_convolution_2d_sampler + spatial_transformer_sampler semantics).
+// ----------------------------------------------------------------------------------------------
+struct DeformGeom {
+  int u0, v0;            // top-left corner in the sampler's doubly padded frame
+  float wu0, wu1, wv0, wv1;
+  bool mu, mv;           // coordinate-gradient masks (not clipped)
+};
+
+__device__ __forceinline__ DeformGeom deform_geom(float offx, float offy, int a, int b, int ky, int kx, int H, int W,
+                                                  int pad) {
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  // _offset2grid: normalise to [-1,1] in fp32, then spatial_transformer_sampler maps back (+1 for its zero ring)
+  float xc = offx + (float)b + (float)kx;
+  float yc = offy + (float)a + (float)ky;
+  xc = (xc / (float)(Wp - 1) - 0.5f) * 2.f;
+  yc = (yc / (float)(Hp - 1) - 0.5f) * 2.f;
+  const float u = (xc + 1.f) * (float)(Wp - 1) / 2.f + 1.f;
+  const float v = (yc + 1.f) * (float)(Hp - 1) / 2.f + 1.f;
+  const float uc = fminf(fmaxf(u, 0.f), (float)(Wp + 1));
+  const float vc = fminf(fmaxf(v, 0.f), (float)(Hp + 1));
+  DeformGeom g;
+  g.u0 = min(max((int)floorf(uc), 0), Wp);
+  g.v0 = min(max((int)floorf(vc), 0), Hp);
+  g.wu0 = uc - (float)g.u0;
+  g.wu1 = (float)(g.u0 + 1) - uc;
+  g.wv0 = vc - (float)g.v0;
+  g.wv1 = (float)(g.v0 + 1) - vc;
+  g.mu = (u > 0.f) && (u < (float)(Wp + 1));
+  g.mv = (v > 0.f) && (v < (float)(Hp + 1));
+  return g;
+}
+
+// corner (vv,uu) of the doubly padded frame -> offset into the unpadded image or -1
+__device__ __forceinline__ int deform_corner(int vv, int uu, int H, int W, int pad) {
+  const int y = vv - pad - 1, x = uu - pad - 1;
+  return ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? y * W + x : -1;
+}
+
+// col[n][c*9+t][p] = bilinear sample of x[n][c] at (tap t position + offset)
+__global__ __launch_bounds__(256) void deform_sample_kernel(const float* __restrict__ x, const float* __restrict__ off,
+                                                            float* __restrict__ col, int N, int C, int H, int W,
+                                                            long offsn) {
+  const int plane = H * W;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * 9 * plane) return;
+  const int p = (int)(e % plane);
+  const int t = (int)((e / plane) % 9);
+  const int n = (int)(e / (9L * plane));
+  const int a = p / W, b = p - a * W;
+  const float* on = off + (long)n * offsn;
+  const DeformGeom g = deform_geom(on[(long)t * plane + p], on[(long)(9 + t) * plane + p], a, b, t / 3, t % 3, H, W, 1);
+  const int o1 = deform_corner(g.v0, g.u0, H, W, 1), o2 = deform_corner(g.v0, g.u0 + 1, H, W, 1);
+  const int o3 = deform_corner(g.v0 + 1, g.u0, H, W, 1), o4 = deform_corner(g.v0 + 1, g.u0 + 1, H, W, 1);
+  const float w1 = g.wu1 * g.wv1, w2 = g.wu0 * g.wv1, w3 = g.wu1 * g.wv0, w4 = g.wu0 * g.wv0;
+  const float* xn = x + (long)n * C * plane;
+  float* cn = col + ((long)n * C * 9 + t) * plane + p;
+  for (int c = 0; c < C; ++c) {
+    const float* xc = xn + (long)c * plane;
+    const float x1 = o1 >= 0 ? xc[o1] : 0.f, x2 = o2 >= 0 ? xc[o2] : 0.f;
+    const float x3 = o3 >= 0 ? xc[o3] : 0.f, x4 = o4 >= 0 ? xc[o4] : 0.f;
+    cn[(long)c * 9 * plane] = w1 * x1 + w2 * x2 + w3 * x3 + w4 * x4;
+  }
+}
+
+void launch_deform_sample(const float* x, const float* off, float* col, int N, int C, int H, int W, long offsn,
+                          hipStream_t s) {
+  const long total = (long)N * 9 * H * W;
+  hipLaunchKernelGGL(deform_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, off, col, N, C,
+                     H, W, offsn);
+  DBM_HIP(hipGetLastError());
+}
+
+// Backward of the sampler.  gcol[n][c*9+t][p] is either read (gcol != null) or, for a single
+// output channel, formed on the fly as w1o[c*9+t] * gy[n][p].  Scatters into gx (atomics; gx
+// must be zero-initialised or hold the gradient it accumulates onto) and writes goff[n][0:18].
+__global__ __launch_bounds__(256) void deform_backward_kernel(const float* __restrict__ x, const float* __restrict__ off,
+                                                              const float* __restrict__ gcol,
+                                                              const float* __restrict__ w1o,
+                                                              const float* __restrict__ gy, float* gx,
+                                                              float* __restrict__ goff, int N, int C, int H, int W,
+                                                              long offsn) {
+  const int plane = H * W;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * 9 * plane) return;
+  const int p = (int)(e % plane);
+  const int t = (int)((e / plane) % 9);
+  const int n = (int)(e / (9L * plane));
+  const int a = p / W, b = p - a * W;
+  const float* on = off + (long)n * offsn;
+  const DeformGeom g = deform_geom(on[(long)t * plane + p], on[(long)(9 + t) * plane + p], a, b, t / 3, t % 3, H, W, 1);
+  const int o1 = deform_corner(g.v0, g.u0, H, W, 1), o2 = deform_corner(g.v0, g.u0 + 1, H, W, 1);
+  const int o3 = deform_corner(g.v0 + 1, g.u0, H, W, 1), o4 = deform_corner(g.v0 + 1, g.u0 + 1, H, W, 1);
+  const float w1 = g.wu1 * g.wv1, w2 = g.wu0 * g.wv1, w3 = g.wu1 * g.wv0, w4 = g.wu0 * g.wv0;
+  const float* xn = x + (long)n * C * plane;
+  float* gxn = gx + (long)n * C * plane;
+  const float gyv = gy ? gy[(long)n * plane + p] : 0.f;
+  float gu = 0.f, gv = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* xc = xn + (long)c * plane;
+    float* gxc = gxn + (long)c * plane;
+    const float gq = gcol ? gcol[((long)n * C * 9 + (long)c * 9 + t) * plane + p] : w1o[c * 9 + t] * gyv;
+    const float x1 = o1 >= 0 ? xc[o1] : 0.f, x2 = o2 >= 0 ? xc[o2] : 0.f;
+    const float x3 = o3 >= 0 ? xc[o3] : 0.f, x4 = o4 >= 0 ? xc[o4] : 0.f;
+    gu += gq * (-g.wv1 * x1 + g.wv1 * x2 - g.wv0 * x3 + g.wv0 * x4);
+    gv += gq * (-g.wu1 * x1 - g.wu0 * x2 + g.wu1 * x3 + g.wu0 * x4);
+    if (o1 >= 0) atomicAdd(gxc + o1, gq * w1);
+    if (o2 >= 0) atomicAdd(gxc + o2, gq * w2);
+    if (o3 >= 0) atomicAdd(gxc + o3, gq * w3);
+    if (o4 >= 0) atomicAdd(gxc + o4, gq * w4);
+  }
+  float* gn = goff + (long)n * offsn;
+  gn[(long)t * plane + p] = g.mu ? gu : 0.f;
+  gn[(long)(9 + t) * plane + p] = g.mv ? gv : 0.f;
+}
+
+void launch_deform_backward(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy,
+                            float* gx, float* goff, int N, int C, int H, int W, long offsn, hipStream_t s) {
+  const long total = (long)N * 9 * H * W;
+  hipLaunchKernelGGL(deform_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, off, gcol, w1o,
+                     gy, gx, goff, N, C, H, W, offsn);
+  DBM_HIP(hipGetLastError());
+}
+
+// y[n][0][p] = b + sum_k w[k] * col[n][k][p]   (final_conv_layer2's 576 -> 1 GEMV, srgan_train.py:574)
+__global__ __launch_bounds__(256) void gemv_cols_kernel(const float* __restrict__ col, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int N,
+                                                        int K, int plane) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * plane) return;
+  const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
+  const float* c = col + (long)n * K * plane + p;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int k = 0;
+  for (; k + 3 < K; k += 4) {
+    a0 = fmaf(w[k], c[(long)k * plane], a0);
+    a1 = fmaf(w[k + 1], c[(long)(k + 1) * plane], a1);
+    a2 = fmaf(w[k + 2], c[(long)(k + 2) * plane], a2);
+    a3 = fmaf(w[k + 3], c[(long)(k + 3) * plane], a3);
+  }
+  for (; k < K; ++k) a0 = fmaf(w[k], c[(long)k * plane], a0);
+  y[e] = (a0 + a1) + (a2 + a3) + (bias ? bias[0] : 0.f);
+}
+
+void launch_gemv_cols(const float* col, const float* w, const float* bias, float* y, int N, int K, int plane,
+                      hipStream_t s) {
+  const long total = (long)N * plane;
+  hipLaunchKernelGGL(gemv_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, col, w, bias, y, N, K,
+                     plane);
+  DBM_HIP(hipGetLastError());
+}
+
+// gw[k] += sum_{n,p} gy[n][p] * col[n][k][p];  gb += sum gy     (backward of the GEMV above)
+__global__ __launch_bounds__(256) void gemv_cols_wgrad_kernel(const float* __restrict__ col,
+                                                              const float* __restrict__ gy, float* gw, float* gb,
+                                                              int N, int K, int plane) {
+  __shared__ float part[4];
+  const int k = blockIdx.x;  // k == K computes the bias gradient
+  const long total = (long)N * plane;
+  const long chunk = (total + gridDim.y - 1) / gridDim.y;
+  const long e0 = blockIdx.y * chunk, e1 = (e0 + chunk < total) ? e0 + chunk : total;
+  float acc = 0.f;
+  for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
+    acc += gy[e] * (k < K ? col[((long)n * K + k) * plane + p] : 1.f);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (part[0] + part[1]) + (part[2] + part[3]);
+    if (k < K) atomicAdd(gw + k, v);
+    else if (gb) atomicAdd(gb, v);
+  }
+}
+
+void launch_gemv_cols_wgrad(const float* col, const float* gy, float* gw, float* gb, int N, int K, int plane,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(gemv_cols_wgrad_kernel, dim3(K + 1, 4), dim3(256), 0, s, col, gy, gw, gb, N, K, plane);
+  DBM_HIP(hipGetLastError());
+}
+
+// ----------------------------------------------------------------------------------------------
+// backward of F.resize_images(mode="nearest") x2 (srgan_train.py:556-566): 2x2 sum pool, with the
+// LeakyReLU derivative of the layer below fused in (mask = that layer's retained output, or null).
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumpool2_kernel(const float* __restrict__ g, const float* __restrict__ mask,
+                                                       float* __restrict__ out, long total, int H, int W, float slope) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int x = (int)(e % W);
+  const int y = (int)((e / W) % H);
+  const long nc = e / ((long)W * H);
+  const float* gp = g + (nc * 2 * H + 2 * y) * 2 * W + 2 * x;
+  float v = (gp[0] + gp[1]) + (gp[2 * W] + gp[2 * W + 1]);
+  if (mask) v = mask[e] >= 0.f ? v : slope * v;
+  out[e] = v;
+}
+
+void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int H, int W, float slope,
+                     hipStream_t s) {
+  const long total = nc * H * W;
+  hipLaunchKernelGGL(sumpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, mask, out, total, H, W,
+                     slope);
+  DBM_HIP(hipGetLastError());
+}
+
+// out = g * lrelu'(mask)   (elementwise; used where the derivative cannot ride on a GEMM epilogue)
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ mask,
+                                                        float* __restrict__ out, long total, float slope) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  out[e] = mask[e] >= 0.f ? g[e] : slope * g[e];
+}
+
+void launch_lrelu_bwd(const float* g, const float* mask, float* out, long total, float slope, hipStream_t s) {
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, mask, out, total,
+                     slope);
+  DBM_HIP(hipGetLastError());
+}

@@ -1,0 +1,114 @@
+// Model objects behind the C ABI: parameter tables in chainer save_npz key order, packed-weight
+// caches for the MFMA kernels, activation workspaces, forward/backward orchestration.
+#pragma once
+#include "dbm_internal.h"
+#include "kernels.h"
+#include "../../include/dbm.h"
+
+struct DevBuf {
+  float* p = nullptr;
+  size_t n = 0;
+  void ensure(size_t count, bool zero = false);
+  void release();
+};
+
+struct dbm_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  std::string err;
+  float* zeros = nullptr;     // 256 B of zeros (igemm out-of-image taps)
+  float* ssim_win[2] = {nullptr, nullptr};  // 9-tap 1-D windows: gaussian(1.5), uniform
+  DevBuf loss_tmp;            // scratch for the loss entry points
+  DevBuf stage[8];            // host<->device staging for the non-DEVICE_PTRS entry points
+};
+
+struct Tensor {
+  std::string key;
+  int ndim;
+  int64_t shape[4];
+  int kind;
+  size_t off;  // float offset inside the param (kind 0) or persistent (kind 1) arena
+  size_t n;
+};
+
+// one L.Convolution2D executed by the implicit-GEMM kernel
+struct IgLayer {
+  int wi = -1, bi = -1;  // tensor indices (bias may be -1)
+  int O = 0, C = 0, K = 0, stride = 1, pad = 1;
+  int Cview = 0, Kview = 0;  // the (C, K) the GEMM sees (deform_conv: C*9, 1)
+  int CinP = 0, CoutP = 0;
+  float* wf = nullptr;       // [T][CinP][CoutP]
+  int OP = 0, CP = 0;
+  float* wb[4] = {nullptr, nullptr, nullptr, nullptr};  // dgrad packs [Tb][OP][CP]
+  int Tb = 0;
+  signed char bky[4][DBM_MAX_TAPS], bkx[4][DBM_MAX_TAPS], bdy[4][DBM_MAX_TAPS], bdx[4][DBM_MAX_TAPS];
+};
+
+struct dbm_model {
+  dbm_ctx* ctx = nullptr;
+  int type = 0;  // 0 generator, 1 discriminator
+  std::vector<Tensor> tensors;
+  std::map<std::string, int> index;
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  size_t nparam = 0;
+  float* pers = nullptr;
+  size_t npers = 0;
+  double alpha = 1.6e-4, beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
+  long adam_t = 0;
+  bool adam_ready = false;
+  bool packed_dirty = true;
+  std::vector<IgLayer> layers;
+  virtual ~dbm_model();
+  int add_tensor(const std::string& key, std::vector<int64_t> shape, int kind);
+  void alloc_arenas();
+  float* P(int ti) const { return params + tensors[ti].off; }
+  float* G(int ti) const { return grads + tensors[ti].off; }
+  float* S(int ti) const { return pers + tensors[ti].off; }
+  int tid(const std::string& key) const;
+  int add_iglayer(const std::string& name, int O, int C, int K, int stride, int pad, bool bias, bool as_1x1 = false);
+  void ensure_packed();
+  // helpers building descriptors
+  ConvDesc fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, float* y, long ysn, int N) const;
+  void run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_fwd) const;
+  void run_wgrad(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, const float* dy, long dysn,
+                 int OH, int OW, int N, float scale) const;
+};
+
+struct Generator : dbm_model {
+  int n_rrdb = 12, out_ch = 1;
+  float rs = 0.1f;
+  // layer indices into `layers`
+  int L_pre, L_post, L_up1, L_up2, L_off1, L_def1, L_off2;
+  std::vector<int> L_rdb;  // nrdb*5
+  int T_in[4][2];          // input block (W, b) tensor ids
+  int T_def2W, T_def2b;
+  // workspace
+  int wsN = 0, wsH = 0, wsW = 0;
+  bool wsTrain = false;
+  bool have_graph = false;
+  const float* bw_in[4] = {nullptr, nullptr, nullptr, nullptr};  // forward inputs, needed by the input-block wgrad
+  std::vector<DevBuf> cat, dA;
+  DevBuf in_x, in_w1, in_w2, in_w3, a0, a3, a41, a42, off1, off2, col1, col2, a51, yout;
+  DevBuf g_a0, g_a3, g_u1, g_z41, g_u2, g_a42, goff1, goff2, gcol, g_a51, g_y;
+  Generator(dbm_ctx* c, int n, float r, int oc);
+  void ensure_ws(int N, int H, int W, bool train);
+  int slot(int j) const { return wsTrain ? j : (j == 0 ? 0 : 1 + ((j - 1) & 3)); }
+  void forward(int N, int H, int W, const float* x, const float* w1, const float* w2, const float* w3, float* y, bool keep);
+  void backward(const float* gy);
+};
+
+struct Discriminator : dbm_model {
+  int L_conv[10];  // 1..9 are igemm layers
+  int T_c0W, T_c0b, T_bn[10][5];  // gamma, beta, avg_mean, avg_var, N
+  int T_l1W, T_l1b, T_l2W, T_l2b;
+  struct Cache {
+    int N = 0, H = 0, W = 0;
+    bool valid = false;
+    DevBuf img, h[10], z[10], mean[10], istd[10], l1, out;
+  } cache[2];
+  DevBuf g_h[2], g_z, g_l1, g_out;
+  Discriminator(dbm_ctx* c);
+  void forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot);
+  void backward(int slot, const float* glogits);
+};

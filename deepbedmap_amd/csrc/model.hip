@@ -1,0 +1,198 @@
+// Shared model machinery: tensor tables, arenas, packed-weight caches, conv descriptors.
+#include "model.h"
+
+void DevBuf::ensure(size_t count, bool zero) {
+  if (count > n) {
+    if (p) DBM_HIP(hipFree(p));
+    p = nullptr;
+    DBM_HIP(hipMalloc((void**)&p, count * sizeof(float)));
+    n = count;
+    zero = true;  // fresh allocations are always zeroed (padding channels rely on it)
+    DBM_HIP(hipMemset(p, 0, count * sizeof(float)));
+    return;
+  }
+  (void)zero;
+}
+
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  n = 0;
+}
+
+dbm_model::~dbm_model() {
+  for (auto& L : layers) {
+    if (L.wf) (void)hipFree(L.wf);
+    for (int i = 0; i < 4; ++i)
+      if (L.wb[i]) (void)hipFree(L.wb[i]);
+  }
+  if (params) (void)hipFree(params);
+  if (grads) (void)hipFree(grads);
+  if (adam_m) (void)hipFree(adam_m);
+  if (adam_v) (void)hipFree(adam_v);
+  if (pers) (void)hipFree(pers);
+}
+
+int dbm_model::add_tensor(const std::string& key, std::vector<int64_t> shape, int kind) {
+  Tensor t;
+  t.key = key;
+  t.ndim = (int)shape.size();
+  t.n = 1;
+  for (int i = 0; i < 4; ++i) t.shape[i] = i < t.ndim ? shape[i] : 1;
+  for (int i = 0; i < t.ndim; ++i) t.n *= (size_t)shape[i];
+  t.kind = kind;
+  size_t& cursor = kind == DBM_KIND_PARAM ? nparam : npers;
+  t.off = cursor;
+  cursor += t.n;
+  tensors.push_back(t);
+  index[key] = (int)tensors.size() - 1;
+  return (int)tensors.size() - 1;
+}
+
+void dbm_model::alloc_arenas() {
+  const size_t np = nparam ? nparam : 1, ns = npers ? npers : 1;
+  DBM_HIP(hipMalloc((void**)&params, np * sizeof(float)));
+  DBM_HIP(hipMalloc((void**)&grads, np * sizeof(float)));
+  DBM_HIP(hipMalloc((void**)&adam_m, np * sizeof(float)));
+  DBM_HIP(hipMalloc((void**)&adam_v, np * sizeof(float)));
+  DBM_HIP(hipMalloc((void**)&pers, ns * sizeof(float)));
+  DBM_HIP(hipMemset(params, 0, np * sizeof(float)));
+  DBM_HIP(hipMemset(grads, 0, np * sizeof(float)));
+  DBM_HIP(hipMemset(adam_m, 0, np * sizeof(float)));
+  DBM_HIP(hipMemset(adam_v, 0, np * sizeof(float)));
+  DBM_HIP(hipMemset(pers, 0, ns * sizeof(float)));
+}
+
+int dbm_model::tid(const std::string& key) const {
+  auto it = index.find(key);
+  DBM_CHECK(it != index.end(), "unknown tensor key " + key);
+  return it->second;
+}
+
+static inline int up32(int v) { return (v + 31) & ~31; }
+
+// Registers a convolution whose tensors `name/W` (+ `name/b`) were already added.
+int dbm_model::add_iglayer(const std::string& name, int O, int C, int K, int stride, int pad, bool bias, bool as_1x1) {
+  IgLayer L;
+  L.wi = tid(name + "/W");
+  L.bi = bias ? tid(name + "/b") : -1;
+  L.O = O; L.C = C; L.K = K; L.stride = stride; L.pad = pad;
+  L.Cview = as_1x1 ? C * K * K : C;
+  L.Kview = as_1x1 ? 1 : K;
+  L.CinP = up32(L.Cview);
+  L.CoutP = up32(O);
+  L.OP = up32(O);
+  L.CP = up32(L.Cview);
+  const int T = L.Kview * L.Kview;
+  DBM_CHECK(T <= DBM_MAX_TAPS, "kernel too large for the igemm path");
+  DBM_HIP(hipMalloc((void**)&L.wf, sizeof(float) * (size_t)T * L.CinP * L.CoutP));
+  if (stride == 1) {
+    L.Tb = T;
+    for (int t = 0; t < T; ++t) {
+      const int ky = t / L.Kview, kx = t % L.Kview;
+      L.bky[0][t] = (signed char)ky; L.bkx[0][t] = (signed char)kx;
+      L.bdy[0][t] = (signed char)(L.pad - ky); L.bdx[0][t] = (signed char)(L.pad - kx);
+    }
+    DBM_HIP(hipMalloc((void**)&L.wb[0], sizeof(float) * (size_t)T * L.OP * L.CP));
+  } else {
+    DBM_CHECK(stride == 2 && L.Kview == 4 && pad == 1, "strided igemm layers must be k4 s2 p1");
+    L.Tb = 4;
+    for (int ph = 0; ph < 4; ++ph) {
+      const int py = ph >> 1, px = ph & 1;
+      int t = 0;
+      for (int ky = 0; ky < 4; ++ky) {
+        if (((py + 1 - ky) & 1) != 0) continue;
+        for (int kx = 0; kx < 4; ++kx) {
+          if (((px + 1 - kx) & 1) != 0) continue;
+          L.bky[ph][t] = (signed char)ky; L.bkx[ph][t] = (signed char)kx;
+          L.bdy[ph][t] = (signed char)((py + 1 - ky) / 2); L.bdx[ph][t] = (signed char)((px + 1 - kx) / 2);
+          ++t;
+        }
+      }
+      DBM_HIP(hipMalloc((void**)&L.wb[ph], sizeof(float) * (size_t)4 * L.OP * L.CP));
+    }
+  }
+  layers.push_back(L);
+  return (int)layers.size() - 1;
+}
+
+void dbm_model::ensure_packed() {
+  if (!packed_dirty) return;
+  hipStream_t s = ctx->stream;
+  for (auto& L : layers) {
+    const int T = L.Kview * L.Kview;
+    signed char ky[DBM_MAX_TAPS], kx[DBM_MAX_TAPS];
+    for (int t = 0; t < T; ++t) { ky[t] = (signed char)(t / L.Kview); kx[t] = (signed char)(t % L.Kview); }
+    launch_pack_weights(P(L.wi), L.O, L.Cview, L.Kview, L.Kview, T, ky, kx, 0, L.CinP, L.CoutP, L.wf, s);
+    const int nph = L.stride == 1 ? 1 : 4;
+    for (int ph = 0; ph < nph; ++ph)
+      launch_pack_weights(P(L.wi), L.O, L.Cview, L.Kview, L.Kview, L.Tb, L.bky[ph], L.bkx[ph], 1, L.OP, L.CP, L.wb[ph], s);
+  }
+  packed_dirty = false;
+}
+
+ConvDesc dbm_model::fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, float* y, long ysn,
+                             int N) const {
+  ConvDesc d;
+  memset(&d, 0, sizeof(d));
+  const int Hl = Hin << ups, Wl = Win << ups;
+  const int OH = (Hl + 2 * L.pad - L.Kview) / L.stride + 1, OW = (Wl + 2 * L.pad - L.Kview) / L.stride + 1;
+  d.x = x; d.xsn = xsn; d.xsc = Hin * Win; d.Cin = L.CinP; d.Hin = Hin; d.Win = Win; d.ups = ups;
+  d.N = N; d.OHl = OH; d.OWl = OW; d.sin = L.stride;
+  d.T = L.Kview * L.Kview;
+  for (int t = 0; t < d.T; ++t) {
+    d.dy[t] = (signed char)(t / L.Kview - L.pad);
+    d.dx[t] = (signed char)(t % L.Kview - L.pad);
+  }
+  d.wp = L.wf; d.CoutP = L.CoutP; d.Cout = L.O;
+  d.bias = L.bi >= 0 ? P(L.bi) : nullptr;
+  d.y = y; d.ysn = ysn; d.ysc = OH * OW; d.OWp = OW; d.so = 1;
+  d.s1 = 1.f; d.r1s = 1.f; d.s2 = 1.f; d.slope = 0.2f;
+  d.zeros = ctx->zeros;
+  return d;
+}
+
+// Data gradient of layer L.  `base` carries the gradient input (x, xsn = dY and its image stride), the output
+// (y, ysn) and every epilogue field; geometry and weights are filled here.  Hin_fwd/Win_fwd: forward INPUT dims
+// (after upsample), i.e. the dims of the gradient being produced.
+void dbm_model::run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_fwd) const {
+  const int OH = (Hin_fwd + 2 * L.pad - L.Kview) / L.stride + 1, OW = (Win_fwd + 2 * L.pad - L.Kview) / L.stride + 1;
+  base.xsc = OH * OW; base.Cin = L.OP; base.Hin = OH; base.Win = OW; base.ups = 0;
+  base.sin = 1;
+  base.CoutP = L.CP; base.Cout = L.Cview;
+  base.bias = nullptr;
+  base.ysc = Hin_fwd * Win_fwd; base.OWp = Win_fwd;
+  base.zeros = ctx->zeros;
+  base.slope = 0.2f;
+  if (L.stride == 1) {
+    base.OHl = Hin_fwd; base.OWl = Win_fwd; base.so = 1; base.oy0 = 0; base.ox0 = 0;
+    base.T = L.Tb;
+    for (int t = 0; t < L.Tb; ++t) { base.dy[t] = L.bdy[0][t]; base.dx[t] = L.bdx[0][t]; }
+    base.wp = L.wb[0];
+    launch_igemm_conv(base, ctx->stream);
+  } else {
+    for (int ph = 0; ph < 4; ++ph) {
+      const int py = ph >> 1, px = ph & 1;
+      base.OHl = (Hin_fwd - py + 1) / 2; base.OWl = (Win_fwd - px + 1) / 2;
+      if (base.OHl <= 0 || base.OWl <= 0) continue;
+      base.so = 2; base.oy0 = py; base.ox0 = px;
+      base.T = 4;
+      for (int t = 0; t < 4; ++t) { base.dy[t] = L.bdy[ph][t]; base.dx[t] = L.bdx[ph][t]; }
+      base.wp = L.wb[ph];
+      launch_igemm_conv(base, ctx->stream);
+    }
+  }
+}
+
+void dbm_model::run_wgrad(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, const float* dy,
+                          long dysn, int OH, int OW, int N, float scale) const {
+  WgradDesc w;
+  memset(&w, 0, sizeof(w));
+  w.x = x; w.xsn = xsn; w.xsc = Hin * Win; w.Cin = L.Cview; w.Hin = Hin; w.Win = Win; w.ups = ups;
+  w.dy = dy; w.dysn = dysn; w.dysc = OH * OW; w.Cout = L.O; w.OH = OH; w.OW = OW;
+  w.KH = L.Kview; w.KW = L.Kview; w.stride = L.stride; w.pad = L.Kview == 1 ? 0 : L.pad;
+  w.N = N; w.scale = scale;
+  w.gW = G(L.wi);
+  w.gb = L.bi >= 0 ? G(L.bi) : nullptr;
+  launch_wgrad(w, ctx->stream);
+}

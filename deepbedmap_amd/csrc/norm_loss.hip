@@ -1,0 +1,446 @@
+// BatchNorm, dense head, losses and Adam: the HBM-bound (non-GEMM) part of the training step.
+#include "dbm_internal.h"
+#include "kernels.h"
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// ----------------------------------------------------------------------------------------------
+// L.BatchNormalization(axis=(0,2,3), eps=1e-5) + F.leaky_relu   (srgan_train.py:636-644, 664-689)
+// One workgroup per channel: two-pass mean / biased variance (as Chainer's x.mean / x.var), running
+// statistics with the unbiased correction m/max(m-1,1) and decay 0.9, then normalise + LeakyReLU.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restrict__ z, float* __restrict__ y,
+                                                           const float* gamma, const float* beta, float* mean_o,
+                                                           float* istd_o, float* avg_mean, float* avg_var, int N, int C,
+                                                           int plane, float eps, float decay, float slope) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x;
+  const long m = (long)N * plane;
+  float s = 0.f;
+  for (long e = threadIdx.x; e < m; e += 256) {
+    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
+    s += z[((long)n * C + c) * plane + p];
+  }
+  const float mean = block_sum_256(s, sh) / (float)m;
+  float q = 0.f;
+  for (long e = threadIdx.x; e < m; e += 256) {
+    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
+    const float d = z[((long)n * C + c) * plane + p] - mean;
+    q += d * d;
+  }
+  const float var = block_sum_256(q, sh) / (float)m;
+  const float istd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_o[c] = mean;
+    istd_o[c] = istd;
+    const float adjust = (float)((double)m / (m - 1 > 1 ? (double)(m - 1) : 1.0));
+    avg_mean[c] = avg_mean[c] * decay + (1.f - decay) * mean;
+    avg_var[c] = avg_var[c] * decay + ((1.f - decay) * adjust) * var;
+  }
+  const float g = gamma[c], b = beta[c];
+  for (long e = threadIdx.x; e < m; e += 256) {
+    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
+    const long idx = ((long)n * C + c) * plane + p;
+    float v = g * ((z[idx] - mean) * istd) + b;
+    y[idx] = v >= 0.f ? v : slope * v;
+  }
+}
+
+void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* inv_std,
+                         float* avg_mean, float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(C), dim3(256), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean, avg_var,
+                     N, C, plane, eps, decay, slope);
+  DBM_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void bn_eval_fwd_kernel(const float* __restrict__ z, float* __restrict__ y,
+                                                          const float* gamma, const float* beta, const float* avg_mean,
+                                                          const float* avg_var, long total, int C, int plane, float eps,
+                                                          float slope) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int c = (int)((e / plane) % C);
+  const float istd = 1.f / sqrtf(avg_var[c] + eps);
+  float v = gamma[c] * (z[e] - avg_mean[c]) * istd + beta[c];
+  y[e] = v >= 0.f ? v : slope * v;
+}
+
+void launch_bn_eval_fwd(const float* z, float* y, const float* gamma, const float* beta, const float* avg_mean,
+                        const float* avg_var, int N, int C, int plane, float eps, float slope, hipStream_t s) {
+  const long total = (long)N * C * plane;
+  hipLaunchKernelGGL(bn_eval_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, y, gamma, beta,
+                     avg_mean, avg_var, total, C, plane, eps, slope);
+  DBM_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gh,
+                                                           const float* gamma, const float* beta, const float* mean_i,
+                                                           const float* istd_i, float* __restrict__ gz, float* ggamma,
+                                                           float* gbeta, int N, int C, int plane, float slope) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x;
+  const long m = (long)N * plane;
+  const float mean = mean_i[c], istd = istd_i[c], g = gamma[c], b = beta[c];
+  float s1 = 0.f, s2 = 0.f;
+  for (long e = threadIdx.x; e < m; e += 256) {
+    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
+    const long idx = ((long)n * C + c) * plane + p;
+    const float xh = (z[idx] - mean) * istd;
+    const float yv = g * xh + b;
+    const float gt = yv >= 0.f ? gh[idx] : slope * gh[idx];
+    s1 += gt;
+    s2 += gt * xh;
+  }
+  const float sg = block_sum_256(s1, sh);
+  const float sgx = block_sum_256(s2, sh);
+  if (threadIdx.x == 0) {
+    ggamma[c] += sgx;
+    gbeta[c] += sg;
+  }
+  const float k = g * istd, im = 1.f / (float)m;
+  for (long e = threadIdx.x; e < m; e += 256) {
+    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
+    const long idx = ((long)n * C + c) * plane + p;
+    const float xh = (z[idx] - mean) * istd;
+    const float yv = g * xh + b;
+    const float gt = yv >= 0.f ? gh[idx] : slope * gh[idx];
+    gz[idx] = k * (gt - (sg + xh * sgx) * im);
+  }
+}
+
+void launch_bn_train_bwd(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
+                         const float* inv_std, float* gz, float* ggamma, float* gbeta, float* scratch, int N, int C,
+                         int plane, float slope, hipStream_t s) {
+  (void)scratch;
+  hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(C), dim3(256), 0, s, z, gh, gamma, beta, mean, inv_std, gz, ggamma,
+                     gbeta, N, C, plane, slope);
+  DBM_HIP(hipGetLastError());
+}
+
+// ----------------------------------------------------------------------------------------------
+// L.Linear head of the discriminator (srgan_train.py:646-647, 693-696).  51 300 + 101 parameters.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ b, float* __restrict__ y, int N,
+                                                         int K, int O, int act, float slope) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * O) return;
+  const int n = e / O, o = e - n * O;
+  const float* xr = x + (long)n * K;
+  const float* wr = W + (long)o * K;
+  float a0 = 0.f, a1 = 0.f;
+  int k = 0;
+  for (; k + 1 < K; k += 2) {
+    a0 = fmaf(xr[k], wr[k], a0);
+    a1 = fmaf(xr[k + 1], wr[k + 1], a1);
+  }
+  if (k < K) a0 = fmaf(xr[k], wr[k], a0);
+  float v = (a0 + a1) + b[o];
+  if (act) v = v >= 0.f ? v : slope * v;
+  y[e] = v;
+}
+
+void launch_linear_fwd(const float* x, const float* W, const float* b, float* y, int N, int K, int O, int act,
+                       float slope, hipStream_t s) {
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((N * O + 255) / 256), dim3(256), 0, s, x, W, b, y, N, K, O, act, slope);
+  DBM_HIP(hipGetLastError());
+}
+
+__device__ __forceinline__ float gyz_of(const float* gy, const float* y_act, int idx, float slope) {
+  const float g = gy[idx];
+  return (y_act == nullptr || y_act[idx] >= 0.f) ? g : slope * g;
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ gy, const float* __restrict__ y_act,
+                                                         float* gx, float* gW, float* gb, int N, int K, int O,
+                                                         float slope) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int nx = N * K, nw = O * K;
+  if (e < nx) {  // gx[n][k]
+    const int n = e / K, k = e - n * K;
+    float a = 0.f;
+    for (int o = 0; o < O; ++o) a = fmaf(gyz_of(gy, y_act, n * O + o, slope), W[(long)o * K + k], a);
+    gx[e] = a;
+  } else if (e < nx + nw) {  // gW[o][k]
+    const int q = e - nx;
+    const int o = q / K, k = q - o * K;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a = fmaf(gyz_of(gy, y_act, n * O + o, slope), x[(long)n * K + k], a);
+    gW[q] += a;
+  } else if (e < nx + nw + O) {
+    const int o = e - nx - nw;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += gyz_of(gy, y_act, n * O + o, slope);
+    gb[o] += a;
+  }
+}
+
+void launch_linear_bwd(const float* x, const float* W, const float* gy, const float* y_act, float* gx, float* gW,
+                       float* gb, int N, int K, int O, float slope, hipStream_t s) {
+  const int total = N * K + O * K + O;
+  hipLaunchKernelGGL(linear_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x, W, gy, y_act, gx, gW, gb, N, K, O,
+                     slope);
+  DBM_HIP(hipGetLastError());
+}
+
+// ----------------------------------------------------------------------------------------------
+// calculate_discriminator_loss (srgan_train.py:960-1009) + F.binary_accuracy (:1156-1158)
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sce_elem(float x, float t) {
+  return -(x * (t - (x >= 0.f ? 1.f : 0.f)) - log1pf(expf(-fabsf(x))));
+}
+
+__global__ __launch_bounds__(256) void ragan_loss_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                                         int N, float tr, float tf, float* out, float* g_real,
+                                                         float* g_fake) {
+  __shared__ float sh[4];
+  float sr = 0.f, sf = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    sr += real[i];
+    sf += fake[i];
+  }
+  const float mr = block_sum_256(sr, sh) / (float)N;
+  const float mf = block_sum_256(sf, sh) / (float)N;
+  float l = 0.f, acc = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float xr = real[i] - mf, xf = fake[i] - mr;
+    l += sce_elem(xr, tr) + sce_elem(xf, tf);
+    acc += (real[i] >= 0.f ? 1.f : 0.f) + (fake[i] >= 0.f ? 0.f : 1.f);
+    s1 += (1.f / (1.f + expf(-xr)) - tr) / (float)N;
+    s2 += (1.f / (1.f + expf(-xf)) - tf) / (float)N;
+  }
+  const float L = block_sum_256(l, sh) / (float)N;
+  const float A = block_sum_256(acc, sh) / (float)(2 * N);
+  const float S1 = block_sum_256(s1, sh);
+  const float S2 = block_sum_256(s2, sh);
+  if (threadIdx.x == 0) {
+    out[0] = L;
+    out[1] = A;
+  }
+  if (g_real && g_fake) {
+    for (int i = threadIdx.x; i < N; i += 256) {
+      const float xr = real[i] - mf, xf = fake[i] - mr;
+      g_real[i] = (1.f / (1.f + expf(-xr)) - tr) / (float)N - S2 / (float)N;
+      g_fake[i] = (1.f / (1.f + expf(-xf)) - tf) / (float)N - S1 / (float)N;
+    }
+  }
+}
+
+void launch_ragan_loss(const float* real, const float* fake, int N, int real_target, int fake_target, float* out,
+                       float* g_real, float* g_fake, hipStream_t s) {
+  hipLaunchKernelGGL(ragan_loss_kernel, dim3(1), dim3(256), 0, s, real, fake, N, (float)real_target, (float)fake_target,
+                     out, g_real, g_fake);
+  DBM_HIP(hipGetLastError());
+}
+
+// ----------------------------------------------------------------------------------------------
+// Generator loss terms (srgan_train.py:841-902): L1, topographic (4x4 mean vs BEDMAP2 interior), SSIM
+// (9x9 separable window, valid positions) and their gradient w.r.t. y_pred.  One workgroup per tile;
+// everything for a 36x36 tile lives in LDS.
+// ----------------------------------------------------------------------------------------------
+#define SSIM_K 9
+__global__ __launch_bounds__(256) void gen_loss_kernel(const float* __restrict__ y, const float* __restrict__ t,
+                                                       const float* __restrict__ X, int N, int H, int W, float cw,
+                                                       float tw, float sw, const float* __restrict__ win, float* sums,
+                                                       float* __restrict__ gy) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ float sh[4];
+  __shared__ float g1[SSIM_K];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int OH = H - (SSIM_K - 1), OW = W - (SSIM_K - 1);
+  const int HW = H * W, HO = H * OW, OO = OH * OW;
+  float* sY = sm;
+  float* sT = sY + HW;
+  float* hb = sT + HW;   // 5 x [H][OW] horizontal passes, later 3 x [H][OW] transposed-vertical passes
+  float* cb = hb + 5 * HO;  // 3 x [OH][OW] coefficient maps
+  if (tid < SSIM_K) g1[tid] = win[tid];
+  const float* yn = y + (long)n * HW;
+  const float* tn = t + (long)n * HW;
+  float l1 = 0.f, sq = 0.f;
+  for (int e = tid; e < HW; e += 256) {
+    const float a = yn[e], b = tn[e];
+    sY[e] = a;
+    sT[e] = b;
+    l1 += fabsf(a - b);
+    sq += (a - b) * (a - b);
+  }
+  __syncthreads();
+  for (int e = tid; e < HO; e += 256) {
+    const int i = e / OW, j = e - i * OW;
+    float h1 = 0.f, h2 = 0.f, h11 = 0.f, h22 = 0.f, h12 = 0.f;
+#pragma unroll
+    for (int b = 0; b < SSIM_K; ++b) {
+      const float w = g1[b], a = sY[i * W + j + b], c = sT[i * W + j + b];
+      h1 += w * a; h2 += w * c; h11 += w * (a * a); h22 += w * (c * c); h12 += w * (a * c);
+    }
+    hb[e] = h1; hb[HO + e] = h2; hb[2 * HO + e] = h11; hb[3 * HO + e] = h22; hb[4 * HO + e] = h12;
+  }
+  __syncthreads();
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  float ss = 0.f;
+  for (int e = tid; e < OO; e += 256) {
+    const int i = e / OW, j = e - i * OW;
+    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+    for (int a = 0; a < SSIM_K; ++a) {
+      const float w = g1[a];
+      const int q = (i + a) * OW + j;
+      m1 += w * hb[q]; m2 += w * hb[HO + q]; e11 += w * hb[2 * HO + q]; e22 += w * hb[3 * HO + q]; e12 += w * hb[4 * HO + q];
+    }
+    const float s11 = e11 - m1 * m1, s22 = e22 - m2 * m2, s12 = e12 - m1 * m2;
+    const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s11 + s22 + C2;
+    const float sv = (A1 * A2) / (B1 * B2);
+    ss += sv;
+    cb[e] = sv * (2.f * m2 / A1 - 2.f * m2 / A2 - 2.f * m1 / B1 + 2.f * m1 / B2);
+    cb[OO + e] = -sv / B2;
+    cb[2 * OO + e] = 2.f * sv / A2;
+  }
+  // topographic term: 4x4 block means vs X[:, :, 1:-1, 1:-1]
+  const int PH = X ? H / 4 : 0, PW = X ? W / 4 : 0, XW = PW + 2;
+  float tp = 0.f;
+  for (int e = tid; e < PH * PW; e += 256) {
+    const int pi = e / PW, pj = e - pi * PW;
+    float a = 0.f;
+    for (int u = 0; u < 4; ++u)
+      for (int v = 0; v < 4; ++v) a += sY[(4 * pi + u) * W + 4 * pj + v];
+    const float dlt = a * (1.f / 16.f) - X[((long)n * (PH + 2) + pi + 1) * XW + pj + 1];
+    tp += fabsf(dlt);
+  }
+  const float L1 = block_sum_256(l1, sh);
+  const float SQ = block_sum_256(sq, sh);
+  const float SS = block_sum_256(ss, sh);
+  const float TP = block_sum_256(tp, sh);
+  if (tid == 0) {
+    atomicAdd(sums + 0, L1);
+    atomicAdd(sums + 1, TP);
+    atomicAdd(sums + 2, SS);
+    atomicAdd(sums + 3, SQ);
+  }
+  if (gy == nullptr) return;
+  __syncthreads();
+  // transposed vertical pass: vb_k[i][j] = sum_a g[a] * c_k[i-a][j]
+  for (int e = tid; e < HO; e += 256) {
+    const int i = e / OW, j = e - i * OW;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < SSIM_K; ++a) {
+      const int r = i - a;
+      if (r >= 0 && r < OH) {
+        const float w = g1[a];
+        v0 += w * cb[r * OW + j]; v1 += w * cb[OO + r * OW + j]; v2 += w * cb[2 * OO + r * OW + j];
+      }
+    }
+    hb[e] = v0; hb[HO + e] = v1; hb[2 * HO + e] = v2;
+  }
+  __syncthreads();
+  const float k_l1 = cw / ((float)N * HW);
+  const float k_tp = X ? tw / (16.f * (float)N * PH * PW) : 0.f;
+  const float k_ss = sw / ((float)N * OO);
+  for (int e = tid; e < HW; e += 256) {
+    const int i = e / W, j = e - i * W;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int b = 0; b < SSIM_K; ++b) {
+      const int c = j - b;
+      if (c >= 0 && c < OW) {
+        const float w = g1[b];
+        s0 += w * hb[i * OW + c]; s1 += w * hb[HO + i * OW + c]; s2 += w * hb[2 * HO + i * OW + c];
+      }
+    }
+    const float a = sY[e], b = sT[e];
+    const float dss = s0 + 2.f * a * s1 + b * s2;
+    const float d = a - b;
+    float g = k_l1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) - k_ss * dss;
+    const int pi = i >> 2, pj = j >> 2;
+    if (pi < PH && pj < PW) {
+      float pm = 0.f;
+      for (int u = 0; u < 4; ++u)
+        for (int v = 0; v < 4; ++v) pm += sY[(4 * pi + u) * W + 4 * pj + v];
+      const float dlt = pm * (1.f / 16.f) - X[((long)n * (PH + 2) + pi + 1) * XW + pj + 1];
+      g += k_tp * (dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f));
+    }
+    gy[(long)n * HW + e] = g;
+  }
+}
+
+void launch_gen_loss(const float* y, const float* t, const float* X, int N, int H, int W, float cw, float tw, float sw,
+                     const float* win1d, float* sums, float* gy, hipStream_t s) {
+  DBM_CHECK(H >= SSIM_K && W >= SSIM_K, "gen_loss: tile must be at least 9x9");
+  DBM_CHECK(X == nullptr || (H % 4 == 0 && W % 4 == 0), "gen_loss: topographic term needs sides that are multiples of 4");
+  const int OH = H - 8, OW = W - 8;
+  const size_t lds = sizeof(float) * ((size_t)2 * H * W + 5 * (size_t)H * OW + 3 * (size_t)OH * OW);
+  DBM_CHECK(lds <= 150 * 1024, "gen_loss: tile too large for the LDS-resident loss kernel");
+  static bool attr_set = false;
+  if (!attr_set) {
+    DBM_HIP(hipFuncSetAttribute((const void*)gen_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gen_loss_kernel, dim3(N), dim3(256), lds, s, y, t, X, N, H, W, cw, tw, sw, win1d, sums, gy);
+  DBM_HIP(hipGetLastError());
+}
+
+// ----------------------------------------------------------------------------------------------
+// chainer.optimizers.Adam  (srgan_train.py:1043-1048; AdamRule.update_core)
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, float alpha_t,
+                                                   float omb1, float omb2, float eps, float gscale) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const float gr = g[e] * gscale;
+    float mm = m[e], vv = v[e];
+    mm += omb1 * (gr - mm);
+    vv += omb2 * (gr * gr - vv);
+    m[e] = mm;
+    v[e] = vv;
+    p[e] -= alpha_t * mm / (sqrtf(vv) + eps);
+  }
+}
+
+void launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha_t, float one_minus_beta1,
+                 float one_minus_beta2, float eps, float gscale, hipStream_t s) {
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, alpha_t, one_minus_beta1,
+                     one_minus_beta2, eps, gscale);
+  DBM_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n, float v) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) p[e] = v;
+}
+
+void launch_fill(float* p, long n, float v, hipStream_t s) {
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
+  DBM_HIP(hipGetLastError());
+}
+
+// sum of squared differences (psnr, srgan_train.py:906-928)
+__global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                     float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const float d = a[e] - b[e];
+    s += d * d;
+  }
+  const float t = block_sum_256(s, sh);
+  if (threadIdx.x == 0) atomicAdd(out, t);
+}
+
+void launch_sqdiff(const float* a, const float* b, long n, float* out, hipStream_t s) {
+  long blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(sqdiff_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, n, out);
+  DBM_HIP(hipGetLastError());
+}

@@ -1,0 +1,114 @@
+"""Data parallelism over the GPUs of one node: one process per GPU, tile minibatches sharded by rank,
+one sum all-reduce of the flat gradient arena per optimizer step (RCCL over xGMI through
+torch.distributed, backend "nccl"; "gloo" on CPU for the tests).  The reference trains on a single
+GPU (srgan_train.py:58-61, 1039-1040); this is new design.
+
+No collective touches the data path: each rank runs the whole D-step/G-step on its own tiles; only
+gradients are exchanged.  BatchNorm statistics and the RaGAN batch means stay per-rank (standard
+data-parallel semantics; they differ from one process at the global batch).
+"""
+import os
+
+import numpy as np
+
+
+def shard_slice(n_total, rank, world):
+    """Rank-contiguous slice of a global batch (remainder spread over the first ranks)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return slice(lo, lo + base + (1 if rank < rem else 0))
+
+
+def shard_batch(arrays, rank, world):
+    n = len(next(iter(arrays.values())))
+    s = shard_slice(n, rank, world)
+    return {k: v[s] for k, v in arrays.items()}
+
+
+class _ForeignCuda:
+    """Hands a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class DataParallel:
+    """comm object accepted by train_eval_discriminator / train_eval_generator (`comm=`)."""
+
+    def __init__(self, backend=None, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.on_gpu = torch.cuda.is_available() if device is None else (device != "cpu")
+        if backend is None:
+            backend = "nccl" if self.on_gpu else "gloo"
+        if self.on_gpu:
+            torch.cuda.set_device(self.local_rank)
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+        self._views = {}
+        self._shared_stream = set()
+
+    def attach(self, ctx):
+        """Run libdbm on torch's current HIP stream: torch then orders the RCCL collective after the backward
+        kernels and the Adam kernel after the collective by stream events alone (no host synchronisation)."""
+        if self.on_gpu:
+            ctx.set_stream(self.torch.cuda.current_stream().cuda_stream)
+            self._shared_stream.add(id(ctx))
+
+    def grad_view(self, model):
+        """torch view of the model's flat gradient arena (device memory owned by libdbm)."""
+        key = id(model)
+        if key not in self._views:
+            arena = model.grad_arena()
+            if isinstance(arena, self.torch.Tensor):
+                t = arena
+            else:
+                t = self.torch.as_tensor(_ForeignCuda(arena.ptr, arena.size), device=f"cuda:{self.local_rank}")
+                assert t.data_ptr() == arena.ptr, "torch copied the gradient arena instead of aliasing it"
+            self._views[key] = t
+        return self._views[key]
+
+    def allreduce_grads(self, model):
+        """Sum the gradient arena over ranks; returns the scale (1/world) the optimizer applies."""
+        if self.world > 1:
+            t = self.grad_view(model)
+            shared = id(model.ctx) in self._shared_stream
+            if self.on_gpu and not shared:
+                model.ctx.synchronize()  # libdbm's own stream: order the collective after it by a host wait
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            if self.on_gpu and not shared:
+                self.torch.cuda.current_stream().synchronize()
+        return 1.0 / self.world
+
+    def broadcast_params(self, model, src=0):
+        """Make every rank start from rank `src`'s parameters."""
+        if self.world > 1:
+            arena = model.param_arena()
+            t = arena if isinstance(arena, self.torch.Tensor) else self.torch.as_tensor(
+                _ForeignCuda(arena.ptr, arena.size), device=f"cuda:{self.local_rank}")
+            if self.on_gpu:
+                model.ctx.synchronize()
+            self.dist.broadcast(t, src=src)
+            if self.on_gpu:
+                self.torch.cuda.current_stream().synchronize()
+            if hasattr(model, "mark_params_changed"):
+                model.mark_params_changed()
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max_over_ranks(self, value):
+        if self.world == 1:
+            return value
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=f"cuda:{self.local_rank}" if self.on_gpu else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())

@@ -1,0 +1,184 @@
+"""compile_srgan_model / train_eval_discriminator / train_eval_generator / trainer /
+save_model_weights_and_architecture with the reference's signatures (srgan_train.py:1014-1383).
+
+The per-minibatch work is ONE C call per model step (dbm_discriminator_step / dbm_generator_step:
+forward, losses, backward, all enqueued on the HIP stream) followed by the optional RCCL gradient
+all-reduce and the fused Adam kernel.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from .srgan import (Adam, DeviceArray, DiscriminatorModel, GeneratorModel, global_config, save_npz, to_device,
+                    _dev_ptr, _is_device)
+
+LOSS_WEIGHTS = (1e-2, 2e-2, 2e-3, 5.25e-0)  # calculate_generator_loss defaults (srgan_train.py:849-852)
+
+
+def compile_srgan_model(num_residual_blocks: int = 12, residual_scaling: float = 0.1, learning_rate: float = 1.6e-4):
+    """srgan_train.py:1014-1055.  Returns (generator_model, generator_optimizer, discriminator_model,
+    discriminator_optimizer)."""
+    generator_model = GeneratorModel(num_residual_blocks=num_residual_blocks, residual_scaling=residual_scaling)
+    discriminator_model = DiscriminatorModel()
+    generator_optimizer = Adam(alpha=learning_rate, eps=1e-8).setup(link=generator_model)
+    discriminator_optimizer = Adam(alpha=learning_rate, eps=1e-8).setup(link=discriminator_model)
+    return generator_model, generator_optimizer, discriminator_model, discriminator_optimizer
+
+
+_KEYS = ("X", "W1", "W2", "W3", "Y")
+_metrics = {}
+
+
+def _metrics_buffer(ctx):
+    if id(ctx) not in _metrics:
+        _metrics[id(ctx)] = DeviceArray((8,), ctx)
+    return _metrics[id(ctx)]
+
+
+def device_batch(input_arrays, ctx=None):
+    """Upload a dict of NumPy arrays once; device arrays pass through (chainer: arrays already `to_gpu`'d,
+    srgan_train.py:110-116)."""
+    return {k: (v if _is_device(v) else to_device(v, ctx)) for k, v in input_arrays.items()}
+
+
+def _check_batch(arrs):
+    n, c, h, w = arrs["X"].shape
+    exp = {"X": (n, 1, h, w), "W1": (n, 1, 10 * h, 10 * w), "W2": (n, 2, 2 * h, 2 * w), "W3": (n, 1, h, w),
+           "Y": (n, 1, 4 * (h - 2), 4 * (w - 2))}
+    for k in _KEYS:
+        if tuple(arrs[k].shape) != exp[k]:
+            raise ValueError(f"Invalid shape for {k}: expected {exp[k]}, got {tuple(arrs[k].shape)}")
+    return n, h, w
+
+
+def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, train: bool = True, comm=None,
+                             sync: bool = True):
+    """srgan_train.py:1084-1166.  Returns (d_loss, d_accu) as floats (like the reference's float(...) D2H syncs);
+    sync=False returns the device metrics buffer instead and keeps the stream running."""
+    global_config.train = train  # srgan_train.py:1125
+    if train is True:
+        assert d_optimizer is not None  # Optimizer required for neural network training
+    dev = device_batch(input_arrays, g_model.ctx)
+    n, h, w = _check_batch(dev)
+    m = _metrics_buffer(g_model.ctx)
+    _lib.check(_lib.lib().dbm_discriminator_step(g_model._h, d_model._h, n, h, w, *[_dev_ptr(dev[k]) for k in _KEYS],
+                                                 int(bool(train)), m.ptr), g_model.ctx.handle)
+    if train is True:
+        scale = comm.allreduce_grads(d_model) if comm is not None else 1.0
+        d_optimizer.update(grad_scale=scale)
+    if not sync:
+        return m
+    out = m.get()
+    return float(out[0]), float(out[1])
+
+
+def train_eval_generator(input_arrays, g_model, d_model, g_optimizer=None, train: bool = True, comm=None,
+                         sync: bool = True):
+    """srgan_train.py:1170-1263.  Returns (g_loss, g_psnr, g_ssim)."""
+    global_config.train = train  # srgan_train.py:1216
+    if train is True:
+        assert g_optimizer is not None  # Optimizer required for neural network training
+    dev = device_batch(input_arrays, g_model.ctx)
+    n, h, w = _check_batch(dev)
+    m = _metrics_buffer(g_model.ctx)
+    wts = (C.c_float * 4)(*LOSS_WEIGHTS)
+    win = {"gaussian": 0, "uniform": 1}[global_config.ssim_window]
+    _lib.check(_lib.lib().dbm_generator_step(g_model._h, d_model._h, n, h, w, *[_dev_ptr(dev[k]) for k in _KEYS], wts,
+                                             win, int(bool(train)), m.ptr), g_model.ctx.handle)
+    if train is True:
+        scale = comm.allreduce_grads(g_model) if comm is not None else 1.0
+        g_optimizer.update(grad_scale=scale)
+    if not sync:
+        return m
+    out = m.get()
+    return float(out[2]), float(out[3]), float(out[4])
+
+
+# --------------------------------------------------------------------------------------
+# chainer.iterators.SerialIterator / chainer.dataset.concat_examples stand-ins (srgan_train.py:132-166, 1286-1288)
+# --------------------------------------------------------------------------------------
+class SerialIterator:
+    """Batches of indices over a dict-of-arrays dataset with Chainer's SerialIterator semantics
+    (repeat=True: batches are always full; the tail of an epoch is completed from the next, reshuffled, order)."""
+
+    def __init__(self, dataset, batch_size, repeat=True, shuffle=True, seed=None):
+        self.dataset = dataset
+        self.n = len(next(iter(dataset.values())))
+        self.batch_size, self.repeat, self.shuffle = batch_size, repeat, shuffle
+        self._rng = np.random.RandomState(seed)
+        self.reset()
+
+    def reset(self):
+        self.epoch = 0
+        self.is_new_epoch = False
+        self.pos = 0
+        self.order = self._rng.permutation(self.n) if self.shuffle else np.arange(self.n)
+
+    def next(self):
+        if not self.repeat and self.epoch > 0:
+            raise StopIteration
+        i, e = self.pos, self.pos + self.batch_size
+        idx = self.order[i:e]
+        if e >= self.n:
+            if self.repeat:
+                rest = e - self.n
+                self.order = self._rng.permutation(self.n) if self.shuffle else np.arange(self.n)
+                if rest > 0:
+                    idx = np.concatenate([idx, self.order[:rest]])
+                self.pos = rest
+            else:
+                self.pos = 0
+            self.epoch += 1
+            self.is_new_epoch = True
+        else:
+            self.is_new_epoch = False
+            self.pos = e
+        return idx
+
+    __next__ = next
+
+
+def concat_examples(dataset, batch):
+    """Gather the rows `batch` (index array) of every array in the dataset dict."""
+    return {k: np.ascontiguousarray(v[batch]) for k, v in dataset.items()}
+
+
+def trainer(i: int, columns: list, train_iter, dev_iter, g_model, g_optimizer, d_model, d_optimizer, comm=None):
+    """srgan_train.py:1267-1329: one epoch of D-step/G-step minibatches, then the dev-set evaluation."""
+    metrics_dict = {mn: [] for mn in columns}
+    while i == train_iter.epoch:
+        train_arrays = concat_examples(train_iter.dataset, train_iter.next())
+        d_train_loss, d_train_accu = train_eval_discriminator(train_arrays, g_model, d_model, d_optimizer, comm=comm)
+        metrics_dict["discriminator_loss"].append(d_train_loss)
+        metrics_dict["discriminator_accu"].append(d_train_accu)
+        g_train_loss, g_train_psnr, g_train_ssim = train_eval_generator(train_arrays, g_model, d_model, g_optimizer,
+                                                                        comm=comm)
+        metrics_dict["generator_loss"].append(g_train_loss)
+        metrics_dict["generator_psnr"].append(g_train_psnr)
+        metrics_dict["generator_ssim"].append(g_train_ssim)
+    while i == dev_iter.epoch:
+        dev_arrays = concat_examples(dev_iter.dataset, dev_iter.next())
+        d_dev_loss, d_dev_accu = train_eval_discriminator(dev_arrays, g_model, d_model, train=False)
+        metrics_dict["val_discriminator_loss"].append(d_dev_loss)
+        metrics_dict["val_discriminator_accu"].append(d_dev_accu)
+        g_dev_loss, g_dev_psnr, g_dev_ssim = train_eval_generator(dev_arrays, g_model, d_model, train=False)
+        metrics_dict["val_generator_loss"].append(g_dev_loss)
+        metrics_dict["val_generator_psnr"].append(g_dev_psnr)
+        metrics_dict["val_generator_ssim"].append(g_dev_ssim)
+    return metrics_dict
+
+
+def save_model_weights_and_architecture(generator_model, discriminator_model, save_path: str = "model/weights"):
+    """srgan_train.py:1333-1383: two Chainer-layout .npz files (+ a plain layer listing as .dot)."""
+    os.makedirs(name=save_path, exist_ok=True)
+    gpath = os.path.join(save_path, "srgan_generator_model_weights.npz")
+    save_npz(file=gpath, obj=generator_model)
+    dpath = os.path.join(save_path, "srgan_discriminator_model_weights.npz")
+    save_npz(file=dpath, obj=discriminator_model)
+    apath = os.path.join(save_path, "srgan_generator_model_architecture.dot")
+    with open(apath, "w") as f:
+        names = [n for n, _ in generator_model.namedparams() if n.endswith("/W")]
+        f.write("digraph generator {\n" + "".join(f'  "{n}";\n' for n in names) + "}\n")
+    return gpath, dpath, apath

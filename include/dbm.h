@@ -1,0 +1,150 @@
+/* libdbm.so -- C ABI of the MI355X-native (gfx950) ESRGAN hot path of weiji14/deepbedmap.
+ *
+ * The reference has no FFI of its own: the path sits behind Python classes/functions of
+ * srgan_train.py that call Chainer.  Each entry point below names the reference interface
+ * (file:line under the reference checkout) it stands in for; INTEGRATION.md shows the ctypes
+ * binding a reference maintainer would add.  Conventions:
+ *   - every function returns 0 on success, non-zero on error; dbm_last_error() gives the text;
+ *     nothing throws across the boundary;
+ *   - tensors are NCHW float32, C-contiguous; weights OIHW, exactly the arrays stored by
+ *     chainer.serializers.save_npz (key layout: SURVEY.md Appendix B);
+ *   - pointers are HOST pointers unless flags contains DBM_DEVICE_PTRS, in which case they are
+ *     device pointers on the context's GPU and the call only enqueues work on the context's
+ *     stream (no synchronisation);
+ *   - a dbm_ctx is bound to one GPU and one HIP stream and is not thread-safe; data parallelism
+ *     is one process (one ctx) per GPU.
+ */
+#ifndef DBM_H
+#define DBM_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dbm_ctx dbm_ctx;
+typedef struct dbm_model dbm_model;
+
+enum {
+  DBM_DEVICE_PTRS = 1, /* array arguments are device pointers; call is asynchronous on the ctx stream */
+  DBM_KEEP_GRAPH = 2,  /* retain activations for a following backward (Chainer: enable_backprop=True) */
+  DBM_BN_TRAIN = 4     /* discriminator BatchNorm uses batch statistics and updates running stats
+                          (chainer.config.train=True, srgan_train.py:1125) */
+};
+enum { DBM_KIND_PARAM = 0, DBM_KIND_PERSISTENT = 1 };
+
+/* ---- context ---- */
+int dbm_init(int hip_device, dbm_ctx** out);      /* replaces model.to_gpu(): srgan_train.py:1038-1040, deepbedmap.py:659 */
+int dbm_shutdown(dbm_ctx* ctx);
+const char* dbm_last_error(dbm_ctx* ctx);         /* ctx may be NULL (error of a failed dbm_init) */
+int dbm_set_stream(dbm_ctx* ctx, void* hip_stream); /* run on a caller-owned hipStream_t (NULL = the ctx's own) */
+int dbm_synchronize(dbm_ctx* ctx);
+/* measurement aid (bench.py roofline leg): while enabled, every launch of the two MFMA kernel families is bracketed
+ * by hipEvents on the launch stream.  out = [ms, algorithmic FLOP, launches] for igemm_conv_kernel (forward + data
+ * gradient), then the same three for wgrad_kernel. */
+int dbm_profile_begin(dbm_ctx* ctx);
+int dbm_profile_end(dbm_ctx* ctx, double out[8]);
+int dbm_malloc(dbm_ctx* ctx, size_t bytes, void** dptr);
+int dbm_free(dbm_ctx* ctx, void* dptr);
+int dbm_memcpy_h2d(dbm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int dbm_memcpy_d2h(dbm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- models ---- */
+/* GeneratorModel.__init__(num_residual_blocks=12, residual_scaling=0.1, out_channels=1): srgan_train.py:450-523.
+ * Parameters are created zero; the caller uploads them (HeNormal init or load_npz) with dbm_model_set_tensor. */
+int dbm_gen_create(dbm_ctx* ctx, int num_residual_blocks, float residual_scaling, int out_channels, dbm_model** out);
+/* DiscriminatorModel.__init__(): srgan_train.py:611-647 */
+int dbm_disc_create(dbm_ctx* ctx, dbm_model** out);
+int dbm_model_destroy(dbm_model* m);
+/* Link.namedparams()/serialize(): tensors in chainer.serializers.save_npz key order -- srgan_train.py:1355-1361, deepbedmap.py:408 */
+int dbm_model_num_tensors(dbm_model* m, int* n);
+int dbm_model_tensor_info(dbm_model* m, int i, const char** npz_key, int* ndim, int64_t shape[4], int* kind);
+int dbm_model_set_tensor(dbm_model* m, const char* npz_key, const float* host, size_t nfloats);
+int dbm_model_get_tensor(dbm_model* m, const char* npz_key, float* host, size_t nfloats);
+int dbm_model_get_grad(dbm_model* m, const char* npz_key, float* host, size_t nfloats);
+/* Link.count_params(): srgan_train.py:446, 607 */
+int dbm_model_count_params(dbm_model* m, int64_t* n);
+/* Link.cleargrads(): srgan_train.py:1162, 1255 */
+int dbm_model_cleargrads(dbm_model* m);
+/* flat fp32 arenas (device pointers) holding every parameter / gradient contiguously in tensor order:
+ * what a data-parallel host all-reduces (RCCL) between backward and update */
+int dbm_model_param_arena(dbm_model* m, void** dptr, size_t* nfloats);
+int dbm_model_grad_arena(dbm_model* m, void** dptr, size_t* nfloats);
+/* tell the library the parameter arena was written from outside (e.g. an RCCL broadcast) so that its packed
+ * MFMA weight images are rebuilt before the next forward */
+int dbm_model_params_changed(dbm_model* m);
+
+/* ---- forward / backward ---- */
+/* GeneratorModel.forward(x, w1, w2, w3): srgan_train.py:525-576.  x (N,1,H,W), w1 (N,1,10H,10W), w2 (N,2,2H,2W),
+ * w3 (N,1,H,W) -> y (N,1,4(H-2),4(W-2)).  flags: DBM_DEVICE_PTRS, DBM_KEEP_GRAPH. */
+int dbm_gen_forward(dbm_model* g, int N, int H, int W, const float* x, const float* w1, const float* w2,
+                    const float* w3, float* y, int flags);
+/* g_loss.backward() through the generator: srgan_train.py:1256.  gy (N,1,4(H-2),4(W-2)) = d loss / d y of the last
+ * DBM_KEEP_GRAPH forward; accumulates into the gradient arena. */
+int dbm_gen_backward(dbm_model* g, const float* gy, int flags);
+/* DiscriminatorModel.forward(x): srgan_train.py:649-699.  img (N,1,36,36) -> logits (N,1).
+ * slot (0/1) selects which retained graph a DBM_KEEP_GRAPH call fills (the D-step runs real and fake batches). */
+int dbm_disc_forward(dbm_model* d, int N, int H, int W, const float* img, float* logits, int flags, int slot);
+int dbm_disc_backward(dbm_model* d, int slot, const float* glogits, int flags);
+
+/* ---- losses / metrics ---- */
+/* calculate_discriminator_loss: srgan_train.py:960-1009 (+ F.binary_accuracy :1156-1158).
+ * out[0] = loss, out[1] = accuracy; g_real/g_fake (N) may be NULL. */
+int dbm_discriminator_loss(dbm_ctx* ctx, const float* real_logits, const float* fake_logits, int N,
+                           int real_minus_fake_target, int fake_minus_real_target, float* out2, float* g_real,
+                           float* g_fake, int flags);
+/* calculate_generator_loss: srgan_train.py:841-902, psnr :906-928, ssim_loss_func :932-956.
+ * y_pred,y_true (N,1,H,W); x (N,1,H/4+2,W/4+2) is the full BEDMAP2 tile (x_topo = x[:,:,1:-1,1:-1], :1248);
+ * fake_logits (N) from the discriminator in eval mode, real_logits (N) or NULL for the reference's ones(N) (:1233);
+ * the adversarial term is calculate_discriminator_loss(real, fake, real_minus_fake_target, fake_minus_real_target)
+ * (:874-879; the G-step passes targets 0 and 1, :1236-1237).  weights[4] = content, adversarial, topographic,
+ * structural.  out[0] = g_loss, out[1] = psnr, out[2] = ssim; gy (N,1,H,W) may be NULL (the adversarial term is
+ * detached from y_pred, :1228-1229).  ssim_window: 0 gaussian(1.5), 1 uniform. */
+int dbm_generator_loss(dbm_ctx* ctx, const float* y_pred, const float* y_true, const float* x,
+                       const float* real_logits, const float* fake_logits, int N, int H, int W,
+                       const float weights[4], int real_minus_fake_target, int fake_minus_real_target,
+                       int ssim_window, float* out3, float* gy, int flags);
+
+/* psnr(y_pred, y_true, data_range=2**32): srgan_train.py:906-928 over n elements; out[0] = 20*log10(range/sqrt(mse)) */
+int dbm_psnr(dbm_ctx* ctx, const float* y_pred, const float* y_true, size_t n, double data_range, float* out,
+             int flags);
+/* ssim_loss_func(y_pred, y_true, window_size=9, stride=1): srgan_train.py:932-956; (N,1,H,W), H,W >= 9 */
+int dbm_ssim(dbm_ctx* ctx, const float* y_pred, const float* y_true, int N, int H, int W, int ssim_window,
+             float* out, int flags);
+
+/* ---- optimizer ---- */
+/* chainer.optimizers.Adam(alpha, eps=1e-8).setup(model): srgan_train.py:1043-1048 */
+int dbm_adam_setup(dbm_model* m, double alpha, double beta1, double beta2, double eps);
+/* optimizer.update(): srgan_train.py:1164, 1257.  grad_scale multiplies the gradient first (1/world after a
+ * sum all-reduce). */
+int dbm_adam_update(dbm_model* m, double grad_scale);
+
+/* ---- fused steps (device-resident inputs, asynchronous) ---- */
+/* train_eval_discriminator: srgan_train.py:1084-1166 up to and including d_loss.backward() (update = dbm_adam_update).
+ * arrays are DEVICE pointers: X (N,1,11,11), W1 (N,1,110,110), W2 (N,2,22,22), W3 (N,1,11,11), Y (N,1,36,36).
+ * metrics_dev (device, >= 8 floats) receives [d_loss, d_accu].  train=0 evaluates with BatchNorm in eval mode. */
+int dbm_discriminator_step(dbm_model* g, dbm_model* d, int N, int H, int W, const float* X, const float* W1,
+                           const float* W2, const float* W3, const float* Y, int train, float* metrics_dev);
+/* train_eval_generator: srgan_train.py:1170-1263 up to and including g_loss.backward().
+ * metrics_dev receives [., ., g_loss, psnr, ssim]. */
+int dbm_generator_step(dbm_model* g, dbm_model* d, int N, int H, int W, const float* X, const float* W1,
+                       const float* W2, const float* W3, const float* Y, const float weights[4], int ssim_window,
+                       int train, float* metrics_dev);
+
+/* ---- op-level entry points (used by the parity tests; same kernels the models run) ---- */
+/* L.Convolution2D forward on the MFMA implicit-GEMM kernel. x (N,C,H,W) w (O,C,k,k) b (O) or NULL -> y; all DEVICE. */
+int dbm_op_conv2d(dbm_ctx* ctx, const float* x, const float* w, const float* b, float* y, int N, int C, int H, int W,
+                  int O, int k, int stride, int pad, int upsample2, int lrelu);
+/* data gradient (gx, may be NULL) and weight/bias gradient (gw, gb accumulated; may be NULL) of the same layer */
+int dbm_op_conv2d_backward(dbm_ctx* ctx, const float* x, const float* w, const float* gy, float* gx, float* gw,
+                           float* gb, int N, int C, int H, int W, int O, int k, int stride, int pad, int upsample2);
+/* L.DeformableConvolution2D sampler + GEMM (stride 1, pad 1, 3x3): off (N,18,H,W) */
+int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y,
+                         int N, int C, int H, int W, int O);
+int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* gy,
+                                  float* gx, float* goff, float* gw, float* gb, int N, int C, int H, int W, int O);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,271 @@
+"""-m gpu: GeneratorModel / DiscriminatorModel / training steps of the HIP path against the NumPy oracle,
+written like the reference's own doctests (srgan_train.py:437-447, 601-608, 1100-1122, 1190-1212).
+
+Tolerance 1e-4 relative (max-norm), fp32, as BASELINE.json's north_star states.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import model as omodel
+from oracle import train as otrain
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def dbm():
+    import deepbedmap_amd as d
+
+    return d
+
+
+@pytest.fixture(autouse=True)
+def _reset_config(dbm):
+    # train_eval_* mutate the global train flag exactly like the reference (srgan_train.py:1125, 1216)
+    dbm.global_config.train = True
+    dbm.global_config.enable_backprop = True
+    dbm.global_config.ssim_window = "gaussian"
+    yield
+
+
+def copy_params(dst, src_params, persistent=None):
+    for name, p in dst._tensors.items():
+        if name in src_params:
+            p.array = src_params[name]
+        elif persistent is not None and name in persistent:
+            p.array = np.asarray(persistent[name], dtype=np.float32)
+    return dst
+
+
+def scaled_oracle_generator(n_blocks, scale, seed=3, rs=0.1):
+    g = omodel.GeneratorModel(num_residual_blocks=n_blocks, residual_scaling=rs, seed=seed)
+    r = np.random.RandomState(seed + 1)
+    for k in g.params:
+        if k.endswith("/W"):
+            g.params[k] *= np.float32(scale)
+        else:
+            g.params[k] += r.normal(0, 0.1, g.params[k].shape).astype(np.float32)
+    return g
+
+
+def tile_inputs(n, seed, h=11, w=11):
+    r = np.random.RandomState(seed)
+    return (r.rand(n, 1, h, w).astype(np.float32), r.rand(n, 1, 10 * h, 10 * w).astype(np.float32),
+            r.rand(n, 2, 2 * h, 2 * w).astype(np.float32), r.rand(n, 1, h, w).astype(np.float32))
+
+
+def test_generator_doctest(dbm):  # srgan_train.py:437-447
+    generator_model = dbm.GeneratorModel()
+    y_pred = generator_model.forward(
+        x=np.random.rand(1, 1, 11, 11).astype("float32"),
+        w1=np.random.rand(1, 1, 110, 110).astype("float32"),
+        w2=np.random.rand(1, 2, 22, 22).astype("float32"),
+        w3=np.random.rand(1, 1, 11, 11).astype("float32"),
+    )
+    assert y_pred.shape == (1, 1, 36, 36)
+    assert generator_model.count_params() == 8907749
+    assert np.isfinite(y_pred.array).all()
+
+
+def test_discriminator_doctest(dbm):  # srgan_train.py:601-608
+    discriminator_model = dbm.DiscriminatorModel()
+    y_pred = discriminator_model.forward(x=np.random.rand(2, 1, 36, 36).astype("float32"))
+    assert y_pred.shape == (2, 1)
+    assert discriminator_model.count_params() == 10370761
+
+
+@pytest.mark.parametrize("n_blocks,scale,n", [(12, 1.0, 1), (2, 10.0, 3), (16, 1.0, 2)])
+def test_generator_forward_parity(dbm, n_blocks, scale, n):
+    """Config 1 of BASELINE.json: generator forward vs the CPU restatement, same weights, same tiles."""
+    og = scaled_oracle_generator(n_blocks, scale)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=n_blocks, initialize=False), og.params)
+    ins = tile_inputs(n, 11)
+    ref = og.forward(*ins)
+    with dbm.using_config("enable_backprop", False):
+        y = g.forward(*ins).array
+    assert y.shape == ref.shape
+    assert rel(y, ref) < TOL
+    # device-resident inputs give the same answer
+    dins = [dbm.to_device(a) for a in ins]
+    with dbm.using_config("enable_backprop", False):
+        yd = g.forward(*dins).array.get()
+    assert rel(yd, ref) < TOL
+
+
+def test_generator_is_fully_convolutional(dbm):  # features/steps/test_deepbedmap.py:35-39, deepbedmap.py:700-741
+    og = scaled_oracle_generator(1, 5.0)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=1, initialize=False), og.params)
+    ins = tile_inputs(1, 5, h=14, w=19)
+    ref = og.forward(*ins)
+    with dbm.using_config("enable_backprop", False):
+        y = g.forward(*ins).array
+    assert y.shape[2] / (14 - 2) == 4 and y.shape[3] / (19 - 2) == 4
+    assert rel(y, ref) < TOL
+
+
+def test_generator_rejects_bad_shapes(dbm):
+    g = dbm.GeneratorModel(num_residual_blocks=1)
+    x, w1, w2, w3 = tile_inputs(1, 0)
+    with pytest.raises(ValueError):
+        g.forward(x, w1[:, :, :100], w2, w3)
+
+
+@pytest.mark.parametrize("scale", [1.0, 10.0])
+def test_generator_backward_parity(dbm, scale):
+    og = scaled_oracle_generator(2, scale, rs=0.3)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=2, residual_scaling=0.3, initialize=False), og.params)
+    ins = tile_inputs(3, 21)
+    ref = og.forward(*ins, keep=True)
+    y = g.forward(*ins)
+    assert rel(y.array, ref) < TOL
+    gy = np.random.RandomState(2).normal(size=ref.shape).astype(np.float32)
+    G = og.backward(gy)
+    g.cleargrads()
+    g.backward(gy)
+    worst = max(((rel(g._tensors[k].grad, G[k]), k) for k in G), key=lambda t: t[0])
+    assert worst[0] < 5e-4, worst  # gradients: sums over 3*81..3*1296 positions in a different order than BLAS
+
+
+def scaled_oracle_discriminator(seed=5):
+    d = omodel.DiscriminatorModel(seed=seed)
+    r = np.random.RandomState(seed + 1)
+    for k in d.params:
+        if k.endswith("/W"):
+            d.params[k] *= np.float32(10.0)
+        elif k.endswith("gamma"):
+            d.params[k] += r.normal(0, 0.2, d.params[k].shape).astype(np.float32)
+        else:
+            d.params[k] += r.normal(0, 0.1, d.params[k].shape).astype(np.float32)
+    return d
+
+
+def test_discriminator_forward_backward_parity(dbm):
+    od = scaled_oracle_discriminator()
+    d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+    r = np.random.RandomState(8)
+    real, fake = r.rand(4, 1, 36, 36).astype(np.float32), r.rand(4, 1, 36, 36).astype(np.float32)
+    dbm.global_config.train = True
+    lr_ref, c_real = od.forward(real, train=True, keep=True)
+    lf_ref, c_fake = od.forward(fake, train=True, keep=True)
+    lr = d.forward(real)
+    lf = d.forward(fake)
+    assert rel(lr.array, lr_ref) < TOL and rel(lf.array, lf_ref) < TOL
+    for name in od.persistent:  # running statistics after two training-mode calls (srgan_train.py:1145-1146)
+        if not name.endswith("/N"):
+            assert rel(d._tensors[name].array, od.persistent[name]) < 1e-5, name
+    t1, t0 = np.ones((4, 1), np.int32), np.zeros((4, 1), np.int32)
+    loss_ref = otrain.calculate_discriminator_loss(lr_ref, lf_ref, t1, t0)
+    loss = dbm.calculate_discriminator_loss(lr, lf, t1, t0)
+    assert abs(float(loss) - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    g_real, g_fake = otrain.calculate_discriminator_loss_backward(lr_ref, lf_ref, t1, t0)
+    G = {}
+    od.backward(g_real, c_real, G)
+    od.backward(g_fake, c_fake, G)
+    d.cleargrads()
+    loss.backward()
+    worst = max(((rel(d._tensors[k].grad, G[k]), k) for k in G), key=lambda t: t[0])
+    assert worst[0] < 1e-3, worst
+    # eval-mode BatchNorm (srgan_train.py:1228)
+    with dbm.using_config("train", False):
+        le = d.forward(fake).array
+    assert rel(le, od.forward(fake, train=False)) < TOL
+
+
+def fixture_arrays(n=2):  # srgan_train.py:1100-1106
+    return {
+        "X": np.random.RandomState(seed=42).rand(n, 1, 11, 11).astype(np.float32),
+        "W1": np.random.RandomState(seed=42).rand(n, 1, 110, 110).astype(np.float32),
+        "W2": np.random.RandomState(seed=42).rand(n, 2, 22, 22).astype(np.float32),
+        "W3": np.random.RandomState(seed=42).rand(n, 1, 11, 11).astype(np.float32),
+        "Y": np.random.RandomState(seed=42).rand(n, 1, 36, 36).astype(np.float32),
+    }
+
+
+def test_train_eval_discriminator_doctest(dbm):  # srgan_train.py:1100-1122
+    train_arrays = fixture_arrays()
+    discriminator_model = dbm.DiscriminatorModel()
+    discriminator_optimizer = dbm.optimizers.Adam(alpha=0.001, eps=1e-7).setup(link=discriminator_model)
+    generator_model = dbm.GeneratorModel()
+    d_weight0 = [d for d in discriminator_model.params()][-3][0].array
+    d_train_loss, d_train_accu = dbm.train_eval_discriminator(
+        input_arrays=train_arrays, g_model=generator_model, d_model=discriminator_model,
+        d_optimizer=discriminator_optimizer)
+    d_weight1 = [d for d in discriminator_model.params()][-3][0].array
+    assert d_weight0 != d_weight1  # check that training has occurred (i.e. weights changed)
+    assert np.isfinite(d_train_loss) and 0.0 <= d_train_accu <= 1.0
+    with pytest.raises(AssertionError):  # srgan_train.py:1126-1127
+        dbm.train_eval_discriminator(train_arrays, generator_model, discriminator_model, None, train=True)
+
+
+def test_train_eval_generator_doctest(dbm):  # srgan_train.py:1190-1212
+    train_arrays = fixture_arrays()
+    generator_model = dbm.GeneratorModel()
+    generator_optimizer = dbm.optimizers.Adam(alpha=0.001, eps=1e-7).setup(link=generator_model)
+    discriminator_model = dbm.DiscriminatorModel()
+    g_weight0 = [g for g in generator_model.params()][8][0, 0, 0, 0].array
+    out = dbm.train_eval_generator(input_arrays=train_arrays, g_model=generator_model, d_model=discriminator_model,
+                                   g_optimizer=generator_optimizer)
+    g_weight1 = [g for g in generator_model.params()][8][0, 0, 0, 0].array
+    assert g_weight0 != g_weight1  # check that training has occurred (i.e. weights changed)
+    assert all(np.isfinite(v) for v in out)
+    with pytest.raises(AssertionError):  # srgan_train.py:1217-1218
+        dbm.train_eval_generator(train_arrays, generator_model, discriminator_model, None, train=True)
+
+
+def test_two_training_iterations_match_oracle(dbm):
+    """D-step + G-step, twice, against the oracle: metrics and the updated parameters (Adam, BatchNorm running
+    statistics, cleargrads, detach points of srgan_train.py:1131-1137 and 1228-1229)."""
+    arrays = fixture_arrays(n=4)
+    og = scaled_oracle_generator(2, 3.0)
+    od = scaled_oracle_discriminator()
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=2, initialize=False), og.params)
+    d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+    g_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(g)
+    d_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(d)
+    og_opt = otrain.Adam(og.params, alpha=1e-3, eps=1e-7)
+    od_opt = otrain.Adam(od.params, alpha=1e-3, eps=1e-7)
+    for it in range(2):
+        ref_d = otrain.train_eval_discriminator(arrays, og, od, od_opt)
+        got_d = dbm.train_eval_discriminator(arrays, g, d, d_opt)
+        ref_g = otrain.train_eval_generator(arrays, og, od, og_opt)
+        got_g = dbm.train_eval_generator(arrays, g, d, g_opt)
+        assert np.allclose(got_d, ref_d, rtol=2e-4, atol=1e-5), (it, got_d, ref_d)
+        assert np.allclose(got_g, ref_g, rtol=2e-4, atol=1e-5), (it, got_g, ref_g)
+    # Adam's first steps move every weight by ~alpha regardless of gradient scale, so compare the parameters
+    # with an absolute tolerance tied to alpha (sign flips of near-zero gradients are the worst case)
+    for k, v in od.params.items():
+        assert np.abs(d._tensors[k].array - v).max() < 2.5e-3, k
+    for k, v in og.params.items():
+        assert np.abs(g._tensors[k].array - v).max() < 2.5e-3, k
+    frac = np.mean([np.mean(np.abs(g._tensors[k].array - v) < 1e-5) for k, v in og.params.items()])
+    assert frac > 0.98, frac
+    # evaluation mode (dev loop, srgan_train.py:1311-1327)
+    ref_e = otrain.train_eval_generator(arrays, og, od, train=False)
+    got_e = dbm.train_eval_generator(arrays, g, d, train=False)
+    assert np.allclose(got_e, ref_e, rtol=2e-4, atol=1e-5)
+
+
+def test_npz_round_trip(dbm, tmp_path):  # srgan_train.py:1351-1361, deepbedmap.py:402-408
+    g = dbm.GeneratorModel(num_residual_blocks=1)
+    d = dbm.DiscriminatorModel()
+    gpath, dpath, apath = dbm.save_model_weights_and_architecture(g, d, save_path=str(tmp_path))
+    assert os.path.basename(gpath) == "srgan_generator_model_weights.npz" and os.path.exists(apath)
+    with np.load(gpath) as f:
+        assert set(f.files) == set(omodel.generator_param_shapes(1))
+        assert f["residual_network/0/residual_dense_block3/conv_layer5/W"].shape == (64, 192, 3, 3)
+    with np.load(dpath) as f:
+        assert set(f.files) == set(omodel.discriminator_param_shapes()) | set(omodel.discriminator_persistent_shapes())
+        assert f["batch_norm3/N"].shape == () and f["batch_norm3/avg_var"].shape == (128,)
+    g2 = dbm.GeneratorModel(num_residual_blocks=1)
+    dbm.serializers.load_npz(gpath, g2)
+    ins = tile_inputs(1, 1)
+    with dbm.using_config("enable_backprop", False):
+        assert np.array_equal(g.forward(*ins).array, g2.forward(*ins).array)

@@ -1,0 +1,181 @@
+"""-m gpu: every HIP kernel family against the NumPy oracle through the C ABI (op-level entry points).
+
+Tolerance: fp32, `max|a-b| / max|b| <= 1e-4` (BASELINE.json north_star); the MFMA kernels accumulate
+in fp32 in a different order than BLAS, so results are compared with that tolerance, not bitwise.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import ops
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def dbm():
+    import deepbedmap_amd as d
+    from deepbedmap_amd import _lib
+
+    ctx = _lib.default_context()
+    return d, _lib, ctx
+
+
+def dev(d, a):
+    return d.to_device(np.ascontiguousarray(a, dtype=np.float32))
+
+
+CONV_CASES = [
+    # N, C, H, W, O, k, stride, pad, ups, lrelu
+    (3, 64, 9, 9, 32, 3, 1, 1, 0, 1),      # RDB conv_layer1
+    (2, 192, 9, 9, 64, 3, 1, 1, 0, 0),     # RDB conv_layer5
+    (5, 128, 9, 9, 64, 3, 1, 1, 0, 1),     # pre_residual (ragged tile: 5*81 = 405 positions)
+    (2, 64, 9, 9, 64, 3, 1, 1, 1, 1),      # post_upsample_1 (nearest x2 folded in)
+    (1, 64, 18, 18, 64, 3, 1, 1, 1, 1),    # post_upsample_2
+    (2, 64, 36, 36, 18, 3, 1, 1, 0, 0),    # offset conv (18 channels padded to 32)
+    (3, 64, 36, 36, 64, 4, 2, 1, 0, 0),    # D conv_layer1 k4 s2
+    (3, 128, 9, 9, 256, 4, 2, 1, 0, 0),    # D conv_layer5 9 -> 4 (odd input)
+    (4, 512, 2, 2, 512, 4, 2, 1, 0, 0),    # D conv_layer9 2 -> 1
+    (2, 256, 4, 4, 256, 3, 1, 1, 0, 0),    # D conv_layer6
+    (1, 64, 13, 17, 32, 3, 1, 1, 0, 1),    # non-square fully convolutional use (deepbedmap.py:726)
+    (2, 576, 6, 6, 64, 1, 1, 0, 0, 1),     # the deformable conv's GEMM (1x1 over 576 columns)
+    (2, 1, 11, 11, 32, 3, 1, 0, 0, 0),     # input block conv_on_X (few-channel kernel)
+    (2, 1, 110, 110, 32, 30, 10, 0, 0, 0),  # input block conv_on_W1
+    (2, 2, 22, 22, 32, 6, 2, 0, 0, 0),     # input block conv_on_W2
+    (2, 1, 36, 36, 64, 3, 1, 1, 0, 1),     # D conv_layer0
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_forward(dbm, case):
+    d, _lib, ctx = dbm
+    N, Cc, H, W, O, k, s, p, ups, act = case
+    rs = np.random.RandomState(hash(case) % 2**31)
+    x = rs.normal(size=(N, Cc, H, W)).astype(np.float32)
+    w = (rs.normal(size=(O, Cc, k, k)) / np.sqrt(Cc * k * k)).astype(np.float32)
+    b = rs.normal(size=(O,)).astype(np.float32)
+    xin = ops.upsample_nearest2(x) if ups else x
+    ref = ops.conv2d(xin, w, b, s, p)
+    if act:
+        ref = ops.leaky_relu(ref)
+    y = d.DeviceArray(ref.shape)
+    _lib.check(_lib.lib().dbm_op_conv2d(ctx.handle, dev(d, x).ptr, dev(d, w).ptr, dev(d, b).ptr, y.ptr, N, Cc, H, W, O,
+                                        k, s, p, ups, act), ctx.handle)
+    assert rel(y.get(), ref) < TOL
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_backward(dbm, case):
+    d, _lib, ctx = dbm
+    N, Cc, H, W, O, k, s, p, ups, _ = case
+    rs = np.random.RandomState(hash(case) % 2**31 + 1)
+    x = rs.normal(size=(N, Cc, H, W)).astype(np.float32)
+    w = (rs.normal(size=(O, Cc, k, k)) / np.sqrt(Cc * k * k)).astype(np.float32)
+    xin = ops.upsample_nearest2(x) if ups else x
+    OH = (xin.shape[2] + 2 * p - k) // s + 1
+    OW = (xin.shape[3] + 2 * p - k) // s + 1
+    # the data gradient needs O % 32 == 0 (the models pad the 18 offset channels to 32)
+    O_pad = O if O % 32 == 0 else 32
+    gy = np.zeros((N, O_pad, OH, OW), np.float32)
+    gy[:, :O] = rs.normal(size=(N, O, OH, OW))
+    w_pad = np.zeros((O_pad, Cc, k, k), np.float32)
+    w_pad[:O] = w
+    gx_ref, gw_ref, gb_ref = ops.conv2d_backward(xin, w_pad, gy, s, p)
+    want_gx = Cc % 32 == 0
+    gx = d.DeviceArray(xin.shape) if want_gx else None
+    gw = dev(d, np.zeros_like(w_pad))
+    gb = dev(d, np.zeros(O_pad, np.float32))
+    _lib.check(_lib.lib().dbm_op_conv2d_backward(ctx.handle, dev(d, x).ptr, dev(d, w_pad).ptr, dev(d, gy).ptr,
+                                                 gx.ptr if want_gx else None, gw.ptr, gb.ptr, N, Cc, H, W, O_pad, k, s,
+                                                 p, ups), ctx.handle)
+    ctx.synchronize()
+    assert rel(gw.get(), gw_ref) < TOL
+    assert rel(gb.get(), gb_ref) < TOL
+    if want_gx:
+        assert rel(gx.get(), gx_ref) < TOL
+
+
+@pytest.mark.parametrize("O,scale", [(64, 0.3), (1, 0.3), (64, 3.0), (1, 3.0)])
+def test_deform_conv_forward_backward(dbm, O, scale):
+    """final_conv_layer1 (64->64) and final_conv_layer2 (64->1); scale 3.0 drives samples out of the image
+    so that the border clipping and the coordinate-gradient masks are exercised."""
+    d, _lib, ctx = dbm
+    N, Cc, H, W = 2, 64, 12, 10
+    rs = np.random.RandomState(int(scale * 10) + O)
+    x = rs.normal(size=(N, Cc, H, W)).astype(np.float32)
+    off = rs.normal(scale=scale, size=(N, 18, H, W)).astype(np.float32)
+    w = (rs.normal(size=(O, Cc, 3, 3)) / np.sqrt(Cc * 9)).astype(np.float32)
+    b = rs.normal(size=(O,)).astype(np.float32)
+    ref = ops.deform_conv2d(x, off, w, b)
+    y = d.DeviceArray(ref.shape)
+    l = _lib.lib()
+    _lib.check(l.dbm_op_deform_conv2d(ctx.handle, dev(d, x).ptr, dev(d, off).ptr, dev(d, w).ptr, dev(d, b).ptr, y.ptr,
+                                      N, Cc, H, W, O), ctx.handle)
+    assert rel(y.get(), ref) < TOL
+    gy = rs.normal(size=ref.shape).astype(np.float32)
+    gx_ref, goff_ref, gw_ref, gb_ref = ops.deform_conv2d_backward(x, off, w, gy)
+    gx, goff = d.DeviceArray(x.shape), d.DeviceArray(off.shape)
+    gw, gb = dev(d, np.zeros_like(w)), dev(d, np.zeros_like(b))
+    _lib.check(l.dbm_op_deform_conv2d_backward(ctx.handle, dev(d, x).ptr, dev(d, off).ptr, dev(d, w).ptr,
+                                               dev(d, gy).ptr, gx.ptr, goff.ptr, gw.ptr, gb.ptr, N, Cc, H, W, O),
+               ctx.handle)
+    ctx.synchronize()
+    assert rel(gx.get(), gx_ref) < TOL
+    assert rel(goff.get(), goff_ref) < 5e-4  # bilinear-gradient sums of +/- terms: a little looser
+    assert rel(gw.get(), gw_ref) < TOL
+    assert rel(gb.get(), gb_ref) < TOL
+
+
+def test_loss_known_answers(dbm):
+    """The reference's doctest values through the HIP loss kernels (fp32)."""
+    d, _, _ = dbm
+    v = d.calculate_discriminator_loss(
+        real_labels_pred=d.Variable(np.array([[1.1], [-0.5]])), fake_labels_pred=d.Variable(np.array([[-0.3], [1.0]])),
+        real_minus_fake_target=np.array([[1], [1]]), fake_minus_real_target=np.array([[0], [0]]))
+    assert abs(float(v) - 1.56670504) < 2e-6  # srgan_train.py:985-991
+    g = d.calculate_generator_loss(
+        y_pred=d.Variable(np.ones(shape=(2, 1, 12, 12))), y_true=np.full(shape=(2, 1, 12, 12), fill_value=10.0),
+        fake_labels=np.array([[-1.2], [0.5]]), real_labels=np.array([[0.5], [-0.8]]),
+        fake_minus_real_target=np.array([[1], [1]]).astype(np.int32),
+        real_minus_fake_target=np.array([[0], [0]]).astype(np.int32), x_topo=np.full(shape=(2, 1, 3, 3), fill_value=9.0))
+    assert abs(float(g) - 4.35108415) < 1e-5  # srgan_train.py:859-868
+    assert abs(d.psnr(np.ones((2, 1, 3, 3)), np.full((2, 1, 3, 3), 2)) - 192.65919722494797) < 1e-3  # :916-920
+    s = d.ssim_loss_func(d.Variable(np.ones((2, 1, 9, 9))), np.full((2, 1, 9, 9), 2.0))
+    assert abs(float(s) - 0.800004) < 1e-6  # :944-948
+    with pytest.raises(ValueError):  # :950-951
+        d.ssim_loss_func(d.Variable(np.ones((2, 1, 9, 9))), np.ones((2, 1, 10, 10)))
+
+
+@pytest.mark.parametrize("window", ["gaussian", "uniform"])
+def test_generator_loss_and_gradient(dbm, window):
+    d, _lib, ctx = dbm
+    from oracle import train as otrain
+
+    rs = np.random.RandomState(3)
+    n = 5
+    y = rs.rand(n, 1, 36, 36).astype(np.float32)
+    t = rs.rand(n, 1, 36, 36).astype(np.float32)
+    X = rs.rand(n, 1, 11, 11).astype(np.float32)
+    fl = rs.normal(size=(n, 1)).astype(np.float32)
+    ref = otrain.calculate_generator_loss(y, t, fl, np.ones((n, 1), np.float32), np.ones((n, 1), np.int32),
+                                          np.zeros((n, 1), np.int32), X[:, :, 1:-1, 1:-1], ssim_window=window)
+    gref = otrain.calculate_generator_loss_backward(y, t, X[:, :, 1:-1, 1:-1], ssim_window=window)
+    out = np.empty(3, np.float32)
+    gy = np.empty_like(y)
+    wts = (C.c_float * 4)(1e-2, 2e-2, 2e-3, 5.25)
+    _lib.check(_lib.lib().dbm_generator_loss(ctx.handle, y.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p),
+                                             X.ctypes.data_as(C.c_void_p), None, fl.ctypes.data_as(C.c_void_p), n, 36,
+                                             36, wts, 0, 1, {"gaussian": 0, "uniform": 1}[window],
+                                             out.ctypes.data_as(C.c_void_p), gy.ctypes.data_as(C.c_void_p), 0),
+               ctx.handle)
+    assert abs(out[0] - ref) / abs(ref) < 1e-5
+    assert abs(out[1] - ops.psnr(y, t)) < 1e-3
+    assert abs(out[2] - ops.ssim(y, t, kind=window)) < 1e-5
+    assert rel(gy, gref) < TOL
