@@ -34,7 +34,7 @@ def synthetic_batch(n, seed):
             "Y": r(n, 1, 36, 36)}
 
 
-def cpu_baseline(sample_tiles=2):
+def cpu_baseline(sample_tiles=8):
     """The oracle (NumPy restatement of the Chainer CPU path: im2col + BLAS sgemm) on this box's host cores, on a
     bounded sample of the same workload: one full D-step + G-step at batch `sample_tiles`, 12 RRDB."""
     from oracle import model as omodel

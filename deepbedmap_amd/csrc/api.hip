@@ -92,6 +92,7 @@ int dbm_init(int hip_device, dbm_ctx** out) {
   for (int i = 0; i < 9; ++i) w[i] = (float)(1.0 / 9.0);
   DBM_HIP(hipMalloc((void**)&c->ssim_win[1], sizeof(w)));
   DBM_HIP(hipMemcpy(c->ssim_win[1], w, sizeof(w), hipMemcpyHostToDevice));
+  DBM_HIP(hipDeviceSynchronize());
   *out = c;
   DBM_API_END
 }

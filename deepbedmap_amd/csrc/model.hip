@@ -9,6 +9,8 @@ void DevBuf::ensure(size_t count, bool zero) {
     n = count;
     zero = true;  // fresh allocations are always zeroed (padding channels rely on it)
     DBM_HIP(hipMemset(p, 0, count * sizeof(float)));
+    // the memset runs on the NULL stream, which the context's non-blocking stream does not wait for
+    DBM_HIP(hipDeviceSynchronize());
     return;
   }
   (void)zero;
@@ -61,6 +63,7 @@ void dbm_model::alloc_arenas() {
   DBM_HIP(hipMemset(adam_m, 0, np * sizeof(float)));
   DBM_HIP(hipMemset(adam_v, 0, np * sizeof(float)));
   DBM_HIP(hipMemset(pers, 0, ns * sizeof(float)));
+  DBM_HIP(hipDeviceSynchronize());  // NULL-stream memsets vs. the context's non-blocking stream
 }
 
 int dbm_model::tid(const std::string& key) const {

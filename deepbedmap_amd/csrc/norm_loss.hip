@@ -264,13 +264,23 @@ __global__ __launch_bounds__(256) void gen_loss_kernel(const float* __restrict__
   if (tid < SSIM_K) g1[tid] = win[tid];
   const float* yn = y + (long)n * HW;
   const float* tn = t + (long)n * HW;
-  float l1 = 0.f, sq = 0.f;
+  float l1 = 0.f, sq = 0.f, tsum = 0.f, ysum = 0.f;
   for (int e = tid; e < HW; e += 256) {
     const float a = yn[e], b = tn[e];
     sY[e] = a;
     sT[e] = b;
     l1 += fabsf(a - b);
     sq += (a - b) * (a - b);
+    tsum += b;
+    ysum += a;
+  }
+  // Variances / covariances are shift invariant: work on (y - cy, t - ct) with the tile means so that
+  // E[x^2] - mu^2 does not cancel catastrophically in fp32 on un-normalised elevations (metres).
+  const float shift_t = block_sum_256(tsum, sh) / (float)HW;
+  const float shift = block_sum_256(ysum, sh) / (float)HW;  // shift of y (also used by the pooled means below)
+  for (int e = tid; e < HW; e += 256) {
+    sY[e] -= shift;
+    sT[e] -= shift_t;
   }
   __syncthreads();
   for (int e = tid; e < HO; e += 256) {
@@ -295,11 +305,12 @@ __global__ __launch_bounds__(256) void gen_loss_kernel(const float* __restrict__
       const int q = (i + a) * OW + j;
       m1 += w * hb[q]; m2 += w * hb[HO + q]; e11 += w * hb[2 * HO + q]; e22 += w * hb[3 * HO + q]; e12 += w * hb[4 * HO + q];
     }
-    const float s11 = e11 - m1 * m1, s22 = e22 - m2 * m2, s12 = e12 - m1 * m2;
-    const float A1 = 2.f * m1 * m2 + C1, A2 = 2.f * s12 + C2, B1 = m1 * m1 + m2 * m2 + C1, B2 = s11 + s22 + C2;
+    const float s11 = e11 - m1 * m1, s22 = e22 - m2 * m2, s12 = e12 - m1 * m2;  // m1, m2: means of the shifted data
+    const float u1 = m1 + shift, u2 = m2 + shift_t;                              // true window means
+    const float A1 = 2.f * u1 * u2 + C1, A2 = 2.f * s12 + C2, B1 = u1 * u1 + u2 * u2 + C1, B2 = s11 + s22 + C2;
     const float sv = (A1 * A2) / (B1 * B2);
     ss += sv;
-    cb[e] = sv * (2.f * m2 / A1 - 2.f * m2 / A2 - 2.f * m1 / B1 + 2.f * m1 / B2);
+    cb[e] = sv * (2.f * u2 / A1 - 2.f * m2 / A2 - 2.f * u1 / B1 + 2.f * m1 / B2);
     cb[OO + e] = -sv / B2;
     cb[2 * OO + e] = 2.f * sv / A2;
   }
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(256) void gen_loss_kernel(const float* __restrict__
     float a = 0.f;
     for (int u = 0; u < 4; ++u)
       for (int v = 0; v < 4; ++v) a += sY[(4 * pi + u) * W + 4 * pj + v];
-    const float dlt = a * (1.f / 16.f) - X[((long)n * (PH + 2) + pi + 1) * XW + pj + 1];
+    const float dlt = (a * (1.f / 16.f) + shift) - X[((long)n * (PH + 2) + pi + 1) * XW + pj + 1];
     tp += fabsf(dlt);
   }
   const float L1 = block_sum_256(l1, sh);
@@ -357,14 +368,14 @@ __global__ __launch_bounds__(256) void gen_loss_kernel(const float* __restrict__
     }
     const float a = sY[e], b = sT[e];
     const float dss = s0 + 2.f * a * s1 + b * s2;
-    const float d = a - b;
+    const float d = yn[e] - tn[e];  // the un-shifted difference decides the sign of the L1 gradient
     float g = k_l1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) - k_ss * dss;
     const int pi = i >> 2, pj = j >> 2;
     if (pi < PH && pj < PW) {
       float pm = 0.f;
       for (int u = 0; u < 4; ++u)
         for (int v = 0; v < 4; ++v) pm += sY[(4 * pi + u) * W + 4 * pj + v];
-      const float dlt = pm * (1.f / 16.f) - X[((long)n * (PH + 2) + pi + 1) * XW + pj + 1];
+      const float dlt = (pm * (1.f / 16.f) + shift) - X[((long)n * (PH + 2) + pi + 1) * XW + pj + 1];
       g += k_tp * (dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f));
     }
     gy[(long)n * HW + e] = g;
@@ -380,7 +391,7 @@ void launch_gen_loss(const float* y, const float* t, const float* X, int N, int 
   DBM_CHECK(lds <= 150 * 1024, "gen_loss: tile too large for the LDS-resident loss kernel");
   static bool attr_set = false;
   if (!attr_set) {
-    DBM_HIP(hipFuncSetAttribute((const void*)gen_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)gen_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL(gen_loss_kernel, dim3(N), dim3(256), lds, s, y, t, X, N, H, W, cw, tw, sw, win1d, sums, gy);
