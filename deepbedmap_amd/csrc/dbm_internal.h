@@ -108,4 +108,38 @@ struct WgradDesc {
   float* gW;        // canonical OIHW, accumulated with atomicAdd
   float* gb;        // may be null; accumulated with atomicAdd
 };
-void launch_wgrad(const WgradDesc& d, hipStream_t s);
+void launch_wgrad(const WgradDesc& d, hipStream_t s);  // single layer, synchronous (tests / op-level API)
+
+struct WgradPlan {
+  WgradDesc d;
+  int groups, coutTiles, S;  // workgroups = groups (input-channel groups) x coutTiles x S (K splits)
+  int wg_count;
+  int G;        // 32-channel input tiles per workgroup (= active wavefronts)
+  int IB, R;    // band = IB images x R output rows
+  int nbr;      // row-bands per image
+  int BP, BPp;  // positions per band, padded to even
+  int YS;       // LDS row stride of the dy slab (odd)
+  int Rin, Wst; // staged logical input patch rows / cols per image
+  int ImgS;     // Rin*Wst
+  int XS;       // LDS channel stride of the patch (odd)
+  int nbands;
+  int dbg;
+};
+size_t wgrad_plan(const WgradDesc& d, WgradPlan& p);  // fills p, returns the dynamic LDS bytes it needs
+
+// All weight gradients of one backward pass: collected as descriptors, planned and uploaded once per
+// workspace shape, then launched as one kernel per kernel size (1x1, 3x3, 4x4).
+struct WgradBatch {
+  std::vector<WgradDesc> descs;
+  bool built = false;
+  WgradPlan* d_plans[3] = {nullptr, nullptr, nullptr};
+  int* d_starts[3] = {nullptr, nullptr, nullptr};
+  int nplans[3] = {0, 0, 0}, total_wg[3] = {0, 0, 0};
+  size_t lds[3] = {0, 0, 0};
+  double flops[3] = {0, 0, 0};
+  void add(const WgradDesc& d) { if (!built) descs.push_back(d); }
+  void build();
+  void launch(hipStream_t s);
+  void reset();
+  ~WgradBatch() { reset(); }
+};

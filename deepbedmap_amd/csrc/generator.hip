@@ -105,6 +105,7 @@ void Generator::ensure_ws(int N, int H, int W, bool train) {
     }
     have_graph = false;
   }
+  if (!same || tr != wsTrain) wb.reset();  // buffers may have moved: re-plan the batched weight gradients
   wsN = N; wsH = H; wsW = W; wsTrain = tr;
 }
 
@@ -205,7 +206,7 @@ void Generator::backward(const float* gy) {
   launch_gemv_cols_wgrad(col2.p, gy, G(T_def2W), G(T_def2b), N, 576, (int)P4, s);
   {
     const IgLayer& L = layers[L_off2];
-    run_wgrad(L, a51.p, 64 * P4, H4, W4, 0, goff2.p, 32 * P4, H4, W4, N, 1.f);
+    run_wgrad(L, a51.p, 64 * P4, H4, W4, 0, goff2.p, 32 * P4, H4, W4, N, 1.f, &wb);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = goff2.p; d.xsn = 32 * P4; d.N = N;
@@ -216,7 +217,7 @@ void Generator::backward(const float* gy) {
   // ---- final_conv_layer1 (deformable, 64 -> 64): g_a51 now holds d loss / d (pre-activation) ----
   {
     const IgLayer& L = layers[L_def1];
-    run_wgrad(L, col1.p, 576 * P4, H4, W4, 0, g_a51.p, 64 * P4, H4, W4, N, 1.f);
+    run_wgrad(L, col1.p, 576 * P4, H4, W4, 0, g_a51.p, 64 * P4, H4, W4, N, 1.f, &wb);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = g_a51.p; d.xsn = 64 * P4; d.N = N;
@@ -227,7 +228,7 @@ void Generator::backward(const float* gy) {
   }
   {
     const IgLayer& L = layers[L_off1];
-    run_wgrad(L, a42.p, 64 * P4, H4, W4, 0, goff1.p, 32 * P4, H4, W4, N, 1.f);
+    run_wgrad(L, a42.p, 64 * P4, H4, W4, 0, goff1.p, 32 * P4, H4, W4, N, 1.f, &wb);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = goff1.p; d.xsn = 32 * P4; d.N = N;
@@ -238,7 +239,7 @@ void Generator::backward(const float* gy) {
   // ---- post_upsample_conv_layer_2 on resize(a41) ----
   {
     const IgLayer& L = layers[L_up2];
-    run_wgrad(L, a41.p, 64 * 4 * hw, 2 * h, 2 * w, 1, g_a42.p, 64 * P4, H4, W4, N, 1.f);
+    run_wgrad(L, a41.p, 64 * 4 * hw, 2 * h, 2 * w, 1, g_a42.p, 64 * P4, H4, W4, N, 1.f, &wb);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = g_a42.p; d.xsn = 64 * P4; d.N = N;
@@ -249,7 +250,7 @@ void Generator::backward(const float* gy) {
   // ---- post_upsample_conv_layer_1 on resize(a3) ----
   {
     const IgLayer& L = layers[L_up1];
-    run_wgrad(L, a3.p, 64 * hw, h, w, 1, g_z41.p, 64 * 4 * hw, 2 * h, 2 * w, N, 1.f);
+    run_wgrad(L, a3.p, 64 * hw, h, w, 1, g_z41.p, 64 * 4 * hw, 2 * h, 2 * w, N, 1.f, &wb);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = g_z41.p; d.xsn = 64 * 4 * hw; d.N = N;
@@ -260,7 +261,7 @@ void Generator::backward(const float* gy) {
   // ---- post_residual_conv_layer: a3 = a1 + conv(a2) ----
   {
     const IgLayer& L = layers[L_post];
-    run_wgrad(L, cat[nrdb].p, 192 * hw, h, w, 0, g_a3.p, 64 * hw, h, w, N, 1.f);
+    run_wgrad(L, cat[nrdb].p, 192 * hw, h, w, 0, g_a3.p, 64 * hw, h, w, N, 1.f, &wb);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = g_a3.p; d.xsn = 64 * hw; d.N = N;
@@ -277,7 +278,7 @@ void Generator::backward(const float* gy) {
     const float* C = cat[j].p;
     {  // conv_layer5: out = a5*rs + a0
       const IgLayer& L = layers[L_rdb[j * 5 + 4]];
-      run_wgrad(L, C, 192 * hw, h, w, 0, Gout, gsn, h, w, N, sc);
+      run_wgrad(L, C, 192 * hw, h, w, 0, Gout, gsn, h, w, N, sc, &wb);
       ConvDesc d;
       memset(&d, 0, sizeof(d));
       d.x = Gout; d.xsn = gsn; d.N = N;
@@ -290,7 +291,7 @@ void Generator::backward(const float* gy) {
     for (int k = 3; k >= 0; --k) {  // conv_layer4 .. conv_layer1
       const int lo = 64 + 32 * k;   // channel offset of a_{k+1} = number of input channels of this conv
       const IgLayer& L = layers[L_rdb[j * 5 + k]];
-      run_wgrad(L, C, 192 * hw, h, w, 0, D + (long)lo * hw, 192 * hw, h, w, N, 1.f);
+      run_wgrad(L, C, 192 * hw, h, w, 0, D + (long)lo * hw, 192 * hw, h, w, N, 1.f, &wb);
       ConvDesc d;
       memset(&d, 0, sizeof(d));
       d.x = D + (long)lo * hw; d.xsn = 192 * hw; d.N = N;
@@ -312,7 +313,7 @@ void Generator::backward(const float* gy) {
   // ---- pre_residual_conv_layer and the input block ----
   {
     const IgLayer& L = layers[L_pre];
-    run_wgrad(L, a0.p, 128 * hw, h, w, 0, dA[0].p, 192 * hw, h, w, N, 1.f);
+    run_wgrad(L, a0.p, 128 * hw, h, w, 0, dA[0].p, 192 * hw, h, w, N, 1.f, &wb);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = dA[0].p; d.xsn = 192 * hw; d.N = N;
@@ -331,4 +332,6 @@ void Generator::backward(const float* gy) {
       launch_smallcin_conv_wgrad(q, g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), s);
     }
   }
+  // every MFMA weight gradient of this pass: one launch per kernel size (their inputs are all retained above)
+  wb.launch(s);
 }

@@ -71,8 +71,9 @@ struct dbm_model {
   // helpers building descriptors
   ConvDesc fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, float* y, long ysn, int N) const;
   void run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_fwd) const;
+  // weight gradient of layer L: queued on `batch` (launched later, all layers at once) or run immediately
   void run_wgrad(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, const float* dy, long dysn,
-                 int OH, int OW, int N, float scale) const;
+                 int OH, int OW, int N, float scale, WgradBatch* batch = nullptr) const;
 };
 
 struct Generator : dbm_model {
@@ -88,6 +89,7 @@ struct Generator : dbm_model {
   bool wsTrain = false;
   bool have_graph = false;
   const float* bw_in[4] = {nullptr, nullptr, nullptr, nullptr};  // forward inputs, needed by the input-block wgrad
+  WgradBatch wb;  // batched weight gradients of one backward pass
   std::vector<DevBuf> cat, dA;
   DevBuf in_x, in_w1, in_w2, in_w3, a0, a3, a41, a42, off1, off2, col1, col2, a51, yout;
   DevBuf g_a0, g_a3, g_u1, g_z41, g_u2, g_a42, goff1, goff2, gcol, g_a51, g_y;
@@ -107,7 +109,8 @@ struct Discriminator : dbm_model {
     bool valid = false;
     DevBuf img, h[10], z[10], mean[10], istd[10], l1, out;
   } cache[2];
-  DevBuf g_h[2], g_z, g_l1, g_out;
+  DevBuf g_h[2], g_z[10], g_l1, g_out;
+  WgradBatch wb[2];  // batched weight gradients, one plan table per retained graph (real / fake batch)
   Discriminator(dbm_ctx* c);
   void forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot);
   void backward(int slot, const float* glogits);

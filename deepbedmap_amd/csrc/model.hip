@@ -188,7 +188,7 @@ void dbm_model::run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_
 }
 
 void dbm_model::run_wgrad(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, const float* dy,
-                          long dysn, int OH, int OW, int N, float scale) const {
+                          long dysn, int OH, int OW, int N, float scale, WgradBatch* batch) const {
   WgradDesc w;
   memset(&w, 0, sizeof(w));
   w.x = x; w.xsn = xsn; w.xsc = Hin * Win; w.Cin = L.Cview; w.Hin = Hin; w.Win = Win; w.ups = ups;
@@ -197,5 +197,6 @@ void dbm_model::run_wgrad(const IgLayer& L, const float* x, long xsn, int Hin, i
   w.N = N; w.scale = scale;
   w.gW = G(L.wi);
   w.gb = L.bi >= 0 ? G(L.bi) : nullptr;
-  launch_wgrad(w, ctx->stream);
+  if (batch) batch->add(w);
+  else launch_wgrad(w, ctx->stream);
 }

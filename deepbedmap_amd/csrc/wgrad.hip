@@ -7,41 +7,52 @@
 // a workgroup stages, for one "band" (IB images x R output rows), the 32 x BP slab of dy and
 // the zero-padded, tap-ready input patch of up to 128 input channels, then each wavefront owns
 // one 32-channel input tile and keeps T (= taps) independent 32x32 accumulators, i.e. T
-// independent MFMA chains fed by 1 + 2/T LDS dwords per MFMA.  Bands are strided over
-// gridDim.z workgroups; partial sums are folded into the canonical OIHW gradient with fp32
-// atomics once per workgroup (the gradient arena is zeroed by cleargrads()).
+// independent MFMA chains fed by 1 + 2/T LDS dwords per MFMA.
+//
+// One layer alone cannot fill 256 CUs (the trunk's weight matrices have 2..12 32x32 tiles), and
+// splitting K harder only multiplies the fp32 atomics that fold the partial sums.  So the launch
+// is BATCHED: a device-resident table of per-layer plans, one workgroup = (layer, input-channel
+// group, output tile, K split); all weight gradients of a backward pass with the same kernel size
+// go out in a single launch after the data-gradient chain (they do not depend on each other).
 #include "dbm_internal.h"
+#include <algorithm>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct WgradPlan {
-  WgradDesc d;
-  int G;        // 32-channel input tiles per workgroup (= wavefronts per workgroup)
-  int IB, R;    // band = IB images x R output rows
-  int nbr;      // row-bands per image
-  int BP, BPp;  // positions per band, padded to even
-  int YS;       // LDS row stride of the dy slab (odd)
-  int Rin, Wst; // staged logical input patch rows / cols per image
-  int ImgS;     // Rin*Wst
-  int XS;       // LDS channel stride of the patch (odd)
-  int nbands;
-};
-
+// T <= 9: capped at 256 registers so that two workgroups share a CU (one stages while the other feeds the MFMA pipe)
 template <int T>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradPlan p) {
+__global__ __launch_bounds__(256, (T <= 9 ? 2 : 1)) void wgrad_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ starts,
+                                                    int nplans) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // ---- which layer does this workgroup belong to? (binary search in the prefix table) ----
+  int lo = 0, hi = nplans - 1;
+  const int wg = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= wg) lo = mid; else hi = mid - 1;
+  }
+  const WgradPlan& p = plans[lo];
   const WgradDesc& d = p.d;
-  float* ldsY = lds;                          // 32 * YS
-  int* pixoff = (int*)(ldsY + 32 * p.YS);     // BPp
-  float* ldsX = (float*)(pixoff + p.BPp);     // G*32 * XS
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  int local = wg - starts[lo];
+  const int bx = local % p.groups;            // input-channel group
+  local /= p.groups;
+  const int by = local % p.coutTiles;         // output-channel tile
+  const int bz = local / p.coutTiles;         // K split
+
+  float* ldsY = lds;                              // 32 * YS
+  int* pixoff = (int*)(ldsY + 32 * p.YS);         // BPp: patch offset of each position
+  int* pixinfo = pixoff + p.BPp;                  // BPp: ib | al << 8 | b << 20
+  int* xinfo = pixinfo + p.BPp;                   // IB*ImgS: ib | ry << 8 | rx << 20
+  float* ldsX = (float*)(xinfo + p.IB * p.ImgS);  // G*32 * XS
+  const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, kh = lane >> 5;
-  const int cout0 = blockIdx.y * 32;
-  const int cin0 = blockIdx.x * p.G * 32;
-  const int cin_w = cin0 + wave * 32;          // this wavefront's input tile
-  const bool wave_active = cin_w < d.Cin;
+  const int cout0 = by * 32;
+  const int cin0 = bx * p.G * 32;
+  const int cin_w = cin0 + wave * 32;
+  const bool wave_active = wave < p.G && cin_w < d.Cin;
   const int Hl = d.Hin << d.ups, Wl = d.Win << d.ups;
+  const int ROW = p.R * d.OW;
 
   f32x16 acc[T];
 #pragma unroll
@@ -49,114 +60,185 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradPlan p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
+  constexpr int KWc = (T == 1) ? 1 : (T == 9 ? 3 : 4);
+  int toff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) toff[t] = (t / KWc) * p.Wst + (t % KWc);
 
-  // position -> patch offset table (band shape is the same for every band; the last row-band of
-  // an image may be short, handled by zeroing dy there)
-  for (int e = tid; e < p.BPp; e += nthr) {
-    int off = 0;
+  // ---- per-band-shape tables (no integer division in the staging loops) ----
+  for (int e = tid; e < p.BPp; e += 256) {
+    int off = 0, info = 0xff;  // ib = 255 marks the padding position
     if (e < p.BP) {
-      const int ib = e / (p.R * d.OW);
-      const int rem = e - ib * (p.R * d.OW);
+      const int ib = e / ROW;
+      const int rem = e - ib * ROW;
       const int al = rem / d.OW, b = rem - al * d.OW;
       off = ib * p.ImgS + al * d.stride * p.Wst + b * d.stride;
+      info = ib | (al << 8) | (b << 20);
     }
     pixoff[e] = off;
+    pixinfo[e] = info;
   }
+  for (int e = tid; e < p.IB * p.ImgS; e += 256) {
+    const int ib = e / p.ImgS;
+    const int rem = e - ib * p.ImgS;
+    const int ry = rem / p.Wst, rx = rem - ry * p.Wst;
+    xinfo[e] = ib | (ry << 8) | (rx << 20);
+  }
+  const int perch = p.IB * p.ImgS;
+  const int nch = p.G * 32;
 
-  for (int band = blockIdx.z; band < p.nbands; band += gridDim.z) {
-    const int ig = band / p.nbr;            // image group
+  for (int band = bz; band < p.nbands; band += p.S) {
+    const int ig = band / p.nbr;
     const int a0 = (band - ig * p.nbr) * p.R;
     const int n0 = ig * p.IB;
-    __syncthreads();  // previous band fully consumed
-    // ---- stage dy slab: 32 x BPp ----
-    for (int e = tid; e < 32 * p.BPp; e += nthr) {
-      const int i = e / p.BPp, pix = e - i * p.BPp;
-      float v = 0.f;
-      if (pix < p.BP && cout0 + i < d.Cout) {
-        const int ib = pix / (p.R * d.OW);
-        const int rem = pix - ib * (p.R * d.OW);
-        const int al = rem / d.OW, b = rem - al * d.OW;
-        const int n = n0 + ib, a = a0 + al;
-        if (n < d.N && a < d.OH) v = d.dy[(long)n * d.dysn + (long)(cout0 + i) * d.dysc + a * d.OW + b];
+    __syncthreads();  // tables written / previous band fully consumed
+    if (!(p.dbg & 1) || band == bz) {
+    // Staging is latency bound (one workgroup per CU, 4 wavefronts).  Each lane decodes ITS positions once
+    // per band and then streams all channels / rows for them with U independent, unconditional loads in flight
+    // (out-of-image or out-of-range elements read a safe address and are zeroed by a select afterwards).
+    constexpr int U = (T == 16) ? 4 : 8;
+    // ---- dy slab: 32 x BPp; wavefront w stages rows w*8 .. w*8+7 ----
+    for (int p0 = 0; p0 < p.BPp; p0 += 64) {
+      const int pix = p0 + lane;
+      const bool inb = pix < p.BPp;
+      const int info = pixinfo[inb ? pix : 0];
+      const int ib = info & 0xff, al = (info >> 8) & 0xfff, b = (int)((unsigned)info >> 20);
+      const int n = n0 + ib, a = a0 + al;
+      const bool ok = inb && ib != 0xff && n < d.N && a < d.OH;
+      const float* src = d.dy + (ok ? (long)n * d.dysn + a * d.OW + b : 0L);
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = wave * 8 + u;
+        v[u] = src[(ok && cout0 + i < d.Cout) ? (long)(cout0 + i) * d.dysc : 0L];
       }
-      ldsY[i * p.YS + pix] = v;
+      if (inb) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = wave * 8 + u;
+          ldsY[i * p.YS + pix] = (ok && cout0 + i < d.Cout) ? v[u] : 0.f;
+        }
+      }
     }
-    // ---- stage input patch: (G*32) x IB x Rin x Wst, logical (upsampled, zero padded) coordinates ----
-    const int perch = p.IB * p.ImgS;
-    const int nch = p.G * 32;
-    for (int e = tid; e < nch * perch; e += nthr) {
-      const int c = e / perch;
-      int rem = e - c * perch;
-      const int ib = rem / p.ImgS;
-      rem -= ib * p.ImgS;
-      const int ry = rem / p.Wst, rx = rem - ry * p.Wst;
+    // ---- input patch in logical (upsampled, zero padded) coordinates; wavefront w stages channels w*nch/4 .. ----
+    const int cpw = nch >> 2;  // nch is a multiple of 32
+    for (int e0 = 0; e0 < perch; e0 += 64) {
+      const int e = e0 + lane;
+      const bool inb = e < perch;
+      const int info = xinfo[inb ? e : 0];
+      const int ib = info & 0xff, ry = (info >> 8) & 0xfff, rx = (int)((unsigned)info >> 20);
       const int iy = a0 * d.stride - d.pad + ry, ix = rx - d.pad;
-      const int n = n0 + ib, ci = cin0 + c;
-      float v = 0.f;
-      if (ci < d.Cin && n < d.N && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl)
-        v = d.x[(long)n * d.xsn + (long)ci * d.xsc + (iy >> d.ups) * d.Win + (ix >> d.ups)];
-      ldsX[c * p.XS + ib * p.ImgS + rem] = v;
+      const int n = n0 + ib;
+      const bool ok = inb && n < d.N && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+      const float* src = d.x + (ok ? (long)n * d.xsn + (iy >> d.ups) * d.Win + (ix >> d.ups) : 0L);
+      for (int cb = 0; cb < cpw; cb += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ci = cin0 + wave * cpw + cb + u;
+          v[u] = src[(ok && ci < d.Cin) ? (long)ci * d.xsc : 0L];
+        }
+        if (inb) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int c = wave * cpw + cb + u;
+            ldsX[c * p.XS + e] = (ok && cin0 + c < d.Cin) ? v[u] : 0.f;
+          }
+        }
+      }
+    }
     }
     __syncthreads();
-    if (d.gb && blockIdx.x == 0 && tid < 32) {
-      const float* row = ldsY + tid * p.YS;
-      for (int pix = 0; pix < p.BP; ++pix) bsum += row[pix];
+    if (d.gb && bx == 0) {  // bias gradient: 8 threads per slab row, folded with wavefront shuffles
+      const float* row = ldsY + (tid >> 3) * p.YS;
+      float part = 0.f;
+      for (int pix = tid & 7; pix < p.BP; pix += 8) part += row[pix];
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      part += __shfl_xor(part, 4, 64);
+      bsum += part;  // every thread of the 8-group holds the row total; only (tid & 7) == 0 publishes it
     }
-    if (wave_active) {
+    if (wave_active && !(p.dbg & 2)) {
+      // K loop, software pipelined by one step: the A value and the patch offset of step k+1 are fetched from LDS
+      // while the T MFMAs of step k issue (the B reads of a step depend on its offset).
       const float* arow = ldsY + j * p.YS + kh;
       const float* xrow = ldsX + (wave * 32 + j) * p.XS;
+      float av = arow[0];
+      int off = pixoff[kh];
       for (int kp = 0; kp < p.BPp; kp += 2) {
-        const float av = arow[kp];
-        const float* xb = xrow + pixoff[kp + kh];
+        const float* xb = xrow + off;
+        float bv[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const int ky = t / d.KW, kx = t - ky * d.KW;  // KW is uniform; strength-reduced by the compiler per t
-          const float bv = xb[ky * p.Wst + kx];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-        }
+        for (int t = 0; t < T; ++t) bv[t] = xb[toff[t]];
+        const int kn = (kp + 2 < p.BPp) ? kp + 2 : kp;
+        const float av_n = arow[kn];
+        const int off_n = pixoff[kn + kh];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        av = av_n;
+        off = off_n;
       }
     }
   }
 
-  if (wave_active) {
-    const int c = cin_w + j;
-    if (c < d.Cin) {
+  // ---- fold the partial sums into gW[o][c][t] (t fastest).  A lane owns (o, c) pairs with a stride of T floats
+  // between lanes, so direct atomics would touch a different cache line per lane; instead each wavefront
+  // transposes 8 output rows at a time through LDS and issues the atomics over consecutive addresses. ----
+  __syncthreads();  // staging buffers are dead: reuse the LDS
+  {
+    constexpr int ROWF = 32 * T;  // floats of one output row of this wavefront's 32-channel tile
+    float* tw = lds + wave * (8 * ROWF);
 #pragma unroll
-      for (int t = 0; t < T; ++t)
+    for (int q = 0; q < 4; ++q) {
+      if (wave_active) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = cout0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (o < d.Cout) atomicAdd(d.gW + ((long)o * d.Cin + c) * T + t, d.scale * acc[t][r]);
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) tw[(rr + 4 * kh) * ROWF + j * T + t] = d.scale * acc[t][4 * q + rr];
+      }
+      __syncthreads();
+      if (wave_active && !(p.dbg & 4)) {
+        for (int e = lane; e < 8 * ROWF; e += 64) {
+          const int rl = e / ROWF;
+          const int rem = e - rl * ROWF;
+          const int o = cout0 + 8 * q + rl;
+          const int c = cin_w + rem / T;
+          if (o < d.Cout && c < d.Cin) atomicAdd(d.gW + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
         }
+      }
+      __syncthreads();
     }
   }
-  if (d.gb && blockIdx.x == 0 && tid < 32 && cout0 + tid < d.Cout) atomicAdd(d.gb + cout0 + tid, d.scale * bsum);
+  if (d.gb && bx == 0 && (tid & 7) == 0 && cout0 + (tid >> 3) < d.Cout)
+    atomicAdd(d.gb + cout0 + (tid >> 3), d.scale * bsum);
 }
 
 static inline int odd_up(int v) { return v | 1; }
 
-void launch_wgrad(const WgradDesc& d, hipStream_t s) {
+size_t wgrad_plan(const WgradDesc& d, WgradPlan& p) {
   const int T = d.KH * d.KW;
   DBM_CHECK(T == 1 || T == 9 || T == 16, "wgrad: supported kernels are 1x1, 3x3, 4x4");
-  WgradPlan p;
+  DBM_CHECK(d.OW < 4096 && d.OH < 4096, "wgrad: image too large");
   p.d = d;
   const int tiles = (d.Cin + 31) / 32;
-  const int groups = (tiles + 3) / 4;
-  p.G = (tiles + groups - 1) / groups;
-  // band selection: whole images if small, else row bands of one image; keep LDS <= ~96 KB
+  p.groups = (tiles + 3) / 4;
+  p.G = (tiles + p.groups - 1) / p.groups;
+  p.coutTiles = (d.Cout + 31) / 32;
+  // band selection: whole images if small, else row bands of one image; keep LDS <= ~100 KB
   const int Wst = (d.OW - 1) * d.stride + d.KW;
-  const long budget = 24000;  // floats
+  const long budget = (T <= 9) ? 19800 : 25000;  // floats; <= 79 KB lets two workgroups share a CU's 160 KB
   auto cost = [&](int IB, int R) {
     const int Rin = (R - 1) * d.stride + d.KH;
-    return (long)p.G * 32 * odd_up(IB * Rin * Wst) + 32L * odd_up((IB * R * d.OW + 1) & ~1) + IB * R * d.OW + 2;
+    const long bpp = (IB * R * d.OW + 1) & ~1;
+    return (long)p.G * 32 * odd_up(IB * Rin * Wst) + 32L * odd_up((int)bpp) + 2 * bpp + (long)IB * Rin * Wst;
   };
   int IB = 1, R = d.OH;
   if (cost(1, d.OH) <= budget) {
-    while (IB * 2 <= d.N && IB * 2 * d.OH * d.OW <= 256 && cost(IB * 2, d.OH) <= budget) IB *= 2;
+    while (IB * 2 <= d.N && IB * 2 <= 128 && IB * 2 * d.OH * d.OW <= 324 && cost(IB * 2, d.OH) <= budget) IB *= 2;
   } else {
     while (R > 1 && cost(1, R) > budget) --R;
   }
-  DBM_CHECK(cost(IB, R) <= 39000, "wgrad: band does not fit in LDS");
+  DBM_CHECK(cost(IB, R) <= 38000, "wgrad: band does not fit in LDS");
   p.IB = IB; p.R = R;
   p.nbr = (d.OH + R - 1) / R;
   p.BP = IB * R * d.OW;
@@ -166,26 +248,96 @@ void launch_wgrad(const WgradDesc& d, hipStream_t s) {
   p.Wst = Wst;
   p.ImgS = p.Rin * p.Wst;
   p.XS = odd_up(IB * p.ImgS);
+  DBM_CHECK(p.Rin < 4096 && p.Wst < 4096, "wgrad: patch too large");
   const int imgGroups = (d.N + IB - 1) / IB;
   p.nbands = imgGroups * p.nbr;
-  const int coutTiles = (d.Cout + 31) / 32;
-  int S = (1024 + groups * coutTiles - 1) / (groups * coutTiles);  // aim at ~1024 workgroups
+  // K split: enough positions per workgroup that the closing atomics stay a small fraction of the MFMA work
+  const long positions = (long)d.N * d.OH * d.OW;
+  int S = (int)((positions + 2591) / 2592);
   if (S > p.nbands) S = p.nbands;
   if (S < 1) S = 1;
-  const size_t lds = sizeof(float) * ((size_t)32 * p.YS + p.BPp + (size_t)p.G * 32 * p.XS);
-  dim3 grid(groups, coutTiles, S), block(64 * p.G);
-#define DBM_WG(TT)                                                                                          \
-  do {                                                                                                      \
-    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                160 * 1024));                                                               \
-    hipLaunchKernelGGL(wgrad_kernel<TT>, grid, block, lds, s, p);                                           \
-  } while (0)
-  if (g_profiler.enabled)
-    g_profiler.begin(s, 1, 2.0 * (double)d.N * d.OH * d.OW * d.Cout * d.Cin * T);
-  if (T == 1) DBM_WG(1);
-  else if (T == 9) DBM_WG(9);
-  else DBM_WG(16);
-#undef DBM_WG
-  if (g_profiler.enabled) g_profiler.end(s);
+  p.S = S;
+  p.dbg = getenv("DBM_WG_DBG") ? atoi(getenv("DBM_WG_DBG")) : 0;
+  p.wg_count = p.groups * p.coutTiles * S;
+  const size_t stage = sizeof(float) * ((size_t)32 * p.YS + 2 * (size_t)p.BPp + (size_t)IB * p.ImgS + (size_t)p.G * 32 * p.XS);
+  const size_t epilogue = sizeof(float) * 4 * 8 * 32 * (size_t)T;  // per-wavefront transpose areas
+  return std::max(stage, epilogue);
+}
+
+template <int T>
+static void launch_T(const WgradPlan* plans, const int* starts, int nplans, int total_wg, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad_kernel<T>, dim3(total_wg), dim3(256), lds, s, plans, starts, nplans);
   DBM_HIP(hipGetLastError());
+}
+
+void WgradBatch::reset() {
+  descs.clear();
+  built = false;
+  for (int g = 0; g < 3; ++g) {
+    if (d_plans[g]) (void)hipFree(d_plans[g]);
+    if (d_starts[g]) (void)hipFree(d_starts[g]);
+    d_plans[g] = nullptr;
+    d_starts[g] = nullptr;
+    nplans[g] = total_wg[g] = 0;
+    lds[g] = 0;
+    flops[g] = 0.0;
+  }
+}
+
+void WgradBatch::build() {
+  static const int TT[3] = {1, 9, 16};
+  for (int g = 0; g < 3; ++g) {
+    std::vector<WgradPlan> plans;
+    std::vector<int> starts;
+    int total = 0;
+    size_t maxlds = 0;
+    double fl = 0.0;
+    for (const auto& d : descs) {
+      if (d.KH * d.KW != TT[g]) continue;
+      WgradPlan p;
+      maxlds = std::max(maxlds, wgrad_plan(d, p));
+      starts.push_back(total);
+      total += p.wg_count;
+      plans.push_back(p);
+      fl += 2.0 * (double)d.N * d.OH * d.OW * d.Cout * d.Cin * TT[g];
+    }
+    starts.push_back(total);
+    nplans[g] = (int)plans.size();
+    total_wg[g] = total;
+    lds[g] = maxlds;
+    flops[g] = fl;
+    if (plans.empty()) continue;
+    DBM_HIP(hipMalloc((void**)&d_plans[g], plans.size() * sizeof(WgradPlan)));
+    DBM_HIP(hipMalloc((void**)&d_starts[g], starts.size() * sizeof(int)));
+    DBM_HIP(hipMemcpy(d_plans[g], plans.data(), plans.size() * sizeof(WgradPlan), hipMemcpyHostToDevice));
+    DBM_HIP(hipMemcpy(d_starts[g], starts.data(), starts.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  DBM_HIP(hipDeviceSynchronize());
+  built = true;
+}
+
+void WgradBatch::launch(hipStream_t s) {
+  if (!built) build();
+  for (int g = 0; g < 3; ++g) {
+    if (nplans[g] == 0) continue;
+    if (g_profiler.enabled) g_profiler.begin(s, 1, flops[g]);
+    if (g == 0) launch_T<1>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else if (g == 1) launch_T<9>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else launch_T<16>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    if (g_profiler.enabled) g_profiler.end(s);
+  }
+}
+
+// single-layer form (op-level entry points / tests)
+void launch_wgrad(const WgradDesc& d, hipStream_t s) {
+  WgradBatch b;
+  b.add(d);
+  b.launch(s);
+  DBM_HIP(hipStreamSynchronize(s));
+  b.reset();
 }
