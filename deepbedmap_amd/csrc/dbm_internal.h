@@ -91,10 +91,17 @@ struct KernelProfiler {
 };
 extern KernelProfiler g_profiler;
 
-// weight packing (pack.hip): dst[t][k][mP] with (k,m) = (cin,cout) (transpose=0) or (cout,cin) (transpose=1);
+// weight packing (igemm.hip): dst[t][k][mP] with (k,m) = (cin,cout) (transpose=0) or (cout,cin) (transpose=1);
 // tap t reads OIHW element (ky[t], kx[t]).  Rows m >= M are zero-filled; k in [K, KP) zero-filled.
-void launch_pack_weights(const float* w_oihw, int O, int C, int KH, int KW, int T, const signed char* ky,
-                         const signed char* kx, int transpose, int KP, int MP, float* dst, hipStream_t s);
+// All layers of a model are packed by ONE launch driven by a device-resident job table.
+struct PackJob {
+  const float* w;
+  float* dst;
+  int O, C, KH, KW, T, transpose, KP, MP;
+  signed char ky[DBM_MAX_TAPS], kx[DBM_MAX_TAPS];
+  int block_start, block_count;
+};
+void launch_pack_jobs(const PackJob* d_jobs, int njobs, int total_blocks, hipStream_t s);
 
 // wgrad (wgrad.hip): gW[o][c][ky][kx] (+)= scale * sum_{n,a,b} dy[n][o][a][b] * x[n][c][(a*stride+ky-pad)>>ups][...]
 struct WgradDesc {

@@ -4,27 +4,32 @@
 // (reference srgan_train.py:292-331, 467-503, 506-523 offset convs, 626-634) for forward,
 // and -- with transposed/flipped packed weights -- the data-gradient of the same layers.
 //
-// Work decomposition (CDNA4): one 256-thread workgroup (4 wavefronts, one per SIMD) owns a
-// 32(out-channel) x 32(output-position) tile.  Output positions are the flattened (n, a, b)
-// index, so a tile may straddle images; each lane keeps its own position's gather offsets.
-// The K dimension (taps x input channels) is split 4-ways across the wavefronts by input
-// channel; the four partial 32x32 accumulators are reduced through 16 KB of LDS and the
-// epilogue (bias, residual axpy's, LeakyReLU, gradient mask) is applied by all 256 threads with
-// 128-byte coalesced stores along the position axis.
+// Work decomposition (CDNA4): one workgroup of WAVES wavefronts owns a 32(out-channel) x 32(output-
+// position) tile.  Output positions are the flattened (n, a, b) index, so a tile may straddle
+// images; each lane keeps its own position's gather offsets (one 32-bit offset per tap).
+// The K dimension (taps x input channels) is split WAVES-ways across the wavefronts by input
+// channel; the partial 32x32 accumulators are reduced through LDS and the epilogue (bias,
+// residual axpy's, LeakyReLU, gradient mask) is applied by all threads with 128-byte coalesced
+// stores along the position axis.  WAVES is 4 when the layer has >= 1024 tiles (tail, discriminator,
+// inference crops) and 8 / 16 for the 9x9 trunk at batch 64, whose 162 - 324 tiles would otherwise
+// leave most SIMDs empty: a 16-wavefront workgroup puts 4 short MFMA chains on every SIMD of its CU.
 //
 // MFMA operand mapping (cdna_hip_programming.md section 3): A[i = lane&31][k = lane>>5] is the
 // packed weight wp[t][ci + (lane>>5)][cout0 + (lane&31)] -> a 2 x 128-byte coalesced load;
 // B[k = lane>>5][j = lane&31] is x[n_j][ci + (lane>>5)][tap-shifted position j] -> gathered
-// straight from global/L2 (the 9 taps re-read the same lines, so they hit the vector L1);
+// straight from global/L2 (the taps re-read the same lines, so they hit the vector L1);
 // D[i][j] has j = lane&31 (position) and i = (r&3) + 8*(r>>2) + 4*(lane>>5) (out channel).
 // At the fp32 MFMA rate (64 cycles per instruction per SIMD) two dword loads per MFMA keep
-// the L1 below half of its bandwidth, so no LDS staging of operands is needed.
+// the L1 below half of its bandwidth, so no LDS staging of operands is needed; what matters is
+// latency: the loop is unrolled over the T taps of one channel pair and the 2T loads of the NEXT
+// pair are issued before the T MFMAs of the current one.
 #include "dbm_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvDesc d) {
-  __shared__ float red[4 * 1024];
+template <int T, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // WAVES * 1024 floats
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -41,36 +46,58 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvDesc d) {
     b = r - a * d.OWl;
   }
   const int cout0 = blockIdx.y * 32;
-  const int cpw = d.Cin >> 2;       // input channels per wavefront
+  const int cpw = d.Cin / WAVES;    // input channels per wavefront (even)
   const int c0 = wave * cpw + kh;   // first input channel of this lane
   const int Hl = d.Hin << d.ups, Wl = d.Win << d.ups;
   const float* xn = d.x + (long)n * d.xsn + (long)c0 * d.xsc;
   const float* wlane = d.wp + (long)c0 * d.CoutP + cout0 + j;
   const long wtap = (long)d.Cin * d.CoutP;
   const long wstep = 2L * d.CoutP;
-  const int iters = cpw >> 1;  // multiple of 4 because Cin % 32 == 0
+  const long xstep = 2L * d.xsc;
+  const int npairs = cpw >> 1;
+
+  // per-tap gather offsets; out-of-image taps read offset 0 (valid memory) and are zeroed by the mask
+  int xoff[T];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int iy = a * d.sin + d.dy[t];
+    const int ix = b * d.sin + d.dx[t];
+    const bool ok = pv && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+    xoff[t] = ok ? (iy >> d.ups) * d.Win + (ix >> d.ups) : 0;
+    okmask |= ok ? (1u << t) : 0u;
+  }
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int t = 0; t < d.T; ++t) {
-    const int iy = a * d.sin + d.dy[t];
-    const int ix = b * d.sin + d.dx[t];
-    const bool ok = pv && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
-    // out-of-image taps read a zero word with stride 0: uniform control flow, no exec masking
-    const float* xp = ok ? xn + ((iy >> d.ups) * d.Win + (ix >> d.ups)) : d.zeros;
-    const long xstep = ok ? 2L * d.xsc : 0L;
-    const float* wp = wlane + t * wtap;
-    for (int s = 0; s < iters; s += 4) {
-      const float b0 = xp[0], b1 = xp[xstep], b2 = xp[2 * xstep], b3 = xp[3 * xstep];
-      const float a0 = wp[0], a1 = wp[wstep], a2 = wp[2 * wstep], a3 = wp[3 * wstep];
-      xp += 4 * xstep;
-      wp += 4 * wstep;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);
+  float av[T], bv[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    bv[t] = xn[xoff[t]];
+    av[t] = wlane[t * wtap];
+  }
+  for (int p = 0; p < npairs; ++p) {
+    // prefetch the next channel pair (the last iteration re-reads the current one: harmless, keeps the loop uniform)
+    const int pn = (p + 1 < npairs) ? p + 1 : p;
+    const float* xc = xn + pn * xstep;
+    const float* wc = wlane + pn * wstep;
+    float an[T], bn[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      bn[t] = xc[xoff[t]];
+      an[t] = wc[t * wtap];
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float bm = ((okmask >> t) & 1u) ? bv[t] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bm, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      av[t] = an[t];
+      bv[t] = bn[t];
     }
   }
 
@@ -84,14 +111,18 @@ __global__ __launch_bounds__(256) void igemm_conv_kernel(const ConvDesc d) {
   __syncthreads();
   if (!pv) return;
   const long pix = (long)(a * d.so + d.oy0) * d.OWp + (b * d.so + d.ox0);
-  const int irow = tid >> 5;  // 0..7
+  constexpr int ROWS_PER_PASS = 2 * WAVES;        // threads / 32
+  constexpr int PASSES = 32 / ROWS_PER_PASS;      // 4, 2, 1 for WAVES = 4, 8, 16
+  const int irow = tid >> 5;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int i = irow + 8 * q;
+  for (int q = 0; q < PASSES; ++q) {
+    const int i = irow + ROWS_PER_PASS * q;
     const int c = cout0 + i;
     if (c >= d.Cout) continue;
     const int e = i * 32 + j;
-    float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += red[w * 1024 + e];
     if (d.bias) v += d.bias[c];
     v *= d.s1;
     const long co = (long)c * d.ysc + pix;
@@ -137,14 +168,34 @@ void KernelProfiler::collect(double out[8]) {
   recs.clear();
 }
 
+template <int T, int WAVES>
+static void launch_tw(const ConvDesc& d, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+}
+
+template <int T>
+static void launch_t(const ConvDesc& d, dim3 grid, int waves, hipStream_t s) {
+  if (waves == 16) launch_tw<T, 16>(d, grid, s);
+  else if (waves == 8) launch_tw<T, 8>(d, grid, s);
+  else launch_tw<T, 4>(d, grid, s);
+}
+
 void launch_igemm_conv(const ConvDesc& d, hipStream_t s) {
   DBM_CHECK(d.Cin % 32 == 0, "igemm: Cin must be a multiple of 32");
   DBM_CHECK(d.CoutP % 32 == 0 && d.Cout <= d.CoutP, "igemm: bad CoutP");
-  DBM_CHECK(d.T >= 1 && d.T <= DBM_MAX_TAPS, "igemm: bad tap count");
+  DBM_CHECK(d.T == 1 || d.T == 4 || d.T == 9 || d.T == 16, "igemm: tap count must be 1, 4, 9 or 16");
   const long total = (long)d.N * d.OHl * d.OWl;
   dim3 grid((unsigned)((total + 31) / 32), (unsigned)((d.Cout + 31) / 32));
+  const long tiles = (long)grid.x * grid.y;
+  // few tiles -> more wavefronts per tile (Cin % 32 == 0 keeps Cin / WAVES even for every choice)
+  const int waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
   if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)total * d.Cout * d.Cin * d.T);
-  hipLaunchKernelGGL(igemm_conv_kernel, grid, dim3(256), 0, s, d);
+  switch (d.T) {
+    case 1: launch_t<1>(d, grid, waves, s); break;
+    case 4: launch_t<4>(d, grid, waves, s); break;
+    case 9: launch_t<9>(d, grid, waves, s); break;
+    default: launch_t<16>(d, grid, waves, s); break;
+  }
   if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
 }
@@ -152,16 +203,18 @@ void launch_igemm_conv(const ConvDesc& d, hipStream_t s) {
 // ----------------------------------------------------------------------------------------------
 // weight packing
 // ----------------------------------------------------------------------------------------------
-struct PackDesc {
-  const float* w;
-  float* dst;
-  int O, C, KH, KW, T, transpose, KP, MP;
-  signed char ky[DBM_MAX_TAPS], kx[DBM_MAX_TAPS];
-};
-
-__global__ void pack_weights_kernel(const PackDesc p) {
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackJob* __restrict__ jobs, int njobs) {
+  // block -> job (binary search over the prefix of block counts), then a block-local stride loop
+  int lo = 0, hi = njobs - 1;
+  const int blk = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_start <= blk) lo = mid; else hi = mid - 1;
+  }
+  const PackJob& p = jobs[lo];
   const long total = (long)p.T * p.KP * p.MP;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+  const int nblk = p.block_count;
+  for (long e = (long)(blk - p.block_start) * 256 + threadIdx.x; e < total; e += (long)nblk * 256) {
     const int m = (int)(e % p.MP);
     const int k = (int)((e / p.MP) % p.KP);
     const int t = (int)(e / ((long)p.MP * p.KP));
@@ -173,15 +226,8 @@ __global__ void pack_weights_kernel(const PackDesc p) {
   }
 }
 
-void launch_pack_weights(const float* w, int O, int C, int KH, int KW, int T, const signed char* ky,
-                         const signed char* kx, int transpose, int KP, int MP, float* dst, hipStream_t s) {
-  DBM_CHECK(T <= DBM_MAX_TAPS, "pack: too many taps");
-  PackDesc p;
-  p.w = w; p.dst = dst; p.O = O; p.C = C; p.KH = KH; p.KW = KW; p.T = T; p.transpose = transpose; p.KP = KP; p.MP = MP;
-  for (int t = 0; t < T; ++t) { p.ky[t] = ky[t]; p.kx[t] = kx[t]; }
-  const long total = (long)T * KP * MP;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, s, p);
+void launch_pack_jobs(const PackJob* d_jobs, int njobs, int total_blocks, hipStream_t s) {
+  if (njobs == 0) return;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(total_blocks), dim3(256), 0, s, d_jobs, njobs);
   DBM_HIP(hipGetLastError());
 }

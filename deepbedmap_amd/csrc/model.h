@@ -59,6 +59,8 @@ struct dbm_model {
   bool adam_ready = false;
   bool packed_dirty = true;
   std::vector<IgLayer> layers;
+  PackJob* d_pack_jobs = nullptr;  // device job table of the one-launch weight repack
+  int n_pack_jobs = 0, n_pack_blocks = 0;
   virtual ~dbm_model();
   int add_tensor(const std::string& key, std::vector<int64_t> shape, int kind);
   void alloc_arenas();

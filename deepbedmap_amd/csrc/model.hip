@@ -33,6 +33,7 @@ dbm_model::~dbm_model() {
   if (adam_m) (void)hipFree(adam_m);
   if (adam_v) (void)hipFree(adam_v);
   if (pers) (void)hipFree(pers);
+  if (d_pack_jobs) (void)hipFree(d_pack_jobs);
 }
 
 int dbm_model::add_tensor(const std::string& key, std::vector<int64_t> shape, int kind) {
@@ -122,15 +123,40 @@ int dbm_model::add_iglayer(const std::string& name, int O, int C, int K, int str
 void dbm_model::ensure_packed() {
   if (!packed_dirty) return;
   hipStream_t s = ctx->stream;
-  for (auto& L : layers) {
-    const int T = L.Kview * L.Kview;
-    signed char ky[DBM_MAX_TAPS], kx[DBM_MAX_TAPS];
-    for (int t = 0; t < T; ++t) { ky[t] = (signed char)(t / L.Kview); kx[t] = (signed char)(t % L.Kview); }
-    launch_pack_weights(P(L.wi), L.O, L.Cview, L.Kview, L.Kview, T, ky, kx, 0, L.CinP, L.CoutP, L.wf, s);
-    const int nph = L.stride == 1 ? 1 : 4;
-    for (int ph = 0; ph < nph; ++ph)
-      launch_pack_weights(P(L.wi), L.O, L.Cview, L.Kview, L.Kview, L.Tb, L.bky[ph], L.bkx[ph], 1, L.OP, L.CP, L.wb[ph], s);
+  if (!d_pack_jobs) {  // the job table only depends on the layer list: build and upload it once
+    std::vector<PackJob> jobs;
+    int blocks = 0;
+    auto add = [&](const IgLayer& L, int T, const signed char* ky, const signed char* kx, int transpose, int KP, int MP,
+                   float* dst) {
+      PackJob j;
+      memset(&j, 0, sizeof(j));
+      j.w = P(L.wi); j.dst = dst; j.O = L.O; j.C = L.Cview; j.KH = L.Kview; j.KW = L.Kview; j.T = T;
+      j.transpose = transpose; j.KP = KP; j.MP = MP;
+      for (int t = 0; t < T; ++t) { j.ky[t] = ky[t]; j.kx[t] = kx[t]; }
+      const long total = (long)T * KP * MP;
+      long nb = (total + 2047) / 2048;  // 8 elements per thread
+      if (nb > 64) nb = 64;
+      j.block_start = blocks; j.block_count = (int)nb;
+      blocks += (int)nb;
+      jobs.push_back(j);
+    };
+    for (auto& L : layers) {
+      const int T = L.Kview * L.Kview;
+      signed char ky[DBM_MAX_TAPS], kx[DBM_MAX_TAPS];
+      for (int t = 0; t < T; ++t) { ky[t] = (signed char)(t / L.Kview); kx[t] = (signed char)(t % L.Kview); }
+      add(L, T, ky, kx, 0, L.CinP, L.CoutP, L.wf);
+      const int nph = L.stride == 1 ? 1 : 4;
+      for (int ph = 0; ph < nph; ++ph) add(L, L.Tb, L.bky[ph], L.bkx[ph], 1, L.OP, L.CP, L.wb[ph]);
+    }
+    n_pack_jobs = (int)jobs.size();
+    n_pack_blocks = blocks;
+    if (n_pack_jobs) {
+      DBM_HIP(hipMalloc((void**)&d_pack_jobs, jobs.size() * sizeof(PackJob)));
+      DBM_HIP(hipMemcpy(d_pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+      DBM_HIP(hipDeviceSynchronize());
+    }
   }
+  launch_pack_jobs(d_pack_jobs, n_pack_jobs, n_pack_blocks, s);
   packed_dirty = false;
 }
 

@@ -19,10 +19,15 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// T <= 9: capped at 256 registers so that two workgroups share a CU (one stages while the other feeds the MFMA pipe)
-template <int T>
-__global__ __launch_bounds__(256, (T <= 9 ? 2 : 1)) void wgrad_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ starts,
-                                                    int nplans) {
+// TPW = taps per wavefront.  3x3 / 1x1: every wavefront keeps all T accumulators (TPW = T, 4 wavefronts, 256
+// registers -> two workgroups share a CU: one stages while the other feeds the MFMA pipe).  4x4: 16 accumulators are
+// 256 registers on their own, so the taps are split over two wavefronts per input tile (TPW = 8, 8 wavefronts).
+template <int T, int TPW>
+__global__ __launch_bounds__(256 * (T / TPW), 2) void wgrad_kernel(const WgradPlan* __restrict__ plans,
+                                                                   const int* __restrict__ starts, int nplans) {
+  constexpr int TG = T / TPW;       // tap groups
+  constexpr int NW = 4 * TG;        // wavefronts per workgroup
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // ---- which layer does this workgroup belong to? (binary search in the prefix table) ----
   int lo = 0, hi = nplans - 1;
@@ -47,26 +52,31 @@ __global__ __launch_bounds__(256, (T <= 9 ? 2 : 1)) void wgrad_kernel(const Wgra
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int j = lane & 31, kh = lane >> 5;
+  const int ct = wave & 3;                    // input tile of this wavefront inside the group
+  const int tg = wave >> 2;                   // tap group of this wavefront
   const int cout0 = by * 32;
   const int cin0 = bx * p.G * 32;
-  const int cin_w = cin0 + wave * 32;
-  const bool wave_active = wave < p.G && cin_w < d.Cin;
+  const int cin_w = cin0 + ct * 32;
+  const bool wave_active = ct < p.G && cin_w < d.Cin;
   const int Hl = d.Hin << d.ups, Wl = d.Win << d.ups;
   const int ROW = p.R * d.OW;
 
-  f32x16 acc[T];
+  f32x16 acc[TPW];
 #pragma unroll
-  for (int t = 0; t < T; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float bsum = 0.f;
   constexpr int KWc = (T == 1) ? 1 : (T == 9 ? 3 : 4);
-  int toff[T];
+  int toff[TPW];
 #pragma unroll
-  for (int t = 0; t < T; ++t) toff[t] = (t / KWc) * p.Wst + (t % KWc);
+  for (int t = 0; t < TPW; ++t) {
+    const int tt = tg * TPW + t;
+    toff[t] = (tt / KWc) * p.Wst + (tt % KWc);
+  }
 
   // ---- per-band-shape tables (no integer division in the staging loops) ----
-  for (int e = tid; e < p.BPp; e += 256) {
+  for (int e = tid; e < p.BPp; e += NT) {
     int off = 0, info = 0xff;  // ib = 255 marks the padding position
     if (e < p.BP) {
       const int ib = e / ROW;
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(256, (T <= 9 ? 2 : 1)) void wgrad_kernel(const Wgra
     pixoff[e] = off;
     pixinfo[e] = info;
   }
-  for (int e = tid; e < p.IB * p.ImgS; e += 256) {
+  for (int e = tid; e < p.IB * p.ImgS; e += NT) {
     const int ib = e / p.ImgS;
     const int rem = e - ib * p.ImgS;
     const int ry = rem / p.Wst, rx = rem - ry * p.Wst;
@@ -92,12 +102,12 @@ __global__ __launch_bounds__(256, (T <= 9 ? 2 : 1)) void wgrad_kernel(const Wgra
     const int a0 = (band - ig * p.nbr) * p.R;
     const int n0 = ig * p.IB;
     __syncthreads();  // tables written / previous band fully consumed
-    if (!(p.dbg & 1) || band == bz) {
-    // Staging is latency bound (one workgroup per CU, 4 wavefronts).  Each lane decodes ITS positions once
-    // per band and then streams all channels / rows for them with U independent, unconditional loads in flight
-    // (out-of-image or out-of-range elements read a safe address and are zeroed by a select afterwards).
-    constexpr int U = (T == 16) ? 4 : 8;
-    // ---- dy slab: 32 x BPp; wavefront w stages rows w*8 .. w*8+7 ----
+    // Staging is latency bound (few wavefronts per CU).  Each lane decodes ITS positions once per band and then
+    // streams all channels / rows for them with U independent, unconditional loads in flight (out-of-image or
+    // out-of-range elements read a safe address and are zeroed by a select afterwards).
+    constexpr int U = 8;
+    constexpr int RPW = 32 / NW;  // dy rows per wavefront
+    // ---- dy slab: 32 x BPp ----
     for (int p0 = 0; p0 < p.BPp; p0 += 64) {
       const int pix = p0 + lane;
       const bool inb = pix < p.BPp;
@@ -106,22 +116,22 @@ __global__ __launch_bounds__(256, (T <= 9 ? 2 : 1)) void wgrad_kernel(const Wgra
       const int n = n0 + ib, a = a0 + al;
       const bool ok = inb && ib != 0xff && n < d.N && a < d.OH;
       const float* src = d.dy + (ok ? (long)n * d.dysn + a * d.OW + b : 0L);
-      float v[8];
+      float v[RPW];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = wave * 8 + u;
+      for (int u = 0; u < RPW; ++u) {
+        const int i = wave * RPW + u;
         v[u] = src[(ok && cout0 + i < d.Cout) ? (long)(cout0 + i) * d.dysc : 0L];
       }
       if (inb) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = wave * 8 + u;
+        for (int u = 0; u < RPW; ++u) {
+          const int i = wave * RPW + u;
           ldsY[i * p.YS + pix] = (ok && cout0 + i < d.Cout) ? v[u] : 0.f;
         }
       }
     }
-    // ---- input patch in logical (upsampled, zero padded) coordinates; wavefront w stages channels w*nch/4 .. ----
-    const int cpw = nch >> 2;  // nch is a multiple of 32
+    // ---- input patch in logical (upsampled, zero padded) coordinates; each wavefront stages nch / NW channels ----
+    const int cpw = nch / NW;  // nch is a multiple of 32, NW of 4 or 8
     for (int e0 = 0; e0 < perch; e0 += 64) {
       const int e = e0 + lane;
       const bool inb = e < perch;
@@ -136,20 +146,19 @@ __global__ __launch_bounds__(256, (T <= 9 ? 2 : 1)) void wgrad_kernel(const Wgra
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int ci = cin0 + wave * cpw + cb + u;
-          v[u] = src[(ok && ci < d.Cin) ? (long)ci * d.xsc : 0L];
+          v[u] = src[(ok && cb + u < cpw && ci < d.Cin) ? (long)ci * d.xsc : 0L];
         }
         if (inb) {
 #pragma unroll
           for (int u = 0; u < U; ++u) {
             const int c = wave * cpw + cb + u;
-            ldsX[c * p.XS + e] = (ok && cin0 + c < d.Cin) ? v[u] : 0.f;
+            if (cb + u < cpw) ldsX[c * p.XS + e] = (ok && cin0 + c < d.Cin) ? v[u] : 0.f;
           }
         }
       }
     }
-    }
     __syncthreads();
-    if (d.gb && bx == 0) {  // bias gradient: 8 threads per slab row, folded with wavefront shuffles
+    if (d.gb && bx == 0 && tid < 256) {  // bias gradient: 8 threads per slab row, folded with wavefront shuffles
       const float* row = ldsY + (tid >> 3) * p.YS;
       float part = 0.f;
       for (int pix = tid & 7; pix < p.BP; pix += 8) part += row[pix];
@@ -158,23 +167,23 @@ __global__ __launch_bounds__(256, (T <= 9 ? 2 : 1)) void wgrad_kernel(const Wgra
       part += __shfl_xor(part, 4, 64);
       bsum += part;  // every thread of the 8-group holds the row total; only (tid & 7) == 0 publishes it
     }
-    if (wave_active && !(p.dbg & 2)) {
+    if (wave_active) {
       // K loop, software pipelined by one step: the A value and the patch offset of step k+1 are fetched from LDS
-      // while the T MFMAs of step k issue (the B reads of a step depend on its offset).
+      // while the TPW MFMAs of step k issue (the B reads of a step depend on its offset).
       const float* arow = ldsY + j * p.YS + kh;
-      const float* xrow = ldsX + (wave * 32 + j) * p.XS;
+      const float* xrow = ldsX + (ct * 32 + j) * p.XS;
       float av = arow[0];
       int off = pixoff[kh];
       for (int kp = 0; kp < p.BPp; kp += 2) {
         const float* xb = xrow + off;
-        float bv[T];
+        float bv[TPW];
 #pragma unroll
-        for (int t = 0; t < T; ++t) bv[t] = xb[toff[t]];
+        for (int t = 0; t < TPW; ++t) bv[t] = xb[toff[t]];
         const int kn = (kp + 2 < p.BPp) ? kp + 2 : kp;
         const float av_n = arow[kn];
         const int off_n = pixoff[kn + kh];
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
         av = av_n;
         off = off_n;
       }
@@ -182,23 +191,24 @@ __global__ __launch_bounds__(256, (T <= 9 ? 2 : 1)) void wgrad_kernel(const Wgra
   }
 
   // ---- fold the partial sums into gW[o][c][t] (t fastest).  A lane owns (o, c) pairs with a stride of T floats
-  // between lanes, so direct atomics would touch a different cache line per lane; instead each wavefront
-  // transposes 8 output rows at a time through LDS and issues the atomics over consecutive addresses. ----
+  // between lanes, so direct atomics would touch a different cache line per lane; instead the wavefronts of one
+  // input tile transpose 8 output rows at a time through LDS and issue the atomics over consecutive addresses. ----
   __syncthreads();  // staging buffers are dead: reuse the LDS
   {
-    constexpr int ROWF = 32 * T;  // floats of one output row of this wavefront's 32-channel tile
-    float* tw = lds + wave * (8 * ROWF);
+    constexpr int ROWF = 32 * T;  // floats of one output row of a 32-channel input tile
+    float* tw = lds + ct * (8 * ROWF);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (wave_active) {
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+        for (int t = 0; t < TPW; ++t)
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) tw[(rr + 4 * kh) * ROWF + j * T + t] = d.scale * acc[t][4 * q + rr];
+          for (int rr = 0; rr < 4; ++rr)
+            tw[(rr + 4 * kh) * ROWF + j * T + tg * TPW + t] = d.scale * acc[t][4 * q + rr];
       }
       __syncthreads();
-      if (wave_active && !(p.dbg & 4)) {
-        for (int e = lane; e < 8 * ROWF; e += 64) {
+      if (wave_active) {
+        for (int e = tg * 64 + lane; e < 8 * ROWF; e += 64 * TG) {
           const int rl = e / ROWF;
           const int rem = e - rl * ROWF;
           const int o = cout0 + 8 * q + rl;
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(256, (T <= 9 ? 2 : 1)) void wgrad_kernel(const Wgra
       __syncthreads();
     }
   }
-  if (d.gb && bx == 0 && (tid & 7) == 0 && cout0 + (tid >> 3) < d.Cout)
+  if (d.gb && bx == 0 && tid < 256 && (tid & 7) == 0 && cout0 + (tid >> 3) < d.Cout)
     atomicAdd(d.gb + cout0 + (tid >> 3), d.scale * bsum);
 }
 
@@ -254,6 +264,7 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p) {
   // K split: enough positions per workgroup that the closing atomics stay a small fraction of the MFMA work
   const long positions = (long)d.N * d.OH * d.OW;
   int S = (int)((positions + 2591) / 2592);
+  if (T == 16) S = (int)((positions + 1295) / 1296);
   if (S > p.nbands) S = p.nbands;
   if (S < 1) S = 1;
   p.S = S;
@@ -264,14 +275,14 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p) {
   return std::max(stage, epilogue);
 }
 
-template <int T>
+template <int T, int TPW>
 static void launch_T(const WgradPlan* plans, const int* starts, int nplans, int total_wg, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T, TPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(wgrad_kernel<T>, dim3(total_wg), dim3(256), lds, s, plans, starts, nplans);
+  hipLaunchKernelGGL((wgrad_kernel<T, TPW>), dim3(total_wg), dim3(256 * (T / TPW)), lds, s, plans, starts, nplans);
   DBM_HIP(hipGetLastError());
 }
 
@@ -326,9 +337,9 @@ void WgradBatch::launch(hipStream_t s) {
   for (int g = 0; g < 3; ++g) {
     if (nplans[g] == 0) continue;
     if (g_profiler.enabled) g_profiler.begin(s, 1, flops[g]);
-    if (g == 0) launch_T<1>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
-    else if (g == 1) launch_T<9>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
-    else launch_T<16>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    if (g == 0) launch_T<1, 1>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else if (g == 1) launch_T<9, 9>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else launch_T<16, 8>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     if (g_profiler.enabled) g_profiler.end(s);
   }
 }

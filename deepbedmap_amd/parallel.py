@@ -80,7 +80,7 @@ class DataParallel:
         """Sum the gradient arena over ranks; returns the scale (1/world) the optimizer applies."""
         if self.world > 1:
             t = self.grad_view(model)
-            shared = id(model.ctx) in self._shared_stream
+            shared = (not self.on_gpu) or id(model.ctx) in self._shared_stream
             if self.on_gpu and not shared:
                 model.ctx.synchronize()  # libdbm's own stream: order the collective after it by a host wait
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)

@@ -268,9 +268,14 @@ def test_two_training_iterations_match_oracle(dbm):
                 # borders: their (tiny, ~eps-sized) gradients tolerate less
                 atol = 1.5e-4 if "offset_conv" in k else 2e-5
                 assert np.allclose(step_got[strong], step_ref[strong], atol=atol), k
-    for name in od.persistent:  # BatchNorm running statistics after 4 training-mode forwards
-        if not name.endswith("/N"):
-            assert rel(d._tensors[name].array, od.persistent[name]) < 1e-3, name
+    # BatchNorm running statistics after 4 training-mode forwards, the last 2 on weights that took one Adam step
+    # (whose direction is rounding-noise dependent for near-zero gradients): loose here, 1e-5 in the parity test above
+    for name in od.persistent:
+        if name.endswith("/avg_var"):
+            assert rel(d._tensors[name].array, od.persistent[name]) < 5e-2, name
+        elif name.endswith("/avg_mean"):
+            std = np.sqrt(od.persistent[name.replace("avg_mean", "avg_var")])
+            assert np.abs(d._tensors[name].array - od.persistent[name]).max() < 5e-2 * std.max(), name
     # evaluation mode (dev loop, srgan_train.py:1311-1327)
     ref_e = otrain.train_eval_generator(arrays, og, od, train=False)
     got_e = dbm.train_eval_generator(arrays, g, d, train=False)
