@@ -83,6 +83,14 @@ int dbm_init(int hip_device, dbm_ctx** out) {
   c->device = hip_device;
   DBM_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
+  {  // the side stream only carries filler work (weight gradients): lowest priority, so that the latency-bound
+     // main chain gets CUs first whenever both have workgroups ready
+    int least = 0, greatest = 0;
+    DBM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    DBM_HIP(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least));
+  }
+  for (auto& e : c->ev_fork) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  DBM_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   DBM_HIP(hipMalloc((void**)&c->zeros, 256));
   DBM_HIP(hipMemset(c->zeros, 0, 256));
   float w[9];
@@ -107,6 +115,10 @@ int dbm_shutdown(dbm_ctx* ctx) {
   (void)hipFree(ctx->ssim_win[1]);
   ctx->loss_tmp.release();
   for (auto& b : ctx->stage) b.release();
+  (void)hipStreamSynchronize(ctx->side);
+  (void)hipStreamDestroy(ctx->side);
+  for (auto& e : ctx->ev_fork) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(ctx->ev_join);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   DBM_API_END
@@ -120,6 +132,7 @@ int dbm_set_stream(dbm_ctx* ctx, void* hip_stream) {
 
 int dbm_synchronize(dbm_ctx* ctx) {
   DBM_API_BEGIN(ctx)
+  DBM_HIP(hipStreamSynchronize(ctx->side));
   DBM_HIP(hipStreamSynchronize(ctx->stream));
   DBM_API_END
 }
@@ -475,8 +488,8 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   launch_ragan_loss(lr, lf, N, 1, 0, metrics, train ? gr : nullptr, train ? gf : nullptr, s);
   if (train) {
     DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));  // cleargrads (:1162)
-    d->backward(0, gr);                                                  // d_loss.backward() (:1163)
-    d->backward(1, gf);
+    d->backward(0, gr, false);                                           // d_loss.backward() (:1163); its weight
+    d->backward(1, gf, true);                                            // gradients overlap the second pass
   }
   DBM_API_END
 }

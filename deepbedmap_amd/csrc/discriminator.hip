@@ -100,7 +100,7 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
   }
 }
 
-void Discriminator::backward(int slot, const float* glogits) {
+void Discriminator::backward(int slot, const float* glogits, bool join) {
   Cache& c = cache[slot];
   DBM_CHECK(c.valid, "discriminator backward without a retained training-mode forward");
   hipStream_t s = ctx->stream;
@@ -111,7 +111,7 @@ void Discriminator::backward(int slot, const float* glogits) {
   g_l1.ensure(n * 100);
   g_h[0].ensure(n * 64 * c.H * c.W);
   g_h[1].ensure(n * 64 * c.H * c.W);
-  for (int i = 1; i < 10; ++i) g_z[i].ensure(n * DC_O[i] * hs[i + 1] * ws[i + 1]);
+  for (int i = 1; i < 10; ++i) g_z[slot][i].ensure(n * DC_O[i] * hs[i + 1] * ws[i + 1]);
   // linear_2, then linear_1 (through its LeakyReLU)
   launch_linear_bwd(c.l1.p, P(T_l2W), glogits, nullptr, g_l1.p, G(T_l2W), G(T_l2b), N, 100, 1, SLOPE, s);
   float* gh = g_h[0].p;
@@ -120,13 +120,13 @@ void Discriminator::backward(int slot, const float* glogits) {
   for (int i = 9; i >= 1; --i) {
     const IgLayer& L = layers[L_conv[i]];
     const int hin = hs[i], win = ws[i], ho = hs[i + 1], wo = ws[i + 1];
-    launch_bn_train_bwd(c.z[i].p, gh, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, g_z[i].p, G(T_bn[i][0]),
+    launch_bn_train_bwd(c.z[i].p, gh, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, g_z[slot][i].p, G(T_bn[i][0]),
                         G(T_bn[i][1]), nullptr, N, DC_O[i], ho * wo, SLOPE, s);
-    run_wgrad(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, g_z[i].p, (long)DC_O[i] * ho * wo, ho, wo, N, 1.f,
+    run_wgrad(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, g_z[slot][i].p, (long)DC_O[i] * ho * wo, ho, wo, N, 1.f,
               &wb[slot]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
-    d.x = g_z[i].p; d.xsn = (long)DC_O[i] * ho * wo; d.N = N;
+    d.x = g_z[slot][i].p; d.xsn = (long)DC_O[i] * ho * wo; d.N = N;
     d.y = gh_next; d.ysn = (long)DC_C[i] * hin * win; d.s1 = 1.f; d.s2 = 1.f;
     if (i == 1) {  // through conv_layer0's LeakyReLU
       d.mask = c.h[0].p; d.masksn = 64L * c.H * c.W; d.mask_c0 = 0;
@@ -141,5 +141,9 @@ void Discriminator::backward(int slot, const float* glogits) {
     q.Cout = 64; q.OH = c.H; q.OW = c.W; q.KH = q.KW = 3; q.stride = 1; q.pad = 1; q.N = N;
     launch_smallcin_conv_wgrad(q, gh, 64L * c.H * c.W, G(T_c0W), G(T_c0b), s);
   }
-  wb[slot].launch(s);  // conv_layer1..9 weight gradients: one launch per kernel size
+  // conv_layer1..9 weight gradients: one launch per kernel size, on the side stream (they overlap the other
+  // batch's backward pass in the D-step); each slot has its own gradient slabs g_z[slot][*]
+  ctx->fork_to_side(slot);
+  wb[slot].launch(ctx->side);
+  if (join) ctx->join_side();
 }

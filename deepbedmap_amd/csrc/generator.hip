@@ -105,7 +105,8 @@ void Generator::ensure_ws(int N, int H, int W, bool train) {
     }
     have_graph = false;
   }
-  if (!same || tr != wsTrain) wb.reset();  // buffers may have moved: re-plan the batched weight gradients
+  if (!same || tr != wsTrain)
+    for (auto& b : wbs) b.reset();  // buffers may have moved: re-plan the batched weight gradients
   wsN = N; wsH = H; wsW = W; wsTrain = tr;
 }
 
@@ -206,7 +207,7 @@ void Generator::backward(const float* gy) {
   launch_gemv_cols_wgrad(col2.p, gy, G(T_def2W), G(T_def2b), N, 576, (int)P4, s);
   {
     const IgLayer& L = layers[L_off2];
-    run_wgrad(L, a51.p, 64 * P4, H4, W4, 0, goff2.p, 32 * P4, H4, W4, N, 1.f, &wb);
+    run_wgrad(L, a51.p, 64 * P4, H4, W4, 0, goff2.p, 32 * P4, H4, W4, N, 1.f, &wbs[0]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = goff2.p; d.xsn = 32 * P4; d.N = N;
@@ -217,7 +218,7 @@ void Generator::backward(const float* gy) {
   // ---- final_conv_layer1 (deformable, 64 -> 64): g_a51 now holds d loss / d (pre-activation) ----
   {
     const IgLayer& L = layers[L_def1];
-    run_wgrad(L, col1.p, 576 * P4, H4, W4, 0, g_a51.p, 64 * P4, H4, W4, N, 1.f, &wb);
+    run_wgrad(L, col1.p, 576 * P4, H4, W4, 0, g_a51.p, 64 * P4, H4, W4, N, 1.f, &wbs[0]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = g_a51.p; d.xsn = 64 * P4; d.N = N;
@@ -228,7 +229,7 @@ void Generator::backward(const float* gy) {
   }
   {
     const IgLayer& L = layers[L_off1];
-    run_wgrad(L, a42.p, 64 * P4, H4, W4, 0, goff1.p, 32 * P4, H4, W4, N, 1.f, &wb);
+    run_wgrad(L, a42.p, 64 * P4, H4, W4, 0, goff1.p, 32 * P4, H4, W4, N, 1.f, &wbs[0]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = goff1.p; d.xsn = 32 * P4; d.N = N;
@@ -239,7 +240,7 @@ void Generator::backward(const float* gy) {
   // ---- post_upsample_conv_layer_2 on resize(a41) ----
   {
     const IgLayer& L = layers[L_up2];
-    run_wgrad(L, a41.p, 64 * 4 * hw, 2 * h, 2 * w, 1, g_a42.p, 64 * P4, H4, W4, N, 1.f, &wb);
+    run_wgrad(L, a41.p, 64 * 4 * hw, 2 * h, 2 * w, 1, g_a42.p, 64 * P4, H4, W4, N, 1.f, &wbs[0]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = g_a42.p; d.xsn = 64 * P4; d.N = N;
@@ -250,7 +251,7 @@ void Generator::backward(const float* gy) {
   // ---- post_upsample_conv_layer_1 on resize(a3) ----
   {
     const IgLayer& L = layers[L_up1];
-    run_wgrad(L, a3.p, 64 * hw, h, w, 1, g_z41.p, 64 * 4 * hw, 2 * h, 2 * w, N, 1.f, &wb);
+    run_wgrad(L, a3.p, 64 * hw, h, w, 1, g_z41.p, 64 * 4 * hw, 2 * h, 2 * w, N, 1.f, &wbs[0]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = g_z41.p; d.xsn = 64 * 4 * hw; d.N = N;
@@ -261,15 +262,26 @@ void Generator::backward(const float* gy) {
   // ---- post_residual_conv_layer: a3 = a1 + conv(a2) ----
   {
     const IgLayer& L = layers[L_post];
-    run_wgrad(L, cat[nrdb].p, 192 * hw, h, w, 0, g_a3.p, 64 * hw, h, w, N, 1.f, &wb);
+    run_wgrad(L, cat[nrdb].p, 192 * hw, h, w, 0, g_a3.p, 64 * hw, h, w, N, 1.f, &wbs[0]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = g_a3.p; d.xsn = 64 * hw; d.N = N;
     d.y = dA[nrdb].p; d.ysn = 64 * hw; d.s1 = 1.f; d.s2 = 1.f;
     run_dgrad(L, d, h, w);
   }
+  // Weight gradients never feed the data-gradient chain, and that chain (one short, latency-bound kernel per conv)
+  // leaves most of the chip idle: the batches go to the side stream as soon as their inputs are final.
+  ctx->fork_to_side(0);
+  wbs[0].launch(ctx->side);
   // ---- trunk, last dense block first ----
+  int prev_grp = -1;
   for (int j = nrdb - 1; j >= 0; --j) {
+    const int grp = 1 + ((j / 3) * 4) / n_rrdb;  // 4 groups of residual-in-residual blocks
+    if (prev_grp >= 0 && grp != prev_grp) {
+      ctx->fork_to_side(prev_grp);
+      wbs[prev_grp].launch(ctx->side);
+    }
+    prev_grp = grp;
     const float* Gout = dA[j + 1].p;
     const long gsn = (j + 1 == nrdb) ? 64 * hw : 192 * hw;
     const bool third = (j % 3 == 2), first = (j % 3 == 0);
@@ -278,7 +290,7 @@ void Generator::backward(const float* gy) {
     const float* C = cat[j].p;
     {  // conv_layer5: out = a5*rs + a0
       const IgLayer& L = layers[L_rdb[j * 5 + 4]];
-      run_wgrad(L, C, 192 * hw, h, w, 0, Gout, gsn, h, w, N, sc, &wb);
+      run_wgrad(L, C, 192 * hw, h, w, 0, Gout, gsn, h, w, N, sc, &wbs[grp]);
       ConvDesc d;
       memset(&d, 0, sizeof(d));
       d.x = Gout; d.xsn = gsn; d.N = N;
@@ -291,7 +303,7 @@ void Generator::backward(const float* gy) {
     for (int k = 3; k >= 0; --k) {  // conv_layer4 .. conv_layer1
       const int lo = 64 + 32 * k;   // channel offset of a_{k+1} = number of input channels of this conv
       const IgLayer& L = layers[L_rdb[j * 5 + k]];
-      run_wgrad(L, C, 192 * hw, h, w, 0, D + (long)lo * hw, 192 * hw, h, w, N, 1.f, &wb);
+      run_wgrad(L, C, 192 * hw, h, w, 0, D + (long)lo * hw, 192 * hw, h, w, N, 1.f, &wbs[grp]);
       ConvDesc d;
       memset(&d, 0, sizeof(d));
       d.x = D + (long)lo * hw; d.xsn = 192 * hw; d.N = N;
@@ -313,7 +325,7 @@ void Generator::backward(const float* gy) {
   // ---- pre_residual_conv_layer and the input block ----
   {
     const IgLayer& L = layers[L_pre];
-    run_wgrad(L, a0.p, 128 * hw, h, w, 0, dA[0].p, 192 * hw, h, w, N, 1.f, &wb);
+    run_wgrad(L, a0.p, 128 * hw, h, w, 0, dA[0].p, 192 * hw, h, w, N, 1.f, &wbs[5]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = dA[0].p; d.xsn = 192 * hw; d.N = N;
@@ -332,6 +344,8 @@ void Generator::backward(const float* gy) {
       launch_smallcin_conv_wgrad(q, g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), s);
     }
   }
-  // every MFMA weight gradient of this pass: one launch per kernel size (their inputs are all retained above)
-  wb.launch(s);
+  ctx->fork_to_side(6);
+  if (prev_grp >= 0) wbs[prev_grp].launch(ctx->side);
+  wbs[5].launch(ctx->side);
+  ctx->join_side();  // the optimizer (and the next cleargrads) must see every gradient
 }

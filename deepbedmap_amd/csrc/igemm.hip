@@ -27,7 +27,11 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int T, int WAVES>
+// NPB > 0: the layer has at most NPB channel pairs per wavefront (the 9x9 trunk with 8/16-way split-K): ALL gathered
+// B operands of the wavefront's K slice are requested up front -- they are first-touch reads of activations another
+// XCD just wrote (Infinity-Cache latency, > 1 us), paid once per kernel instead of once per channel pair -- and only
+// the (L2-hot) weights are streamed with a one-pair prefetch.  NPB == 0: streaming loop, one pair of prefetch.
+template <int T, int WAVES, int NPB>
 __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // WAVES * 1024 floats
   const int tid = threadIdx.x;
@@ -72,32 +76,62 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  float av[T], bv[T];
+  if constexpr (NPB > 0) {
+    float bq[NPB][T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    bv[t] = xn[xoff[t]];
-    av[t] = wlane[t * wtap];
-  }
-  for (int p = 0; p < npairs; ++p) {
-    // prefetch the next channel pair (the last iteration re-reads the current one: harmless, keeps the loop uniform)
-    const int pn = (p + 1 < npairs) ? p + 1 : p;
-    const float* xc = xn + pn * xstep;
-    const float* wc = wlane + pn * wstep;
-    float an[T], bn[T];
+    for (int q = 0; q < NPB; ++q) {
+      if (q < npairs) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      bn[t] = xc[xoff[t]];
-      an[t] = wc[t * wtap];
+        for (int t = 0; t < T; ++t) bq[q][t] = xn[q * xstep + xoff[t]];
+      }
     }
+    float av[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const float bm = ((okmask >> t) & 1u) ? bv[t] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bm, acc, 0, 0, 0);
+    for (int t = 0; t < T; ++t) av[t] = wlane[t * wtap];
+#pragma unroll
+    for (int q = 0; q < NPB; ++q) {
+      if (q < npairs) {
+        float an[T];
+        const float* wc = wlane + ((q + 1 < npairs) ? q + 1 : q) * wstep;
+#pragma unroll
+        for (int t = 0; t < T; ++t) an[t] = wc[t * wtap];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float bm = ((okmask >> t) & 1u) ? bq[q][t] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bm, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) av[t] = an[t];
+      }
     }
+  } else {
+    float av[T], bv[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      av[t] = an[t];
-      bv[t] = bn[t];
+      bv[t] = xn[xoff[t]];
+      av[t] = wlane[t * wtap];
+    }
+    for (int p = 0; p < npairs; ++p) {
+      // prefetch the next channel pair (the last iteration re-reads the current one: harmless, keeps the loop uniform)
+      const int pn = (p + 1 < npairs) ? p + 1 : p;
+      const float* xc = xn + pn * xstep;
+      const float* wc = wlane + pn * wstep;
+      float an[T], bn[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        bn[t] = xc[xoff[t]];
+        an[t] = wc[t * wtap];
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float bm = ((okmask >> t) & 1u) ? bv[t] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bm, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        av[t] = an[t];
+        bv[t] = bn[t];
+      }
     }
   }
 
@@ -168,9 +202,18 @@ void KernelProfiler::collect(double out[8]) {
   recs.clear();
 }
 
+constexpr int IGEMM_NPB = 6;  // channel pairs a wavefront may hold entirely in registers (T = 9 -> 54 VGPRs)
+
 template <int T, int WAVES>
 static void launch_tw(const ConvDesc& d, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+  const int npairs = d.Cin / WAVES / 2;
+  if constexpr (T <= 9 && WAVES >= 8) {
+    if (npairs <= IGEMM_NPB) {
+      hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, IGEMM_NPB>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, 0>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
 }
 
 template <int T>

@@ -16,6 +16,11 @@ struct dbm_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
+  hipStream_t side = nullptr;        // library-owned side stream: independent work overlapping the main chain
+  hipEvent_t ev_fork[8] = {};        // main -> side dependencies
+  hipEvent_t ev_join = nullptr;      // side -> main
+  void fork_to_side(int k);          // side waits for everything enqueued on `stream` so far
+  void join_side();                  // `stream` waits for everything enqueued on `side` so far
   std::string err;
   float* zeros = nullptr;     // 256 B of zeros (igemm out-of-image taps)
   float* ssim_win[2] = {nullptr, nullptr};  // 9-tap 1-D windows: gaussian(1.5), uniform
@@ -91,7 +96,8 @@ struct Generator : dbm_model {
   bool wsTrain = false;
   bool have_graph = false;
   const float* bw_in[4] = {nullptr, nullptr, nullptr, nullptr};  // forward inputs, needed by the input-block wgrad
-  WgradBatch wb;  // batched weight gradients of one backward pass
+  static const int NWB = 6;
+  WgradBatch wbs[NWB];  // batched weight gradients: tail, 4 trunk groups, pre-residual (launched on the side stream)
   std::vector<DevBuf> cat, dA;
   DevBuf in_x, in_w1, in_w2, in_w3, a0, a3, a41, a42, off1, off2, col1, col2, a51, yout;
   DevBuf g_a0, g_a3, g_u1, g_z41, g_u2, g_a42, goff1, goff2, gcol, g_a51, g_y;
@@ -111,9 +117,9 @@ struct Discriminator : dbm_model {
     bool valid = false;
     DevBuf img, h[10], z[10], mean[10], istd[10], l1, out;
   } cache[2];
-  DevBuf g_h[2], g_z[10], g_l1, g_out;
+  DevBuf g_h[2], g_z[2][10], g_l1, g_out;
   WgradBatch wb[2];  // batched weight gradients, one plan table per retained graph (real / fake batch)
   Discriminator(dbm_ctx* c);
   void forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot);
-  void backward(int slot, const float* glogits);
+  void backward(int slot, const float* glogits, bool join = true);
 };

@@ -16,6 +16,16 @@ void DevBuf::ensure(size_t count, bool zero) {
   (void)zero;
 }
 
+void dbm_ctx::fork_to_side(int k) {
+  DBM_HIP(hipEventRecord(ev_fork[k & 7], stream));
+  DBM_HIP(hipStreamWaitEvent(side, ev_fork[k & 7], 0));
+}
+
+void dbm_ctx::join_side() {
+  DBM_HIP(hipEventRecord(ev_join, side));
+  DBM_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+}
+
 void DevBuf::release() {
   if (p) (void)hipFree(p);
   p = nullptr;

@@ -263,8 +263,7 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p) {
   p.nbands = imgGroups * p.nbr;
   // K split: enough positions per workgroup that the closing atomics stay a small fraction of the MFMA work
   const long positions = (long)d.N * d.OH * d.OW;
-  int S = (int)((positions + 2591) / 2592);
-  if (T == 16) S = (int)((positions + 1295) / 1296);
+  int S = (int)((positions + 647) / 648);  // ~8 images of the 9x9 trunk per workgroup
   if (S > p.nbands) S = p.nbands;
   if (S < 1) S = 1;
   p.S = S;
