@@ -89,6 +89,7 @@ int dbm_init(int hip_device, dbm_ctx** out) {
     DBM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     DBM_HIP(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least));
   }
+  for (auto& st : c->chain) DBM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   for (auto& e : c->ev_fork) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   DBM_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   DBM_HIP(hipMalloc((void**)&c->zeros, 256));
@@ -117,6 +118,7 @@ int dbm_shutdown(dbm_ctx* ctx) {
   for (auto& b : ctx->stage) b.release();
   (void)hipStreamSynchronize(ctx->side);
   (void)hipStreamDestroy(ctx->side);
+  for (auto& st : ctx->chain) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   for (auto& e : ctx->ev_fork) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ctx->ev_join);
   (void)hipStreamDestroy(ctx->own_stream);
@@ -156,13 +158,18 @@ int dbm_profile_end(dbm_ctx* ctx, double out[8]) {
 
 int dbm_malloc(dbm_ctx* ctx, size_t bytes, void** dptr) {
   DBM_API_BEGIN(ctx)
-  DBM_HIP(hipMalloc(dptr, bytes ? bytes : 4));
+  // 128-byte guards on both sides (see DevBuf): kernels may read one word outside a tensor
+  char* base = nullptr;
+  DBM_HIP(hipMalloc((void**)&base, bytes + 256));
+  DBM_HIP(hipMemset(base, 0, bytes + 256));
+  DBM_HIP(hipDeviceSynchronize());
+  *dptr = base + 128;
   DBM_API_END
 }
 int dbm_free(dbm_ctx* ctx, void* dptr) {
   DBM_API_BEGIN(ctx)
   DBM_HIP(hipStreamSynchronize(ctx->stream));
-  DBM_HIP(hipFree(dptr));
+  DBM_HIP(hipFree(dptr ? (char*)dptr - 128 : nullptr));
   DBM_API_END
 }
 int dbm_memcpy_h2d(dbm_ctx* ctx, void* dst, const void* src, size_t bytes) {

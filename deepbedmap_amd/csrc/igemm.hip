@@ -31,7 +31,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // B operands of the wavefront's K slice are requested up front -- they are first-touch reads of activations another
 // XCD just wrote (Infinity-Cache latency, > 1 us), paid once per kernel instead of once per channel pair -- and only
 // the (L2-hot) weights are streamed with a one-pair prefetch.  NPB == 0: streaming loop, one pair of prefetch.
-template <int T, int WAVES, int NPB>
+// ROW (3x3, stride 1, no resize only): the three taps of a kernel row are adjacent in memory, so they are fetched by
+// ONE 12-byte load per lane instead of three dword loads -- the texture-addresser, not the MFMA pipe, is what the
+// gathers saturate first.  The word before / after a row may belong to the neighbouring row, channel or image (or to
+// the 128-byte guard every activation buffer carries); such taps are zeroed by the validity mask as before.
+struct __attribute__((packed, aligned(4))) f32x3 { float x, y, z; };
+
+template <int T, int WAVES, int NPB, bool ROW>
 __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // WAVES * 1024 floats
   const int tid = threadIdx.x;
@@ -72,6 +78,30 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     okmask |= ok ? (1u << t) : 0u;
   }
 
+  int roff[3] = {0, 0, 0};
+  if constexpr (ROW) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = a + d.dy[3 * r];
+      roff[r] = (pv && (unsigned)iy < (unsigned)Hl) ? iy * d.Win + b - 1 : 0;
+    }
+  }
+  const bool rev = ROW && d.dx[0] > 0;  // data-gradient tap order: dx = +1, 0, -1
+  auto load_b = [&](const float* xc, float (&out)[T]) {
+    if constexpr (ROW) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const f32x3 v = *reinterpret_cast<const f32x3*>(xc + roff[r]);
+        out[3 * r + 0] = rev ? v.z : v.x;
+        out[3 * r + 1] = v.y;
+        out[3 * r + 2] = rev ? v.x : v.z;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < T; ++t) out[t] = xc[xoff[t]];
+    }
+  };
+
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -81,8 +111,7 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
 #pragma unroll
     for (int q = 0; q < NPB; ++q) {
       if (q < npairs) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) bq[q][t] = xn[q * xstep + xoff[t]];
+        load_b(xn + q * xstep, bq[q]);
       }
     }
     float av[T];
@@ -107,10 +136,8 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
   } else {
     float av[T], bv[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      bv[t] = xn[xoff[t]];
-      av[t] = wlane[t * wtap];
-    }
+    for (int t = 0; t < T; ++t) av[t] = wlane[t * wtap];
+    load_b(xn, bv);
     for (int p = 0; p < npairs; ++p) {
       // prefetch the next channel pair (the last iteration re-reads the current one: harmless, keeps the loop uniform)
       const int pn = (p + 1 < npairs) ? p + 1 : p;
@@ -118,10 +145,8 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
       const float* wc = wlane + pn * wstep;
       float an[T], bn[T];
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        bn[t] = xc[xoff[t]];
-        an[t] = wc[t * wtap];
-      }
+      for (int t = 0; t < T; ++t) an[t] = wc[t * wtap];
+      load_b(xc, bn);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float bm = ((okmask >> t) & 1u) ? bv[t] : 0.f;
@@ -204,16 +229,31 @@ void KernelProfiler::collect(double out[8]) {
 
 constexpr int IGEMM_NPB = 6;  // channel pairs a wavefront may hold entirely in registers (T = 9 -> 54 VGPRs)
 
-template <int T, int WAVES>
-static void launch_tw(const ConvDesc& d, dim3 grid, hipStream_t s) {
+template <int T, int WAVES, bool ROW>
+static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s) {
   const int npairs = d.Cin / WAVES / 2;
   if constexpr (T <= 9 && WAVES >= 8) {
     if (npairs <= IGEMM_NPB) {
-      hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, IGEMM_NPB>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+      hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, IGEMM_NPB, ROW>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
       return;
     }
   }
-  hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, 0>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+  hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, 0, ROW>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+}
+
+template <int T, int WAVES>
+static void launch_tw(const ConvDesc& d, dim3 grid, hipStream_t s) {
+  if constexpr (T == 9) {
+    // row-contiguous taps: 3x3, unit stride, no folded resize, taps ordered (dy, dx) with dx = -1,0,1 or 1,0,-1
+    const bool row = d.sin == 1 && d.ups == 0 && d.dy[0] == d.dy[1] && d.dy[1] == d.dy[2] && d.dx[1] == 0 &&
+                     d.dx[0] == -d.dx[2] && (d.dx[0] == 1 || d.dx[0] == -1) && d.dy[3] == d.dy[5] && d.dy[6] == d.dy[8] &&
+                     d.dx[3] == d.dx[0] && d.dx[6] == d.dx[0] && d.dx[4] == 0 && d.dx[7] == 0;
+    if (row) {
+      launch_twr<T, WAVES, true>(d, grid, s);
+      return;
+    }
+  }
+  launch_twr<T, WAVES, false>(d, grid, s);
 }
 
 template <int T>

@@ -19,6 +19,8 @@ struct dbm_ctx {
   hipStream_t side = nullptr;        // library-owned side stream: independent work overlapping the main chain
   hipEvent_t ev_fork[8] = {};        // main -> side dependencies
   hipEvent_t ev_join = nullptr;      // side -> main
+  hipStream_t chain[3] = {};         // library-owned streams for the batch-split generator chains
+  void fork(hipStream_t from, hipStream_t to, int k);  // `to` waits for everything enqueued on `from` so far
   void fork_to_side(int k);          // side waits for everything enqueued on `stream` so far
   void join_side();                  // `stream` waits for everything enqueued on `side` so far
   std::string err;

@@ -1,14 +1,18 @@
 // Shared model machinery: tensor tables, arenas, packed-weight caches, conv descriptors.
 #include "model.h"
 
+static const size_t GUARD = 32;  // floats on each side: the row-tap loads of igemm touch one word outside a tensor
+
 void DevBuf::ensure(size_t count, bool zero) {
   if (count > n) {
-    if (p) DBM_HIP(hipFree(p));
+    if (p) DBM_HIP(hipFree(p - GUARD));
     p = nullptr;
-    DBM_HIP(hipMalloc((void**)&p, count * sizeof(float)));
+    float* base = nullptr;
+    DBM_HIP(hipMalloc((void**)&base, (count + 2 * GUARD) * sizeof(float)));
     n = count;
     zero = true;  // fresh allocations are always zeroed (padding channels rely on it)
-    DBM_HIP(hipMemset(p, 0, count * sizeof(float)));
+    DBM_HIP(hipMemset(base, 0, (count + 2 * GUARD) * sizeof(float)));
+    p = base + GUARD;
     // the memset runs on the NULL stream, which the context's non-blocking stream does not wait for
     DBM_HIP(hipDeviceSynchronize());
     return;
@@ -21,13 +25,18 @@ void dbm_ctx::fork_to_side(int k) {
   DBM_HIP(hipStreamWaitEvent(side, ev_fork[k & 7], 0));
 }
 
+void dbm_ctx::fork(hipStream_t from, hipStream_t to, int k) {
+  DBM_HIP(hipEventRecord(ev_fork[k & 7], from));
+  DBM_HIP(hipStreamWaitEvent(to, ev_fork[k & 7], 0));
+}
+
 void dbm_ctx::join_side() {
   DBM_HIP(hipEventRecord(ev_join, side));
   DBM_HIP(hipStreamWaitEvent(stream, ev_join, 0));
 }
 
 void DevBuf::release() {
-  if (p) (void)hipFree(p);
+  if (p) (void)hipFree(p - GUARD);
   p = nullptr;
   n = 0;
 }
