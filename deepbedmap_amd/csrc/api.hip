@@ -637,7 +637,6 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
   DevBuf col, gcol;
   col.ensure((size_t)N * C * 9 * P);
   launch_deform_sample(x, off, col.p, N, C, H, W, 18 * P, s);
-  DBM_HIP(hipMemsetAsync(gx, 0, sizeof(float) * N * C * P, s));
   if (O == 1) {
     launch_deform_backward(x, off, nullptr, w, gy, gx, goff, N, C, H, W, 18 * P, s);
     launch_gemv_cols_wgrad(col.p, gy, gw, gb, N, C * 9, (int)P, s);

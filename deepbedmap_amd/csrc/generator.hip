@@ -230,7 +230,6 @@ void Generator::backward(const float* gy) {
   const long hw = (long)h * w, P4 = 16 * hw;
   const int H4 = 4 * h, W4 = 4 * w, nrdb = 3 * n_rrdb;
   // ---- final_conv_layer2 (deformable, 64 -> 1) ----
-  DBM_HIP(hipMemsetAsync(g_a51.p, 0, sizeof(float) * N * 64 * P4, s));
   launch_deform_backward(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, goff2.p, N, 64, H4, W4, 32 * P4, s);
   launch_gemv_cols_wgrad(col2.p, gy, G(T_def2W), G(T_def2b), N, 576, (int)P4, s);
   {
@@ -252,7 +251,6 @@ void Generator::backward(const float* gy) {
     d.x = g_a51.p; d.xsn = 64 * P4; d.N = N;
     d.y = gcol.p; d.ysn = 576 * P4; d.s1 = 1.f; d.s2 = 1.f;
     run_dgrad(L, d, H4, W4);
-    DBM_HIP(hipMemsetAsync(g_a42.p, 0, sizeof(float) * N * 64 * P4, s));
     launch_deform_backward(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, goff1.p, N, 64, H4, W4, 32 * P4, s);
   }
   {
@@ -301,11 +299,25 @@ void Generator::backward(const float* gy) {
   // leaves most of the chip idle: the batches go to the side stream as soon as their inputs are final.
   ctx->fork_to_side(0);
   wbs[0].launch(ctx->side);
-  // ---- trunk, last dense block first ----
+  // ---- trunk, last dense block first; like the forward, as `nsplit` image ranges on separate streams ----
+  const int nsplit = trunk_split(N, hw);
+  const int Nc = N / nsplit;
+  auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[c - 1]; };
+  auto chunk = [&](ConvDesc d, int c) {  // descriptor restricted to image range c
+    const long n0 = (long)c * Nc;
+    d.x += n0 * d.xsn; d.y += n0 * d.ysn; d.N = Nc;
+    if (d.r1) d.r1 += n0 * d.r1sn;
+    if (d.r2) d.r2 += n0 * d.r2sn;
+    if (d.mask) d.mask += n0 * d.masksn;
+    return d;
+  };
+  auto join_chains = [&]() { for (int c = 1; c < nsplit; ++c) ctx->fork(ctx->chain[c - 1], s, 7); };
+  for (int c = 1; c < nsplit; ++c) ctx->fork(s, ctx->chain[c - 1], 7);
   int prev_grp = -1;
   for (int j = nrdb - 1; j >= 0; --j) {
     const int grp = 1 + ((j / 3) * 4) / n_rrdb;  // 4 groups of residual-in-residual blocks
     if (prev_grp >= 0 && grp != prev_grp) {
+      join_chains();
       ctx->fork_to_side(prev_grp);
       wbs[prev_grp].launch(ctx->side);
     }
@@ -326,7 +338,7 @@ void Generator::backward(const float* gy) {
       d.s1 = sc; d.s2 = 1.f;
       d.r1 = Gout; d.r1sn = gsn; d.r1_nch = 64; d.r1s = third ? rs : 1.f;
       d.mask = C; d.masksn = 192 * hw; d.mask_c0 = 160;
-      run_dgrad(L, d, h, w);
+      for (int c = 0; c < nsplit; ++c) run_dgrad(L, chunk(d, c), h, w, cstream(c));
     }
     for (int k = 3; k >= 0; --k) {  // conv_layer4 .. conv_layer1
       const int lo = 64 + 32 * k;   // channel offset of a_{k+1} = number of input channels of this conv
@@ -347,9 +359,10 @@ void Generator::backward(const float* gy) {
           d.mask = cat[0].p; d.masksn = 192 * hw; d.mask_c0 = 0;
         }
       }
-      run_dgrad(L, d, h, w);
+      for (int c = 0; c < nsplit; ++c) run_dgrad(L, chunk(d, c), h, w, cstream(c));
     }
   }
+  join_chains();
   // ---- pre_residual_conv_layer and the input block ----
   {
     const IgLayer& L = layers[L_pre];

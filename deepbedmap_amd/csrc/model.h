@@ -79,7 +79,7 @@ struct dbm_model {
   void ensure_packed();
   // helpers building descriptors
   ConvDesc fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, float* y, long ysn, int N) const;
-  void run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_fwd) const;
+  void run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_fwd, hipStream_t s = nullptr) const;
   // weight gradient of layer L: queued on `batch` (launched later, all layers at once) or run immediately
   void run_wgrad(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, const float* dy, long dysn,
                  int OH, int OW, int N, float scale, WgradBatch* batch = nullptr) const;

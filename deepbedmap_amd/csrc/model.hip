@@ -203,7 +203,8 @@ ConvDesc dbm_model::fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin
 // Data gradient of layer L.  `base` carries the gradient input (x, xsn = dY and its image stride), the output
 // (y, ysn) and every epilogue field; geometry and weights are filled here.  Hin_fwd/Win_fwd: forward INPUT dims
 // (after upsample), i.e. the dims of the gradient being produced.
-void dbm_model::run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_fwd) const {
+void dbm_model::run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_fwd, hipStream_t s) const {
+  if (!s) s = ctx->stream;
   const int OH = (Hin_fwd + 2 * L.pad - L.Kview) / L.stride + 1, OW = (Win_fwd + 2 * L.pad - L.Kview) / L.stride + 1;
   base.xsc = OH * OW; base.Cin = L.OP; base.Hin = OH; base.Win = OW; base.ups = 0;
   base.sin = 1;
@@ -217,7 +218,7 @@ void dbm_model::run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_
     base.T = L.Tb;
     for (int t = 0; t < L.Tb; ++t) { base.dy[t] = L.bdy[0][t]; base.dx[t] = L.bdx[0][t]; }
     base.wp = L.wb[0];
-    launch_igemm_conv(base, ctx->stream);
+    launch_igemm_conv(base, s);
   } else {
     for (int ph = 0; ph < 4; ++ph) {
       const int py = ph >> 1, px = ph & 1;
@@ -227,7 +228,7 @@ void dbm_model::run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_
       base.T = 4;
       for (int t = 0; t < 4; ++t) { base.dy[t] = L.bdy[ph][t]; base.dx[t] = L.bdx[ph][t]; }
       base.wp = L.wb[ph];
-      launch_igemm_conv(base, ctx->stream);
+      launch_igemm_conv(base, s);
     }
   }
 }
