@@ -15,3 +15,4 @@ from .training import (  # noqa: F401
     train_eval_discriminator, train_eval_generator, trainer,
 )
 from .parallel import DataParallel, shard_batch, shard_slice  # noqa: F401
+from .inference import Shape, clip_inputs, crop_bounds, merge_ranks, predict_tiled, tile_steps  # noqa: F401

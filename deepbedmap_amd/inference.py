@@ -1,0 +1,75 @@
+"""Whole-area tiled inference with the generator (reference deepbedmap.py:634-741).
+
+The reference cuts Antarctica into 1000 x 1000 px (250 km) output tiles, feeds each one's low-resolution crop --
+extended by `xtrapad` low-resolution pixels of halo plus the 1-pixel border the valid input convolutions consume --
+through `model.forward`, trims 4*xtrapad output pixels of halo on every side and pastes the rest into a NaN-filled
+canvas.  Same loop, same index arithmetic, crops copied to the GPU per tile exactly like the reference's
+`xp.asarray(...)` (deepbedmap.py:707-722); the GPU-resident crop/stitch pipeline is listed as the next step in
+DESIGN.md section 7.
+"""
+import dataclasses
+
+import numpy as np
+
+from .srgan import using_config
+
+
+@dataclasses.dataclass(frozen=True)
+class Shape:  # deepbedmap.py:680-684
+    y: int
+    x: int
+
+
+def clip_inputs(W1_tile, W2_tile, W3_tile):
+    """deepbedmap.py:663-665: ice surface elevation, velocity and accumulation clipped to >= 0."""
+    return (np.clip(a=W1_tile, a_min=0.0, a_max=None), np.clip(a=W2_tile, a_min=0.0, a_max=None),
+            np.clip(a=W3_tile, a_min=0.0, a_max=None))
+
+
+def tile_steps(final_shape: Shape, stride: Shape):
+    """deepbedmap.py:700-703"""
+    return [Shape(y=y_step, x=x_step) for y_step in range(0, final_shape.y, stride.y)
+            for x_step in range(0, final_shape.x, stride.x)]
+
+
+def crop_bounds(step: Shape, final_shape: Shape, ary_shape: Shape, xtrapad: Shape):
+    """Low-resolution crop window of one output tile (deepbedmap.py:706-711)."""
+    y0 = max(0, (step.y // 4) - xtrapad.y - 1)
+    y1 = min(final_shape.y // 4, ((step.y + ary_shape.y) // 4) + xtrapad.y + 1)
+    x0 = max(0, (step.x // 4) - xtrapad.x - 1)
+    x1 = min(final_shape.x // 4, ((step.x + ary_shape.x) // 4) + xtrapad.x + 1)
+    return y0, y1, x0, x1
+
+
+def predict_tiled(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=18000, x=22000),
+                  ary_shape=Shape(y=1000, x=1000), stride=Shape(y=1000, x=1000), xtrapad=Shape(y=18, x=18), rank=0,
+                  world=1):
+    """deepbedmap.py:689-741.  X (1,1,H,W), W1 (1,1,10H,10W), W2 (1,2,2H,2W), W3 (1,1,H,W) with
+    (4H, 4W) == final_shape.  Returns Y_hat (1, 4H, 4W) float32, NaN where nothing was written (the outer frame and,
+    for world > 1, the tiles of the other ranks: tiles are dealt round-robin, no collective on the data path)."""
+    Y_hat = np.full(shape=(1, final_shape.y, final_shape.x), fill_value=np.nan, dtype=np.float32)
+    steps = tile_steps(final_shape, stride)
+    for i, step in enumerate(steps):
+        if i % world != rank:
+            continue
+        y0, y1, x0, x1 = crop_bounds(step, final_shape, ary_shape, xtrapad)
+        X_crop = np.ascontiguousarray(X_tile[:, :, y0:y1, x0:x1], dtype=np.float32)
+        W1_crop = np.ascontiguousarray(W1_tile[:, :, y0 * 10:y1 * 10, x0 * 10:x1 * 10], dtype=np.float32)
+        W2_crop = np.ascontiguousarray(W2_tile[:, :, y0 * 2:y1 * 2, x0 * 2:x1 * 2], dtype=np.float32)
+        W3_crop = np.ascontiguousarray(W3_tile[:, :, y0:y1, x0:x1], dtype=np.float32)
+        with using_config(name="enable_backprop", value=False):
+            Y_pred = model.forward(x=X_crop, w1=W1_crop, w2=W2_crop, w3=W3_crop)
+        y_slice = slice((y0 + xtrapad.y + 1) * 4, (y1 - xtrapad.y - 1) * 4)
+        x_slice = slice((x0 + xtrapad.x + 1) * 4, (x1 - xtrapad.x - 1) * 4)
+        Y_pred_uncut = np.asarray(Y_pred.array)[0, :, :, :]
+        Y_hat[:, y_slice, x_slice] = Y_pred_uncut[:, xtrapad.y * 4:-xtrapad.y * 4, xtrapad.x * 4:-xtrapad.x * 4]
+    return Y_hat
+
+
+def merge_ranks(parts):
+    """Combine the per-rank canvases of predict_tiled (each pixel is written by exactly one rank)."""
+    out = np.array(parts[0], copy=True)
+    for p in parts[1:]:
+        m = ~np.isnan(p)
+        out[m] = p[m]
+    return out

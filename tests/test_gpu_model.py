@@ -306,3 +306,67 @@ def test_npz_round_trip(dbm, tmp_path):  # srgan_train.py:1351-1361, deepbedmap.
     ins = tile_inputs(1, 1)
     with dbm.using_config("enable_backprop", False):
         assert np.array_equal(g.forward(*ins).array, g2.forward(*ins).array)
+
+
+def test_tiled_area_inference_matches_oracle_loop(dbm):
+    """deepbedmap.py:689-741 on a small synthetic area: overlapping crops with a halo, trimmed and stitched; the
+    outer (xtrapad+1)*4 frame stays NaN.  Reference = the same tiling walked with the oracle's forward."""
+    og = scaled_oracle_generator(1, 5.0)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=1, initialize=False), og.params)
+    r = np.random.RandomState(17)
+    H, W = 26, 34
+    X = r.rand(1, 1, H, W).astype(np.float32)
+    W1 = r.rand(1, 1, 10 * H, 10 * W).astype(np.float32) - 0.2
+    W2 = r.rand(1, 2, 2 * H, 2 * W).astype(np.float32) - 0.2
+    W3 = r.rand(1, 1, H, W).astype(np.float32) - 0.2
+    W1, W2, W3 = dbm.clip_inputs(W1, W2, W3)  # deepbedmap.py:663-665
+    assert W1.min() == 0.0
+    S = dbm.Shape
+    final, ary, stride, pad = S(y=4 * H, x=4 * W), S(y=40, x=48), S(y=40, x=48), S(y=3, x=3)
+    Y = dbm.predict_tiled(g, X, W1, W2, W3, final_shape=final, ary_shape=ary, stride=stride, xtrapad=pad)
+    # the same walk with the oracle
+    ref = np.full((1, final.y, final.x), np.nan, np.float32)
+    for y_step in range(0, final.y, stride.y):
+        for x_step in range(0, final.x, stride.x):
+            y0 = max(0, y_step // 4 - pad.y - 1)
+            y1 = min(final.y // 4, (y_step + ary.y) // 4 + pad.y + 1)
+            x0 = max(0, x_step // 4 - pad.x - 1)
+            x1 = min(final.x // 4, (x_step + ary.x) // 4 + pad.x + 1)
+            yp = og.forward(X[:, :, y0:y1, x0:x1], W1[:, :, 10 * y0:10 * y1, 10 * x0:10 * x1],
+                            W2[:, :, 2 * y0:2 * y1, 2 * x0:2 * x1], W3[:, :, y0:y1, x0:x1])[0]
+            ref[:, (y0 + pad.y + 1) * 4:(y1 - pad.y - 1) * 4, (x0 + pad.x + 1) * 4:(x1 - pad.x - 1) * 4] = \
+                yp[:, pad.y * 4:-pad.y * 4, pad.x * 4:-pad.x * 4]
+    assert np.array_equal(np.isnan(Y), np.isnan(ref))
+    frame = (pad.y + 1) * 4
+    assert np.isnan(Y[:, :frame]).all() and not np.isnan(Y[:, frame:-frame, frame:-frame]).any()
+    m = ~np.isnan(ref)
+    assert rel(Y[m], ref[m]) < TOL
+    # tiles dealt round-robin over two "ranks" reproduce the single-process canvas
+    parts = [dbm.predict_tiled(g, X, W1, W2, W3, final, ary, stride, pad, rank=k, world=2) for k in range(2)]
+    assert np.array_equal(np.nan_to_num(dbm.merge_ranks(parts), nan=-1.0), np.nan_to_num(Y, nan=-1.0))
+
+
+def test_trainer_epoch_no_nan(dbm):
+    """features/srgan_train.feature:11-19: 1-RRDB model (residual_scaling 0.3, lr 5e-4), one `trainer` epoch with
+    batch 1, no metric is NaN -- on synthetic tiles instead of the Quilt download."""
+    np.random.seed(3)
+    n_train, n_dev = 5, 2
+    r = np.random.RandomState(0)
+
+    def dataset(n):
+        return {"X": r.rand(n, 1, 11, 11).astype(np.float32), "W1": r.rand(n, 1, 110, 110).astype(np.float32),
+                "W2": r.rand(n, 2, 22, 22).astype(np.float32), "W3": r.rand(n, 1, 11, 11).astype(np.float32),
+                "Y": r.rand(n, 1, 36, 36).astype(np.float32)}
+
+    train_iter = dbm.SerialIterator(dataset(n_train), batch_size=1, repeat=True, shuffle=True, seed=42)
+    dev_iter = dbm.SerialIterator(dataset(n_dev), batch_size=1, repeat=True, shuffle=False)
+    g, g_opt, d, d_opt = dbm.compile_srgan_model(num_residual_blocks=1, residual_scaling=0.3, learning_rate=5e-4)
+    columns = ["discriminator_loss", "discriminator_accu", "generator_loss", "generator_psnr", "generator_ssim",
+               "val_discriminator_loss", "val_discriminator_accu", "val_generator_loss", "val_generator_psnr",
+               "val_generator_ssim"]
+    metrics = dbm.trainer(i=0, columns=columns, train_iter=train_iter, dev_iter=dev_iter, g_model=g, g_optimizer=g_opt,
+                          d_model=d, d_optimizer=d_opt)
+    assert train_iter.epoch == 1 and dev_iter.epoch == 1
+    assert len(metrics["generator_loss"]) == n_train and len(metrics["val_generator_loss"]) == n_dev
+    for k in columns:
+        assert not np.isnan(metrics[k]).any(), k

@@ -1,0 +1,74 @@
+"""CPU tests of the host-side logic that needs no GPU: iterator semantics (srgan_train.py:132-166, 1286-1288,
+1311-1313), tiling index arithmetic (deepbedmap.py:689-741), Chainer parameter ordering, config flags."""
+import numpy as np
+
+import deepbedmap_amd as dbm
+from deepbedmap_amd.srgan import _chainer_order
+from oracle import model as omodel
+
+
+def test_serial_iterator_full_batches_and_epochs():
+    # 3826 training tiles at batch 128 -> 30 iterations per epoch, always full batches
+    data = {"X": np.arange(3826)}
+    it = dbm.SerialIterator(data, batch_size=128, repeat=True, shuffle=True, seed=42)
+    n_iter, seen = 0, []
+    while it.epoch == 0:
+        idx = it.next()
+        assert len(idx) == 128
+        seen.append(idx)
+        n_iter += 1
+    assert n_iter == 30
+    first_epoch = np.concatenate(seen)[:3826]
+    assert np.array_equal(np.sort(first_epoch), np.arange(3826))  # every tile exactly once before wrapping
+    # dev iterator: 202 tiles, no shuffle -> 2 iterations
+    dev = dbm.SerialIterator({"X": np.arange(202)}, batch_size=128, repeat=True, shuffle=False)
+    k = 0
+    while dev.epoch == 0:
+        dev.next()
+        k += 1
+    assert k == 2
+    batch = dbm.concat_examples({"X": np.arange(10) * 2.0}, np.array([3, 1]))
+    assert np.array_equal(batch["X"], [6.0, 2.0])
+
+
+def test_tiling_covers_everything_but_the_frame():
+    S = dbm.Shape
+    final, ary, stride, pad = S(y=18000, x=22000), S(y=1000, x=1000), S(y=1000, x=1000), S(y=18, x=18)
+    steps = dbm.tile_steps(final, stride)
+    assert len(steps) == 396  # 18 x 22 crops (deepbedmap.py:700-703)
+    cover = np.zeros((final.y // 4, final.x // 4), np.int32)  # in units of 4x4 output pixels
+    sizes = set()
+    for st in steps:
+        y0, y1, x0, x1 = dbm.crop_bounds(st, final, ary, pad)
+        sizes.add((y1 - y0, x1 - x0))
+        cover[y0 + pad.y + 1:y1 - pad.y - 1, x0 + pad.x + 1:x1 - pad.x - 1] += 1
+    assert (288, 288) in sizes  # interior crops: 250 + 2*18 + 2 low-resolution pixels
+    frame = pad.y + 1
+    assert (cover[frame:-frame, frame:-frame] == 1).all()  # written exactly once
+    assert cover[:frame].sum() == 0 and cover[:, :frame].sum() == 0  # the outer 76-px frame stays NaN
+
+
+def test_chainer_param_order_matches_the_doctest_indices():
+    names = list(omodel.generator_param_shapes(12))
+    order = _chainer_order(names)
+    assert order[8] == "input_block/conv_on_W1/W"  # srgan_train.py:1203
+    assert order[:4] == ["final_conv_layer1/deform_conv/W", "final_conv_layer1/deform_conv/b",
+                         "final_conv_layer1/offset_conv/W", "final_conv_layer1/offset_conv/b"]
+    dorder = _chainer_order(list(omodel.discriminator_param_shapes()))
+    assert dorder[-3] == "linear_1/b"  # srgan_train.py:1113
+    assert order == omodel.chainer_param_order(names)
+
+
+def test_using_config_restores_flags():
+    assert dbm.global_config.enable_backprop is True
+    with dbm.using_config("enable_backprop", False):
+        assert dbm.global_config.enable_backprop is False
+        with dbm.using_config("train", False):
+            assert dbm.global_config.train is False
+    assert dbm.global_config.enable_backprop is True
+
+
+def test_residual_scaling_and_blocks_are_plain_attributes():
+    # deepbedmap.py:402-405 / srgan_train.py:1577-1578 read them back; they are not serialized
+    shapes = omodel.generator_param_shapes(3)
+    assert not any("residual_scaling" in k or "num_residual_blocks" in k for k in shapes)
