@@ -23,6 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r1", "traffic_pmc.json")  # tools/pmc_traffic.sh (separate --pmc passes)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BATCH_PER_GPU = 64
 N_RRDB = 12
@@ -145,6 +146,12 @@ def main():
                                   "launches_per_step": int(wg_n), "avg_launch_us": 1e3 * wg_ms / max(wg_n, 1)},
             },
         }
+        try:  # HBM bytes per launch of the dominant kernel: PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, from the committed pass
+            with open(TRAFFIC_JSON) as f:
+                out["roofline"]["traffic"] = json.load(f)["igemm_conv_kernel"]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r1/traffic_pmc.json (rocprofv3 --pmc, separate passes)"
+        except Exception:
+            pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
