@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void deform_backward_kernel(const float* __res
 // The bilinear scatter goes to LDS with ds_add_f32 and leaves as plain coalesced stores -- no global atomics on gx, no
 // zero-fill of gx; only the 18 offset-gradient planes are folded across channel groups with global atomics.
 template <int CH>
-__global__ __launch_bounds__(256) void deform_backward_lds_kernel(const float* __restrict__ x, const float* __restrict__ off,
+__global__ __launch_bounds__(1024) void deform_backward_lds_kernel(const float* __restrict__ x, const float* __restrict__ off,
                                                                   const float* __restrict__ gcol,
                                                                   const float* __restrict__ w1o,
                                                                   const float* __restrict__ gy, float* __restrict__ gx,
@@ -235,14 +235,14 @@ __global__ __launch_bounds__(256) void deform_backward_lds_kernel(const float* _
   float* sg = sm + CH * plane;
   const int n = blockIdx.x, c0 = blockIdx.y * CH, tid = threadIdx.x;
   const float* xn = x + ((long)n * C + c0) * plane;
-  for (int e = tid; e < CH * plane; e += 256) {
+  for (int e = tid; e < CH * plane; e += 1024) {
     sx[e] = xn[e];
     sg[e] = 0.f;
   }
   __syncthreads();
   const float* on = off + (long)n * offsn;
   float* gn = goff + (long)n * offsn;
-  for (int e = tid; e < 9 * plane; e += 256) {
+  for (int e = tid; e < 9 * plane; e += 1024) {
     const int t = e / plane, p = e - t * plane;
     const int a = p / W, b = p - a * W;
     const DeformGeom g = deform_geom(on[(long)t * plane + p], on[(long)(9 + t) * plane + p], a, b, t / 3, t % 3, H, W, 1);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void deform_backward_lds_kernel(const float* _
   }
   __syncthreads();
   float* gxn = gx + ((long)n * C + c0) * plane;
-  for (int e = tid; e < CH * plane; e += 256) gxn[e] = sg[e];
+  for (int e = tid; e < CH * plane; e += 1024) gxn[e] = sg[e];
 }
 
 // gx is fully overwritten; goff[n][0:18] is overwritten (channels 18.. of a padded offset tensor are left alone).
@@ -287,7 +287,7 @@ void launch_deform_backward(const float* x, const float* off, const float* gcol,
       attr_set = true;
     }
     DBM_HIP(hipMemset2DAsync(goff, sizeof(float) * offsn, 0, sizeof(float) * 18 * plane, N, s));
-    hipLaunchKernelGGL(deform_backward_lds_kernel<CH>, dim3(N, C / CH), dim3(256), lds, s, x, off, gcol, w1o, gy, gx, goff, N,
+    hipLaunchKernelGGL(deform_backward_lds_kernel<CH>, dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx, goff, N,
                        C, H, W, offsn);
   } else {
     DBM_HIP(hipMemsetAsync(gx, 0, sizeof(float) * N * C * plane, s));

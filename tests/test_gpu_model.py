@@ -370,3 +370,39 @@ def test_trainer_epoch_no_nan(dbm):
     assert len(metrics["generator_loss"]) == n_train and len(metrics["val_generator_loss"]) == n_dev
     for k in columns:
         assert not np.isnan(metrics[k]).any(), k
+
+
+def test_rccl_plumbing_on_one_gpu(dbm):
+    """The data-parallel plumbing on a single GPU (world_size 1, backend nccl = RCCL): torch must ALIAS the library's
+    gradient / parameter arenas (no copy), the all-reduce must leave a 1-rank sum unchanged and return scale 1."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    comm = dbm.DataParallel()
+    try:
+        assert comm.on_gpu and comm.world == 1
+        g = dbm.GeneratorModel(num_residual_blocks=1)
+        view = comm.grad_view(g)
+        arena = g.grad_arena()
+        assert view.data_ptr() == arena.ptr and view.numel() == g.count_params()
+        g.cleargrads()
+        view.fill_(2.0)  # written through torch ...
+        torch.cuda.synchronize()
+        name = "pre_residual_conv_layer/b"
+        assert np.all(g._tensors[name].grad == 2.0)  # ... visible to the library
+        comm.world = 2  # force the collective path (a 1-rank all-reduce is the identity)
+        scale = comm.allreduce_grads(g)
+        comm.world = 1
+        assert scale == 0.5
+        torch.cuda.synchronize()
+        assert np.all(g._tensors[name].grad == 2.0)
+        p0 = g._tensors[name].array.copy()
+        comm.world = 2
+        comm.broadcast_params(g, src=0)
+        comm.world = 1
+        assert np.array_equal(g._tensors[name].array, p0)
+    finally:
+        dist.destroy_process_group()
