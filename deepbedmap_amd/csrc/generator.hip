@@ -26,6 +26,8 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
     T_in[i][0] = tid(std::string(in_names[i]) + "/W");
     T_in[i][1] = tid(std::string(in_names[i]) + "/b");
   }
+  L_in[1] = add_iglayer(in_names[1], 32, 1, 30, 1, 0, true, /*as_1x1=*/true);  // GEMM over the 900 im2col rows
+  L_in[2] = add_iglayer(in_names[2], 32, 2, 6, 1, 0, true, /*as_1x1=*/true);   // 72 rows
   conv("pre_residual_conv_layer", 64, 128, 3, 3);  // :467-474
   L_pre = add_iglayer("pre_residual_conv_layer", 64, 128, 3, 1, 1, true);
   const int cin[5] = {64, 96, 128, 160, 192}, cout[5] = {32, 32, 32, 32, 64};
@@ -79,6 +81,8 @@ void Generator::ensure_ws(int N, int H, int W, bool train) {
   in_w2.ensure(n * 2 * 4 * H * W);
   in_w3.ensure(n * H * W);
   a0.ensure(n * 128 * hw);
+  colW1.ensure(n * layers[L_in[1]].CinP * hw);
+  colW2.ensure(n * layers[L_in[2]].CinP * hw);
   const int ncat = tr ? nrdb + 1 : 5;
   if ((int)cat.size() < ncat) cat.resize(ncat);
   for (int i = 0; i < ncat; ++i) cat[i].ensure(n * 192 * hw);
@@ -143,7 +147,15 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       d.KH = d.KW = br[i].K; d.stride = br[i].stride; d.pad = 0; d.N = N; d.act = 0; d.slope = SLOPE;
       DBM_CHECK((br[i].Hin - br[i].K) / br[i].stride + 1 == h && (br[i].Win - br[i].K) / br[i].stride + 1 == w,
                 "input block branch does not produce the (H-2, W-2) grid");
-      launch_smallcin_conv_fwd(d, s);
+      if (L_in[i] >= 0) {  // wide kernels: im2col (0.1 % of the generator's bytes) + MFMA GEMM
+        const IgLayer& L = layers[L_in[i]];
+        float* col = (i == 1 ? colW1 : colW2).p;
+        launch_im2col(br[i].in, col, N, br[i].Cin, br[i].Hin, br[i].Win, br[i].K, br[i].K, br[i].stride, h, w, L.CinP, s);
+        ConvDesc g = fwd_desc(L, col, (long)L.CinP * hw, h, w, 0, d.y, 128 * hw, N);
+        launch_igemm_conv(g, s);
+      } else {
+        launch_smallcin_conv_fwd(d, s);
+      }
     }
   }
   // The 9x9 stage is a chain of ~180 short, latency-bound kernels (162-324 tiles each at batch 64).  The generator
@@ -382,7 +394,13 @@ void Generator::backward(const float* gy) {
       q.x = bw_in[i] ? bw_in[i] : br[i].in;
       q.xsn = (long)br[i].Cin * br[i].Hin * br[i].Win; q.Cin = br[i].Cin; q.Hin = br[i].Hin; q.Win = br[i].Win;
       q.Cout = 32; q.OH = h; q.OW = w; q.KH = q.KW = br[i].K; q.stride = br[i].stride; q.pad = 0; q.N = N;
-      launch_smallcin_conv_wgrad(q, g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), s);
+      if (L_in[i] >= 0) {
+        const IgLayer& L = layers[L_in[i]];
+        run_wgrad(L, (i == 1 ? colW1 : colW2).p, (long)L.CinP * hw, h, w, 0, g_a0.p + (long)i * 32 * hw, 128 * hw, h, w, N,
+                  1.f, &wbs[5]);
+      } else {
+        launch_smallcin_conv_wgrad(q, g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), s);
+      }
     }
   }
   ctx->fork_to_side(6);

@@ -14,6 +14,8 @@ struct SmallConvDesc {
 void launch_smallcin_conv_fwd(const SmallConvDesc& d, hipStream_t s);
 void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dysn, float* gW, float* gb, hipStream_t s);
 
+void launch_im2col(const float* x, float* col, int N, int Cin, int Hin, int Win, int KH, int KW, int stride, int OH, int OW,
+                   int KP, hipStream_t s);
 void launch_deform_sample(const float* x, const float* off, float* col, int N, int C, int H, int W, long offsn, hipStream_t s);
 void launch_deform_backward(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy,
                             float* gx, float* goff, int N, int C, int H, int W, long offsn, hipStream_t s);

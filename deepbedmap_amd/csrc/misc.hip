@@ -103,6 +103,39 @@ void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dy
   DBM_HIP(hipGetLastError());
 }
 
+// col[n][k][p] = x[n][c][a*s+ky][b*s+kx] for k = (c*KH+ky)*KW+kx < K, 0 for K <= k < KP (valid convolution, no padding).
+// Turns the two wide-kernel input-block branches (k30 s10 on REMA, k6 s2 on MEaSUREs, srgan_train.py:231-246) into
+// 900- / 72-deep GEMMs for the MFMA kernels; the OIHW weight flattening is exactly this k order.
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int N, int Cin,
+                                                     int Hin, int Win, int KH, int KW, int stride, int OH, int OW, int K,
+                                                     int KP) {
+  const int plane = OH * OW;
+  const long total = (long)N * KP * plane;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int p = (int)(e % plane);
+    const int k = (int)((e / plane) % KP);
+    const int n = (int)(e / ((long)plane * KP));
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / (KH * KW), kr = k - c * KH * KW;
+      const int ky = kr / KW, kx = kr - ky * KW;
+      const int a = p / OW, b = p - a * OW;
+      v = x[((long)n * Cin + c) * Hin * Win + (long)(a * stride + ky) * Win + b * stride + kx];
+    }
+    col[e] = v;
+  }
+}
+
+void launch_im2col(const float* x, float* col, int N, int Cin, int Hin, int Win, int KH, int KW, int stride, int OH, int OW,
+                   int KP, hipStream_t s) {
+  const long total = (long)N * KP * OH * OW;
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, col, N, Cin, Hin, Win, KH, KW, stride, OH, OW,
+                     Cin * KH * KW, KP);
+  DBM_HIP(hipGetLastError());
+}
+
 // ----------------------------------------------------------------------------------------------
 // Deformable convolution sampler (reference srgan_train.py:506-523, :572-574; Chainer
 // deformable_convolution_2d_sampler + spatial_transformer_sampler semantics).

@@ -92,6 +92,8 @@ struct Generator : dbm_model {
   int L_pre, L_post, L_up1, L_up2, L_off1, L_def1, L_off2;
   std::vector<int> L_rdb;  // nrdb*5
   int T_in[4][2];          // input block (W, b) tensor ids
+  int L_in[4] = {-1, -1, -1, -1};  // W1 / W2 branches run as im2col + GEMM on the MFMA kernels
+  DevBuf colW1, colW2;
   int T_def2W, T_def2b;
   // workspace
   int wsN = 0, wsH = 0, wsW = 0;
