@@ -306,21 +306,139 @@ __global__ __launch_bounds__(1024) void deform_backward_lds_kernel(const float* 
   for (int e = tid; e < CH * plane; e += 1024) gxn[e] = sg[e];
 }
 
+// Same contract, without floating-point atomics on gx (ds_add_f32 retires about one lane per clock: the scatter
+// version keeps the LDS 100 % busy).  The sampling pattern of a tap is shared by all channels, so per (image, tap) the
+// workgroup builds the TRANSPOSED sparse sampling operator once -- a CSR list, per input pixel q, of the output
+// positions p and bilinear weights that touch q (counting sort with integer LDS atomics) -- and then every channel
+// GATHERS: gx[c][q] += sum_{(p,w) in list(q)} w * gcol[c][t][p], each q owned by one lane.
+template <int CH, int NT>
+__global__ __launch_bounds__(NT) void deform_backward_csr_kernel(const float* __restrict__ x, const float* __restrict__ off,
+                                                                  const float* __restrict__ gcol,
+                                                                  const float* __restrict__ w1o,
+                                                                  const float* __restrict__ gy, float* __restrict__ gx,
+                                                                  float* goff, int N, int C, int H, int W, long offsn) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int wtot[NT / 64];
+  const int plane = H * W;
+  float* sx = sm;                              // CH * plane
+  float* sg = sx + CH * plane;                 // CH * plane
+  int* offs = (int*)(sg + CH * plane);         // plane + 1  (counts, then exclusive offsets)
+  int* cur = offs + plane + 1;                 // plane      (fill cursors)
+  int* ent_p = cur + plane;                    // 4 * plane
+  float* ent_w = (float*)(ent_p + 4 * plane);  // 4 * plane
+  const int n = blockIdx.x, c0 = blockIdx.y * CH, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const float* xn = x + ((long)n * C + c0) * plane;
+  for (int e = tid; e < CH * plane; e += NT) {
+    sx[e] = xn[e];
+    sg[e] = 0.f;
+  }
+  const float* on = off + (long)n * offsn;
+  float* gn = goff + (long)n * offsn;
+  const int per = (plane + NT - 1) / NT;  // elements of the scan owned by one thread
+  for (int t = 0; t < 9; ++t) {
+    for (int e = tid; e <= plane; e += NT) offs[e] = 0;
+    __syncthreads();
+    // ---- pass 1: how many samples touch each input pixel ----
+    for (int p = tid; p < plane; p += NT) {
+      const int a = p / W, b = p - a * W;
+      const DeformGeom g = deform_geom(on[(long)t * plane + p], on[(long)(9 + t) * plane + p], a, b, t / 3, t % 3, H, W, 1);
+      const int o1 = deform_corner(g.v0, g.u0, H, W, 1), o2 = deform_corner(g.v0, g.u0 + 1, H, W, 1);
+      const int o3 = deform_corner(g.v0 + 1, g.u0, H, W, 1), o4 = deform_corner(g.v0 + 1, g.u0 + 1, H, W, 1);
+      if (o1 >= 0) atomicAdd(offs + o1, 1);
+      if (o2 >= 0) atomicAdd(offs + o2, 1);
+      if (o3 >= 0) atomicAdd(offs + o3, 1);
+      if (o4 >= 0) atomicAdd(offs + o4, 1);
+    }
+    __syncthreads();
+    // ---- exclusive scan of the counts (each thread owns `per` consecutive entries) ----
+    {
+      const int base = tid * per;
+      int loc = 0;
+      for (int i = 0; i < per; ++i)
+        if (base + i < plane) loc += offs[base + i];
+      int inc = loc;
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+      }
+      if (lane == 63) wtot[wave] = inc;
+      __syncthreads();
+      int pre = inc - loc;
+      for (int w2 = 0; w2 < wave; ++w2) pre += wtot[w2];
+      for (int i = 0; i < per; ++i)
+        if (base + i < plane) {
+          const int cnt = offs[base + i];
+          offs[base + i] = pre;
+          cur[base + i] = pre;
+          pre += cnt;
+        }
+      if (tid == NT - 1) offs[plane] = pre;  // the last thread owns the tail (possibly empty): pre == grand total
+    }
+    __syncthreads();
+    // ---- pass 2: fill the lists; offset gradients (a gather already: 4 corner reads per channel) ----
+    for (int p = tid; p < plane; p += NT) {
+      const int a = p / W, b = p - a * W;
+      const DeformGeom g = deform_geom(on[(long)t * plane + p], on[(long)(9 + t) * plane + p], a, b, t / 3, t % 3, H, W, 1);
+      const int o1 = deform_corner(g.v0, g.u0, H, W, 1), o2 = deform_corner(g.v0, g.u0 + 1, H, W, 1);
+      const int o3 = deform_corner(g.v0 + 1, g.u0, H, W, 1), o4 = deform_corner(g.v0 + 1, g.u0 + 1, H, W, 1);
+      const float w1 = g.wu1 * g.wv1, w2 = g.wu0 * g.wv1, w3 = g.wu1 * g.wv0, w4 = g.wu0 * g.wv0;
+      if (o1 >= 0) { const int sl = atomicAdd(cur + o1, 1); ent_p[sl] = p; ent_w[sl] = w1; }
+      if (o2 >= 0) { const int sl = atomicAdd(cur + o2, 1); ent_p[sl] = p; ent_w[sl] = w2; }
+      if (o3 >= 0) { const int sl = atomicAdd(cur + o3, 1); ent_p[sl] = p; ent_w[sl] = w3; }
+      if (o4 >= 0) { const int sl = atomicAdd(cur + o4, 1); ent_p[sl] = p; ent_w[sl] = w4; }
+      const float gyv = gy ? gy[(long)n * plane + p] : 0.f;
+      float gu = 0.f, gv = 0.f;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float gq = gcol ? gcol[((long)n * C * 9 + (long)(c0 + c) * 9 + t) * plane + p] : w1o[(c0 + c) * 9 + t] * gyv;
+        const float* xc = sx + c * plane;
+        const float x1 = o1 >= 0 ? xc[o1] : 0.f, x2 = o2 >= 0 ? xc[o2] : 0.f;
+        const float x3 = o3 >= 0 ? xc[o3] : 0.f, x4 = o4 >= 0 ? xc[o4] : 0.f;
+        gu += gq * (-g.wv1 * x1 + g.wv1 * x2 - g.wv0 * x3 + g.wv0 * x4);
+        gv += gq * (-g.wu1 * x1 - g.wu0 * x2 + g.wu1 * x3 + g.wu0 * x4);
+      }
+      if (g.mu) atomicAdd(gn + (long)t * plane + p, gu);
+      if (g.mv) atomicAdd(gn + (long)(9 + t) * plane + p, gv);
+    }
+    __syncthreads();
+    // ---- gather: every input pixel q sums its list, channel by channel ----
+    for (int q = tid; q < plane; q += NT) {
+      const int s0 = offs[q], s1 = offs[q + 1];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const float* gc = gcol ? gcol + ((long)n * C * 9 + (long)(c0 + c) * 9 + t) * plane : nullptr;
+        const float wq = gcol ? 0.f : w1o[(c0 + c) * 9 + t];
+        float acc = 0.f;
+        for (int sl = s0; sl < s1; ++sl) {
+          const int p = ent_p[sl];
+          const float gq = gc ? gc[p] : wq * gy[(long)n * plane + p];
+          acc += ent_w[sl] * gq;
+        }
+        sg[c * plane + q] += acc;
+      }
+    }
+    __syncthreads();
+  }
+  float* gxn = gx + ((long)n * C + c0) * plane;
+  for (int e = tid; e < CH * plane; e += NT) gxn[e] = sg[e];
+}
+
 // gx is fully overwritten; goff[n][0:18] is overwritten (channels 18.. of a padded offset tensor are left alone).
 void launch_deform_backward(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy,
                             float* gx, float* goff, int N, int C, int H, int W, long offsn, hipStream_t s) {
   const long plane = (long)H * W;
   constexpr int CH = 8;
-  const size_t lds = sizeof(float) * 2 * CH * (size_t)plane;
+  const size_t lds = sizeof(float) * ((size_t)2 * CH * plane + 10 * plane + 1);
   if (lds <= 150 * 1024 && C % CH == 0) {
     static bool attr_set = false;
     if (!attr_set) {
-      DBM_HIP(hipFuncSetAttribute((const void*)deform_backward_lds_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      DBM_HIP(hipFuncSetAttribute((const void*)deform_backward_csr_kernel<CH, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   152 * 1024));
       attr_set = true;
     }
     DBM_HIP(hipMemset2DAsync(goff, sizeof(float) * offsn, 0, sizeof(float) * 18 * plane, N, s));
-    hipLaunchKernelGGL(deform_backward_lds_kernel<CH>, dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx, goff, N,
+    hipLaunchKernelGGL((deform_backward_csr_kernel<CH, 1024>), dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx, goff, N,
                        C, H, W, offsn);
   } else {
     DBM_HIP(hipMemsetAsync(gx, 0, sizeof(float) * N * C * plane, s));
