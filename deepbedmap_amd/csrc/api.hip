@@ -233,6 +233,7 @@ int dbm_model_set_tensor(dbm_model* m, const char* key, const float* host, size_
   DBM_HIP(hipMemcpyAsync(tensor_ptr(m, t, false), host, n * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
   DBM_HIP(hipStreamSynchronize(m->ctx->stream));
   m->packed_dirty = true;
+  m->param_version++;
   DBM_API_END
 }
 int dbm_model_get_tensor(dbm_model* m, const char* key, float* host, size_t n) {
@@ -276,6 +277,7 @@ int dbm_model_grad_arena(dbm_model* m, void** dptr, size_t* n) {
 int dbm_model_params_changed(dbm_model* m) {
   DBM_API_BEGIN(m->ctx)
   m->packed_dirty = true;
+  m->param_version++;
   DBM_API_END
 }
 
@@ -469,6 +471,7 @@ int dbm_adam_update(dbm_model* m, double grad_scale) {
   launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (long)m->nparam, (float)alpha_t, (float)(1.0 - m->beta1),
               (float)(1.0 - m->beta2), (float)m->eps, (float)grad_scale, m->ctx->stream);
   m->packed_dirty = true;
+  m->param_version++;
   DBM_API_END
 }
 
@@ -482,9 +485,13 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   dbm_ctx* c = g->ctx;
   hipStream_t s = c->stream;
   const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
-  g->ensure_ws(N, H, W, false);
+  const bool share = (train & 2) != 0;  // opt-in: keep this forward's graph for the G-step of the same iteration
+  train &= 1;
+  g->ensure_ws(N, H, W, share && train);
   // fake images under enable_backprop=False (:1131-1137)
-  g->forward(N, H, W, X, W1, W2, W3, g->yout.p, false);
+  g->forward(N, H, W, X, W1, W2, W3, g->yout.p, share && train);
+  g->graph_version = g->param_version;
+  g->graph_in[0] = X; g->graph_in[1] = W1; g->graph_in[2] = W2; g->graph_in[3] = W3;
   d->g_out.ensure(4 * (size_t)N);
   float* lr = d->g_out.p;
   float* lf = lr + N;
@@ -511,8 +518,17 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
   dbm_ctx* c = g->ctx;
   hipStream_t s = c->stream;
   const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
-  g->ensure_ws(N, H, W, train != 0);
-  g->forward(N, H, W, X, W1, W2, W3, g->yout.p, train != 0);  // (:1222-1227)
+  const bool share = (train & 2) != 0;
+  train &= 1;
+  // Opt-in: the generator and its inputs are unchanged since the D-step of this iteration, so that step's forward
+  // (bitwise the same numbers) is reused instead of recomputed.  Off by default: the reference runs it twice.
+  const bool reuse = share && train && g->have_graph && g->wsTrain && g->graph_version == g->param_version &&
+                     g->wsN == N && g->wsH == H && g->wsW == W && g->graph_in[0] == X && g->graph_in[1] == W1 &&
+                     g->graph_in[2] == W2 && g->graph_in[3] == W3;
+  if (!reuse) {
+    g->ensure_ws(N, H, W, train != 0);
+    g->forward(N, H, W, X, W1, W2, W3, g->yout.p, train != 0);  // (:1222-1227)
+  }
   d->g_out.ensure(4 * (size_t)N);
   float* lf = d->g_out.p;
   d->forward(N, H4, W4, g->yout.p, lf, false, false, 1);  // eval-mode BatchNorm, detached (:1228-1229)

@@ -65,6 +65,7 @@ struct dbm_model {
   long adam_t = 0;
   bool adam_ready = false;
   bool packed_dirty = true;
+  long param_version = 0;  // bumped by every write to the parameter arena
   std::vector<IgLayer> layers;
   PackJob* d_pack_jobs = nullptr;  // device job table of the one-launch weight repack
   int n_pack_jobs = 0, n_pack_blocks = 0;
@@ -99,6 +100,9 @@ struct Generator : dbm_model {
   int wsN = 0, wsH = 0, wsW = 0;
   bool wsTrain = false;
   bool have_graph = false;
+  // what the retained graph was computed from (opt-in reuse of the D-step's generator forward by the G-step)
+  long graph_version = -1;
+  const float* graph_in[4] = {nullptr, nullptr, nullptr, nullptr};
   const float* bw_in[4] = {nullptr, nullptr, nullptr, nullptr};  // forward inputs, needed by the input-block wgrad
   static const int NWB = 6;
   WgradBatch wbs[NWB];  // batched weight gradients: tail, 4 trunk groups, pre-residual (launched on the side stream)

@@ -54,9 +54,12 @@ def _check_batch(arrs):
 
 
 def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, train: bool = True, comm=None,
-                             sync: bool = True):
+                             sync: bool = True, share_generator_forward: bool = False):
     """srgan_train.py:1084-1166.  Returns (d_loss, d_accu) as floats (like the reference's float(...) D2H syncs);
-    sync=False returns the device metrics buffer instead and keeps the stream running."""
+    sync=False returns the device metrics buffer instead and keeps the stream running.
+    share_generator_forward=True (opt-in, not the reference's behaviour) retains this call's generator forward so
+    that train_eval_generator(..., share_generator_forward=True) on the same device arrays reuses it: the generator
+    and its inputs do not change in between, so the numbers are bitwise the same and one forward pass is saved."""
     global_config.train = train  # srgan_train.py:1125
     if train is True:
         assert d_optimizer is not None  # Optimizer required for neural network training
@@ -64,7 +67,8 @@ def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, t
     n, h, w = _check_batch(dev)
     m = _metrics_buffer(g_model.ctx)
     _lib.check(_lib.lib().dbm_discriminator_step(g_model._h, d_model._h, n, h, w, *[_dev_ptr(dev[k]) for k in _KEYS],
-                                                 int(bool(train)), m.ptr), g_model.ctx.handle)
+                                                 int(bool(train)) | (2 if share_generator_forward else 0), m.ptr),
+               g_model.ctx.handle)
     if train is True:
         scale = comm.allreduce_grads(d_model) if comm is not None else 1.0
         d_optimizer.update(grad_scale=scale)
@@ -75,7 +79,7 @@ def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, t
 
 
 def train_eval_generator(input_arrays, g_model, d_model, g_optimizer=None, train: bool = True, comm=None,
-                         sync: bool = True):
+                         sync: bool = True, share_generator_forward: bool = False):
     """srgan_train.py:1170-1263.  Returns (g_loss, g_psnr, g_ssim)."""
     global_config.train = train  # srgan_train.py:1216
     if train is True:
@@ -86,7 +90,8 @@ def train_eval_generator(input_arrays, g_model, d_model, g_optimizer=None, train
     wts = (C.c_float * 4)(*LOSS_WEIGHTS)
     win = {"gaussian": 0, "uniform": 1}[global_config.ssim_window]
     _lib.check(_lib.lib().dbm_generator_step(g_model._h, d_model._h, n, h, w, *[_dev_ptr(dev[k]) for k in _KEYS], wts,
-                                             win, int(bool(train)), m.ptr), g_model.ctx.handle)
+                                             win, int(bool(train)) | (2 if share_generator_forward else 0), m.ptr),
+               g_model.ctx.handle)
     if train is True:
         scale = comm.allreduce_grads(g_model) if comm is not None else 1.0
         g_optimizer.update(grad_scale=scale)

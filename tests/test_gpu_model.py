@@ -406,3 +406,23 @@ def test_rccl_plumbing_on_one_gpu(dbm):
         assert np.array_equal(g._tensors[name].array, p0)
     finally:
         dist.destroy_process_group()
+
+
+def test_shared_generator_forward_is_equivalent(dbm):
+    """Opt-in reuse of the D-step's generator forward by the G-step gives the numbers of the two-forward path."""
+    arrays = dbm.device_batch(fixture_arrays(n=4))
+    results = []
+    for share in (False, True):
+        og = scaled_oracle_generator(1, 3.0)
+        od = omodel.DiscriminatorModel(seed=5)
+        g = copy_params(dbm.GeneratorModel(num_residual_blocks=1, initialize=False), og.params)
+        d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+        g_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(g)
+        d_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(d)
+        out = []
+        for _ in range(2):
+            out += list(dbm.train_eval_discriminator(arrays, g, d, d_opt, share_generator_forward=share))
+            out += list(dbm.train_eval_generator(arrays, g, d, g_opt, share_generator_forward=share))
+        results.append(out)
+    assert np.allclose(results[0][:5], results[1][:5], rtol=0, atol=0)  # first iteration: bitwise
+    assert np.allclose(results[0], results[1], rtol=1e-3, atol=1e-5)     # second: gradients were folded by atomics
