@@ -488,16 +488,31 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   const bool share = (train & 2) != 0;  // opt-in: keep this forward's graph for the G-step of the same iteration
   train &= 1;
   g->ensure_ws(N, H, W, share && train);
-  // fake images under enable_backprop=False (:1131-1137)
-  g->forward(N, H, W, X, W1, W2, W3, g->yout.p, share && train);
-  g->graph_version = g->param_version;
-  g->graph_in[0] = X; g->graph_in[1] = W1; g->graph_in[2] = W2; g->graph_in[3] = W3;
   d->g_out.ensure(4 * (size_t)N);
   float* lr = d->g_out.p;
   float* lf = lr + N;
   float* gr = lf + N;
   float* gf = gr + N;
-  d->forward(N, H4, W4, Y, lr, train, train, 0);           // real batch (:1145)
+  // D(real) does not depend on the generator: it runs on the side stream underneath the (latency-bound) generator
+  // forward.  D(fake) starts only after it has finished, so the two BatchNorm running-average updates keep the
+  // reference's order (real, then fake: srgan_train.py:1145-1146).
+  c->fork_to_side(0);
+  {
+    hipStream_t main_stream = c->stream;
+    c->stream = c->side;
+    try {
+      d->forward(N, H4, W4, Y, lr, train, train, 0);  // real batch (:1145)
+    } catch (...) {
+      c->stream = main_stream;
+      throw;
+    }
+    c->stream = main_stream;
+  }
+  // fake images under enable_backprop=False (:1131-1137)
+  g->forward(N, H, W, X, W1, W2, W3, g->yout.p, share && train);
+  g->graph_version = g->param_version;
+  g->graph_in[0] = X; g->graph_in[1] = W1; g->graph_in[2] = W2; g->graph_in[3] = W3;
+  c->join_side();
   d->forward(N, H4, W4, g->yout.p, lf, train, train, 1);   // fake batch (:1146) -- separate BatchNorm statistics
   launch_ragan_loss(lr, lf, N, 1, 0, metrics, train ? gr : nullptr, train ? gf : nullptr, s);
   if (train) {

@@ -64,8 +64,8 @@ static int trunk_split(int N, long hw) {
   const long tiles = ((long)N * hw + 31) / 32;
   // two ranges: measured +4 % on the training step; four ranges oversubscribe the hardware queues (2.4x slower)
   int ns = 1;
-  if (tiles <= 1024 && N % 2 == 0 && tiles >= 64) ns = 2;
-  if (forced > 0 && N % forced == 0) ns = forced;
+  if (tiles <= 1024 && N >= 2 && tiles >= 64) ns = 2;
+  if (forced > 0 && forced <= 4 && N >= forced) ns = forced;
   return ns;
 }
 
@@ -162,13 +162,14 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   // has no cross-sample coupling, so the batch is cut into `nsplit` image ranges that run the same chain on
   // separate HIP streams: while one range's kernel is in its prologue / epilogue the other's feeds the MFMA pipes.
   const int nsplit = trunk_split(N, hw);
-  const int Nc = N / nsplit;
+  auto cn0 = [&](int c) { return (long)(((long)c * N) / nsplit); };          // first image of range c
+  auto cnc = [&](int c) { return (int)(cn0(c + 1) - cn0(c)); };                // images in range c
   auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[c - 1]; };
   for (int c = 1; c < nsplit; ++c) ctx->fork(s, ctx->chain[c - 1], c);
   // ---- pre-residual conv + LeakyReLU -> cat[0][:, :64]  (:541-542) ----
   for (int c = 0; c < nsplit; ++c) {
-    const long n0 = (long)c * Nc;
-    ConvDesc d = fwd_desc(layers[L_pre], a0.p + n0 * 128 * hw, 128 * hw, h, w, 0, cat[0].p + n0 * 192 * hw, 192 * hw, Nc);
+    const long n0 = cn0(c);
+    ConvDesc d = fwd_desc(layers[L_pre], a0.p + n0 * 128 * hw, 128 * hw, h, w, 0, cat[0].p + n0 * 192 * hw, 192 * hw, cnc(c));
     d.act = 1;
     launch_igemm_conv(d, cstream(c));
   }
@@ -176,7 +177,8 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   for (int j = 0; j < nrdb; ++j) {
     for (int c = 0; c < nsplit; ++c) {  // one dense block per range at a time: fewer stream switches on the host
       for (int k = 0; k < 5; ++k) {
-        const long n0 = (long)c * Nc * 192 * hw;
+        const long n0 = cn0(c) * 192 * hw;
+        const int Nc = cnc(c);
         float* C = cat[slot(j)].p + n0;
         if (k < 4) {
           const int cin = 64 + 32 * k;
@@ -197,8 +199,8 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   }
   // ---- post-residual conv, a3 = a1 + conv(a2)  (:550-551) ----
   for (int c = 0; c < nsplit; ++c) {
-    const long n0 = (long)c * Nc;
-    ConvDesc d = fwd_desc(layers[L_post], cat[slot(nrdb)].p + n0 * 192 * hw, 192 * hw, h, w, 0, a3.p + n0 * 64 * hw, 64 * hw, Nc);
+    const long n0 = cn0(c);
+    ConvDesc d = fwd_desc(layers[L_post], cat[slot(nrdb)].p + n0 * 192 * hw, 192 * hw, h, w, 0, a3.p + n0 * 64 * hw, 64 * hw, cnc(c));
     d.r1 = cat[0].p + n0 * 192 * hw; d.r1sn = 192 * hw; d.r1_nch = 64;
     launch_igemm_conv(d, cstream(c));
   }
@@ -313,11 +315,10 @@ void Generator::backward(const float* gy) {
   wbs[0].launch(ctx->side);
   // ---- trunk, last dense block first; like the forward, as `nsplit` image ranges on separate streams ----
   const int nsplit = trunk_split(N, hw);
-  const int Nc = N / nsplit;
   auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[c - 1]; };
   auto chunk = [&](ConvDesc d, int c) {  // descriptor restricted to image range c
-    const long n0 = (long)c * Nc;
-    d.x += n0 * d.xsn; d.y += n0 * d.ysn; d.N = Nc;
+    const long n0 = ((long)c * N) / nsplit;
+    d.x += n0 * d.xsn; d.y += n0 * d.ysn; d.N = (int)(((long)(c + 1) * N) / nsplit - n0);
     if (d.r1) d.r1 += n0 * d.r1sn;
     if (d.r2) d.r2 += n0 * d.r2sn;
     if (d.mask) d.mask += n0 * d.masksn;
