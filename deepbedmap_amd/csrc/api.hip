@@ -517,8 +517,20 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   launch_ragan_loss(lr, lf, N, 1, 0, metrics, train ? gr : nullptr, train ? gf : nullptr, s);
   if (train) {
     DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));  // cleargrads (:1162)
-    d->backward(0, gr, false);                                           // d_loss.backward() (:1163); its weight
-    d->backward(1, gf, true);                                            // gradients overlap the second pass
+    // d_loss.backward() (:1163): the real- and the fake-batch graphs are independent (gradients are accumulated
+    // with atomics), so the fake batch's pass runs on a second stream; both hand their weight gradients to the side stream
+    c->fork(s, c->chain[0], 7);
+    c->stream = c->chain[0];
+    try {
+      d->backward(1, gf, false);
+    } catch (...) {
+      c->stream = s;
+      throw;
+    }
+    c->stream = s;
+    d->backward(0, gr, false);
+    c->fork(c->chain[0], s, 7);
+    c->join_side();
   }
   DBM_API_END
 }

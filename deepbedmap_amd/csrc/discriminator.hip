@@ -108,15 +108,15 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
   int hs[11], ws[11];
   layer_dims(c.H, c.W, hs, ws);
   const size_t n = (size_t)N;
-  g_l1.ensure(n * 100);
-  g_h[0].ensure(n * 64 * c.H * c.W);
-  g_h[1].ensure(n * 64 * c.H * c.W);
+  g_l1[slot].ensure(n * 100);
+  g_h[slot][0].ensure(n * 64 * c.H * c.W);
+  g_h[slot][1].ensure(n * 64 * c.H * c.W);
   for (int i = 1; i < 10; ++i) g_z[slot][i].ensure(n * DC_O[i] * hs[i + 1] * ws[i + 1]);
   // linear_2, then linear_1 (through its LeakyReLU)
-  launch_linear_bwd(c.l1.p, P(T_l2W), glogits, nullptr, g_l1.p, G(T_l2W), G(T_l2b), N, 100, 1, SLOPE, s);
-  float* gh = g_h[0].p;
-  float* gh_next = g_h[1].p;
-  launch_linear_bwd(c.h[9].p, P(T_l1W), g_l1.p, c.l1.p, gh, G(T_l1W), G(T_l1b), N, 512, 100, SLOPE, s);
+  launch_linear_bwd(c.l1.p, P(T_l2W), glogits, nullptr, g_l1[slot].p, G(T_l2W), G(T_l2b), N, 100, 1, SLOPE, s);
+  float* gh = g_h[slot][0].p;
+  float* gh_next = g_h[slot][1].p;
+  launch_linear_bwd(c.h[9].p, P(T_l1W), g_l1[slot].p, c.l1.p, gh, G(T_l1W), G(T_l1b), N, 512, 100, SLOPE, s);
   for (int i = 9; i >= 1; --i) {
     const IgLayer& L = layers[L_conv[i]];
     const int hin = hs[i], win = ws[i], ho = hs[i + 1], wo = ws[i + 1];

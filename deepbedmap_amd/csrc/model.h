@@ -125,7 +125,7 @@ struct Discriminator : dbm_model {
     bool valid = false;
     DevBuf img, h[10], z[10], mean[10], istd[10], l1, out;
   } cache[2];
-  DevBuf g_h[2], g_z[2][10], g_l1, g_out;
+  DevBuf g_h[2][2], g_z[2][10], g_l1[2], g_out;  // per retained graph: the two backward passes overlap
   WgradBatch wb[2];  // batched weight gradients, one plan table per retained graph (real / fake batch)
   Discriminator(dbm_ctx* c);
   void forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot);

@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* __restri
   const float sg = block_sum_256(s1, sh);
   const float sgx = block_sum_256(s2, sh);
   if (threadIdx.x == 0) {
-    ggamma[c] += sgx;
-    gbeta[c] += sg;
+    atomicAdd(ggamma + c, sgx);  // atomics: the real- and fake-batch backward passes run concurrently
+    atomicAdd(gbeta + c, sg);
   }
   const float k = g * istd, im = 1.f / (float)m;
   for (long e = threadIdx.x; e < m; e += 256) {
@@ -174,12 +174,12 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict
     const int o = q / K, k = q - o * K;
     float a = 0.f;
     for (int n = 0; n < N; ++n) a = fmaf(gyz_of(gy, y_act, n * O + o, slope), x[(long)n * K + k], a);
-    gW[q] += a;
+    atomicAdd(gW + q, a);
   } else if (e < nx + nw + O) {
     const int o = e - nx - nw;
     float a = 0.f;
     for (int n = 0; n < N; ++n) a += gyz_of(gy, y_act, n * O + o, slope);
-    gb[o] += a;
+    atomicAdd(gb + o, a);
   }
 }
 

@@ -424,7 +424,9 @@ def test_shared_generator_forward_is_equivalent(dbm):
             out += list(dbm.train_eval_discriminator(arrays, g, d, d_opt, share_generator_forward=share))
             out += list(dbm.train_eval_generator(arrays, g, d, g_opt, share_generator_forward=share))
         results.append(out)
-    assert np.allclose(results[0][:5], results[1][:5], rtol=0, atol=0)  # first iteration: bitwise
+    assert results[0][:2] == results[1][:2]  # D-step of the first iteration: bitwise (same forward numbers)
+    # its G-step sees a discriminator whose update folded gradients with fp32 atomics (run-dependent order)
+    assert np.allclose(results[0][2:5], results[1][2:5], rtol=1e-4, atol=1e-6)
     # second iteration: gradients were folded by fp32 atomics in a run-dependent order and went through Adam's
     # sign-like first step, so only a loose agreement is meaningful
     assert np.allclose(results[0], results[1], rtol=1e-2, atol=1e-4)
