@@ -130,7 +130,6 @@ struct WgradPlan {
   int ImgS;     // Rin*Wst
   int XS;       // LDS channel stride of the patch (odd)
   int nbands;
-  int dbg;
 };
 size_t wgrad_plan(const WgradDesc& d, WgradPlan& p);  // fills p, returns the dynamic LDS bytes it needs
 

@@ -267,7 +267,6 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p) {
   if (S > p.nbands) S = p.nbands;
   if (S < 1) S = 1;
   p.S = S;
-  p.dbg = getenv("DBM_WG_DBG") ? atoi(getenv("DBM_WG_DBG")) : 0;
   p.wg_count = p.groups * p.coutTiles * S;
   const size_t stage = sizeof(float) * ((size_t)32 * p.YS + 2 * (size_t)p.BPp + (size_t)IB * p.ImgS + (size_t)p.G * 32 * p.XS);
   const size_t epilogue = sizeof(float) * 4 * 8 * 32 * (size_t)T;  // per-wavefront transpose areas
