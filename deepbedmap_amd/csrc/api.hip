@@ -552,10 +552,16 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
   const bool reuse = share && train && g->have_graph && g->wsTrain && g->graph_version == g->param_version &&
                      g->wsN == N && g->wsH == H && g->wsW == W && g->graph_in[0] == X && g->graph_in[1] == W1 &&
                      g->graph_in[2] == W2 && g->graph_in[3] == W3;
+  const bool pack_aside = d->packed_dirty && !reuse;
+  if (pack_aside) {  // the discriminator's weight images (stale since its Adam step) are rebuilt under the generator forward
+    c->fork_to_side(5);
+    d->ensure_packed(c->side);
+  }
   if (!reuse) {
     g->ensure_ws(N, H, W, train != 0);
     g->forward(N, H, W, X, W1, W2, W3, g->yout.p, train != 0);  // (:1222-1227)
   }
+  if (pack_aside) c->join_side();
   d->g_out.ensure(4 * (size_t)N);
   float* lf = d->g_out.p;
   d->forward(N, H4, W4, g->yout.p, lf, false, false, 1);  // eval-mode BatchNorm, detached (:1228-1229)

@@ -131,7 +131,7 @@ struct WgradPlan {
   int XS;       // LDS channel stride of the patch (odd)
   int nbands;
 };
-size_t wgrad_plan(const WgradDesc& d, WgradPlan& p);  // fills p, returns the dynamic LDS bytes it needs
+size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level = 0);  // fills p, returns the dynamic LDS bytes it needs
 
 // All weight gradients of one backward pass: collected as descriptors, planned and uploaded once per
 // workspace shape, then launched as one kernel per kernel size (1x1, 3x3, 4x4).

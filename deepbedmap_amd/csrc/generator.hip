@@ -328,7 +328,10 @@ void Generator::backward(const float* gy) {
   for (int c = 1; c < nsplit; ++c) ctx->fork(s, ctx->chain[c - 1], 7);
   int prev_grp = -1;
   for (int j = nrdb - 1; j >= 0; --j) {
-    const int grp = 1 + ((j / 3) * 4) / n_rrdb;  // 4 groups of residual-in-residual blocks
+    // groups of residual-in-residual blocks, shrinking towards the end of the chain: what is still to do once the
+    // data-gradient chain has finished (the last group + the pre-residual / input-block batch) is exposed time
+    const int r = j / 3;
+    const int grp = r == 0 ? 5 : r == 1 ? 4 : r <= 3 ? 3 : (r >= 4 + (n_rrdb - 3) / 2 ? 1 : 2);
     if (prev_grp >= 0 && grp != prev_grp) {
       join_chains();
       ctx->fork_to_side(prev_grp);
@@ -379,7 +382,7 @@ void Generator::backward(const float* gy) {
   // ---- pre_residual_conv_layer and the input block ----
   {
     const IgLayer& L = layers[L_pre];
-    run_wgrad(L, a0.p, 128 * hw, h, w, 0, dA[0].p, 192 * hw, h, w, N, 1.f, &wbs[5]);
+    run_wgrad(L, a0.p, 128 * hw, h, w, 0, dA[0].p, 192 * hw, h, w, N, 1.f, &wbs[6]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = dA[0].p; d.xsn = 192 * hw; d.N = N;
@@ -398,7 +401,7 @@ void Generator::backward(const float* gy) {
       if (L_in[i] >= 0) {
         const IgLayer& L = layers[L_in[i]];
         run_wgrad(L, (i == 1 ? colW1 : colW2).p, (long)L.CinP * hw, h, w, 0, g_a0.p + (long)i * 32 * hw, 128 * hw, h, w, N,
-                  1.f, &wbs[5]);
+                  1.f, &wbs[6]);
       } else {
         launch_smallcin_conv_wgrad(q, g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), s);
       }
@@ -406,6 +409,6 @@ void Generator::backward(const float* gy) {
   }
   ctx->fork_to_side(6);
   if (prev_grp >= 0) wbs[prev_grp].launch(ctx->side);
-  wbs[5].launch(ctx->side);
+  wbs[6].launch(ctx->side);
   ctx->join_side();  // the optimizer (and the next cleargrads) must see every gradient
 }

@@ -77,7 +77,7 @@ struct dbm_model {
   float* S(int ti) const { return pers + tensors[ti].off; }
   int tid(const std::string& key) const;
   int add_iglayer(const std::string& name, int O, int C, int K, int stride, int pad, bool bias, bool as_1x1 = false);
-  void ensure_packed();
+  void ensure_packed(hipStream_t on = nullptr);  // rebuild the packed weight images if the parameters changed
   // helpers building descriptors
   ConvDesc fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, float* y, long ysn, int N) const;
   void run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_fwd, hipStream_t s = nullptr) const;
@@ -104,8 +104,8 @@ struct Generator : dbm_model {
   long graph_version = -1;
   const float* graph_in[4] = {nullptr, nullptr, nullptr, nullptr};
   const float* bw_in[4] = {nullptr, nullptr, nullptr, nullptr};  // forward inputs, needed by the input-block wgrad
-  static const int NWB = 6;
-  WgradBatch wbs[NWB];  // batched weight gradients: tail, 4 trunk groups, pre-residual (launched on the side stream)
+  static const int NWB = 7;
+  WgradBatch wbs[NWB];  // batched weight gradients: tail, 5 trunk groups, pre-residual + input block (launched on the side stream)
   std::vector<DevBuf> cat, dA;
   DevBuf in_x, in_w1, in_w2, in_w3, a0, a3, a41, a42, off1, off2, col1, col2, a51, yout;
   DevBuf g_a0, g_a3, g_u1, g_z41, g_u2, g_a42, goff1, goff2, gcol, g_a51, g_y;
@@ -126,7 +126,7 @@ struct Discriminator : dbm_model {
     DevBuf img, h[10], z[10], mean[10], istd[10], l1, out;
   } cache[2];
   DevBuf g_h[2][2], g_z[2][10], g_l1[2], g_out;  // per retained graph: the two backward passes overlap
-  WgradBatch wb[2];  // batched weight gradients, one plan table per retained graph (real / fake batch)
+  WgradBatch wb[2][2];  // batched weight gradients per retained graph (real / fake batch): layers 9..5, layers 4..1
   Discriminator(dbm_ctx* c);
   void forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot);
   void backward(int slot, const float* glogits, bool join = true);

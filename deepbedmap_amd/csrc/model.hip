@@ -139,9 +139,9 @@ int dbm_model::add_iglayer(const std::string& name, int O, int C, int K, int str
   return (int)layers.size() - 1;
 }
 
-void dbm_model::ensure_packed() {
+void dbm_model::ensure_packed(hipStream_t on) {
   if (!packed_dirty) return;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = on ? on : ctx->stream;
   if (!d_pack_jobs) {  // the job table only depends on the layer list: build and upload it once
     std::vector<PackJob> jobs;
     int blocks = 0;

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256 * (T / TPW), 2) void wgrad_kernel(const WgradPl
 
 static inline int odd_up(int v) { return v | 1; }
 
-size_t wgrad_plan(const WgradDesc& d, WgradPlan& p) {
+size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level) {
   const int T = d.KH * d.KW;
   DBM_CHECK(T == 1 || T == 9 || T == 16, "wgrad: supported kernels are 1x1, 3x3, 4x4");
   DBM_CHECK(d.OW < 4096 && d.OH < 4096, "wgrad: image too large");
@@ -244,7 +244,7 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p) {
   };
   int IB = 1, R = d.OH;
   if (cost(1, d.OH) <= budget) {
-    while (IB * 2 <= d.N && IB * 2 <= 128 && IB * 2 * d.OH * d.OW <= 324 && cost(IB * 2, d.OH) <= budget) IB *= 2;
+    while (IB * 2 <= d.N && IB * 2 <= 128 && IB * 2 * d.OH * d.OW <= (324 >> level) && cost(IB * 2, d.OH) <= budget) IB *= 2;
   } else {
     while (R > 1 && cost(1, R) > budget) --R;
   }
@@ -263,7 +263,10 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p) {
   p.nbands = imgGroups * p.nbr;
   // K split: enough positions per workgroup that the closing atomics stay a small fraction of the MFMA work
   const long positions = (long)d.N * d.OH * d.OW;
-  int S = (int)((positions + 647) / 648);  // ~8 images of the 9x9 trunk per workgroup
+  // (~8 images of the 9x9 trunk per workgroup; `level` > 0 halves that, and the band, per step: used by batches
+  // that would otherwise leave most of the chip idle)
+  const long per_wg = std::max(1L, 648L >> level);
+  int S = (int)((positions + per_wg - 1) / per_wg);
   if (S > p.nbands) S = p.nbands;
   if (S < 1) S = 1;
   p.S = S;
@@ -306,14 +309,20 @@ void WgradBatch::build() {
     int total = 0;
     size_t maxlds = 0;
     double fl = 0.0;
-    for (const auto& d : descs) {
-      if (d.KH * d.KW != TT[g]) continue;
-      WgradPlan p;
-      maxlds = std::max(maxlds, wgrad_plan(d, p));
-      starts.push_back(total);
-      total += p.wg_count;
-      plans.push_back(p);
-      fl += 2.0 * (double)d.N * d.OH * d.OW * d.Cout * d.Cin * TT[g];
+    // a launch should offer about two workgroups per CU; small batches split their position axis finer
+    for (int level = 0; level < 4; ++level) {
+      plans.clear(); starts.clear();
+      total = 0; maxlds = 0; fl = 0.0;
+      for (const auto& d : descs) {
+        if (d.KH * d.KW != TT[g]) continue;
+        WgradPlan p;
+        maxlds = std::max(maxlds, wgrad_plan(d, p, level));
+        starts.push_back(total);
+        total += p.wg_count;
+        plans.push_back(p);
+        fl += 2.0 * (double)d.N * d.OH * d.OW * d.Cout * d.Cin * TT[g];
+      }
+      if (total >= 448 || plans.empty()) break;
     }
     starts.push_back(total);
     nplans[g] = (int)plans.size();

@@ -8,18 +8,19 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT" -o trace -- python3 bench.py --no-cpu-baseline "$@" > "$OUT/bench.log" 2>&1
 grep '^{' "$OUT/bench.log" > "$OUT/bench.json" || true
-# per-dispatch trace is large: keep only the last 1200 dispatches (about one training step) for inspection
+# per-dispatch trace is large: keep only the last 2600 dispatches (about two training step) for inspection
 python3 - "$OUT" <<'PY'
 import csv, sys, os
 out = sys.argv[1]
 src = os.path.join(out, "trace_kernel_trace.csv")
 rows = list(csv.DictReader(open(src)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-tail = rows[-1200:]
+tail = rows[-2600:]
 with open(os.path.join(out, "last_step_dispatches.csv"), "w") as f:
-    f.write("kernel,duration_us,grid,workgroup,lds,vgpr\n")
+    t0 = int(tail[0]["Start_Timestamp"])
+    f.write("kernel,start_us,duration_us,queue,grid,workgroup,lds,vgpr\n")
     for r in tail:
-        f.write('"%s",%.2f,%s,%s,%s,%s\n' % (r["Kernel_Name"][:60], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+        f.write('"%s",%.2f,%.2f,%s,%s,%s,%s,%s\n' % (r["Kernel_Name"][:60], (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Queue_Id", ""),
                                            r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")),
                                            r.get("LDS_Block_Size", ""), r.get("VGPR_Count", "")))
 os.remove(src)
