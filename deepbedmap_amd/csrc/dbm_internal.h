@@ -130,6 +130,10 @@ struct WgradPlan {
   int ImgS;     // Rin*Wst
   int XS;       // LDS channel stride of the patch (odd)
   int nbands;
+  // whole-image bands of plain (not upsampled) planes: both operands are contiguous per image and are staged with
+  // 16-byte loads; `fast` = 0 falls back to the per-element gather
+  int fast;
+  unsigned planeM, winM;  // ceil(2^32 / (Hin*Win)), ceil(2^32 / Win): exact quotients for the sizes staged here
 };
 size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level = 0);  // fills p, returns the dynamic LDS bytes it needs
 

@@ -96,6 +96,10 @@ __global__ __launch_bounds__(256 * (T / TPW), 2) void wgrad_kernel(const WgradPl
   }
   const int perch = p.IB * p.ImgS;
   const int nch = p.G * 32;
+  if (p.fast) {
+    for (int e = tid; e < nch * p.XS; e += NT) ldsX[e] = 0.f;
+    for (int e = tid; e < 32 * p.YS; e += NT) ldsY[e] = 0.f;
+  }
 
   for (int band = bz; band < p.nbands; band += p.S) {
     const int ig = band / p.nbr;
@@ -105,54 +109,115 @@ __global__ __launch_bounds__(256 * (T / TPW), 2) void wgrad_kernel(const WgradPl
     // Staging is latency bound (few wavefronts per CU).  Each lane decodes ITS positions once per band and then
     // streams all channels / rows for them with U independent, unconditional loads in flight (out-of-image or
     // out-of-range elements read a safe address and are zeroed by a select afterwards).
-    constexpr int U = 8;
-    constexpr int RPW = 32 / NW;  // dy rows per wavefront
-    // ---- dy slab: 32 x BPp ----
-    for (int p0 = 0; p0 < p.BPp; p0 += 64) {
-      const int pix = p0 + lane;
-      const bool inb = pix < p.BPp;
-      const int info = pixinfo[inb ? pix : 0];
-      const int ib = info & 0xff, al = (info >> 8) & 0xfff, b = (int)((unsigned)info >> 20);
-      const int n = n0 + ib, a = a0 + al;
-      const bool ok = inb && ib != 0xff && n < d.N && a < d.OH;
-      const float* src = d.dy + (ok ? (long)n * d.dysn + a * d.OW + b : 0L);
-      float v[RPW];
+    if (p.fast) {
+      // Whole images of plain planes: per image the 32 dy planes and the nch input planes of this workgroup are ONE
+      // contiguous run each.  16-byte loads, four in flight per lane, then scattered into the padded LDS planes
+      // (the zero border was written once before the band loop and is never overwritten).
+      const int oplane = d.OH * d.OW;
+      const int nco = min(32, d.Cout - cout0);
+      const int nci = min(nch, d.Cin - cin0);
+      const int plane = d.Hin * d.Win;
+      for (int ib = 0; ib < p.IB; ++ib) {
+        const int n = n0 + ib;
+        const bool okn = n < d.N;
+        {  // dy: nco x oplane floats -> ldsY[i * YS + ib * oplane + pos]
+          const int q4 = (nco * oplane) >> 2;
+          const float4* src = (const float4*)(d.dy + (okn ? (long)n * d.dysn : 0L) + (long)cout0 * d.dysc);
+          const unsigned oM = p.winM;  // (unused for dy) keep the register pressure flat
+          (void)oM;
+          for (int i = tid; i < q4; i += NT) {
+            float4 v = src[i];
+            if (!okn) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int u = 0; u < RPW; ++u) {
-        const int i = wave * RPW + u;
-        v[u] = src[(ok && cout0 + i < d.Cout) ? (long)(cout0 + i) * d.dysc : 0L];
+            for (int u = 0; u < 4; ++u) {
+              const int f = 4 * i + u;
+              const int row = f / oplane;  // oplane is not a compile-time constant: one division per element (few per band)
+              ldsY[row * p.YS + ib * oplane + (f - row * oplane)] = vv[u];
+            }
+          }
+        }
+        {  // x: nci x plane floats -> ldsX[c * XS + ib * ImgS + (y + pad) * Wst + (x + pad)]
+          const int q4 = (nci * plane) >> 2;
+          const float4* src = (const float4*)(d.x + (okn ? (long)n * d.xsn : 0L) + (long)cin0 * d.xsc);
+          float* dstb = ldsX + ib * p.ImgS + d.pad * p.Wst + d.pad;
+          for (int i0 = tid; i0 < q4; i0 += 4 * NT) {
+            float4 v[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const int i = i0 + w * NT;
+              v[w] = src[i < q4 ? i : 0];
+            }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const int i = i0 + w * NT;
+              if (i < q4) {
+                const float vv[4] = {v[w].x, v[w].y, v[w].z, v[w].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const unsigned f = 4u * (unsigned)i + u;
+                  const unsigned c = __umulhi(f, p.planeM);
+                  const unsigned r = f - c * (unsigned)plane;
+                  const unsigned y = __umulhi(r, p.winM);
+                  const unsigned xx = r - y * (unsigned)d.Win;
+                  if ((int)(y + d.pad) < p.Rin && (int)(xx + d.pad) < p.Wst)
+                    dstb[c * p.XS + y * p.Wst + xx] = okn ? vv[u] : 0.f;
+                }
+              }
+            }
+          }
+        }
       }
-      if (inb) {
-#pragma unroll
+    } else {
+      constexpr int U = 8;
+      constexpr int RPW = 32 / NW;  // dy rows per wavefront
+      // ---- dy slab: 32 x BPp ----
+      for (int p0 = 0; p0 < p.BPp; p0 += 64) {
+        const int pix = p0 + lane;
+        const bool inb = pix < p.BPp;
+        const int info = pixinfo[inb ? pix : 0];
+        const int ib = info & 0xff, al = (info >> 8) & 0xfff, b = (int)((unsigned)info >> 20);
+        const int n = n0 + ib, a = a0 + al;
+        const bool ok = inb && ib != 0xff && n < d.N && a < d.OH;
+        const float* src = d.dy + (ok ? (long)n * d.dysn + a * d.OW + b : 0L);
+        float v[RPW];
+  #pragma unroll
         for (int u = 0; u < RPW; ++u) {
           const int i = wave * RPW + u;
-          ldsY[i * p.YS + pix] = (ok && cout0 + i < d.Cout) ? v[u] : 0.f;
-        }
-      }
-    }
-    // ---- input patch in logical (upsampled, zero padded) coordinates; each wavefront stages nch / NW channels ----
-    const int cpw = nch / NW;  // nch is a multiple of 32, NW of 4 or 8
-    for (int e0 = 0; e0 < perch; e0 += 64) {
-      const int e = e0 + lane;
-      const bool inb = e < perch;
-      const int info = xinfo[inb ? e : 0];
-      const int ib = info & 0xff, ry = (info >> 8) & 0xfff, rx = (int)((unsigned)info >> 20);
-      const int iy = a0 * d.stride - d.pad + ry, ix = rx - d.pad;
-      const int n = n0 + ib;
-      const bool ok = inb && n < d.N && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
-      const float* src = d.x + (ok ? (long)n * d.xsn + (iy >> d.ups) * d.Win + (ix >> d.ups) : 0L);
-      for (int cb = 0; cb < cpw; cb += U) {
-        float v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int ci = cin0 + wave * cpw + cb + u;
-          v[u] = src[(ok && cb + u < cpw && ci < d.Cin) ? (long)ci * d.xsc : 0L];
+          v[u] = src[(ok && cout0 + i < d.Cout) ? (long)(cout0 + i) * d.dysc : 0L];
         }
         if (inb) {
-#pragma unroll
+  #pragma unroll
+          for (int u = 0; u < RPW; ++u) {
+            const int i = wave * RPW + u;
+            ldsY[i * p.YS + pix] = (ok && cout0 + i < d.Cout) ? v[u] : 0.f;
+          }
+        }
+      }
+      // ---- input patch in logical (upsampled, zero padded) coordinates; each wavefront stages nch / NW channels ----
+      const int cpw = nch / NW;  // nch is a multiple of 32, NW of 4 or 8
+      for (int e0 = 0; e0 < perch; e0 += 64) {
+        const int e = e0 + lane;
+        const bool inb = e < perch;
+        const int info = xinfo[inb ? e : 0];
+        const int ib = info & 0xff, ry = (info >> 8) & 0xfff, rx = (int)((unsigned)info >> 20);
+        const int iy = a0 * d.stride - d.pad + ry, ix = rx - d.pad;
+        const int n = n0 + ib;
+        const bool ok = inb && n < d.N && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+        const float* src = d.x + (ok ? (long)n * d.xsn + (iy >> d.ups) * d.Win + (ix >> d.ups) : 0L);
+        for (int cb = 0; cb < cpw; cb += U) {
+          float v[U];
+  #pragma unroll
           for (int u = 0; u < U; ++u) {
-            const int c = wave * cpw + cb + u;
-            if (cb + u < cpw) ldsX[c * p.XS + e] = (ok && cin0 + c < d.Cin) ? v[u] : 0.f;
+            const int ci = cin0 + wave * cpw + cb + u;
+            v[u] = src[(ok && cb + u < cpw && ci < d.Cin) ? (long)ci * d.xsc : 0L];
+          }
+          if (inb) {
+  #pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int c = wave * cpw + cb + u;
+              if (cb + u < cpw) ldsX[c * p.XS + e] = (ok && cin0 + c < d.Cin) ? v[u] : 0.f;
+            }
           }
         }
       }
@@ -271,6 +336,16 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level) {
   if (S < 1) S = 1;
   p.S = S;
   p.wg_count = p.groups * p.coutTiles * S;
+  auto magic = [](unsigned dv) { return (unsigned)((0x100000000ULL + dv - 1) / dv); };
+  const int plane = d.Hin * d.Win;
+  p.planeM = magic((unsigned)plane);
+  p.winM = magic((unsigned)d.Win);
+  const int tail_ci = d.Cin - (p.groups - 1) * p.G * 32;  // channels of the last input group
+  p.fast = p.nbr == 1 && d.ups == 0 && d.xsc == plane && d.dysc == d.OH * d.OW && (d.xsn % 4) == 0 && (d.dysn % 4) == 0 &&
+           ((uintptr_t)d.x % 16) == 0 && ((uintptr_t)d.dy % 16) == 0 && ((32L * d.dysc) % 4) == 0 &&
+           (((long)p.G * 32 * d.xsc) % 4) == 0 && ((long)std::min(32, d.Cout) * d.OH * d.OW) % 4 == 0 &&
+           ((long)(d.Cout % 32 ? d.Cout % 32 : 32) * d.OH * d.OW) % 4 == 0 && ((long)std::min(p.G * 32, tail_ci) * plane) % 4 == 0 &&
+           ((long)std::min(p.G * 32, d.Cin) * plane) % 4 == 0 && (long)p.G * 32 * plane < (1L << 22);
   const size_t stage = sizeof(float) * ((size_t)32 * p.YS + 2 * (size_t)p.BPp + (size_t)IB * p.ImgS + (size_t)p.G * 32 * p.XS);
   const size_t epilogue = sizeof(float) * 4 * 8 * 32 * (size_t)T;  // per-wavefront transpose areas
   return std::max(stage, epilogue);
