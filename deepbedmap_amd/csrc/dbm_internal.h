@@ -134,19 +134,23 @@ struct WgradPlan {
   // 16-byte loads; `fast` = 0 falls back to the per-element gather
   int fast;
   unsigned planeM, winM;  // ceil(2^32 / (Hin*Win)), ceil(2^32 / Win): exact quotients for the sizes staged here
+  unsigned oplaneM;       // ceil(2^32 / (OH*OW))
+  int wave_task;          // 1: planned for wgrad_wave_kernel (one wavefront per task), 2: wgrad_wave_dma_kernel
 };
-size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level = 0);  // fills p, returns the dynamic LDS bytes it needs
+// fills p, returns the dynamic LDS bytes it needs (0: not eligible for the wave-task form)
+size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level = 0, int wave_task = 0, int S_fixed = 0);
 
 // All weight gradients of one backward pass: collected as descriptors, planned and uploaded once per
 // workspace shape, then launched as one kernel per kernel size (1x1, 3x3, 4x4).
 struct WgradBatch {
   std::vector<WgradDesc> descs;
   bool built = false;
-  WgradPlan* d_plans[3] = {nullptr, nullptr, nullptr};
-  int* d_starts[3] = {nullptr, nullptr, nullptr};
-  int nplans[3] = {0, 0, 0}, total_wg[3] = {0, 0, 0};
-  size_t lds[3] = {0, 0, 0};
-  double flops[3] = {0, 0, 0};
+  static const int NCAT = 5;  // 1x1, 3x3 (workgroup form), 4x4, 3x3 wave tasks, 3x3 wave tasks with LDS-DMA staging
+  WgradPlan* d_plans[NCAT] = {};
+  int* d_starts[NCAT] = {};
+  int nplans[NCAT] = {}, total_wg[NCAT] = {};
+  size_t lds[NCAT] = {};
+  double flops[NCAT] = {};
   void add(const WgradDesc& d) { if (!built) descs.push_back(d); }
   void build();
   void launch(hipStream_t s);

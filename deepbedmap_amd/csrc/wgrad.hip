@@ -16,8 +16,19 @@
 // go out in a single launch after the data-gradient chain (they do not depend on each other).
 #include "dbm_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Phase timing of the wave-task kernels for the micro-benchmark under scratch/ (compiled out of the library).
+#ifdef DBM_WG_TIMING
+__device__ unsigned long long g_dbg[4 * 8192];
+#define WG_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define WG_TACC(acc, a, b) acc += (b) - (a)
+#else
+#define WG_T(var)
+#define WG_TACC(acc, a, b)
+#endif
 
 // TPW = taps per wavefront.  3x3 / 1x1: every wavefront keeps all T accumulators (TPW = T, 4 wavefronts, 256
 // registers -> two workgroups share a CU: one stages while the other feeds the MFMA pipe).  4x4: 16 accumulators are
@@ -233,24 +244,35 @@ __global__ __launch_bounds__(256 * (T / TPW), 2) void wgrad_kernel(const WgradPl
       bsum += part;  // every thread of the 8-group holds the row total; only (tid & 7) == 0 publishes it
     }
     if (wave_active) {
-      // K loop, software pipelined by one step: the A value and the patch offset of step k+1 are fetched from LDS
-      // while the TPW MFMAs of step k issue (the B reads of a step depend on its offset).
+      // K loop, software pipelined by one full step: the A value and the TPW patch values of step k+1 (and the patch
+      // offset of step k+2) are in flight while the MFMAs of step k issue.  hipcc would otherwise sink every LDS read
+      // to just before its MFMA (one exposed LDS latency per read); the scheduling barriers pin the order.
       const float* arow = ldsY + j * p.YS + kh;
       const float* xrow = ldsX + (ct * 32 + j) * p.XS;
       float av = arow[0];
-      int off = pixoff[kh];
-      for (int kp = 0; kp < p.BPp; kp += 2) {
-        const float* xb = xrow + off;
-        float bv[TPW];
+      float bv[TPW];
+      {
+        const int off = pixoff[kh];
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) bv[t] = xb[toff[t]];
+        for (int t = 0; t < TPW; ++t) bv[t] = xrow[off + toff[t]];
+      }
+      int off_n = pixoff[((2 < p.BPp) ? 2 : 0) + kh];
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the loop is entered with nothing pending
+      for (int kp = 0; kp < p.BPp; kp += 2) {
         const int kn = (kp + 2 < p.BPp) ? kp + 2 : kp;
+        const int kn2 = (kp + 4 < p.BPp) ? kp + 4 : kn;
         const float av_n = arow[kn];
-        const int off_n = pixoff[kn + kh];
+        float bv_n[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) bv_n[t] = xrow[off_n + toff[t]];
+        off_n = pixoff[kn2 + kh];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         av = av_n;
-        off = off_n;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) bv[t] = bv_n[t];
       }
     }
   }
@@ -288,29 +310,383 @@ __global__ __launch_bounds__(256 * (T / TPW), 2) void wgrad_kernel(const WgradPl
     atomicAdd(d.gb + cout0 + (tid >> 3), d.scale * bsum);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-task form for whole-image bands of small planes (the 9x9 trunk, the deep discriminator layers): one
+// WAVEFRONT = one (32 input channels, 32 output channels, K slice) task with its own 26 KB of LDS, six per CU.
+// Against the workgroup form above this gives up sharing the dy slab between input tiles, and gains: no idle
+// wavefront slots when a layer has fewer than four input tiles per group (28 % of the trunk's slots), no
+// workgroup barriers, and scheduling at wavefront granularity (tasks are equally long; the chip runs them in
+// ceil(tasks / 1536) rounds instead of ceil(workgroups / 512) rounds of four-wavefront groups).
+// ---------------------------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(64, 2) void wgrad_wave_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ starts,
+                                                           int nplans) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int lo = 0, hi = nplans - 1;
+  const int wg = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= wg) lo = mid; else hi = mid - 1;
+  }
+  const WgradPlan& p = plans[lo];
+  const WgradDesc& d = p.d;
+  int local = wg - starts[lo];
+  const int ct = local % p.groups;   // input tile
+  local /= p.groups;
+  const int by = local % p.coutTiles;
+  const int bz = local / p.coutTiles;
+  float* ldsY = lds;                            // 32 * YS
+  int* pixoff = (int*)(ldsY + 32 * p.YS);       // BPp
+  float* ldsX = (float*)(pixoff + p.BPp);       // 32 * XS
+  const int lane = threadIdx.x;
+  const int j = lane & 31, kh = lane >> 5;
+  const int cout0 = by * 32, cin_w = ct * 32;
+  constexpr int KWc = (T == 1) ? 1 : (T == 9 ? 3 : 4);
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  int toff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) toff[t] = (t / KWc) * p.Wst + (t % KWc);
+  const int oplane = d.OH * d.OW, plane = d.Hin * d.Win;
+  for (int e = lane; e < p.BPp; e += 64) {
+    int off = 0;
+    if (e < p.BP) {
+      const int ib = e / oplane;
+      const int rem = e - ib * oplane;
+      const int al = rem / d.OW, b = rem - al * d.OW;
+      off = ib * p.ImgS + al * d.stride * p.Wst + b * d.stride;
+    }
+    pixoff[e] = off;
+  }
+  for (int e = lane; e < 32 * p.XS; e += 64) ldsX[e] = 0.f;
+  for (int e = lane; e < 32 * p.YS; e += 64) ldsY[e] = 0.f;
+  const int nco = min(32, d.Cout - cout0), nci = min(32, d.Cin - cin_w);
+  const int q4y = (nco * oplane) >> 2, q4x = (nci * plane) >> 2;
+  float bsum = 0.f;
+  constexpr int U = 4;
+  for (int band = bz; band < p.nbands; band += p.S) {
+    const int n0 = band * p.IB;
+    for (int ib = 0; ib < p.IB; ++ib) {
+      const int n = n0 + ib;
+      const bool okn = n < d.N;
+      const float4* srcy = (const float4*)(d.dy + (okn ? (long)n * d.dysn : 0L) + (long)cout0 * d.dysc);
+      const float4* srcx = (const float4*)(d.x + (okn ? (long)n * d.xsn : 0L) + (long)cin_w * d.xsc);
+      float* dsty = ldsY + ib * oplane;
+      float* dstx = ldsX + ib * p.ImgS + d.pad * p.Wst + d.pad;
+      for (int i0 = lane; i0 < q4y; i0 += 64 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int w = 0; w < U; ++w) {
+          const int i = i0 + 64 * w;
+          v[w] = srcy[i < q4y ? i : 0];
+        }
+#pragma unroll
+        for (int w = 0; w < U; ++w) {
+          const int i = i0 + 64 * w;
+          if (i < q4y) {
+            const float vv[4] = {v[w].x, v[w].y, v[w].z, v[w].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const unsigned f = 4u * (unsigned)i + u;
+              const unsigned row = __umulhi(f, p.oplaneM);
+              dsty[row * p.YS + (f - row * (unsigned)oplane)] = okn ? vv[u] : 0.f;
+            }
+          }
+        }
+      }
+      for (int i0 = lane; i0 < q4x; i0 += 64 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int w = 0; w < U; ++w) {
+          const int i = i0 + 64 * w;
+          v[w] = srcx[i < q4x ? i : 0];
+        }
+#pragma unroll
+        for (int w = 0; w < U; ++w) {
+          const int i = i0 + 64 * w;
+          if (i < q4x) {
+            const float vv[4] = {v[w].x, v[w].y, v[w].z, v[w].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const unsigned f = 4u * (unsigned)i + u;
+              const unsigned c = __umulhi(f, p.planeM);
+              const unsigned r = f - c * (unsigned)plane;
+              const unsigned y = __umulhi(r, p.winM);
+              const unsigned xx = r - y * (unsigned)d.Win;
+              if ((int)(y + d.pad) < p.Rin && (int)(xx + d.pad) < p.Wst) dstx[c * p.XS + y * p.Wst + xx] = okn ? vv[u] : 0.f;
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (d.gb && ct == 0) {  // bias gradient: lane (j, kh) sums every other position of dy row j
+      const float* row = ldsY + j * p.YS;
+      float part = 0.f;
+      for (int pix = kh; pix < p.BP; pix += 2) part += row[pix];
+      bsum += part;
+    }
+    {
+      const float* arow = ldsY + j * p.YS + kh;
+      const float* xrow = ldsX + j * p.XS;
+      float av = arow[0];
+      int off = pixoff[kh];
+      for (int kp = 0; kp < p.BPp; kp += 2) {
+        const float* xb = xrow + off;
+        float bv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) bv[t] = xb[toff[t]];
+        const int kn = (kp + 2 < p.BPp) ? kp + 2 : kp;
+        const float av_n = arow[kn];
+        const int off_n = pixoff[kn + kh];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        av = av_n;
+        off = off_n;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- fold into gW[o][c][t]: 8 output rows at a time through LDS so that the atomics run over consecutive addresses ----
+  {
+    constexpr int ROWF = 32 * T;
+    float* tw = lds;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) tw[(rr + 4 * kh) * ROWF + j * T + t] = d.scale * acc[t][4 * q + rr];
+      __builtin_amdgcn_wave_barrier();
+      for (int e = lane; e < 8 * ROWF; e += 64) {
+        const int rl = e / ROWF;
+        const int rem = e - rl * ROWF;
+        const int o = cout0 + 8 * q + rl;
+        const int c = cin_w + rem / T;
+        if (o < d.Cout && c < d.Cin) atomicAdd(d.gW + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (d.gb && ct == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (kh == 0 && cout0 + j < d.Cout) atomicAdd(d.gb + cout0 + j, d.scale * bsum);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-task form with LDS-DMA staging: 3x3 / stride 1 / pad 1 layers on small planes (the 9x9 trunk).  No staging
+// registers and no staging arithmetic: dy (32 planes, contiguous in memory) lands with `global_load_lds_dwordx4`;
+// x lands with `global_load_lds_dword`, two instructions per channel plane, into a zero-framed plane of
+// (H+2) x (W+1) cells (one zero row above and below, one zero column shared by neighbouring rows) so that the K loop
+// needs no border logic.  Every load of a band is in flight at once.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128, 2) void wgrad_wave_dma_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ starts,
+                                                               int nplans) {
+  constexpr int T = 9;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int lo = 0, hi = nplans - 1;
+  const int wg = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= wg) lo = mid; else hi = mid - 1;
+  }
+  const WgradPlan& p = plans[lo];
+  const WgradDesc& d = p.d;
+  int local = wg - starts[lo];
+  const int wave = threadIdx.x >> 6;
+  const int ct = 2 * (local % p.groups) + wave;  // two wavefronts = two input tiles share one dy slab
+  local /= p.groups;
+  const int by = local % p.coutTiles;
+  const int bz = local / p.coutTiles;
+  const int H = d.OH, W = d.OW, W1 = W + 1;
+  const int plane = H * W;          // == Hin * Win
+  const int slab = 32 * plane;      // floats of one image's 32 dy planes
+  const int PS = p.ImgS;            // (H + 2) * (W + 1): framed x plane
+  float* ldsY = lds;                            // IB * slab
+  float* ldsX0 = ldsY + p.IB * slab + 4;        // 2 x IB * 32 * PS, behind a 4-float zero guard (tap (0,0) of cell (0,0))
+  float* ldsX = ldsX0 + wave * p.IB * 32 * PS;  // this wavefront's framed planes
+  int* pinfo = (int*)(ldsX0 + 2 * p.IB * 32 * PS);  // BPp + 8: position -> dy offset | x offset of tap (0,0) << 16
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int j = lane & 31, kh = lane >> 5;
+  const int cout0 = by * 32, cin_w = ct * 32;
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  int toff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) toff[t] = (t / 3) * W1 + (t % 3);
+  for (int e = tid; e < p.BPp + 8; e += 128) {
+    int info = 0;  // padding positions: dy offset of position 0, x offset 0 -- their dy is zero (see below)
+    if (e < p.BP) {
+      const int ib = e / plane;
+      const int rem = e - ib * plane;
+      const int y = rem / W, x = rem - y * W;
+      info = (ib * slab + rem) | ((ib * 32 * PS + y * W1 + x) << 16);  // x offset is relative to ldsX - 1
+    }
+    pinfo[e] = info;
+  }
+  const int tot = p.IB * slab + 4 + 2 * p.IB * 32 * PS;
+  for (int e = tid; e < tot; e += 128) lds[e] = 0.f;  // frames, guard, and the planes of ragged tiles
+  // per-lane source cell of the two DMA instructions that fill one framed plane (cells lane, lane + 64)
+  int soff[2];
+  bool sval[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int r = lane + 64 * k;
+    const int yy = r / W1, xx = r - yy * W1;
+    sval[k] = r < PS && yy >= 1 && yy <= H && xx < W;
+    soff[k] = sval[k] ? (yy - 1) * W + xx : 0;
+  }
+  const int nco = min(32, d.Cout - cout0), nci = max(0, min(32, d.Cin - cin_w));
+  const bool wave_active = nci > 0;
+  const int q4y = (nco * plane) >> 2;
+  float bsum = 0.f;
+#ifdef DBM_WG_TIMING
+  unsigned long long tS = 0, tK = 0;
+#endif
+  WG_T(t00);
+  for (int band = bz; band < p.nbands; band += p.S) {
+    const int n0 = band * p.IB;
+    WG_T(tA);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // LDS stores / reads of the previous round (both wavefronts) are done before the DMA lands
+    for (int ib = 0; ib < p.IB; ++ib) {
+      const int n = n0 + ib;
+      float* dsty = ldsY + ib * slab;
+      float* dstx = ldsX + ib * 32 * PS;
+      if (n < d.N) {
+        const float4* srcy = (const float4*)(d.dy + (long)n * d.dysn + (long)cout0 * d.dysc);
+        for (int i0 = 64 * wave; i0 < q4y; i0 += 128)  // the two wavefronts split the shared slab
+          if (i0 + lane < q4y) __builtin_amdgcn_global_load_lds(srcy + i0 + lane, (lds_ptr)(dsty + 4 * i0), 16, 0, 0);
+        const float* srcx = d.x + (long)n * d.xsn + (long)cin_w * d.xsc;
+        for (int c = 0; c < nci; ++c) {
+          if (sval[0]) __builtin_amdgcn_global_load_lds(srcx + c * plane + soff[0], (lds_ptr)(dstx + c * PS), 4, 0, 0);
+          if (sval[1]) __builtin_amdgcn_global_load_lds(srcx + c * plane + soff[1], (lds_ptr)(dstx + c * PS + 64), 4, 0, 0);
+        }
+      } else {  // ragged last band: this image does not exist
+        for (int e = tid; e < slab; e += 128) dsty[e] = 0.f;
+        for (int e = lane; e < 32 * PS; e += 64) dstx[e] = 0.f;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    WG_T(tB);
+    WG_TACC(tS, tA, tB);
+    if (d.gb && ct == 0) {  // bias gradient: lane (j, kh) sums every other position of dy plane j
+      float part = 0.f;
+      for (int pix = kh; pix < p.BP; pix += 2) part += ldsY[(pinfo[pix] & 0xffff) + j * plane];
+      bsum += part;
+    }
+    if (wave_active) {
+      // K loop, software pipelined by one full step: all eleven LDS reads of step k+1 (and the table entry of step
+      // k+2) are in flight while the nine MFMAs of step k issue.  hipcc would sink every read to just before its MFMA
+      // (one exposed LDS latency per read); the scheduling barriers pin the order.
+      const float* arow = ldsY + j * plane;
+      const float* xrow = ldsX - 1 + j * PS;
+      // the odd padding position of a band has table entry 0: it re-reads position 0, so its A value is forced to 0
+      const bool odd_tail = (p.BP & 1) != 0;
+      int info = pinfo[kh];
+      float av = (odd_tail && kh == 1 && p.BPp == 2) ? 0.f : arow[info & 0xffff];
+      float bv[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) bv[t] = xrow[(info >> 16) + toff[t]];
+      info = pinfo[2 + kh];
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the loop is entered with nothing pending
+      for (int kp = 0; kp < p.BPp; kp += 2) {
+        float av_n = arow[info & 0xffff];  // step k+1 (past the end: the guard entries)
+        float bv_n[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) bv_n[t] = xrow[(info >> 16) + toff[t]];
+        if (odd_tail && kh == 1 && kp + 4 >= p.BPp) av_n = 0.f;
+        info = pinfo[kp + 4 + kh];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        av = av_n;
+#pragma unroll
+        for (int t = 0; t < T; ++t) bv[t] = bv_n[t];
+      }
+    }
+#ifdef DBM_WG_TIMING
+    asm volatile("s_nop 0" ::"v"(acc[8][15]));
+#endif
+    WG_T(tC);
+    WG_TACC(tK, tB, tC);
+  }
+  WG_T(tE);
+  __syncthreads();  // the slabs are dead: each wavefront transposes through its own piece of the LDS
+  if (wave_active) {
+    constexpr int ROWF = 32 * T;
+    float* tw = lds + wave * (8 * ROWF);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) tw[(rr + 4 * kh) * ROWF + j * T + t] = d.scale * acc[t][4 * q + rr];
+      __builtin_amdgcn_wave_barrier();
+      for (int e = lane; e < 8 * ROWF; e += 64) {
+        const int rl = e / ROWF;
+        const int rem = e - rl * ROWF;
+        const int o = cout0 + 8 * q + rl;
+        const int c = cin_w + rem / T;
+        if (o < d.Cout && c < d.Cin) atomicAdd(d.gW + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (d.gb && ct == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (kh == 0 && cout0 + j < d.Cout) atomicAdd(d.gb + cout0 + j, d.scale * bsum);
+  }
+#ifdef DBM_WG_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  if (tid == 0 && blockIdx.x < 8192) {
+    WG_T(tZ);
+    g_dbg[4 * blockIdx.x] = tS; g_dbg[4 * blockIdx.x + 1] = tK; g_dbg[4 * blockIdx.x + 2] = tZ - tE; g_dbg[4 * blockIdx.x + 3] = tZ - t00;
+  }
+#endif
+}
+
 static inline int odd_up(int v) { return v | 1; }
 
-size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level) {
+size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level, int wave_task, int S_fixed) {
   const int T = d.KH * d.KW;
   DBM_CHECK(T == 1 || T == 9 || T == 16, "wgrad: supported kernels are 1x1, 3x3, 4x4");
   DBM_CHECK(d.OW < 4096 && d.OH < 4096, "wgrad: image too large");
   p.d = d;
+  p.wave_task = wave_task;
+  const bool dma = wave_task == 2;
+  if (dma && !(T == 9 && d.stride == 1 && d.pad == 1 && d.OH == d.Hin && d.OW == d.Win && (d.OH + 2) * (d.OW + 1) <= 128)) return 0;
   const int tiles = (d.Cin + 31) / 32;
-  p.groups = (tiles + 3) / 4;
-  p.G = (tiles + p.groups - 1) / p.groups;
+  p.groups = dma ? (tiles + 1) / 2 : wave_task ? tiles : (tiles + 3) / 4;
+  p.G = dma ? 2 : (tiles + p.groups - 1) / p.groups;
   p.coutTiles = (d.Cout + 31) / 32;
-  // band selection: whole images if small, else row bands of one image; keep LDS <= ~100 KB
+  // band selection: whole images if small, else row bands of one image
   const int Wst = (d.OW - 1) * d.stride + d.KW;
-  const long budget = (T <= 9) ? 19800 : 25000;  // floats; <= 79 KB lets two workgroups share a CU's 160 KB
+  // floats; workgroup form: <= 79 KB lets two workgroups share a CU's 160 KB; wave-task form: six tasks per CU
+  const long budget = dma ? 10000 : wave_task ? 6700 : (T <= 9) ? 19800 : 25000;  // dma: four two-wavefront groups per CU
   auto cost = [&](int IB, int R) {
     const int Rin = (R - 1) * d.stride + d.KH;
     const long bpp = (IB * R * d.OW + 1) & ~1;
+    if (dma) return 32L * IB * d.OH * d.OW + 4 + 64L * IB * (d.OH + 2) * (d.OW + 1) + bpp + 8;
+    if (wave_task) return 32L * odd_up(IB * Rin * Wst) + 32L * odd_up((int)bpp) + bpp;
     return (long)p.G * 32 * odd_up(IB * Rin * Wst) + 32L * odd_up((int)bpp) + 2 * bpp + (long)IB * Rin * Wst;
   };
   int IB = 1, R = d.OH;
   if (cost(1, d.OH) <= budget) {
-    while (IB * 2 <= d.N && IB * 2 <= 128 && IB * 2 * d.OH * d.OW <= (324 >> level) && cost(IB * 2, d.OH) <= budget) IB *= 2;
+    while (IB * 2 <= d.N && IB * 2 <= 128 && IB * 2 * d.OH * d.OW <= (324 >> std::max(level, 0)) && cost(IB * 2, d.OH) <= budget) IB *= 2;
   } else {
+    if (wave_task) return 0;
     while (R > 1 && cost(1, R) > budget) --R;
   }
   DBM_CHECK(cost(IB, R) <= 38000, "wgrad: band does not fit in LDS");
@@ -327,25 +703,41 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level) {
   const int imgGroups = (d.N + IB - 1) / IB;
   p.nbands = imgGroups * p.nbr;
   // K split: enough positions per workgroup that the closing atomics stay a small fraction of the MFMA work
-  const long positions = (long)d.N * d.OH * d.OW;
   // (~8 images of the 9x9 trunk per workgroup; `level` > 0 halves that, and the band, per step: used by batches
   // that would otherwise leave most of the chip idle)
-  const long per_wg = std::max(1L, 648L >> level);
+  const long positions = (long)d.N * d.OH * d.OW;
+  const long per_wg = level >= 0 ? std::max(1L, 648L >> level) : (648L << -level);
   int S = (int)((positions + per_wg - 1) / per_wg);
+  if (S_fixed > 0) S = S_fixed;
   if (S > p.nbands) S = p.nbands;
   if (S < 1) S = 1;
   p.S = S;
   p.wg_count = p.groups * p.coutTiles * S;
   auto magic = [](unsigned dv) { return (unsigned)((0x100000000ULL + dv - 1) / dv); };
-  const int plane = d.Hin * d.Win;
+  const int plane = d.Hin * d.Win, oplane = d.OH * d.OW;
   p.planeM = magic((unsigned)plane);
   p.winM = magic((unsigned)d.Win);
-  const int tail_ci = d.Cin - (p.groups - 1) * p.G * 32;  // channels of the last input group
-  p.fast = p.nbr == 1 && d.ups == 0 && d.xsc == plane && d.dysc == d.OH * d.OW && (d.xsn % 4) == 0 && (d.dysn % 4) == 0 &&
-           ((uintptr_t)d.x % 16) == 0 && ((uintptr_t)d.dy % 16) == 0 && ((32L * d.dysc) % 4) == 0 &&
-           (((long)p.G * 32 * d.xsc) % 4) == 0 && ((long)std::min(32, d.Cout) * d.OH * d.OW) % 4 == 0 &&
-           ((long)(d.Cout % 32 ? d.Cout % 32 : 32) * d.OH * d.OW) % 4 == 0 && ((long)std::min(p.G * 32, tail_ci) * plane) % 4 == 0 &&
-           ((long)std::min(p.G * 32, d.Cin) * plane) % 4 == 0 && (long)p.G * 32 * plane < (1L << 22);
+  p.oplaneM = magic((unsigned)oplane);
+  // contiguous 16-byte staging: whole-image bands of plain planes, every per-image run 16-byte aligned and a
+  // multiple of four floats (all channel counts of a run: full tiles / groups and the ragged last one)
+  const int chx = p.G * 32;
+  const int tail_ci = d.Cin - (p.groups - 1) * chx, tail_co = d.Cout - (p.coutTiles - 1) * 32;
+  auto mult4 = [](long v) { return (v % 4) == 0; };
+  p.fast = p.nbr == 1 && d.ups == 0 && d.xsc == plane && d.dysc == oplane && mult4(d.xsn) && mult4(d.dysn) &&
+           ((uintptr_t)d.x % 16) == 0 && ((uintptr_t)d.dy % 16) == 0 && mult4(32L * oplane) && mult4((long)chx * plane) &&
+           mult4((long)std::min(32, tail_co) * oplane) && mult4((long)std::min(chx, tail_ci) * plane) &&
+           (long)chx * plane < (1L << 20) && 32L * oplane < (1L << 20) && plane < 4096 && oplane < 4096;
+  if (dma) {
+    if (!p.fast || (long)IB * 32 * oplane >= 65536 || (long)IB * 32 * (d.OH + 2) * (d.OW + 1) >= 32768) return 0;
+    p.ImgS = (d.OH + 2) * (d.OW + 1);
+    const size_t stage = sizeof(float) * ((size_t)32 * IB * oplane + 4 + (size_t)64 * IB * p.ImgS + (size_t)p.BPp + 8);
+    return std::max(stage, sizeof(float) * 2 * 8 * 32 * (size_t)T);
+  }
+  if (wave_task) {
+    if (!p.fast) return 0;
+    const size_t stage = sizeof(float) * ((size_t)32 * p.YS + (size_t)p.BPp + (size_t)32 * p.XS);
+    return std::max(stage, sizeof(float) * 8 * 32 * (size_t)T);
+  }
   const size_t stage = sizeof(float) * ((size_t)32 * p.YS + 2 * (size_t)p.BPp + (size_t)IB * p.ImgS + (size_t)p.G * 32 * p.XS);
   const size_t epilogue = sizeof(float) * 4 * 8 * 32 * (size_t)T;  // per-wavefront transpose areas
   return std::max(stage, epilogue);
@@ -365,7 +757,7 @@ static void launch_T(const WgradPlan* plans, const int* starts, int nplans, int 
 void WgradBatch::reset() {
   descs.clear();
   built = false;
-  for (int g = 0; g < 3; ++g) {
+  for (int g = 0; g < NCAT; ++g) {
     if (d_plans[g]) (void)hipFree(d_plans[g]);
     if (d_starts[g]) (void)hipFree(d_starts[g]);
     d_plans[g] = nullptr;
@@ -376,28 +768,62 @@ void WgradBatch::reset() {
   }
 }
 
+static int wave_task_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DBM_WGRAD_WAVE");
+    v = e ? atoi(e) : 2;
+  }
+  return v;
+}
+
 void WgradBatch::build() {
-  static const int TT[3] = {1, 9, 16};
-  for (int g = 0; g < 3; ++g) {
+  static const int TT[NCAT] = {1, 9, 16, 9, 9};
+  // 3x3 layers whose whole-image band fits a wavefront's share of the LDS go to the wave-task kernel
+  std::vector<int> cat(descs.size());
+  for (size_t i = 0; i < descs.size(); ++i) {
+    const int T = descs[i].KH * descs[i].KW;
+    WgradPlan p;
+    const int wt = wave_task_enabled();  // 0: workgroup form only, 1: + wave tasks, 2 (default): + LDS-DMA wave tasks
+    cat[i] = T == 1 ? 0 : T == 16 ? 2 : (wt >= 2 && wgrad_plan(descs[i], p, 0, 2) != 0) ? 4 :
+             (wt >= 1 && wgrad_plan(descs[i], p, 0, 1) != 0) ? 3 : 1;
+  }
+  for (int g = 0; g < NCAT; ++g) {
     std::vector<WgradPlan> plans;
     std::vector<int> starts;
     int total = 0;
     size_t maxlds = 0;
     double fl = 0.0;
-    // a launch should offer about two workgroups per CU; small batches split their position axis finer
-    for (int level = 0; level < 4; ++level) {
+    // a launch should offer about two workgroups per CU (wave tasks: four per CU); small batches split their
+    // position axis finer
+    static const int wave_target = getenv("DBM_WGRAD_TARGET") ? atoi(getenv("DBM_WGRAD_TARGET")) : 1024;
+    const int target = g >= 3 ? wave_target : 448;
+    // wave tasks start from long K slices (few, long tasks: fewer closing atomics) and split finer until the launch
+    // offers `target` tasks
+    // LDS-DMA form: four two-wavefront groups fit a CU; the K split is chosen so that the launch is ONE round of
+    // ~1024 equally long groups
+    int S_fixed = 0;
+    if (g == 4) {
+      long units = 0;
+      for (size_t i = 0; i < descs.size(); ++i)
+        if (cat[i] == g) units += (long)((descs[i].Cin + 63) / 64) * ((descs[i].Cout + 31) / 32);
+      static const int slots = getenv("DBM_WGRAD_SLOTS") ? atoi(getenv("DBM_WGRAD_SLOTS")) : 1024;
+      if (units > 0) S_fixed = (int)std::max(1L, slots / units);
+    }
+    for (int level = (g == 3 ? -3 : 0); level < 4; ++level) {
       plans.clear(); starts.clear();
       total = 0; maxlds = 0; fl = 0.0;
-      for (const auto& d : descs) {
-        if (d.KH * d.KW != TT[g]) continue;
+      for (size_t i = 0; i < descs.size(); ++i) {
+        if (cat[i] != g) continue;
+        const WgradDesc& d = descs[i];
         WgradPlan p;
-        maxlds = std::max(maxlds, wgrad_plan(d, p, level));
+        maxlds = std::max(maxlds, wgrad_plan(d, p, g == 4 ? 0 : level, g == 3 ? 1 : g == 4 ? 2 : 0, S_fixed));
         starts.push_back(total);
         total += p.wg_count;
         plans.push_back(p);
         fl += 2.0 * (double)d.N * d.OH * d.OW * d.Cout * d.Cin * TT[g];
       }
-      if (total >= 448 || plans.empty()) break;
+      if (total >= target || plans.empty() || g == 4) break;
     }
     starts.push_back(total);
     nplans[g] = (int)plans.size();
@@ -414,14 +840,24 @@ void WgradBatch::build() {
   built = true;
 }
 
+static void launch_wave9(const WgradPlan* plans, const int* starts, int nplans, int total_wg, size_t lds, hipStream_t s) {
+  hipLaunchKernelGGL((wgrad_wave_kernel<9>), dim3(total_wg), dim3(64), lds, s, plans, starts, nplans);
+  DBM_HIP(hipGetLastError());
+}
+
 void WgradBatch::launch(hipStream_t s) {
   if (!built) build();
-  for (int g = 0; g < 3; ++g) {
+  for (int g = 0; g < NCAT; ++g) {
     if (nplans[g] == 0) continue;
     if (g_profiler.enabled) g_profiler.begin(s, 1, flops[g]);
     if (g == 0) launch_T<1, 1>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else if (g == 1) launch_T<9, 9>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
-    else launch_T<16, 8>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else if (g == 2) launch_T<16, 8>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else if (g == 3) launch_wave9(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else {
+      hipLaunchKernelGGL(wgrad_wave_dma_kernel, dim3(total_wg[g]), dim3(128), lds[g], s, d_plans[g], d_starts[g], nplans[g]);
+      DBM_HIP(hipGetLastError());
+    }
     if (g_profiler.enabled) g_profiler.end(s);
   }
 }
