@@ -27,6 +27,7 @@ SIGNATURES = {
     "dbm_synchronize": [C.c_void_p],
     "dbm_profile_begin": [C.c_void_p],
     "dbm_profile_end": [C.c_void_p, C.POINTER(C.c_double)],
+    "dbm_phase_marks": [C.c_void_p, C.c_int, C.c_char_p, C.c_int],
     "dbm_malloc": [C.c_void_p, C.c_size_t, c_void_pp],
     "dbm_free": [C.c_void_p, C.c_void_p],
     "dbm_memcpy_h2d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],

@@ -156,6 +156,25 @@ int dbm_profile_end(dbm_ctx* ctx, double out[8]) {
   DBM_API_END
 }
 
+int dbm_phase_marks(dbm_ctx* ctx, int enable, char* out, int cap) {
+  DBM_API_BEGIN(ctx)
+  if (enable) {
+    (void)g_profiler.dump_marks();
+    g_profiler.marks_enabled = true;
+  } else {
+    g_profiler.marks_enabled = false;
+    DBM_HIP(hipStreamSynchronize(ctx->side));
+    DBM_HIP(hipStreamSynchronize(ctx->stream));
+    const std::string txt = g_profiler.dump_marks();
+    if (out && cap > 0) {
+      const size_t n = std::min(txt.size(), (size_t)cap - 1);
+      memcpy(out, txt.data(), n);
+      out[n] = 0;
+    }
+  }
+  DBM_API_END
+}
+
 int dbm_malloc(dbm_ctx* ctx, size_t bytes, void** dptr) {
   DBM_API_BEGIN(ctx)
   // 128-byte guards on both sides (see DevBuf): kernels may read one word outside a tensor
@@ -468,8 +487,10 @@ int dbm_adam_update(dbm_model* m, double grad_scale) {
   const double fix1 = 1.0 - std::pow(m->beta1, (double)m->adam_t);
   const double fix2 = 1.0 - std::pow(m->beta2, (double)m->adam_t);
   const double alpha_t = m->alpha * std::sqrt(fix2) / fix1;  // AdamRule.alpha_t
+  DBM_MARK(m->ctx->stream, m->type == 0 ? "G:optimizer_begin" : "D:optimizer_begin");
   launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (long)m->nparam, (float)alpha_t, (float)(1.0 - m->beta1),
               (float)(1.0 - m->beta2), (float)m->eps, (float)grad_scale, m->ctx->stream);
+  DBM_MARK(m->ctx->stream, m->type == 0 ? "G:optimizer" : "D:optimizer");
   m->packed_dirty = true;
   m->param_version++;
   DBM_API_END
@@ -496,6 +517,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   // D(real) does not depend on the generator: it runs on the side stream underneath the (latency-bound) generator
   // forward.  D(fake) starts only after it has finished, so the two BatchNorm running-average updates keep the
   // reference's order (real, then fake: srgan_train.py:1145-1146).
+  DBM_MARK(s, "D:begin");
   c->fork_to_side(0);
   {
     hipStream_t main_stream = c->stream;
@@ -512,9 +534,11 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   g->forward(N, H, W, X, W1, W2, W3, g->yout.p, share && train);
   g->graph_version = g->param_version;
   g->graph_in[0] = X; g->graph_in[1] = W1; g->graph_in[2] = W2; g->graph_in[3] = W3;
+  DBM_MARK(s, "D:generator_forward");
   c->join_side();
   d->forward(N, H4, W4, g->yout.p, lf, train, train, 1);   // fake batch (:1146) -- separate BatchNorm statistics
   launch_ragan_loss(lr, lf, N, 1, 0, metrics, train ? gr : nullptr, train ? gf : nullptr, s);
+  DBM_MARK(s, "D:disc_forward_fake+loss");
   if (train) {
     DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));  // cleargrads (:1162)
     // d_loss.backward() (:1163): the real- and the fake-batch graphs are independent (gradients are accumulated
@@ -529,8 +553,11 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     }
     c->stream = s;
     d->backward(0, gr, false);
+    DBM_MARK(s, "D:disc_backward_real_chain");
     c->fork(c->chain[0], s, 7);
+    DBM_MARK(s, "D:disc_backward_fake_chain_joined");
     c->join_side();
+    DBM_MARK(s, "D:weight_gradients_joined");
   }
   DBM_API_END
 }
@@ -552,6 +579,7 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
   const bool reuse = share && train && g->have_graph && g->wsTrain && g->graph_version == g->param_version &&
                      g->wsN == N && g->wsH == H && g->wsW == W && g->graph_in[0] == X && g->graph_in[1] == W1 &&
                      g->graph_in[2] == W2 && g->graph_in[3] == W3;
+  DBM_MARK(s, "G:begin");
   const bool pack_aside = d->packed_dirty && !reuse;
   if (pack_aside) {  // the discriminator's weight images (stale since its Adam step) are rebuilt under the generator forward
     c->fork_to_side(5);
@@ -561,15 +589,18 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
     g->ensure_ws(N, H, W, train != 0);
     g->forward(N, H, W, X, W1, W2, W3, g->yout.p, train != 0);  // (:1222-1227)
   }
+  DBM_MARK(s, "G:generator_forward");
   if (pack_aside) c->join_side();
   d->g_out.ensure(4 * (size_t)N);
   float* lf = d->g_out.p;
   d->forward(N, H4, W4, g->yout.p, lf, false, false, 1);  // eval-mode BatchNorm, detached (:1228-1229)
   gen_loss_device(c, g->yout.p, Y, X, nullptr, lf, N, H4, W4, weights, 0, 1, ssim_window, metrics + 2,
                   train ? g->g_y.p : nullptr);
+  DBM_MARK(s, "G:disc_forward+loss");
   if (train) {
     DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), s));  // cleargrads (:1255)
     g->backward(g->g_y.p);                                               // g_loss.backward() (:1256)
+    DBM_MARK(s, "G:generator_backward_joined");
   }
   DBM_API_END
 }

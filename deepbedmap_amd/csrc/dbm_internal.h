@@ -88,7 +88,13 @@ struct KernelProfiler {
   void begin(hipStream_t s, int family, double flops);
   void end(hipStream_t s);
   void collect(double out[8]);  // [ms, flops, launches] per family, then clears
+  // phase marks: one event per named point of a training step on the main stream (dbm_phase_marks)
+  bool marks_enabled = false;
+  std::vector<std::pair<std::string, hipEvent_t>> marks;
+  void mark(hipStream_t s, const char* name);
+  std::string dump_marks();  // "name ms_since_first_mark\n" per mark, then clears
 };
+#define DBM_MARK(s, name) do { if (g_profiler.marks_enabled) g_profiler.mark((s), (name)); } while (0)
 extern KernelProfiler g_profiler;
 
 // weight packing (igemm.hip): dst[t][k][mP] with (k,m) = (cin,cout) (transpose=0) or (cout,cin) (transpose=1);

@@ -311,6 +311,7 @@ void Generator::backward(const float* gy) {
   }
   // Weight gradients never feed the data-gradient chain, and that chain (one short, latency-bound kernel per conv)
   // leaves most of the chip idle: the batches go to the side stream as soon as their inputs are final.
+  DBM_MARK(s, "G:backward_tail_layers");
   ctx->fork_to_side(0);
   wbs[0].launch(ctx->side);
   // ---- trunk, last dense block first; like the forward, as `nsplit` image ranges on separate streams ----
@@ -379,6 +380,7 @@ void Generator::backward(const float* gy) {
     }
   }
   join_chains();
+  DBM_MARK(s, "G:backward_trunk_chain");
   // ---- pre_residual_conv_layer and the input block ----
   {
     const IgLayer& L = layers[L_pre];
@@ -407,6 +409,7 @@ void Generator::backward(const float* gy) {
       }
     }
   }
+  DBM_MARK(s, "G:backward_input_block");
   ctx->fork_to_side(6);
   if (prev_grp >= 0) wbs[prev_grp].launch(ctx->side);
   wbs[6].launch(ctx->side);

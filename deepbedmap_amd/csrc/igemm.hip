@@ -24,6 +24,7 @@
 // latency: the loop is unrolled over the T taps of one channel pair and the 2T loads of the NEXT
 // pair are issued before the T MFMAs of the current one.
 #include "dbm_internal.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -227,6 +228,28 @@ void KernelProfiler::collect(double out[8]) {
   recs.clear();
 }
 
+void KernelProfiler::mark(hipStream_t s, const char* name) {
+  hipEvent_t e;
+  DBM_HIP(hipEventCreate(&e));
+  DBM_HIP(hipEventRecord(e, s));
+  marks.emplace_back(name, e);
+}
+
+std::string KernelProfiler::dump_marks() {
+  std::string out;
+  for (auto& m : marks) {
+    DBM_HIP(hipEventSynchronize(m.second));
+    float ms = 0.f;
+    DBM_HIP(hipEventElapsedTime(&ms, marks.front().second, m.second));
+    char line[160];
+    snprintf(line, sizeof(line), "%s %.4f\n", m.first.c_str(), ms);
+    out += line;
+  }
+  for (auto& m : marks) (void)hipEventDestroy(m.second);
+  marks.clear();
+  return out;
+}
+
 constexpr int IGEMM_NPB = 6;  // channel pairs a wavefront may hold entirely in registers (T = 9 -> 54 VGPRs)
 
 template <int T, int WAVES, bool ROW>
@@ -271,7 +294,12 @@ void launch_igemm_conv(const ConvDesc& d, hipStream_t s) {
   dim3 grid((unsigned)((total + 31) / 32), (unsigned)((d.Cout + 31) / 32));
   const long tiles = (long)grid.x * grid.y;
   // few tiles -> more wavefronts per tile (Cin % 32 == 0 keeps Cin / WAVES even for every choice)
-  const int waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
+  int waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
+  // ... but a wavefront should own a few channel pairs: with a short K (the 32-channel data gradients of the dense
+  // blocks) the cross-wavefront reduction and a 1024-thread workgroup cost more than the MFMAs they spread
+  static const int min_pairs = getenv("DBM_IGEMM_MINPAIRS") ? atoi(getenv("DBM_IGEMM_MINPAIRS")) : 6;
+  static const int min_tiles = getenv("DBM_IGEMM_MINTILES") ? atoi(getenv("DBM_IGEMM_MINTILES")) : 96;
+  while (tiles > min_tiles && waves > 4 && d.Cin / (2 * waves) < min_pairs) waves >>= 1;
   if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)total * d.Cout * d.Cin * d.T);
   switch (d.T) {
     case 1: launch_t<1>(d, grid, waves, s); break;

@@ -44,6 +44,9 @@ int dbm_synchronize(dbm_ctx* ctx);
  * gradient), then the same three for wgrad_kernel. */
 int dbm_profile_begin(dbm_ctx* ctx);
 int dbm_profile_end(dbm_ctx* ctx, double out[8]);
+/* measurement aid: while enabled, the step entry points record one hipEvent per phase boundary on the main stream;
+ * enable = 0 stops, synchronises and writes "name milliseconds-since-the-first-mark" lines into out (cap bytes). */
+int dbm_phase_marks(dbm_ctx* ctx, int enable, char* out, int cap);
 int dbm_malloc(dbm_ctx* ctx, size_t bytes, void** dptr);
 int dbm_free(dbm_ctx* ctx, void* dptr);
 int dbm_memcpy_h2d(dbm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
