@@ -88,7 +88,7 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
       launch_bn_eval_fwd(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), S(T_bn[i][2]), S(T_bn[i][3]), N, DC_O[i],
                          ho * wo, 1e-5f, SLOPE, s);
   }
-  if (c.N != N || c.H != H || c.W != W) { wb[slot][0].reset(); wb[slot][1].reset(); }  // buffers may move: re-plan the batched weight gradients
+  if (c.N != N || c.H != H || c.W != W) for (auto& b : wb[slot]) b.reset();  // buffers may move: re-plan the batched weight gradients
   c.l1.ensure(n * 100);
   launch_linear_fwd(c.h[9].p, P(T_l1W), P(T_l1b), c.l1.p, N, 512, 100, 1, SLOPE, s);  // :693-695
   launch_linear_fwd(c.l1.p, P(T_l2W), P(T_l2b), logits, N, 100, 1, 0, SLOPE, s);       // :696
@@ -99,6 +99,8 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
     DBM_HIP(hipMemcpyAsync(c.img.p, img, n * H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
 }
+
+static inline int wgroup(int layer) { return layer >= 6 ? 0 : layer >= 4 ? 1 : layer >= 2 ? 2 : 3; }
 
 void Discriminator::backward(int slot, const float* glogits, bool join) {
   Cache& c = cache[slot];
@@ -123,7 +125,7 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
     launch_bn_train_bwd(c.z[i].p, gh, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, g_z[slot][i].p, G(T_bn[i][0]),
                         G(T_bn[i][1]), nullptr, N, DC_O[i], ho * wo, SLOPE, s);
     run_wgrad(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, g_z[slot][i].p, (long)DC_O[i] * ho * wo, ho, wo, N, 1.f,
-              &wb[slot][i >= 5 ? 0 : 1]);
+              &wb[slot][wgroup(i)]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = g_z[slot][i].p; d.xsn = (long)DC_O[i] * ho * wo; d.N = N;
@@ -133,9 +135,9 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
     }
     run_dgrad(L, d, hin, win);
     float* t = gh; gh = gh_next; gh_next = t;
-    if (i == 5) {  // the deep layers' weight gradients start underneath the rest of the chain
+    if (i > 1 && wgroup(i - 1) != wgroup(i)) {  // this group's weight gradients start underneath the rest of the chain
       ctx->fork_to_side(2 + slot);
-      wb[slot][0].launch(ctx->side);
+      wb[slot][wgroup(i)].launch(ctx->side);
     }
   }
   {  // conv_layer0 weight / bias gradient
@@ -148,6 +150,6 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
   // conv_layer1..9 weight gradients: one launch per kernel size and half of the stack, on the side stream (they
   // overlap the data-gradient chain and the other batch's backward pass); each slot has its own slabs g_z[slot][*]
   ctx->fork_to_side(slot);
-  wb[slot][1].launch(ctx->side);
+  wb[slot][NWG - 1].launch(ctx->side);
   if (join) ctx->join_side();
 }

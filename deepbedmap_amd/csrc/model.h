@@ -126,7 +126,8 @@ struct Discriminator : dbm_model {
     DevBuf img, h[10], z[10], mean[10], istd[10], l1, out;
   } cache[2];
   DevBuf g_h[2][2], g_z[2][10], g_l1[2], g_out;  // per retained graph: the two backward passes overlap
-  WgradBatch wb[2][2];  // batched weight gradients per retained graph (real / fake batch): layers 9..5, layers 4..1
+  static const int NWG = 4;
+  WgradBatch wb[2][NWG];  // batched weight gradients per retained graph (real / fake batch): layers 9..6, 5..4, 3..2, 1
   Discriminator(dbm_ctx* c);
   void forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot);
   void backward(int slot, const float* glogits, bool join = true);

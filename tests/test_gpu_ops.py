@@ -50,6 +50,15 @@ CONV_CASES = [
     (2, 1, 110, 110, 32, 30, 10, 0, 0, 0),  # input block conv_on_W1
     (2, 2, 22, 22, 32, 6, 2, 0, 0, 0),     # input block conv_on_W2
     (2, 1, 36, 36, 64, 3, 1, 1, 0, 1),     # D conv_layer0
+    # weight-gradient kernel forms: LDS-DMA two-wavefront tasks (9x9 / 4x4 / 2x2 planes), odd tile counts, ragged
+    # image groups, many K slices; register-staged wave tasks; the workgroup form with row bands
+    (67, 96, 9, 9, 32, 3, 1, 1, 0, 1),     # 3 input tiles (one idle wavefront), 67 images
+    (70, 160, 9, 9, 32, 3, 1, 1, 0, 0),    # 5 input tiles
+    (64, 32, 9, 9, 64, 3, 1, 1, 0, 0),     # a single input tile, two output tiles
+    (33, 256, 4, 4, 512, 3, 1, 1, 0, 0),   # D conv_layer6: several images per band, ragged last band
+    (37, 512, 2, 2, 512, 3, 1, 1, 0, 0),   # D conv_layer8
+    (9, 64, 18, 18, 128, 3, 1, 1, 0, 0),   # D conv_layer2: whole-image bands do not fit a wavefront's LDS share
+    (5, 64, 11, 13, 32, 3, 1, 1, 0, 0),    # odd, non-square plane (contiguous runs not a multiple of 16 bytes)
 ]
 
 
