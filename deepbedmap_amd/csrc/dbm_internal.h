@@ -75,6 +75,8 @@ struct ConvDesc {
   long masksn;
   int mask_c0;
   const float* zeros;  // >= 4 bytes of device zeros
+  int ksplit;          // set by the launcher: > 1 = blockIdx.z owns Cin / ksplit input channels and the plain result is
+                       // folded into a pre-zeroed y with atomics (few-tile, long-K layers: the deep discriminator convs)
 };
 
 void launch_igemm_conv(const ConvDesc& d, hipStream_t s);

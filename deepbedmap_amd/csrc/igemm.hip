@@ -57,8 +57,9 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     b = r - a * d.OWl;
   }
   const int cout0 = blockIdx.y * 32;
-  const int cpw = d.Cin / WAVES;    // input channels per wavefront (even)
-  const int c0 = wave * cpw + kh;   // first input channel of this lane
+  const int ks = d.ksplit > 1 ? d.ksplit : 1;
+  const int cpw = d.Cin / ks / WAVES;                                // input channels per wavefront (even)
+  const int c0 = (int)blockIdx.z * (d.Cin / ks) + wave * cpw + kh;   // first input channel of this lane
   const int Hl = d.Hin << d.ups, Wl = d.Win << d.ups;
   const float* xn = d.x + (long)n * d.xsn + (long)c0 * d.xsc;
   const float* wlane = d.wp + (long)c0 * d.CoutP + cout0 + j;
@@ -134,6 +135,41 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
         for (int t = 0; t < T; ++t) av[t] = an[t];
       }
     }
+  } else if constexpr (NPB < 0) {
+    // (NPB = -1) 4x4 stride-2 layers on tiny planes (2x2 -> 1x1: 12 of the 16 taps fall outside the image for EVERY position of
+    // the tile): taps that no lane of the wavefront needs are skipped, loads and MFMA alike
+    unsigned live = 0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) live |= (__ballot((okmask >> t) & 1u) != 0ull) ? (1u << t) : 0u;
+    float av[T], bv[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      av[t] = 0.f; bv[t] = 0.f;
+      if (live & (1u << t)) { av[t] = wlane[t * wtap]; bv[t] = xn[xoff[t]]; }
+    }
+    for (int p = 0; p < npairs; ++p) {
+      const int pn = (p + 1 < npairs) ? p + 1 : p;
+      const float* xc = xn + pn * xstep;
+      const float* wc = wlane + pn * wstep;
+      float an[T], bn[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        an[t] = 0.f; bn[t] = 0.f;
+        if (live & (1u << t)) { an[t] = wc[t * wtap]; bn[t] = xc[xoff[t]]; }
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        if (live & (1u << t)) {
+          const float bm = ((okmask >> t) & 1u) ? bv[t] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bm, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        av[t] = an[t];
+        bv[t] = bn[t];
+      }
+    }
   } else {
     float av[T], bv[T];
 #pragma unroll
@@ -183,6 +219,10 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) v += red[w * 1024 + e];
+    if (ks > 1) {  // plain layer, output pre-zeroed by the launcher
+      atomicAdd(d.y + (long)n * d.ysn + (long)c * d.ysc + pix, v);
+      continue;
+    }
     if (d.bias) v += d.bias[c];
     v *= d.s1;
     const long co = (long)c * d.ysc + pix;
@@ -254,10 +294,16 @@ constexpr int IGEMM_NPB = 6;  // channel pairs a wavefront may hold entirely in 
 
 template <int T, int WAVES, bool ROW>
 static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s) {
-  const int npairs = d.Cin / WAVES / 2;
+  const int npairs = d.Cin / (d.ksplit > 1 ? d.ksplit : 1) / WAVES / 2;
   if constexpr (T <= 9 && WAVES >= 8) {
     if (npairs <= IGEMM_NPB) {
       hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, IGEMM_NPB, ROW>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+      return;
+    }
+  }
+  if constexpr (T == 16 && !ROW) {
+    if (d.Hin * d.Win <= 16) {  // most taps of a 4x4 window fall outside such planes: the tap-skipping variant
+      hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -1, ROW>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
       return;
     }
   }
@@ -286,7 +332,9 @@ static void launch_t(const ConvDesc& d, dim3 grid, int waves, hipStream_t s) {
   else launch_tw<T, 4>(d, grid, s);
 }
 
-void launch_igemm_conv(const ConvDesc& d, hipStream_t s) {
+void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
+  ConvDesc d = d_in;
+  d.ksplit = 1;
   DBM_CHECK(d.Cin % 32 == 0, "igemm: Cin must be a multiple of 32");
   DBM_CHECK(d.CoutP % 32 == 0 && d.Cout <= d.CoutP, "igemm: bad CoutP");
   DBM_CHECK(d.T == 1 || d.T == 4 || d.T == 9 || d.T == 16, "igemm: tap count must be 1, 4, 9 or 16");
@@ -300,6 +348,21 @@ void launch_igemm_conv(const ConvDesc& d, hipStream_t s) {
   static const int min_pairs = getenv("DBM_IGEMM_MINPAIRS") ? atoi(getenv("DBM_IGEMM_MINPAIRS")) : 6;
   static const int min_tiles = getenv("DBM_IGEMM_MINTILES") ? atoi(getenv("DBM_IGEMM_MINTILES")) : 96;
   while (tiles > min_tiles && waves > 4 && d.Cin / (2 * waves) < min_pairs) waves >>= 1;
+  // Few tiles and a long K (the deep discriminator layers: 8..128 tiles, K = 2304..8192): the input channels are
+  // also split across workgroups; only for plain layers (no bias / residual / activation / mask / accumulate) whose
+  // output is one dense [N][Cout][OH*OW] block, which is zeroed first and folded with atomics.
+  static const int ks_enable = getenv("DBM_IGEMM_KSPLIT") ? atoi(getenv("DBM_IGEMM_KSPLIT")) : 0;  // opt-in: costs the forward its run-to-run bitwise reproducibility for ~0.1 ms per step
+  if (ks_enable && tiles <= 128 && (long)d.Cin * d.T >= 2048 && !d.bias && !d.r1 && !d.r2 && !d.act && !d.mask && !d.accumulate &&
+      d.s1 == 1.f && d.so == 1 && d.oy0 == 0 && d.ox0 == 0 && d.OWp == d.OWl && d.ysc == d.OHl * d.OWl &&
+      d.ysn == (long)d.Cout * d.ysc) {
+    int ks = 1;
+    while (ks < 16 && tiles * ks * 2 <= 512 && (d.Cin / (ks * 2)) % (2 * waves) == 0 && d.Cin / (ks * 2) / waves >= 4) ks *= 2;
+    if (ks > 1) {
+      d.ksplit = ks;
+      grid.z = ks;
+      DBM_HIP(hipMemsetAsync(d.y, 0, sizeof(float) * (size_t)d.N * d.ysn, s));
+    }
+  }
   if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)total * d.Cout * d.Cin * d.T);
   switch (d.T) {
     case 1: launch_t<1>(d, grid, waves, s); break;
