@@ -545,14 +545,17 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     // with atomics), so the fake batch's pass runs on a second stream; both hand their weight gradients to the side stream
     c->fork(s, c->chain[0], 7);
     c->stream = c->chain[0];
+    d->merge_slots = true;  // one weight-gradient launch per layer group for both graphs
     try {
       d->backward(1, gf, false);
+      c->stream = s;
+      d->backward(0, gr, false);
     } catch (...) {
       c->stream = s;
+      d->merge_slots = false;
       throw;
     }
-    c->stream = s;
-    d->backward(0, gr, false);
+    d->merge_slots = false;
     DBM_MARK(s, "D:disc_backward_real_chain");
     c->fork(c->chain[0], s, 7);
     DBM_MARK(s, "D:disc_backward_fake_chain_joined");

@@ -143,7 +143,8 @@ struct WgradPlan {
   int fast;
   unsigned planeM, winM;  // ceil(2^32 / (Hin*Win)), ceil(2^32 / Win): exact quotients for the sizes staged here
   unsigned oplaneM;       // ceil(2^32 / (OH*OW))
-  int wave_task;          // 1: planned for wgrad_wave_kernel (one wavefront per task), 2: wgrad_wave_dma_kernel
+  int wave_task;          // 0: wgrad_kernel (workgroup form), 2: wgrad_wave_dma_kernel, 3: wgrad_band_dma_kernel
+  const float* zeros;     // >= 4 bytes of device zeros (out-of-image rows of the row-band DMA form)
 };
 // fills p, returns the dynamic LDS bytes it needs (0: not eligible for the wave-task form)
 size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level = 0, int wave_task = 0, int S_fixed = 0);
@@ -153,7 +154,7 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level = 0, int wave_task
 struct WgradBatch {
   std::vector<WgradDesc> descs;
   bool built = false;
-  static const int NCAT = 5;  // 1x1, 3x3 (workgroup form), 4x4, 3x3 wave tasks, 3x3 wave tasks with LDS-DMA staging
+  static const int NCAT = 6;  // see WgradBatch::build
   WgradPlan* d_plans[NCAT] = {};
   int* d_starts[NCAT] = {};
   int nplans[NCAT] = {}, total_wg[NCAT] = {};

@@ -88,7 +88,10 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
       launch_bn_eval_fwd(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), S(T_bn[i][2]), S(T_bn[i][3]), N, DC_O[i],
                          ho * wo, 1e-5f, SLOPE, s);
   }
-  if (c.N != N || c.H != H || c.W != W) for (auto& b : wb[slot]) b.reset();  // buffers may move: re-plan the batched weight gradients
+  if (c.N != N || c.H != H || c.W != W) {
+    for (auto& b : wb[slot]) b.reset();
+    for (auto& b : wbm) b.reset();
+  }  // buffers may move: re-plan the batched weight gradients
   c.l1.ensure(n * 100);
   launch_linear_fwd(c.h[9].p, P(T_l1W), P(T_l1b), c.l1.p, N, 512, 100, 1, SLOPE, s);  // :693-695
   launch_linear_fwd(c.l1.p, P(T_l2W), P(T_l2b), logits, N, 100, 1, 0, SLOPE, s);       // :696
@@ -97,6 +100,24 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
   if (c.valid) {  // conv_layer0's weight gradient needs the input image: keep a private copy
     c.img.ensure(n * H * W);
     DBM_HIP(hipMemcpyAsync(c.img.p, img, n * H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+}
+
+// Weight gradients of one layer group go to the side stream once their inputs are final.  Merged mode (the fused
+// D-step): the fake batch's pass (slot 1, enqueued first, on its own stream) only records an event; the real batch's
+// pass (slot 0) launches the group for both graphs behind both events.
+void Discriminator::launch_group(int slot, int g) {
+  if (!merge_slots) {
+    ctx->fork_to_side(2 + slot);
+    wb[slot][g].launch(ctx->side);
+    return;
+  }
+  if (!ev_grp[slot][g]) DBM_HIP(hipEventCreateWithFlags(&ev_grp[slot][g], hipEventDisableTiming));
+  DBM_HIP(hipEventRecord(ev_grp[slot][g], ctx->stream));
+  if (slot == 0) {
+    DBM_HIP(hipStreamWaitEvent(ctx->side, ev_grp[0][g], 0));
+    if (ev_grp[1][g]) DBM_HIP(hipStreamWaitEvent(ctx->side, ev_grp[1][g], 0));
+    wbm[g].launch(ctx->side);
   }
 }
 
@@ -125,7 +146,7 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
     launch_bn_train_bwd(c.z[i].p, gh, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, g_z[slot][i].p, G(T_bn[i][0]),
                         G(T_bn[i][1]), nullptr, N, DC_O[i], ho * wo, SLOPE, s);
     run_wgrad(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, g_z[slot][i].p, (long)DC_O[i] * ho * wo, ho, wo, N, 1.f,
-              &wb[slot][wgroup(i)]);
+              merge_slots ? &wbm[wgroup(i)] : &wb[slot][wgroup(i)]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = g_z[slot][i].p; d.xsn = (long)DC_O[i] * ho * wo; d.N = N;
@@ -135,10 +156,7 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
     }
     run_dgrad(L, d, hin, win);
     float* t = gh; gh = gh_next; gh_next = t;
-    if (i > 1 && wgroup(i - 1) != wgroup(i)) {  // this group's weight gradients start underneath the rest of the chain
-      ctx->fork_to_side(2 + slot);
-      wb[slot][wgroup(i)].launch(ctx->side);
-    }
+    if (i > 1 && wgroup(i - 1) != wgroup(i)) launch_group(slot, wgroup(i));  // underneath the rest of the chain
   }
   {  // conv_layer0 weight / bias gradient
     SmallConvDesc q;
@@ -149,7 +167,6 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
   }
   // conv_layer1..9 weight gradients: one launch per kernel size and half of the stack, on the side stream (they
   // overlap the data-gradient chain and the other batch's backward pass); each slot has its own slabs g_z[slot][*]
-  ctx->fork_to_side(slot);
-  wb[slot][NWG - 1].launch(ctx->side);
+  launch_group(slot, NWG - 1);
   if (join) ctx->join_side();
 }

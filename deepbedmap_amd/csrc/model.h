@@ -127,6 +127,10 @@ struct Discriminator : dbm_model {
   } cache[2];
   DevBuf g_h[2][2], g_z[2][10], g_l1[2], g_out;  // per retained graph: the two backward passes overlap
   static const int NWG = 4;
+  WgradBatch wbm[NWG];     // the same for BOTH graphs in one launch per group (the fused D-step: twice the work per launch)
+  hipEvent_t ev_grp[2][NWG] = {};
+  bool merge_slots = false;  // set by dbm_discriminator_step around its two backward calls (fake first, then real)
+  void launch_group(int slot, int g);
   WgradBatch wb[2][NWG];  // batched weight gradients per retained graph (real / fake batch): layers 9..6, 5..4, 3..2, 1
   Discriminator(dbm_ctx* c);
   void forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot);

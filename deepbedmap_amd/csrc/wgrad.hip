@@ -311,173 +311,6 @@ __global__ __launch_bounds__(256 * (T / TPW), 2) void wgrad_kernel(const WgradPl
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Wave-task form for whole-image bands of small planes (the 9x9 trunk, the deep discriminator layers): one
-// WAVEFRONT = one (32 input channels, 32 output channels, K slice) task with its own 26 KB of LDS, six per CU.
-// Against the workgroup form above this gives up sharing the dy slab between input tiles, and gains: no idle
-// wavefront slots when a layer has fewer than four input tiles per group (28 % of the trunk's slots), no
-// workgroup barriers, and scheduling at wavefront granularity (tasks are equally long; the chip runs them in
-// ceil(tasks / 1536) rounds instead of ceil(workgroups / 512) rounds of four-wavefront groups).
-// ---------------------------------------------------------------------------------------------------------------
-template <int T>
-__global__ __launch_bounds__(64, 2) void wgrad_wave_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ starts,
-                                                           int nplans) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  int lo = 0, hi = nplans - 1;
-  const int wg = blockIdx.x;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (starts[mid] <= wg) lo = mid; else hi = mid - 1;
-  }
-  const WgradPlan& p = plans[lo];
-  const WgradDesc& d = p.d;
-  int local = wg - starts[lo];
-  const int ct = local % p.groups;   // input tile
-  local /= p.groups;
-  const int by = local % p.coutTiles;
-  const int bz = local / p.coutTiles;
-  float* ldsY = lds;                            // 32 * YS
-  int* pixoff = (int*)(ldsY + 32 * p.YS);       // BPp
-  float* ldsX = (float*)(pixoff + p.BPp);       // 32 * XS
-  const int lane = threadIdx.x;
-  const int j = lane & 31, kh = lane >> 5;
-  const int cout0 = by * 32, cin_w = ct * 32;
-  constexpr int KWc = (T == 1) ? 1 : (T == 9 ? 3 : 4);
-  f32x16 acc[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  int toff[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) toff[t] = (t / KWc) * p.Wst + (t % KWc);
-  const int oplane = d.OH * d.OW, plane = d.Hin * d.Win;
-  for (int e = lane; e < p.BPp; e += 64) {
-    int off = 0;
-    if (e < p.BP) {
-      const int ib = e / oplane;
-      const int rem = e - ib * oplane;
-      const int al = rem / d.OW, b = rem - al * d.OW;
-      off = ib * p.ImgS + al * d.stride * p.Wst + b * d.stride;
-    }
-    pixoff[e] = off;
-  }
-  for (int e = lane; e < 32 * p.XS; e += 64) ldsX[e] = 0.f;
-  for (int e = lane; e < 32 * p.YS; e += 64) ldsY[e] = 0.f;
-  const int nco = min(32, d.Cout - cout0), nci = min(32, d.Cin - cin_w);
-  const int q4y = (nco * oplane) >> 2, q4x = (nci * plane) >> 2;
-  float bsum = 0.f;
-  constexpr int U = 4;
-  for (int band = bz; band < p.nbands; band += p.S) {
-    const int n0 = band * p.IB;
-    for (int ib = 0; ib < p.IB; ++ib) {
-      const int n = n0 + ib;
-      const bool okn = n < d.N;
-      const float4* srcy = (const float4*)(d.dy + (okn ? (long)n * d.dysn : 0L) + (long)cout0 * d.dysc);
-      const float4* srcx = (const float4*)(d.x + (okn ? (long)n * d.xsn : 0L) + (long)cin_w * d.xsc);
-      float* dsty = ldsY + ib * oplane;
-      float* dstx = ldsX + ib * p.ImgS + d.pad * p.Wst + d.pad;
-      for (int i0 = lane; i0 < q4y; i0 += 64 * U) {
-        float4 v[U];
-#pragma unroll
-        for (int w = 0; w < U; ++w) {
-          const int i = i0 + 64 * w;
-          v[w] = srcy[i < q4y ? i : 0];
-        }
-#pragma unroll
-        for (int w = 0; w < U; ++w) {
-          const int i = i0 + 64 * w;
-          if (i < q4y) {
-            const float vv[4] = {v[w].x, v[w].y, v[w].z, v[w].w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const unsigned f = 4u * (unsigned)i + u;
-              const unsigned row = __umulhi(f, p.oplaneM);
-              dsty[row * p.YS + (f - row * (unsigned)oplane)] = okn ? vv[u] : 0.f;
-            }
-          }
-        }
-      }
-      for (int i0 = lane; i0 < q4x; i0 += 64 * U) {
-        float4 v[U];
-#pragma unroll
-        for (int w = 0; w < U; ++w) {
-          const int i = i0 + 64 * w;
-          v[w] = srcx[i < q4x ? i : 0];
-        }
-#pragma unroll
-        for (int w = 0; w < U; ++w) {
-          const int i = i0 + 64 * w;
-          if (i < q4x) {
-            const float vv[4] = {v[w].x, v[w].y, v[w].z, v[w].w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const unsigned f = 4u * (unsigned)i + u;
-              const unsigned c = __umulhi(f, p.planeM);
-              const unsigned r = f - c * (unsigned)plane;
-              const unsigned y = __umulhi(r, p.winM);
-              const unsigned xx = r - y * (unsigned)d.Win;
-              if ((int)(y + d.pad) < p.Rin && (int)(xx + d.pad) < p.Wst) dstx[c * p.XS + y * p.Wst + xx] = okn ? vv[u] : 0.f;
-            }
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (d.gb && ct == 0) {  // bias gradient: lane (j, kh) sums every other position of dy row j
-      const float* row = ldsY + j * p.YS;
-      float part = 0.f;
-      for (int pix = kh; pix < p.BP; pix += 2) part += row[pix];
-      bsum += part;
-    }
-    {
-      const float* arow = ldsY + j * p.YS + kh;
-      const float* xrow = ldsX + j * p.XS;
-      float av = arow[0];
-      int off = pixoff[kh];
-      for (int kp = 0; kp < p.BPp; kp += 2) {
-        const float* xb = xrow + off;
-        float bv[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) bv[t] = xb[toff[t]];
-        const int kn = (kp + 2 < p.BPp) ? kp + 2 : kp;
-        const float av_n = arow[kn];
-        const int off_n = pixoff[kn + kh];
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
-        av = av_n;
-        off = off_n;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  // ---- fold into gW[o][c][t]: 8 output rows at a time through LDS so that the atomics run over consecutive addresses ----
-  {
-    constexpr int ROWF = 32 * T;
-    float* tw = lds;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) tw[(rr + 4 * kh) * ROWF + j * T + t] = d.scale * acc[t][4 * q + rr];
-      __builtin_amdgcn_wave_barrier();
-      for (int e = lane; e < 8 * ROWF; e += 64) {
-        const int rl = e / ROWF;
-        const int rem = e - rl * ROWF;
-        const int o = cout0 + 8 * q + rl;
-        const int c = cin_w + rem / T;
-        if (o < d.Cout && c < d.Cin) atomicAdd(d.gW + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  if (d.gb && ct == 0) {
-    bsum += __shfl_xor(bsum, 32, 64);
-    if (kh == 0 && cout0 + j < d.Cout) atomicAdd(d.gb + cout0 + j, d.scale * bsum);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Wave-task form with LDS-DMA staging: 3x3 / stride 1 / pad 1 layers on small planes (the 9x9 trunk).  No staging
 // registers and no staging arithmetic: dy (32 planes, contiguous in memory) lands with `global_load_lds_dwordx4`;
 // x lands with `global_load_lds_dword`, two instructions per channel plane, into a zero-framed plane of
@@ -657,7 +490,262 @@ __global__ __launch_bounds__(128, 2) void wgrad_wave_dma_kernel(const WgradPlan*
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row-band LDS-DMA form: 3x3 and 4x4 layers on planes too large for whole-image bands (the 18x18 / 36x36 layers of
+// the generator tail and of the discriminator), any stride, with or without the folded nearest x2 resize.
+// A band = R output rows of one image.  Both operands land with `global_load_lds_dword` (per-lane source address,
+// lane-linear destination): dy rows into 32 slabs of odd stride, x into zero-framed rows of Wl + 1 cells per channel
+// (out-of-image rows are fetched from a device zero word; the shared zero column is never written).  Two
+// wavefronts per workgroup share the dy slab: for 3x3 they own two input tiles, for 4x4 the two halves of the
+// sixteen taps of one input tile (sixteen 32x32 accumulators do not fit one wavefront).
+// ---------------------------------------------------------------------------------------------------------------
+template <int T, int TPW>
+__global__ __launch_bounds__(128, 2) void wgrad_band_dma_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ starts,
+                                                                int nplans) {
+  constexpr int TG = T / TPW;  // 1: wavefronts = input tiles, 2: wavefronts = tap halves
+  constexpr int KWc = (T == 9) ? 3 : 4;
+  constexpr int NI = 8;        // DMA instructions per channel band / dy row band (<= 512 cells)
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int lo = 0, hi = nplans - 1;
+  const int wg = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= wg) lo = mid; else hi = mid - 1;
+  }
+  const WgradPlan& p = plans[lo];
+  const WgradDesc& d = p.d;
+  int local = wg - starts[lo];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ct = (TG == 1) ? 2 * (local % p.groups) + wave : (local % p.groups);
+  const int tg = (TG == 1) ? 0 : wave;
+  local /= p.groups;
+  const int by = local % p.coutTiles;
+  const int bz = local / p.coutTiles;
+  const int j = lane & 31, kh = lane >> 5;
+  const int cout0 = by * 32, cin_w = ct * 32;
+  const int st = d.stride, Hl = d.Hin << d.ups, Wl = d.Win << d.ups;
+  const int Wf = Wl + 1, Rin = p.Rin, PSb = p.XS, YS = p.YS;
+  const int xcells = Rin * Wf, ycells = p.R * d.OW;
+  float* ldsY = lds;                                   // 32 * YS
+  float* ldsX0 = ldsY + 32 * YS + 4;                   // behind a 4-float zero guard
+  float* ldsX = ldsX0 + ((TG == 1) ? wave * 32 * PSb : 0);
+  int* pinfo = (int*)(ldsX0 + ((TG == 1) ? 2 : 1) * 32 * PSb);  // BPp + 8
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  int toff[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tt = tg * TPW + t;
+    toff[t] = (tt / KWc) * Wf + (tt % KWc);
+  }
+  for (int e = tid; e < p.BPp + 8; e += 128) {
+    int info = p.BP;  // padding positions: the (never written, zero) cell behind the last dy position of a slab
+    if (e < p.BP) {
+      const int al = e / d.OW, b = e - al * d.OW;
+      info = e | ((al * st * Wf + b * st) << 16);
+    }
+    pinfo[e] = info;
+  }
+  const int tot = 32 * YS + 4 + ((TG == 1) ? 2 : 1) * 32 * PSb;
+  for (int e = tid; e < tot; e += 128) lds[e] = 0.f;
+  // per-lane cells of the DMA instructions that fill one channel band of x / one slab row band of dy
+  int xry[NI], xrx[NI];
+  bool xok[NI], yok[NI];
+  int yal[NI];
+#pragma unroll
+  for (int k = 0; k < NI; ++k) {
+    const int cell = lane + 64 * k;
+    const int ry = cell / Wf, rx = cell - ry * Wf;
+    xok[k] = cell < xcells && rx < Wl;   // the last cell of a framed row is the shared zero column
+    xry[k] = ry;
+    xrx[k] = rx >> d.ups;
+    yok[k] = cell < ycells;
+    yal[k] = cell / d.OW;
+  }
+  const bool wave_active = cin_w < d.Cin;
+  float bsum = 0.f;
+#ifdef DBM_WG_TIMING
+  unsigned long long tS = 0, tK = 0;
+#endif
+  WG_T(t00);
+  for (int band = bz; band < p.nbands; band += p.S) {
+    WG_T(tA);
+    const int n = band / p.nbr;
+    const int a0 = (band - n * p.nbr) * p.R;
+    const int iy0 = a0 * st - d.pad;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // the previous band is consumed (and the LDS stores before the first band have landed)
+    // ---- dy: slab rows are split between the two wavefronts ----
+    for (int i = wave; i < 32; i += 2) {
+      const bool rowok = cout0 + i < d.Cout;
+      const float* src = d.dy + (long)n * d.dysn + (long)(cout0 + (rowok ? i : 0)) * d.dysc + (long)a0 * d.OW;
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        if (64 * k < ycells) {
+          if (yok[k]) {
+            const float* g = (rowok && a0 + yal[k] < d.OH) ? src + lane + 64 * k : p.zeros;
+            __builtin_amdgcn_global_load_lds(g, (lds_ptr)(ldsY + i * YS + 64 * k), 4, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- x: TG == 1: each wavefront fills its own 32 channels; TG == 2: the two wavefronts share one tile ----
+    {
+      const int c_lo = (TG == 1) ? 0 : 16 * wave, c_hi = (TG == 1) ? 32 : 16 * wave + 16;
+      const float* srcn = d.x + (long)n * d.xsn;
+      int soff[NI];
+      bool rok[NI];
+#pragma unroll
+      for (int k = 0; k < NI; ++k) {
+        const int iy = iy0 + xry[k];
+        rok[k] = (unsigned)iy < (unsigned)Hl;
+        soff[k] = rok[k] ? (iy >> d.ups) * d.Win + xrx[k] : 0;
+      }
+      if (wave_active) {
+        for (int c = c_lo; c < c_hi; ++c) {
+          const bool cok = cin_w + c < d.Cin;
+          const float* srcc = srcn + (long)(cin_w + (cok ? c : 0)) * d.xsc;
+#pragma unroll
+          for (int k = 0; k < NI; ++k) {
+            if (64 * k < xcells) {
+              if (xok[k]) {
+                const float* g = (cok && rok[k]) ? srcc + soff[k] : p.zeros;
+                __builtin_amdgcn_global_load_lds(g, (lds_ptr)(ldsX + c * PSb + 64 * k), 4, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    WG_T(tB);
+    WG_TACC(tS, tA, tB);
+    if (d.gb && ct == 0 && tg == 0) {  // bias gradient: lane (j, kh) sums every other position of slab row j
+      float part = 0.f;
+      for (int pix = kh; pix < p.BP; pix += 2) part += ldsY[j * YS + pix];
+      bsum += part;
+    }
+    if (wave_active) {
+      // K loop, software pipelined by one full step (see wgrad_wave_dma_kernel)
+      const float* arow = ldsY + j * YS;
+      const float* xrow = ldsX - d.pad + j * PSb;
+      int info = pinfo[kh];
+      float av = arow[info & 0xffff];
+      float bv[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) bv[t] = xrow[(info >> 16) + toff[t]];
+      info = pinfo[2 + kh];
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the loop is entered with nothing pending
+      for (int kp = 0; kp < p.BPp; kp += 2) {
+        const float av_n = arow[info & 0xffff];
+        float bv_n[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) bv_n[t] = xrow[(info >> 16) + toff[t]];
+        info = pinfo[kp + 4 + kh];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        av = av_n;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) bv[t] = bv_n[t];
+      }
+    }
+#ifdef DBM_WG_TIMING
+    asm volatile("s_nop 0" ::"v"(acc[TPW - 1][15]));
+#endif
+    WG_T(tC);
+    WG_TACC(tK, tB, tC);
+  }
+  WG_T(tE);
+  // ---- fold into gW[o][c][t] (t fastest): 8 output rows at a time through LDS, atomics over consecutive addresses ----
+  __syncthreads();
+  {
+    constexpr int ROWF = 32 * T;
+    float* tw = lds + ((TG == 1) ? wave * (8 * ROWF) : 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (wave_active) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) tw[(rr + 4 * kh) * ROWF + j * T + tg * TPW + t] = d.scale * acc[t][4 * q + rr];
+      }
+      if (TG == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+      if (wave_active) {
+        for (int e = ((TG == 1) ? lane : tid); e < 8 * ROWF; e += ((TG == 1) ? 64 : 128)) {
+          const int rl = e / ROWF;
+          const int rem = e - rl * ROWF;
+          const int o = cout0 + 8 * q + rl;
+          const int c = cin_w + rem / T;
+          if (o < d.Cout && c < d.Cin) atomicAdd(d.gW + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
+        }
+      }
+      if (TG == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+    }
+  }
+  if (d.gb && ct == 0 && tg == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (kh == 0 && cout0 + j < d.Cout) atomicAdd(d.gb + cout0 + j, d.scale * bsum);
+  }
+#ifdef DBM_WG_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  if (tid == 0 && blockIdx.x < 8192) {
+    WG_T(tZ);
+    g_dbg[4 * blockIdx.x] = tS; g_dbg[4 * blockIdx.x + 1] = tK; g_dbg[4 * blockIdx.x + 2] = tZ - tE; g_dbg[4 * blockIdx.x + 3] = tZ - t00;
+  }
+#endif
+}
+
 static inline int odd_up(int v) { return v | 1; }
+
+static size_t band_plan(const WgradDesc& d, WgradPlan& p, int S_fixed) {
+  // row-band LDS-DMA form (wgrad_band_dma_kernel): the largest band of R output rows whose slabs fit half a CU's LDS
+  const int T = d.KH * d.KW;
+  if (!(T == 9 || T == 16) || d.KH != d.KW) return 0;
+  const int tiles = (d.Cin + 31) / 32;
+  p.groups = T == 9 ? (tiles + 1) / 2 : tiles;
+  p.G = T == 9 ? 2 : 1;
+  p.coutTiles = (d.Cout + 31) / 32;
+  const int nx = T == 9 ? 2 : 1;
+  const int Wl = d.Win << d.ups, Wf = Wl + 1;
+  auto floats = [&](int R) {
+    const int Rin = (R - 1) * d.stride + d.KH;
+    const int bpp = (R * d.OW + 1) & ~1;
+    return 32L * odd_up(bpp) + 4 + (long)nx * 32 * odd_up(Rin * Wf) + bpp + 8;
+  };
+  auto fits = [&](int R) {
+    const int Rin = (R - 1) * d.stride + d.KH;
+    return Rin * Wf <= 512 && R * d.OW <= 512 && floats(R) <= 19400 && (R * d.stride + d.KH) * Wf < 32768;
+  };
+  if (!fits(1) || d.OH * d.OW < 64) return 0;  // tiny planes: several images per band (workgroup / trunk forms)
+  int R = 1;
+  while (R < d.OH && fits(R + 1)) ++R;
+  // equal bands: the smallest R with the same number of bands per image
+  const int nbr = (d.OH + R - 1) / R;
+  R = (d.OH + nbr - 1) / nbr;
+  p.IB = 1; p.R = R; p.nbr = nbr;
+  p.BP = R * d.OW;
+  p.BPp = (p.BP + 1) & ~1;
+  p.YS = odd_up(p.BPp);
+  p.Rin = (R - 1) * d.stride + d.KH;
+  p.Wst = Wf;
+  p.ImgS = p.Rin * Wf;
+  p.XS = odd_up(p.ImgS);
+  p.nbands = d.N * nbr;
+  int S = S_fixed > 0 ? S_fixed : 1;
+  if (S > p.nbands) S = p.nbands;
+  p.S = S;
+  p.wg_count = p.groups * p.coutTiles * S;
+  p.fast = 0; p.planeM = p.winM = p.oplaneM = 0;
+  const size_t stage = sizeof(float) * (size_t)floats(R);
+  return std::max(stage, sizeof(float) * 2 * 8 * 32 * (size_t)9);
+}
 
 size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level, int wave_task, int S_fixed) {
   const int T = d.KH * d.KW;
@@ -665,28 +753,29 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level, int wave_task, in
   DBM_CHECK(d.OW < 4096 && d.OH < 4096, "wgrad: image too large");
   p.d = d;
   p.wave_task = wave_task;
+  p.zeros = nullptr;
+  if (wave_task == 3) return band_plan(d, p, S_fixed);
   const bool dma = wave_task == 2;
   if (dma && !(T == 9 && d.stride == 1 && d.pad == 1 && d.OH == d.Hin && d.OW == d.Win && (d.OH + 2) * (d.OW + 1) <= 128)) return 0;
   const int tiles = (d.Cin + 31) / 32;
-  p.groups = dma ? (tiles + 1) / 2 : wave_task ? tiles : (tiles + 3) / 4;
+  p.groups = dma ? (tiles + 1) / 2 : (tiles + 3) / 4;
   p.G = dma ? 2 : (tiles + p.groups - 1) / p.groups;
   p.coutTiles = (d.Cout + 31) / 32;
   // band selection: whole images if small, else row bands of one image
   const int Wst = (d.OW - 1) * d.stride + d.KW;
-  // floats; workgroup form: <= 79 KB lets two workgroups share a CU's 160 KB; wave-task form: six tasks per CU
-  const long budget = dma ? 10000 : wave_task ? 6700 : (T <= 9) ? 19800 : 25000;  // dma: four two-wavefront groups per CU
+  // floats; workgroup form: <= 79 KB lets two workgroups share a CU's 160 KB; dma: four two-wavefront groups per CU
+  const long budget = dma ? 10000 : (T <= 9) ? 19800 : 25000;
   auto cost = [&](int IB, int R) {
     const int Rin = (R - 1) * d.stride + d.KH;
     const long bpp = (IB * R * d.OW + 1) & ~1;
     if (dma) return 32L * IB * d.OH * d.OW + 4 + 64L * IB * (d.OH + 2) * (d.OW + 1) + bpp + 8;
-    if (wave_task) return 32L * odd_up(IB * Rin * Wst) + 32L * odd_up((int)bpp) + bpp;
     return (long)p.G * 32 * odd_up(IB * Rin * Wst) + 32L * odd_up((int)bpp) + 2 * bpp + (long)IB * Rin * Wst;
   };
   int IB = 1, R = d.OH;
   if (cost(1, d.OH) <= budget) {
     while (IB * 2 <= d.N && IB * 2 <= 128 && IB * 2 * d.OH * d.OW <= (324 >> std::max(level, 0)) && cost(IB * 2, d.OH) <= budget) IB *= 2;
   } else {
-    if (wave_task) return 0;
+    if (dma) return 0;
     while (R > 1 && cost(1, R) > budget) --R;
   }
   DBM_CHECK(cost(IB, R) <= 38000, "wgrad: band does not fit in LDS");
@@ -733,11 +822,6 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level, int wave_task, in
     const size_t stage = sizeof(float) * ((size_t)32 * IB * oplane + 4 + (size_t)64 * IB * p.ImgS + (size_t)p.BPp + 8);
     return std::max(stage, sizeof(float) * 2 * 8 * 32 * (size_t)T);
   }
-  if (wave_task) {
-    if (!p.fast) return 0;
-    const size_t stage = sizeof(float) * ((size_t)32 * p.YS + (size_t)p.BPp + (size_t)32 * p.XS);
-    return std::max(stage, sizeof(float) * 8 * 32 * (size_t)T);
-  }
   const size_t stage = sizeof(float) * ((size_t)32 * p.YS + 2 * (size_t)p.BPp + (size_t)IB * p.ImgS + (size_t)p.G * 32 * p.XS);
   const size_t epilogue = sizeof(float) * 4 * 8 * 32 * (size_t)T;  // per-wavefront transpose areas
   return std::max(stage, epilogue);
@@ -768,7 +852,7 @@ void WgradBatch::reset() {
   }
 }
 
-static int wave_task_enabled() {
+static int dma_forms_enabled() {  // DBM_WGRAD_WAVE: 0 = workgroup form only, 1 = + trunk LDS-DMA tasks, 2 (default) = + row-band LDS-DMA
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("DBM_WGRAD_WAVE");
@@ -777,16 +861,29 @@ static int wave_task_enabled() {
   return v;
 }
 
+static const float* device_zeros() {
+  static float* z = nullptr;
+  if (!z) {
+    DBM_HIP(hipMalloc((void**)&z, 256));
+    DBM_HIP(hipMemset(z, 0, 256));
+    DBM_HIP(hipDeviceSynchronize());
+  }
+  return z;
+}
+
 void WgradBatch::build() {
-  static const int TT[NCAT] = {1, 9, 16, 9, 9};
-  // 3x3 layers whose whole-image band fits a wavefront's share of the LDS go to the wave-task kernel
+  // categories: 0 = 1x1, 1 = 3x3 workgroup form, 2 = 4x4 workgroup form, 3 = 3x3 trunk LDS-DMA tasks (whole-image bands
+  // of small planes), 4 = 3x3 row-band LDS-DMA, 5 = 4x4 row-band LDS-DMA
+  static const int TT[NCAT] = {1, 9, 16, 9, 9, 16};
+  static const int MODE[NCAT] = {0, 0, 0, 2, 3, 3};
   std::vector<int> cat(descs.size());
+  const int forms = dma_forms_enabled();
   for (size_t i = 0; i < descs.size(); ++i) {
     const int T = descs[i].KH * descs[i].KW;
     WgradPlan p;
-    const int wt = wave_task_enabled();  // 0: workgroup form only, 1: + wave tasks, 2 (default): + LDS-DMA wave tasks
-    cat[i] = T == 1 ? 0 : T == 16 ? 2 : (wt >= 2 && wgrad_plan(descs[i], p, 0, 2) != 0) ? 4 :
-             (wt >= 1 && wgrad_plan(descs[i], p, 0, 1) != 0) ? 3 : 1;
+    if (T == 1) cat[i] = 0;
+    else if (T == 9) cat[i] = (forms >= 1 && wgrad_plan(descs[i], p, 0, 2) != 0) ? 3 : (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 4 : 1;
+    else cat[i] = (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 5 : 2;
   }
   for (int g = 0; g < NCAT; ++g) {
     std::vector<WgradPlan> plans;
@@ -794,36 +891,38 @@ void WgradBatch::build() {
     int total = 0;
     size_t maxlds = 0;
     double fl = 0.0;
-    // a launch should offer about two workgroups per CU (wave tasks: four per CU); small batches split their
-    // position axis finer
-    static const int wave_target = getenv("DBM_WGRAD_TARGET") ? atoi(getenv("DBM_WGRAD_TARGET")) : 1024;
-    const int target = g >= 3 ? wave_target : 448;
-    // wave tasks start from long K slices (few, long tasks: fewer closing atomics) and split finer until the launch
-    // offers `target` tasks
-    // LDS-DMA form: four two-wavefront groups fit a CU; the K split is chosen so that the launch is ONE round of
-    // ~1024 equally long groups
+    // LDS-DMA forms: the K split is chosen so that the launch is ONE round of equally long two-wavefront groups
+    // (four per CU for the trunk form; two or four per CU for row bands, by their LDS footprint)
     int S_fixed = 0;
-    if (g == 4) {
+    if (g >= 3) {
       long units = 0;
-      for (size_t i = 0; i < descs.size(); ++i)
-        if (cat[i] == g) units += (long)((descs[i].Cin + 63) / 64) * ((descs[i].Cout + 31) / 32);
-      static const int slots = getenv("DBM_WGRAD_SLOTS") ? atoi(getenv("DBM_WGRAD_SLOTS")) : 1024;
+      size_t need = 0;
+      for (size_t i = 0; i < descs.size(); ++i) {
+        if (cat[i] != g) continue;
+        WgradPlan p;
+        need = std::max(need, wgrad_plan(descs[i], p, 0, MODE[g], 1));
+        units += (long)p.groups * p.coutTiles;
+      }
+      static const int slots_env = getenv("DBM_WGRAD_SLOTS") ? atoi(getenv("DBM_WGRAD_SLOTS")) : 0;
+      const int slots = slots_env ? slots_env : (need > 40 * 1024 ? 512 : 1024);
       if (units > 0) S_fixed = (int)std::max(1L, slots / units);
     }
-    for (int level = (g == 3 ? -3 : 0); level < 4; ++level) {
+    // workgroup forms: a launch should offer about two workgroups per CU; small batches split their position axis finer
+    for (int level = 0; level < 4; ++level) {
       plans.clear(); starts.clear();
       total = 0; maxlds = 0; fl = 0.0;
       for (size_t i = 0; i < descs.size(); ++i) {
         if (cat[i] != g) continue;
         const WgradDesc& d = descs[i];
         WgradPlan p;
-        maxlds = std::max(maxlds, wgrad_plan(d, p, g == 4 ? 0 : level, g == 3 ? 1 : g == 4 ? 2 : 0, S_fixed));
+        maxlds = std::max(maxlds, wgrad_plan(d, p, g >= 3 ? 0 : level, MODE[g], S_fixed));
+        p.zeros = device_zeros();
         starts.push_back(total);
         total += p.wg_count;
         plans.push_back(p);
         fl += 2.0 * (double)d.N * d.OH * d.OW * d.Cout * d.Cin * TT[g];
       }
-      if (total >= target || plans.empty() || g == 4) break;
+      if (total >= 448 || plans.empty() || g >= 3) break;
     }
     starts.push_back(total);
     nplans[g] = (int)plans.size();
@@ -840,8 +939,16 @@ void WgradBatch::build() {
   built = true;
 }
 
-static void launch_wave9(const WgradPlan* plans, const int* starts, int nplans, int total_wg, size_t lds, hipStream_t s) {
-  hipLaunchKernelGGL((wgrad_wave_kernel<9>), dim3(total_wg), dim3(64), lds, s, plans, starts, nplans);
+template <typename K>
+static void launch_dma(K kernel, const WgradPlan* plans, const int* starts, int nplans, int total_wg, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {  // (one flag for the three kernels: they share this instantiation's signature)
+    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_wave_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_band_dma_kernel<9, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_band_dma_kernel<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kernel, dim3(total_wg), dim3(128), lds, s, plans, starts, nplans);
   DBM_HIP(hipGetLastError());
 }
 
@@ -853,11 +960,9 @@ void WgradBatch::launch(hipStream_t s) {
     if (g == 0) launch_T<1, 1>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else if (g == 1) launch_T<9, 9>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else if (g == 2) launch_T<16, 8>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
-    else if (g == 3) launch_wave9(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
-    else {
-      hipLaunchKernelGGL(wgrad_wave_dma_kernel, dim3(total_wg[g]), dim3(128), lds[g], s, d_plans[g], d_starts[g], nplans[g]);
-      DBM_HIP(hipGetLastError());
-    }
+    else if (g == 3) launch_dma(wgrad_wave_dma_kernel, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else if (g == 4) launch_dma(wgrad_band_dma_kernel<9, 9>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else launch_dma(wgrad_band_dma_kernel<16, 8>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     if (g_profiler.enabled) g_profiler.end(s);
   }
 }
