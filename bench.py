@@ -145,7 +145,7 @@ def main():
                 "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                 "launches_per_step": int(ig_n), "avg_launch_us": 1e3 * ig_ms / max(ig_n, 1),
                 "algorithmic_gflop_per_launch": ig_flop / max(ig_n, 1) / 1e9,
-                "second_kernel": {"kernel": "weight gradients (wgrad_wave_dma_kernel, wgrad_wave_kernel, wgrad_kernel)", "achieved": (wg_flop / (wg_ms * 1e-3) / 1e12) if wg_ms > 0 else 0.0,
+                "second_kernel": {"kernel": "weight gradients (wgrad_wave_dma_kernel, wgrad_band_dma_kernel, wgrad_kernel)", "achieved": (wg_flop / (wg_ms * 1e-3) / 1e12) if wg_ms > 0 else 0.0,
                                   "launches_per_step": int(wg_n), "avg_launch_us": 1e3 * wg_ms / max(wg_n, 1)},
             },
         }
