@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="tiles per GPU (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not enqueue the G-step's generator forward underneath the D-step's discriminator passes")
     ap.add_argument("--share-generator-forward", action="store_true",
                     help="NOT the headline configuration: reuse the D-step's generator forward in the G-step")
     args = ap.parse_args()
@@ -91,8 +93,11 @@ def main():
         comm.broadcast_params(d)
     batch = dbm.device_batch(synthetic_batch(args.batch, 42 + rank), ctx)  # inputs resident in HBM before timing
 
-    def step():
-        dbm.train_eval_discriminator(batch, g, d, d_opt, comm=comm, share_generator_forward=args.share_generator_forward)
+    prefetch = not (args.share_generator_forward or args.no_prefetch)
+
+    def step():  # one minibatch of deepbedmap_amd.trainer (srgan_train.py:1286-1309)
+        dbm.train_eval_discriminator(batch, g, d, d_opt, comm=comm, share_generator_forward=args.share_generator_forward,
+                                     prefetch_generator_forward=prefetch)
         dbm.train_eval_generator(batch, g, d, g_opt, comm=comm, share_generator_forward=args.share_generator_forward)
 
     for _ in range(args.warmup):
@@ -138,7 +143,8 @@ def main():
                                    "11x11 -> 36x36 tiles, fp32",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}",
-                       "generator_forwards_per_iteration": 1 if args.share_generator_forward else 2},
+                       "generator_forwards_per_iteration": 1 if args.share_generator_forward else 2,
+                       "g_step_forward_prefetched_under_d_step": bool(prefetch)},
             "roofline": {
                 "bound": "mfma", "kernel": "igemm_conv_kernel (conv forward + data gradient, v_mfma_f32_32x32x2_f32)",
                 "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -507,6 +507,11 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   hipStream_t s = c->stream;
   const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
   const bool share = (train & 2) != 0;  // opt-in: keep this forward's graph for the G-step of the same iteration
+  // opt-in (the trainer's pattern: the G-step of the same minibatch follows): that step's generator forward -- same
+  // weights, same inputs, its own workspace -- is enqueued on separate streams behind this step's forward, so that it
+  // runs underneath the discriminator passes instead of after them.  Nothing is skipped; the order of independent
+  // work changes.
+  const bool prefetch = (train & 4) != 0 && !share;
   train &= 1;
   g->ensure_ws(N, H, W, share && train);
   d->g_out.ensure(4 * (size_t)N);
@@ -535,6 +540,23 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   g->graph_version = g->param_version;
   g->graph_in[0] = X; g->graph_in[1] = W1; g->graph_in[2] = W2; g->graph_in[3] = W3;
   DBM_MARK(s, "D:generator_forward");
+  if (prefetch && train) {
+    Generator* t = g->get_twin();
+    t->ensure_ws(N, H, W, true);
+    if (!g->ev_prefetch) DBM_HIP(hipEventCreateWithFlags(&g->ev_prefetch, hipEventDisableTiming));
+    c->fork(s, c->chain[1], 6);  // weights packed, inputs final, and not before this step's own forward is done
+    c->stream = c->chain[1];
+    try {
+      t->forward(N, H, W, X, W1, W2, W3, t->yout.p, true);
+    } catch (...) {
+      c->stream = s;
+      throw;
+    }
+    DBM_HIP(hipEventRecord(g->ev_prefetch, c->chain[1]));
+    c->stream = s;
+    t->graph_version = g->param_version;
+    t->graph_in[0] = X; t->graph_in[1] = W1; t->graph_in[2] = W2; t->graph_in[3] = W3;
+  }
   c->join_side();
   d->forward(N, H4, W4, g->yout.p, lf, train, train, 1);   // fake batch (:1146) -- separate BatchNorm statistics
   launch_ragan_loss(lr, lf, N, 1, 0, metrics, train ? gr : nullptr, train ? gf : nullptr, s);
@@ -543,8 +565,12 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));  // cleargrads (:1162)
     // d_loss.backward() (:1163): the real- and the fake-batch graphs are independent (gradients are accumulated
     // with atomics), so the fake batch's pass runs on a second stream; both hand their weight gradients to the side stream
-    c->fork(s, c->chain[0], 7);
-    c->stream = c->chain[0];
+    // (while a prefetched generator forward owns chain[0] / chain[1], both passes stay on the main stream)
+    const bool two_streams = !(prefetch && train);
+    if (two_streams) {
+      c->fork(s, c->chain[0], 7);
+      c->stream = c->chain[0];
+    }
     d->merge_slots = true;  // one weight-gradient launch per layer group for both graphs
     try {
       d->backward(1, gf, false);
@@ -557,7 +583,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     }
     d->merge_slots = false;
     DBM_MARK(s, "D:disc_backward_real_chain");
-    c->fork(c->chain[0], s, 7);
+    if (two_streams) c->fork(c->chain[0], s, 7);
     DBM_MARK(s, "D:disc_backward_fake_chain_joined");
     c->join_side();
     DBM_MARK(s, "D:weight_gradients_joined");
@@ -583,12 +609,21 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
                      g->wsN == N && g->wsH == H && g->wsW == W && g->graph_in[0] == X && g->graph_in[1] == W1 &&
                      g->graph_in[2] == W2 && g->graph_in[3] == W3;
   DBM_MARK(s, "G:begin");
-  const bool pack_aside = d->packed_dirty && !reuse;
+  Generator* t = g->twin;
+  const bool prefetched = train && t && t->have_graph && t->wsTrain && t->graph_version == g->param_version && t->wsN == N &&
+                          t->wsH == H && t->wsW == W && t->graph_in[0] == X && t->graph_in[1] == W1 && t->graph_in[2] == W2 &&
+                          t->graph_in[3] == W3;
+  Generator* gg = prefetched ? t : g;  // the workspace that holds this step's graph
+  const bool pack_aside = d->packed_dirty && !reuse && !prefetched;
   if (pack_aside) {  // the discriminator's weight images (stale since its Adam step) are rebuilt under the generator forward
     c->fork_to_side(5);
     d->ensure_packed(c->side);
   }
-  if (!reuse) {
+  if (prefetched) {
+    d->ensure_packed();  // (the main stream has nothing else to do until the prefetched forward has finished)
+    DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));
+    t->graph_version = -1;  // consumed
+  } else if (!reuse) {
     g->ensure_ws(N, H, W, train != 0);
     g->forward(N, H, W, X, W1, W2, W3, g->yout.p, train != 0);  // (:1222-1227)
   }
@@ -596,13 +631,13 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
   if (pack_aside) c->join_side();
   d->g_out.ensure(4 * (size_t)N);
   float* lf = d->g_out.p;
-  d->forward(N, H4, W4, g->yout.p, lf, false, false, 1);  // eval-mode BatchNorm, detached (:1228-1229)
-  gen_loss_device(c, g->yout.p, Y, X, nullptr, lf, N, H4, W4, weights, 0, 1, ssim_window, metrics + 2,
-                  train ? g->g_y.p : nullptr);
+  d->forward(N, H4, W4, gg->yout.p, lf, false, false, 1);  // eval-mode BatchNorm, detached (:1228-1229)
+  gen_loss_device(c, gg->yout.p, Y, X, nullptr, lf, N, H4, W4, weights, 0, 1, ssim_window, metrics + 2,
+                  train ? gg->g_y.p : nullptr);
   DBM_MARK(s, "G:disc_forward+loss");
   if (train) {
     DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), s));  // cleargrads (:1255)
-    g->backward(g->g_y.p);                                               // g_loss.backward() (:1256)
+    gg->backward(gg->g_y.p);                                             // g_loss.backward() (:1256)
     DBM_MARK(s, "G:generator_backward_joined");
   }
   DBM_API_END

@@ -57,15 +57,39 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
   alloc_arenas();
 }
 
+Generator::~Generator() {
+  if (twin) delete twin;
+  if (ev_prefetch) (void)hipEventDestroy(ev_prefetch);
+}
+
+Generator* Generator::get_twin() {
+  if (twin) return twin;
+  Generator* t = new Generator(ctx, n_rrdb, rs, out_ch);
+  // drop what the constructor allocated and alias this model's parameters, gradients and packed weight images
+  for (auto& L : t->layers) {
+    if (L.wf) (void)hipFree(L.wf);
+    for (int i = 0; i < 4; ++i)
+      if (L.wb[i]) (void)hipFree(L.wb[i]);
+  }
+  (void)hipFree(t->params); (void)hipFree(t->grads); (void)hipFree(t->adam_m); (void)hipFree(t->adam_v); (void)hipFree(t->pers);
+  t->layers = layers;
+  t->params = params; t->grads = grads; t->adam_m = adam_m; t->adam_v = adam_v; t->pers = pers;
+  t->is_view = true;
+  t->packed_dirty = false;
+  t->chain_base = 0;  // its main stream is chain[1] (set by the caller); the second image range shares chain[0]
+  twin = t;
+  return t;
+}
+
 // number of image ranges the 9x9 stage is cut into (1 or 2): only when a single range would leave the chip
 // mostly idle (few tiles) and the ranges stay equal
 static int trunk_split(int N, long hw) {
   static const int forced = getenv("DBM_TRUNK_SPLIT") ? atoi(getenv("DBM_TRUNK_SPLIT")) : 0;
   const long tiles = ((long)N * hw + 31) / 32;
-  // two ranges: measured +4 % on the training step; four ranges oversubscribe the hardware queues (2.4x slower)
+  // two ranges: measured +4 % on the training step; more streams than hardware queues (four) serialise: 2.4x slower
   int ns = 1;
   if (tiles <= 1024 && N >= 2 && tiles >= 64) ns = 2;
-  if (forced > 0 && forced <= 4 && N >= forced) ns = forced;
+  if (forced > 0 && forced <= 2 && N >= forced) ns = forced;
   return ns;
 }
 
@@ -164,8 +188,8 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   const int nsplit = trunk_split(N, hw);
   auto cn0 = [&](int c) { return (long)(((long)c * N) / nsplit); };          // first image of range c
   auto cnc = [&](int c) { return (int)(cn0(c + 1) - cn0(c)); };                // images in range c
-  auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[c - 1]; };
-  for (int c = 1; c < nsplit; ++c) ctx->fork(s, ctx->chain[c - 1], c);
+  auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[chain_base + c - 1]; };
+  for (int c = 1; c < nsplit; ++c) ctx->fork(s, cstream(c), c);
   // ---- pre-residual conv + LeakyReLU -> cat[0][:, :64]  (:541-542) ----
   for (int c = 0; c < nsplit; ++c) {
     const long n0 = cn0(c);
@@ -204,7 +228,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     d.r1 = cat[0].p + n0 * 192 * hw; d.r1sn = 192 * hw; d.r1_nch = 64;
     launch_igemm_conv(d, cstream(c));
   }
-  for (int c = 1; c < nsplit; ++c) ctx->fork(ctx->chain[c - 1], s, 4 + c);
+  for (int c = 1; c < nsplit; ++c) ctx->fork(cstream(c), s, 4 + c);
   // ---- nearest x2 + conv + LeakyReLU, twice; the resize is folded into the conv's gather (:556-568) ----
   {
     ConvDesc d = fwd_desc(layers[L_up1], a3.p, 64 * hw, h, w, 1, a41.p, 64 * 4 * hw, N);
@@ -316,7 +340,7 @@ void Generator::backward(const float* gy) {
   wbs[0].launch(ctx->side);
   // ---- trunk, last dense block first; like the forward, as `nsplit` image ranges on separate streams ----
   const int nsplit = trunk_split(N, hw);
-  auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[c - 1]; };
+  auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[chain_base + c - 1]; };
   auto chunk = [&](ConvDesc d, int c) {  // descriptor restricted to image range c
     const long n0 = ((long)c * N) / nsplit;
     d.x += n0 * d.xsn; d.y += n0 * d.ysn; d.N = (int)(((long)(c + 1) * N) / nsplit - n0);
@@ -325,8 +349,8 @@ void Generator::backward(const float* gy) {
     if (d.mask) d.mask += n0 * d.masksn;
     return d;
   };
-  auto join_chains = [&]() { for (int c = 1; c < nsplit; ++c) ctx->fork(ctx->chain[c - 1], s, 7); };
-  for (int c = 1; c < nsplit; ++c) ctx->fork(s, ctx->chain[c - 1], 7);
+  auto join_chains = [&]() { for (int c = 1; c < nsplit; ++c) ctx->fork(cstream(c), s, 7); };
+  for (int c = 1; c < nsplit; ++c) ctx->fork(s, cstream(c), 7);
   int prev_grp = -1;
   for (int j = nrdb - 1; j >= 0; --j) {
     // groups of residual-in-residual blocks, shrinking towards the end of the chain: what is still to do once the

@@ -19,7 +19,8 @@ struct dbm_ctx {
   hipStream_t side = nullptr;        // library-owned side stream: independent work overlapping the main chain
   hipEvent_t ev_fork[8] = {};        // main -> side dependencies
   hipEvent_t ev_join = nullptr;      // side -> main
-  hipStream_t chain[3] = {};         // library-owned streams for the batch-split generator chains
+  hipStream_t chain[2] = {};         // library-owned streams: second image range of the 9x9 stage / fake-batch D backward;
+                                     // main stream of a prefetched generator forward (never more than four streams busy)
   void fork(hipStream_t from, hipStream_t to, int k);  // `to` waits for everything enqueued on `from` so far
   void fork_to_side(int k);          // side waits for everything enqueued on `stream` so far
   void join_side();                  // `stream` waits for everything enqueued on `side` so far
@@ -66,6 +67,7 @@ struct dbm_model {
   bool adam_ready = false;
   bool packed_dirty = true;
   long param_version = 0;  // bumped by every write to the parameter arena
+  bool is_view = false;    // arenas and packed weight images belong to another model (Generator::twin)
   std::vector<IgLayer> layers;
   PackJob* d_pack_jobs = nullptr;  // device job table of the one-launch weight repack
   int n_pack_jobs = 0, n_pack_blocks = 0;
@@ -109,6 +111,16 @@ struct Generator : dbm_model {
   std::vector<DevBuf> cat, dA;
   DevBuf in_x, in_w1, in_w2, in_w3, a0, a3, a41, a42, off1, off2, col1, col2, a51, yout;
   DevBuf g_a0, g_a3, g_u1, g_z41, g_u2, g_a42, goff1, goff2, gcol, g_a51, g_y;
+  // A second workspace on the same parameters: the G-step's generator forward can be enqueued while the D-step's
+  // discriminator passes are still running (dbm_discriminator_step, prefetch flag).  The twin aliases this model's
+  // arenas and packed weight images.  NOTE the library never has more than FOUR streams busy at once (main, side,
+  // chain[0], chain[1]): with a fifth, streams share a hardware queue and independent chains serialise (measured:
+  // every phase of the step 2x slower).
+  Generator* twin = nullptr;
+  int chain_base = 0;
+  hipEvent_t ev_prefetch = nullptr;
+  Generator* get_twin();
+  ~Generator() override;
   Generator(dbm_ctx* c, int n, float r, int oc);
   void ensure_ws(int N, int H, int W, bool train);
   int slot(int j) const { return wsTrain ? j : (j == 0 ? 0 : 1 + ((j - 1) & 3)); }

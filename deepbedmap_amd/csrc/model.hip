@@ -42,6 +42,7 @@ void DevBuf::release() {
 }
 
 dbm_model::~dbm_model() {
+  if (is_view) return;  // nothing here is owned
   for (auto& L : layers) {
     if (L.wf) (void)hipFree(L.wf);
     for (int i = 0; i < 4; ++i)

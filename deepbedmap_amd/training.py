@@ -54,12 +54,17 @@ def _check_batch(arrs):
 
 
 def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, train: bool = True, comm=None,
-                             sync: bool = True, share_generator_forward: bool = False):
+                             sync: bool = True, share_generator_forward: bool = False,
+                             prefetch_generator_forward: bool = False):
     """srgan_train.py:1084-1166.  Returns (d_loss, d_accu) as floats (like the reference's float(...) D2H syncs);
     sync=False returns the device metrics buffer instead and keeps the stream running.
     share_generator_forward=True (opt-in, not the reference's behaviour) retains this call's generator forward so
     that train_eval_generator(..., share_generator_forward=True) on the same device arrays reuses it: the generator
-    and its inputs do not change in between, so the numbers are bitwise the same and one forward pass is saved."""
+    and its inputs do not change in between, so the numbers are bitwise the same and one forward pass is saved.
+    prefetch_generator_forward=True (what `trainer` does): the caller promises that train_eval_generator on the SAME
+    device arrays follows; that call's generator forward (its own workspace, nothing shared or skipped) is enqueued
+    now, on separate HIP streams, so that it runs underneath this step's discriminator passes.  If the promise is
+    broken the prefetched pass is simply discarded."""
     global_config.train = train  # srgan_train.py:1125
     if train is True:
         assert d_optimizer is not None  # Optimizer required for neural network training
@@ -67,7 +72,8 @@ def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, t
     n, h, w = _check_batch(dev)
     m = _metrics_buffer(g_model.ctx)
     _lib.check(_lib.lib().dbm_discriminator_step(g_model._h, d_model._h, n, h, w, *[_dev_ptr(dev[k]) for k in _KEYS],
-                                                 int(bool(train)) | (2 if share_generator_forward else 0), m.ptr),
+                                                 int(bool(train)) | (2 if share_generator_forward else 0) |
+                                                 (4 if prefetch_generator_forward else 0), m.ptr),
                g_model.ctx.handle)
     if train is True:
         scale = comm.allreduce_grads(d_model) if comm is not None else 1.0
@@ -154,8 +160,9 @@ def trainer(i: int, columns: list, train_iter, dev_iter, g_model, g_optimizer, d
     """srgan_train.py:1267-1329: one epoch of D-step/G-step minibatches, then the dev-set evaluation."""
     metrics_dict = {mn: [] for mn in columns}
     while i == train_iter.epoch:
-        train_arrays = concat_examples(train_iter.dataset, train_iter.next())
-        d_train_loss, d_train_accu = train_eval_discriminator(train_arrays, g_model, d_model, d_optimizer, comm=comm)
+        train_arrays = device_batch(concat_examples(train_iter.dataset, train_iter.next()), g_model.ctx)
+        d_train_loss, d_train_accu = train_eval_discriminator(train_arrays, g_model, d_model, d_optimizer, comm=comm,
+                                                              prefetch_generator_forward=True)
         metrics_dict["discriminator_loss"].append(d_train_loss)
         metrics_dict["discriminator_accu"].append(d_train_accu)
         g_train_loss, g_train_psnr, g_train_ssim = train_eval_generator(train_arrays, g_model, d_model, g_optimizer,

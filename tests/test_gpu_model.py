@@ -408,8 +408,10 @@ def test_rccl_plumbing_on_one_gpu(dbm):
         dist.destroy_process_group()
 
 
-def test_shared_generator_forward_is_equivalent(dbm):
-    """Opt-in reuse of the D-step's generator forward by the G-step gives the numbers of the two-forward path."""
+@pytest.mark.parametrize("mode", ["share_generator_forward", "prefetch_generator_forward"])
+def test_shared_generator_forward_is_equivalent(dbm, mode):
+    """Opt-in reuse of the D-step's generator forward by the G-step -- and the trainer's prefetch of the G-step's own
+    forward underneath the D-step's discriminator passes -- give the numbers of the plain sequential path."""
     arrays = dbm.device_batch(fixture_arrays(n=4))
     results = []
     for share in (False, True):
@@ -421,8 +423,9 @@ def test_shared_generator_forward_is_equivalent(dbm):
         d_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(d)
         out = []
         for _ in range(2):
-            out += list(dbm.train_eval_discriminator(arrays, g, d, d_opt, share_generator_forward=share))
-            out += list(dbm.train_eval_generator(arrays, g, d, g_opt, share_generator_forward=share))
+            out += list(dbm.train_eval_discriminator(arrays, g, d, d_opt, **{mode: share}))
+            kw = {mode: share} if mode == "share_generator_forward" else {}
+            out += list(dbm.train_eval_generator(arrays, g, d, g_opt, **kw))
         results.append(out)
     assert results[0][:2] == results[1][:2]  # D-step of the first iteration: bitwise (same forward numbers)
     # its G-step sees a discriminator whose update folded gradients with fp32 atomics (run-dependent order)
