@@ -512,6 +512,9 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   // runs underneath the discriminator passes instead of after them.  Nothing is skipped; the order of independent
   // work changes.
   const bool prefetch = (train & 4) != 0 && !share;
+  // bit 8: the caller runs collectives on a stream of its own (RCCL): the prefetched forward then stays on ONE library
+  // stream so that, with the caller's two, no more than four are ever busy (see Generator::twin)
+  const bool narrow = (train & 8) != 0;
   train &= 1;
   g->ensure_ws(N, H, W, share && train);
   d->g_out.ensure(4 * (size_t)N);
@@ -544,15 +547,18 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     Generator* t = g->get_twin();
     t->ensure_ws(N, H, W, true);
     if (!g->ev_prefetch) DBM_HIP(hipEventCreateWithFlags(&g->ev_prefetch, hipEventDisableTiming));
-    c->fork(s, c->chain[1], 6);  // weights packed, inputs final, and not before this step's own forward is done
-    c->stream = c->chain[1];
+    t->max_split = narrow ? 1 : 2;
+    hipStream_t pf = narrow ? c->chain[0] : c->chain[1];
+    c->fork(s, pf, 6);  // weights packed, inputs final, and not before this step's own forward is done
+    c->stream = pf;
     try {
       t->forward(N, H, W, X, W1, W2, W3, t->yout.p, true);
     } catch (...) {
       c->stream = s;
       throw;
     }
-    DBM_HIP(hipEventRecord(g->ev_prefetch, c->chain[1]));
+    DBM_HIP(hipEventRecord(g->ev_prefetch, pf));
+    t->max_split = 2;
     c->stream = s;
     t->graph_version = g->param_version;
     t->graph_in[0] = X; t->graph_in[1] = W1; t->graph_in[2] = W2; t->graph_in[3] = W3;

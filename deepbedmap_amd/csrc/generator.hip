@@ -185,7 +185,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   // The 9x9 stage is a chain of ~180 short, latency-bound kernels (162-324 tiles each at batch 64).  The generator
   // has no cross-sample coupling, so the batch is cut into `nsplit` image ranges that run the same chain on
   // separate HIP streams: while one range's kernel is in its prologue / epilogue the other's feeds the MFMA pipes.
-  const int nsplit = trunk_split(N, hw);
+  const int nsplit = std::min(trunk_split(N, hw), max_split);
   auto cn0 = [&](int c) { return (long)(((long)c * N) / nsplit); };          // first image of range c
   auto cnc = [&](int c) { return (int)(cn0(c + 1) - cn0(c)); };                // images in range c
   auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[chain_base + c - 1]; };
@@ -339,7 +339,7 @@ void Generator::backward(const float* gy) {
   ctx->fork_to_side(0);
   wbs[0].launch(ctx->side);
   // ---- trunk, last dense block first; like the forward, as `nsplit` image ranges on separate streams ----
-  const int nsplit = trunk_split(N, hw);
+  const int nsplit = std::min(trunk_split(N, hw), max_split);
   auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[chain_base + c - 1]; };
   auto chunk = [&](ConvDesc d, int c) {  // descriptor restricted to image range c
     const long n0 = ((long)c * N) / nsplit;

@@ -118,6 +118,7 @@ struct Generator : dbm_model {
   // every phase of the step 2x slower).
   Generator* twin = nullptr;
   int chain_base = 0;
+  int max_split = 2;  // image ranges the 9x9 stage may be cut into (1: everything on the caller's stream)
   hipEvent_t ev_prefetch = nullptr;
   Generator* get_twin();
   ~Generator() override;

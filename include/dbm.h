@@ -125,7 +125,13 @@ int dbm_adam_update(dbm_model* m, double grad_scale);
 /* ---- fused steps (device-resident inputs, asynchronous) ---- */
 /* train_eval_discriminator: srgan_train.py:1084-1166 up to and including d_loss.backward() (update = dbm_adam_update).
  * arrays are DEVICE pointers: X (N,1,11,11), W1 (N,1,110,110), W2 (N,2,22,22), W3 (N,1,11,11), Y (N,1,36,36).
- * metrics_dev (device, >= 8 floats) receives [d_loss, d_accu].  train=0 evaluates with BatchNorm in eval mode. */
+ * metrics_dev (device, >= 8 floats) receives [d_loss, d_accu].
+ * train: bit 0 = training mode (0 evaluates with BatchNorm in eval mode); scheduling options, all numerically neutral:
+ * bit 1 (2) = keep this call's generator forward for the following dbm_generator_step on the same arrays (that step
+ * then skips its own forward: NOT what the reference does, off by default); bit 2 (4) = the following
+ * dbm_generator_step's forward is enqueued now, in its own workspace and on separate streams, underneath this
+ * step's discriminator passes (the trainer's pattern; discarded if the next call does not match); bit 3 (8) = the
+ * caller runs collectives on a stream of its own: the prefetched forward stays on one library stream. */
 int dbm_discriminator_step(dbm_model* g, dbm_model* d, int N, int H, int W, const float* X, const float* W1,
                            const float* W2, const float* W3, const float* Y, int train, float* metrics_dev);
 /* train_eval_generator: srgan_train.py:1170-1263 up to and including g_loss.backward().

@@ -41,7 +41,7 @@ def test_every_entry_point_cites_the_reference():
                  "dbm_discriminator_loss", "dbm_adam_setup", "dbm_adam_update", "dbm_discriminator_step",
                  "dbm_generator_step", "dbm_model_cleargrads", "dbm_model_count_params"):
         i = text.index(name + "(")
-        assert re.search(r"(srgan_train|deepbedmap)\.py:\d+", text[max(0, i - 900):i]), name
+        assert re.search(r"(srgan_train|deepbedmap)\.py:\d+", text[max(0, i - 1800):i]), name
 
 
 def test_no_gpu_means_loud_failure(built):
