@@ -197,6 +197,30 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     }
   }
 
+  const long pix = (long)(a * d.so + d.oy0) * d.OWp + (b * d.so + d.ox0);
+  constexpr int ROWS_PER_PASS = 2 * WAVES;        // threads / 32
+  constexpr int PASSES = 32 / ROWS_PER_PASS;      // 4, 2, 1 for WAVES = 4, 8, 16
+  const int irow = tid >> 5;
+  // Two phases: first every global read of the epilogue (residuals, accumulate target, mask) for ALL of this thread's
+  // outputs is issued -- before the cross-wavefront reduction, whose LDS traffic and barrier hide their latency --
+  // then the arithmetic and the stores.  (One pass at a time, the compiler cannot hoist the next
+  // pass's loads above the previous pass's store -- y, r1, r2 and mask may alias -- and a short-K layer then spends
+  // more time in PASSES serialised memory round trips than in its MFMAs.)
+  float e_r1[PASSES], e_r2[PASSES], e_y[PASSES], e_m[PASSES], e_b[PASSES];
+#pragma unroll
+  for (int q = 0; q < PASSES; ++q) {
+    const int i = irow + ROWS_PER_PASS * q;
+    const int c = cout0 + i;
+    e_r1[q] = e_r2[q] = e_y[q] = e_b[q] = 0.f;
+    e_m[q] = 1.f;
+    if (!pv || c >= d.Cout || ks > 1) continue;
+    const long co = (long)c * d.ysc + pix;
+    if (d.bias) e_b[q] = d.bias[c];
+    if (d.r1 && c < d.r1_nch) e_r1[q] = d.r1[(long)n * d.r1sn + co];
+    if (d.r2) e_r2[q] = d.r2[(long)n * d.r2sn + co];
+    if (d.accumulate) e_y[q] = d.y[(long)n * d.ysn + co];
+    if (d.mask && c >= d.mask_c0) e_m[q] = d.mask[(long)n * d.masksn + co];
+  }
   // split-K reduction through LDS
   float* mine = red + wave * 1024;
 #pragma unroll
@@ -206,10 +230,6 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
   }
   __syncthreads();
   if (!pv) return;
-  const long pix = (long)(a * d.so + d.oy0) * d.OWp + (b * d.so + d.ox0);
-  constexpr int ROWS_PER_PASS = 2 * WAVES;        // threads / 32
-  constexpr int PASSES = 32 / ROWS_PER_PASS;      // 4, 2, 1 for WAVES = 4, 8, 16
-  const int irow = tid >> 5;
 #pragma unroll
   for (int q = 0; q < PASSES; ++q) {
     const int i = irow + ROWS_PER_PASS * q;
@@ -219,22 +239,17 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) v += red[w * 1024 + e];
+    const long co = (long)c * d.ysc + pix;
+    float* yp = d.y + (long)n * d.ysn + co;
     if (ks > 1) {  // plain layer, output pre-zeroed by the launcher
-      atomicAdd(d.y + (long)n * d.ysn + (long)c * d.ysc + pix, v);
+      atomicAdd(yp, v);
       continue;
     }
-    if (d.bias) v += d.bias[c];
-    v *= d.s1;
-    const long co = (long)c * d.ysc + pix;
-    if (d.r1 && c < d.r1_nch) v += d.r1s * d.r1[(long)n * d.r1sn + co];
-    if (d.r2) v = d.s2 * v + d.r2[(long)n * d.r2sn + co];
-    float* yp = d.y + (long)n * d.ysn + co;
-    if (d.accumulate) v += *yp;
+    v = (v + e_b[q]) * d.s1 + d.r1s * e_r1[q];
+    if (d.r2) v = d.s2 * v + e_r2[q];
+    v += e_y[q];
     if (d.act) v = v >= 0.f ? v : d.slope * v;
-    if (d.mask && c >= d.mask_c0) {
-      const float m = d.mask[(long)n * d.masksn + co];
-      v = m >= 0.f ? v : d.slope * v;
-    }
+    v = e_m[q] >= 0.f ? v : d.slope * v;
     *yp = v;
   }
 }
