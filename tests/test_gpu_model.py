@@ -408,7 +408,14 @@ def test_rccl_plumbing_on_one_gpu(dbm):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["share_generator_forward", "prefetch_generator_forward"])
+class _NoComm:
+    """Stands in for DataParallel on one GPU: selects the one-stream ("narrow") form of the prefetch."""
+
+    def allreduce_grads(self, model):
+        return 1.0
+
+
+@pytest.mark.parametrize("mode", ["share_generator_forward", "prefetch_generator_forward", "prefetch_narrow"])
 def test_shared_generator_forward_is_equivalent(dbm, mode):
     """Opt-in reuse of the D-step's generator forward by the G-step -- and the trainer's prefetch of the G-step's own
     forward underneath the D-step's discriminator passes -- give the numbers of the plain sequential path."""
@@ -423,7 +430,11 @@ def test_shared_generator_forward_is_equivalent(dbm, mode):
         d_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(d)
         out = []
         for _ in range(2):
-            out += list(dbm.train_eval_discriminator(arrays, g, d, d_opt, **{mode: share}))
+            if mode == "prefetch_narrow":
+                out += list(dbm.train_eval_discriminator(arrays, g, d, d_opt, prefetch_generator_forward=share,
+                                                         comm=_NoComm() if share else None))
+            else:
+                out += list(dbm.train_eval_discriminator(arrays, g, d, d_opt, **{mode: share}))
             kw = {mode: share} if mode == "share_generator_forward" else {}
             out += list(dbm.train_eval_generator(arrays, g, d, g_opt, **kw))
         results.append(out)
