@@ -2,6 +2,18 @@
 #include "dbm_internal.h"
 #include "kernels.h"
 
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* sh) {  // sh: NT / 64 floats
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) t += sh[w];
+  return t;
+}
+
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   __syncthreads();
@@ -15,26 +27,38 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 // One workgroup per channel: two-pass mean / biased variance (as Chainer's x.mean / x.var), running
 // statistics with the unbiased correction m/max(m-1,1) and decay 0.9, then normalise + LeakyReLU.
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restrict__ z, float* __restrict__ y,
-                                                           const float* gamma, const float* beta, float* mean_o,
-                                                           float* istd_o, float* avg_mean, float* avg_var, int N, int C,
-                                                           int plane, float eps, float decay, float slope) {
-  __shared__ float sh[4];
+// NT = 256: flat index over (n, p) (tiny planes: the deep layers, 512 channels = 512 workgroups).  NT = 1024: one
+// wavefront per image, lanes along the plane (the 64..128-channel layers on 18x18 / 9x9 planes would otherwise run on
+// 64 workgroups of 256 threads: 66 us for a 21 MB tensor).
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_train_fwd_kernel(const float* __restrict__ z, float* __restrict__ y,
+                                                          const float* gamma, const float* beta, float* mean_o,
+                                                          float* istd_o, float* avg_mean, float* avg_var, int N, int C,
+                                                          int plane, float eps, float decay, float slope) {
+  __shared__ float sh[NT / 64];
   const int c = blockIdx.x;
   const long m = (long)N * plane;
+  constexpr bool WIDE = NT > 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto for_each = [&](auto&& f) {
+    if constexpr (WIDE) {
+      for (int n = wave; n < N; n += NT / 64) {
+        const long base = ((long)n * C + c) * plane;
+        for (int p = lane; p < plane; p += 64) f(base + p);
+      }
+    } else {
+      for (long e = threadIdx.x; e < m; e += NT) {
+        const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
+        f(((long)n * C + c) * plane + p);
+      }
+    }
+  };
   float s = 0.f;
-  for (long e = threadIdx.x; e < m; e += 256) {
-    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
-    s += z[((long)n * C + c) * plane + p];
-  }
-  const float mean = block_sum_256(s, sh) / (float)m;
+  for_each([&](long idx) { s += z[idx]; });
+  const float mean = block_sum<NT>(s, sh) / (float)m;
   float q = 0.f;
-  for (long e = threadIdx.x; e < m; e += 256) {
-    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
-    const float d = z[((long)n * C + c) * plane + p] - mean;
-    q += d * d;
-  }
-  const float var = block_sum_256(q, sh) / (float)m;
+  for_each([&](long idx) { const float d = z[idx] - mean; q += d * d; });
+  const float var = block_sum<NT>(q, sh) / (float)m;
   const float istd = 1.f / sqrtf(var + eps);
   if (threadIdx.x == 0) {
     mean_o[c] = mean;
@@ -44,19 +68,21 @@ __global__ __launch_bounds__(256) void bn_train_fwd_kernel(const float* __restri
     avg_var[c] = avg_var[c] * decay + ((1.f - decay) * adjust) * var;
   }
   const float g = gamma[c], b = beta[c];
-  for (long e = threadIdx.x; e < m; e += 256) {
-    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
-    const long idx = ((long)n * C + c) * plane + p;
-    float v = g * ((z[idx] - mean) * istd) + b;
+  for_each([&](long idx) {
+    const float v = g * ((z[idx] - mean) * istd) + b;
     y[idx] = v >= 0.f ? v : slope * v;
-  }
+  });
 }
 
 void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* inv_std,
                          float* avg_mean, float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
                          hipStream_t s) {
-  hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(C), dim3(256), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean, avg_var,
-                     N, C, plane, eps, decay, slope);
+  if (plane >= 64 && C <= 256)
+    hipLaunchKernelGGL(bn_train_fwd_kernel<1024>, dim3(C), dim3(1024), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean,
+                       avg_var, N, C, plane, eps, decay, slope);
+  else
+    hipLaunchKernelGGL(bn_train_fwd_kernel<256>, dim3(C), dim3(256), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean,
+                       avg_var, N, C, plane, eps, decay, slope);
   DBM_HIP(hipGetLastError());
 }
 
@@ -80,47 +106,63 @@ void launch_bn_eval_fwd(const float* z, float* y, const float* gamma, const floa
   DBM_HIP(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void bn_train_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gh,
-                                                           const float* gamma, const float* beta, const float* mean_i,
-                                                           const float* istd_i, float* __restrict__ gz, float* ggamma,
-                                                           float* gbeta, int N, int C, int plane, float slope) {
-  __shared__ float sh[4];
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_train_bwd_kernel(const float* __restrict__ z, const float* __restrict__ gh,
+                                                          const float* gamma, const float* beta, const float* mean_i,
+                                                          const float* istd_i, float* __restrict__ gz, float* ggamma,
+                                                          float* gbeta, int N, int C, int plane, float slope) {
+  __shared__ float sh[NT / 64];
   const int c = blockIdx.x;
   const long m = (long)N * plane;
   const float mean = mean_i[c], istd = istd_i[c], g = gamma[c], b = beta[c];
+  constexpr bool WIDE = NT > 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto for_each = [&](auto&& f) {
+    if constexpr (WIDE) {
+      for (int n = wave; n < N; n += NT / 64) {
+        const long base = ((long)n * C + c) * plane;
+        for (int p = lane; p < plane; p += 64) f(base + p);
+      }
+    } else {
+      for (long e = threadIdx.x; e < m; e += NT) {
+        const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
+        f(((long)n * C + c) * plane + p);
+      }
+    }
+  };
   float s1 = 0.f, s2 = 0.f;
-  for (long e = threadIdx.x; e < m; e += 256) {
-    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
-    const long idx = ((long)n * C + c) * plane + p;
+  for_each([&](long idx) {
     const float xh = (z[idx] - mean) * istd;
     const float yv = g * xh + b;
     const float gt = yv >= 0.f ? gh[idx] : slope * gh[idx];
     s1 += gt;
     s2 += gt * xh;
-  }
-  const float sg = block_sum_256(s1, sh);
-  const float sgx = block_sum_256(s2, sh);
+  });
+  const float sg = block_sum<NT>(s1, sh);
+  const float sgx = block_sum<NT>(s2, sh);
   if (threadIdx.x == 0) {
     atomicAdd(ggamma + c, sgx);  // atomics: the real- and fake-batch backward passes run concurrently
     atomicAdd(gbeta + c, sg);
   }
   const float k = g * istd, im = 1.f / (float)m;
-  for (long e = threadIdx.x; e < m; e += 256) {
-    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
-    const long idx = ((long)n * C + c) * plane + p;
+  for_each([&](long idx) {
     const float xh = (z[idx] - mean) * istd;
     const float yv = g * xh + b;
     const float gt = yv >= 0.f ? gh[idx] : slope * gh[idx];
     gz[idx] = k * (gt - (sg + xh * sgx) * im);
-  }
+  });
 }
 
 void launch_bn_train_bwd(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
                          const float* inv_std, float* gz, float* ggamma, float* gbeta, float* scratch, int N, int C,
                          int plane, float slope, hipStream_t s) {
   (void)scratch;
-  hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(C), dim3(256), 0, s, z, gh, gamma, beta, mean, inv_std, gz, ggamma,
-                     gbeta, N, C, plane, slope);
+  if (plane >= 64 && C <= 256)
+    hipLaunchKernelGGL(bn_train_bwd_kernel<1024>, dim3(C), dim3(1024), 0, s, z, gh, gamma, beta, mean, inv_std, gz, ggamma,
+                       gbeta, N, C, plane, slope);
+  else
+    hipLaunchKernelGGL(bn_train_bwd_kernel<256>, dim3(C), dim3(256), 0, s, z, gh, gamma, beta, mean, inv_std, gz, ggamma,
+                       gbeta, N, C, plane, slope);
   DBM_HIP(hipGetLastError());
 }
 
