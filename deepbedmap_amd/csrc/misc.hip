@@ -389,9 +389,13 @@ __global__ __launch_bounds__(NT) void deform_backward_csr_kernel(const float* __
       if (o4 >= 0) { const int sl = atomicAdd(cur + o4, 1); ent_p[sl] = p; ent_w[sl] = w4; }
       const float gyv = gy ? gy[(long)n * plane + p] : 0.f;
       float gu = 0.f, gv = 0.f;
+      float gqs[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        gqs[c] = gcol ? gcol[((long)n * C * 9 + (long)(c0 + c) * 9 + t) * plane + p] : w1o[(c0 + c) * 9 + t] * gyv;
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
-        const float gq = gcol ? gcol[((long)n * C * 9 + (long)(c0 + c) * 9 + t) * plane + p] : w1o[(c0 + c) * 9 + t] * gyv;
+        const float gq = gqs[c];
         const float* xc = sx + c * plane;
         const float x1 = o1 >= 0 ? xc[o1] : 0.f, x2 = o2 >= 0 ? xc[o2] : 0.f;
         const float x3 = o3 >= 0 ? xc[o3] : 0.f, x4 = o4 >= 0 ? xc[o4] : 0.f;
@@ -403,20 +407,30 @@ __global__ __launch_bounds__(NT) void deform_backward_csr_kernel(const float* __
     }
     __syncthreads();
     // ---- gather: every input pixel q sums its list, channel by channel ----
+    // (entries outer, channels inner: the CH gathers of one list entry are independent loads in flight together)
     for (int q = tid; q < plane; q += NT) {
       const int s0 = offs[q], s1 = offs[q + 1];
+      float acc[CH];
 #pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const float* gc = gcol ? gcol + ((long)n * C * 9 + (long)(c0 + c) * 9 + t) * plane : nullptr;
-        const float wq = gcol ? 0.f : w1o[(c0 + c) * 9 + t];
-        float acc = 0.f;
-        for (int sl = s0; sl < s1; ++sl) {
-          const int p = ent_p[sl];
-          const float gq = gc ? gc[p] : wq * gy[(long)n * plane + p];
-          acc += ent_w[sl] * gq;
+      for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+      const float* gc0 = gcol ? gcol + ((long)n * C * 9 + (long)c0 * 9 + t) * plane : nullptr;
+      for (int sl = s0; sl < s1; ++sl) {
+        const int p = ent_p[sl];
+        const float w = ent_w[sl];
+        if (gc0) {
+          float gq[CH];
+#pragma unroll
+          for (int c = 0; c < CH; ++c) gq[c] = gc0[(long)c * 9 * plane + p];
+#pragma unroll
+          for (int c = 0; c < CH; ++c) acc[c] += w * gq[c];
+        } else {
+          const float gyv = w * gy[(long)n * plane + p];
+#pragma unroll
+          for (int c = 0; c < CH; ++c) acc[c] += gyv * w1o[(c0 + c) * 9 + t];
         }
-        sg[c * plane + q] += acc;
       }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) sg[c * plane + q] += acc[c];
     }
     __syncthreads();
   }
