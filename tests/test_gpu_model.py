@@ -146,6 +146,57 @@ def test_generator_backward_parity(dbm, scale):
     assert worst[0] < 5e-4, worst  # gradients: sums over 3*81..3*1296 positions in a different order than BLAS
 
 
+def test_config2_generator_only_l1_16_rrdb(dbm):
+    """BASELINE.json config 2: generator-only fwd+bwd, 16 RRDB, pixel-L1 loss only.  Parity of loss and gradients
+    at batch 2 against the oracle; at the full batch of 32 the size-independent properties: a repeated pass gives
+    the same loss bitwise, the gradient of the batch is the sum of the gradients of its halves (linearity in gy),
+    and three Adam steps lower the loss."""
+    og = scaled_oracle_generator(16, 1.0)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=16, initialize=False), og.params)
+    r = np.random.RandomState(7)
+
+    def l1(y, t):  # F.mean_absolute_error and its gradient
+        return float(np.abs(y - t).mean()), (np.sign(y - t) / y.size).astype(np.float32)
+
+    ins = tile_inputs(2, 31)
+    t = r.rand(2, 1, 36, 36).astype(np.float32)
+    ref = og.forward(*ins, keep=True)
+    y = g.forward(*ins)
+    loss_ref, gy_ref = l1(ref, t)
+    loss, gy = l1(y.array, t)
+    assert rel(y.array, ref) < TOL and abs(loss - loss_ref) < 1e-5
+    G = og.backward(gy_ref)
+    g.cleargrads()
+    g.backward(gy_ref)
+    worst = grad_errors(g, G)[0]
+    assert worst[0] < 5e-4, worst
+    # ---- full size ----
+    ins = [dbm.to_device(a) for a in tile_inputs(32, 32)]
+    t = r.rand(32, 1, 36, 36).astype(np.float32)
+    opt = dbm.optimizers.Adam(alpha=1e-4, eps=1e-8).setup(g)
+    y0 = g.forward(*ins).array.get()
+    y1 = g.forward(*ins).array.get()
+    assert np.array_equal(y0, y1)
+    loss0, gy = l1(y0, t)
+    g.cleargrads(); g.backward(gy)
+    full = {k: p.grad.copy() for k, p in g._tensors.items() if p.grad is not None}
+    half = gy.copy(); half[16:] = 0
+    g.forward(*ins); g.cleargrads(); g.backward(half)
+    part = {k: p.grad.copy() for k, p in g._tensors.items() if p.grad is not None}
+    other = gy.copy(); other[:16] = 0
+    g.forward(*ins); g.cleargrads(); g.backward(other)
+    gmax = max(float(np.abs(v).max()) for v in full.values())
+    for k in full:
+        assert np.abs(part[k] + g._tensors[k].grad - full[k]).max() <= 2e-4 * max(float(np.abs(full[k]).max()), 1e-3 * gmax), k
+    losses = [loss0]
+    for _ in range(3):
+        yv = g.forward(*ins).array.get()
+        ls, gy = l1(yv, t)
+        losses.append(ls)
+        g.cleargrads(); g.backward(gy); opt.update()
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
 def scaled_oracle_discriminator(seed=5):
     d = omodel.DiscriminatorModel(seed=seed)
     r = np.random.RandomState(seed + 1)
