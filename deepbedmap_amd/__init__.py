@@ -15,4 +15,5 @@ from .training import (  # noqa: F401
     train_eval_discriminator, train_eval_generator, trainer,
 )
 from .parallel import DataParallel, shard_batch, shard_slice  # noqa: F401
-from .inference import Shape, clip_inputs, crop_bounds, merge_ranks, predict_tiled, tile_steps  # noqa: F401
+from .inference import (Shape, clip_inputs, crop_bounds, merge_ranks, predict_tiled, predict_tiled_resident,  # noqa: F401
+                        tile_steps)

@@ -156,6 +156,20 @@ int dbm_profile_end(dbm_ctx* ctx, double out[8]) {
   DBM_API_END
 }
 
+int dbm_memcpy2d_d2d(dbm_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
+                     size_t height) {
+  DBM_API_BEGIN(ctx)
+  if (width_bytes && height)
+    DBM_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDeviceToDevice, ctx->stream));
+  DBM_API_END
+}
+
+int dbm_fill_f32(dbm_ctx* ctx, float* dst, size_t n, float value) {
+  DBM_API_BEGIN(ctx)
+  if (n) launch_fill(dst, (long)n, value, ctx->stream);
+  DBM_API_END
+}
+
 int dbm_phase_marks(dbm_ctx* ctx, int enable, char* out, int cap) {
   DBM_API_BEGIN(ctx)
   if (enable) {

@@ -3,15 +3,18 @@
 The reference cuts Antarctica into 1000 x 1000 px (250 km) output tiles, feeds each one's low-resolution crop --
 extended by `xtrapad` low-resolution pixels of halo plus the 1-pixel border the valid input convolutions consume --
 through `model.forward`, trims 4*xtrapad output pixels of halo on every side and pastes the rest into a NaN-filled
-canvas.  Same loop, same index arithmetic, crops copied to the GPU per tile exactly like the reference's
-`xp.asarray(...)` (deepbedmap.py:707-722); the GPU-resident crop/stitch pipeline is listed as the next step in
-DESIGN.md section 7.
+canvas.  Same loop, same index arithmetic, in two forms: `predict_tiled` copies the crops to the GPU per tile
+exactly like the reference's `xp.asarray(...)` (deepbedmap.py:707-722); `predict_tiled_resident` keeps the four
+input grids and the output canvas in HBM (12.5 GB for the whole continent: 4 % of an MI355X) and crops / pastes
+with pitched device-to-device copies, so that nothing crosses PCIe between the upload and the final download.
 """
+import ctypes as C
 import dataclasses
 
 import numpy as np
 
-from .srgan import using_config
+from . import _lib
+from .srgan import DeviceArray, to_device, using_config
 
 
 @dataclasses.dataclass(frozen=True)
@@ -64,6 +67,46 @@ def predict_tiled(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=
         Y_pred_uncut = np.asarray(Y_pred.array)[0, :, :, :]
         Y_hat[:, y_slice, x_slice] = Y_pred_uncut[:, xtrapad.y * 4:-xtrapad.y * 4, xtrapad.x * 4:-xtrapad.x * 4]
     return Y_hat
+
+
+def predict_tiled_resident(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=18000, x=22000),
+                           ary_shape=Shape(y=1000, x=1000), stride=Shape(y=1000, x=1000), xtrapad=Shape(y=18, x=18), rank=0,
+                           world=1, download=True):
+    """predict_tiled with the grids resident in HBM.  Inputs are NumPy arrays (uploaded once) or DeviceArrays of the
+    same shapes as for predict_tiled.  Returns Y_hat as a NumPy array (download=True) or as the device canvas."""
+    ctx = model.ctx
+    lib = _lib.lib()
+    grids = [a if isinstance(a, DeviceArray) else to_device(a, ctx) for a in (X_tile, W1_tile, W2_tile, W3_tile)]
+    scale = (1, 10, 2, 1)  # pixels of each grid per low-resolution pixel
+    canvas = DeviceArray((1, final_shape.y, final_shape.x), ctx)
+    _lib.check(lib.dbm_fill_f32(ctx.handle, C.c_void_p(canvas.ptr), canvas.size, float("nan")), ctx.handle)
+
+    def copy2d(dst, dpitch, src, spitch, width, height):  # in floats
+        _lib.check(lib.dbm_memcpy2d_d2d(ctx.handle, C.c_void_p(dst), 4 * dpitch, C.c_void_p(src), 4 * spitch, 4 * width,
+                                        height), ctx.handle)
+
+    crops = {}
+    for i, step in enumerate(tile_steps(final_shape, stride)):
+        if i % world != rank:
+            continue
+        y0, y1, x0, x1 = crop_bounds(step, final_shape, ary_shape, xtrapad)
+        h, w = y1 - y0, x1 - x0
+        if (h, w) not in crops:  # crop staging buffers, reused by every tile of the same shape (320 of 396 are 288 x 288)
+            crops[(h, w)] = [DeviceArray((1, g.shape[1], k * h, k * w), ctx) for g, k in zip(grids, scale)]
+        bufs = crops[(h, w)]
+        for g, k, b in zip(grids, scale, bufs):
+            H, W = g.shape[2], g.shape[3]
+            for c in range(g.shape[1]):
+                copy2d(b.ptr + 4 * c * (k * h) * (k * w), k * w, g.ptr + 4 * (c * H * W + (k * y0) * W + k * x0), W, k * w, k * h)
+        with using_config(name="enable_backprop", value=False):
+            Y_pred = model.forward(x=bufs[0], w1=bufs[1], w2=bufs[2], w3=bufs[3])
+        Wo = 4 * (w - 2)
+        rows = 4 * (h - 2) - 8 * xtrapad.y
+        cols = Wo - 8 * xtrapad.x
+        ys, xs = (y0 + xtrapad.y + 1) * 4, (x0 + xtrapad.x + 1) * 4
+        copy2d(canvas.ptr + 4 * (ys * final_shape.x + xs), final_shape.x,
+               Y_pred.array.ptr + 4 * (4 * xtrapad.y * Wo + 4 * xtrapad.x), Wo, cols, rows)
+    return canvas.get() if download else canvas
 
 
 def merge_ranks(parts):

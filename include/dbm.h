@@ -51,6 +51,12 @@ int dbm_malloc(dbm_ctx* ctx, size_t bytes, void** dptr);
 int dbm_free(dbm_ctx* ctx, void* dptr);
 int dbm_memcpy_h2d(dbm_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int dbm_memcpy_d2h(dbm_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* device-resident area inference (deepbedmap.py:706-737: the per-tile `xp.asarray(...)` crops and the paste into Y_hat,
+ * without leaving HBM): pitched device-to-device copy of `height` rows of `width_bytes`, and a float fill (NaN canvas).
+ * Asynchronous on the context's stream. */
+int dbm_memcpy2d_d2d(dbm_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_dev, size_t src_pitch,
+                     size_t width_bytes, size_t height);
+int dbm_fill_f32(dbm_ctx* ctx, float* dst_dev, size_t n, float value);
 
 /* ---- models ---- */
 /* GeneratorModel.__init__(num_residual_blocks=12, residual_scaling=0.1, out_channels=1): srgan_train.py:450-523.

@@ -395,6 +395,11 @@ def test_tiled_area_inference_matches_oracle_loop(dbm):
     # tiles dealt round-robin over two "ranks" reproduce the single-process canvas
     parts = [dbm.predict_tiled(g, X, W1, W2, W3, final, ary, stride, pad, rank=k, world=2) for k in range(2)]
     assert np.array_equal(np.nan_to_num(dbm.merge_ranks(parts), nan=-1.0), np.nan_to_num(Y, nan=-1.0))
+    # grids and canvas resident in HBM (pitched device-to-device crops and pastes): bitwise the per-tile-upload result
+    Yr = dbm.predict_tiled_resident(g, X, W1, W2, W3, final_shape=final, ary_shape=ary, stride=stride, xtrapad=pad)
+    assert np.array_equal(np.nan_to_num(Yr, nan=-1.0), np.nan_to_num(Y, nan=-1.0))
+    parts = [dbm.predict_tiled_resident(g, X, W1, W2, W3, final, ary, stride, pad, rank=k, world=2) for k in range(2)]
+    assert np.array_equal(np.nan_to_num(dbm.merge_ranks(parts), nan=-1.0), np.nan_to_num(Y, nan=-1.0))
 
 
 def test_trainer_epoch_no_nan(dbm):
