@@ -169,29 +169,29 @@ void launch_bn_train_bwd(const float* z, const float* gh, const float* gamma, co
 // ----------------------------------------------------------------------------------------------
 // L.Linear head of the discriminator (srgan_train.py:646-647, 693-696).  51 300 + 101 parameters.
 // ----------------------------------------------------------------------------------------------
+// one wavefront per output element: both rows are read coalesced, then a shuffle reduction
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                          const float* __restrict__ b, float* __restrict__ y, int N,
                                                          int K, int O, int act, float slope) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= N * O) return;
+  const int lane = threadIdx.x & 63;
   const int n = e / O, o = e - n * O;
   const float* xr = x + (long)n * K;
   const float* wr = W + (long)o * K;
-  float a0 = 0.f, a1 = 0.f;
-  int k = 0;
-  for (; k + 1 < K; k += 2) {
-    a0 = fmaf(xr[k], wr[k], a0);
-    a1 = fmaf(xr[k + 1], wr[k + 1], a1);
+  float a = 0.f;
+  for (int k = lane; k < K; k += 64) a = fmaf(xr[k], wr[k], a);
+  for (int s = 32; s > 0; s >>= 1) a += __shfl_down(a, s, 64);
+  if (lane == 0) {
+    float v = a + b[o];
+    if (act) v = v >= 0.f ? v : slope * v;
+    y[e] = v;
   }
-  if (k < K) a0 = fmaf(xr[k], wr[k], a0);
-  float v = (a0 + a1) + b[o];
-  if (act) v = v >= 0.f ? v : slope * v;
-  y[e] = v;
 }
 
 void launch_linear_fwd(const float* x, const float* W, const float* b, float* y, int N, int K, int O, int act,
                        float slope, hipStream_t s) {
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3((N * O + 255) / 256), dim3(256), 0, s, x, W, b, y, N, K, O, act, slope);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((N * O + 3) / 4), dim3(256), 0, s, x, W, b, y, N, K, O, act, slope);
   DBM_HIP(hipGetLastError());
 }
 
@@ -209,12 +209,14 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict
   if (e < nx) {  // gx[n][k]
     const int n = e / K, k = e - n * K;
     float a = 0.f;
+#pragma unroll 10
     for (int o = 0; o < O; ++o) a = fmaf(gyz_of(gy, y_act, n * O + o, slope), W[(long)o * K + k], a);
     gx[e] = a;
   } else if (e < nx + nw) {  // gW[o][k]
     const int q = e - nx;
     const int o = q / K, k = q - o * K;
     float a = 0.f;
+#pragma unroll 8
     for (int n = 0; n < N; ++n) a = fmaf(gyz_of(gy, y_act, n * O + o, slope), x[(long)n * K + k], a);
     atomicAdd(gW + q, a);
   } else if (e < nx + nw + O) {
