@@ -54,37 +54,51 @@ void launch_smallcin_conv_fwd(const SmallConvDesc& d, hipStream_t s) {
 }
 
 // gW[o][c][ky][kx] += sum_{n,a,b} dy[n][o][a][b] * x[n][c][a*s-p+ky][b*s-p+kx];  gb[o] += sum dy.
-// One thread per (o, c, ky, kx); positions are split over gridDim.y workgroups; fp32 atomics.
+// One thread per (o, c, ky, kx); whole output rows are split over gridDim.y workgroups (no integer division in the
+// loop, few partial sums per address: same-address fp32 atomics serialise in L2).
 __global__ __launch_bounds__(256) void smallcin_conv_wgrad_kernel(const SmallConvDesc d, const float* __restrict__ dy,
                                                                   long dysn, float* gW, float* gb) {
   const int K = d.Cin * d.KH * d.KW;
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int plane = d.OH * d.OW;
-  const long total = (long)d.N * plane;
-  const long chunk = (total + gridDim.y - 1) / gridDim.y;
-  const long p0 = blockIdx.y * chunk, p1 = (p0 + chunk < total) ? p0 + chunk : total;
+  const long rows = (long)d.N * d.OH;  // (n, a) pairs
+  const long chunk = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = blockIdx.y * chunk, r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
   if (e < d.Cout * K) {
     const int o = e / K, k = e - o * K;
     const int c = k / (d.KH * d.KW), kr = k - c * d.KH * d.KW;
     const int ky = kr / d.KW, kx = kr - ky * d.KW;
+    // valid output columns for this tap: 0 <= b*stride - pad + kx < Win
+    int b0 = 0, b1 = d.OW;
+    while (b0 < b1 && b0 * d.stride - d.pad + kx < 0) ++b0;
+    while (b1 > b0 && (b1 - 1) * d.stride - d.pad + kx >= d.Win) --b1;
     float acc = 0.f;
-    for (long P = p0; P < p1; ++P) {
-      const int n = (int)(P / plane);
-      const int r = (int)(P - (long)n * plane);
-      const int a = r / d.OW, b = r - a * d.OW;
-      const int iy = a * d.stride - d.pad + ky, ix = b * d.stride - d.pad + kx;
-      if ((unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
-        acc = fmaf(dy[(long)n * dysn + (long)o * plane + r],
-                   d.x[(long)n * d.xsn + (long)c * d.Hin * d.Win + (long)iy * d.Win + ix], acc);
+    int n = (int)(r0 / d.OH), a = (int)(r0 - (long)n * d.OH);
+    for (long r = r0; r < r1; ++r) {
+      const int iy = a * d.stride - d.pad + ky;
+      if ((unsigned)iy < (unsigned)d.Hin) {
+        const float* dyr = dy + (long)n * dysn + (long)o * plane + (long)a * d.OW;
+        const float* xr = d.x + (long)n * d.xsn + (long)c * d.Hin * d.Win + (long)iy * d.Win - d.pad + kx;
+        float a0 = 0.f, a1 = 0.f;
+        int b = b0;
+        for (; b + 1 < b1; b += 2) {
+          a0 = fmaf(dyr[b], xr[b * d.stride], a0);
+          a1 = fmaf(dyr[b + 1], xr[(b + 1) * d.stride], a1);
+        }
+        if (b < b1) a0 = fmaf(dyr[b], xr[b * d.stride], a0);
+        acc += a0 + a1;
+      }
+      if (++a == d.OH) { a = 0; ++n; }
     }
     atomicAdd(gW + e, acc);
   }
   if (gb && blockIdx.x == 0 && threadIdx.x < d.Cout) {
     float acc = 0.f;
-    for (long P = p0; P < p1; ++P) {
-      const int n = (int)(P / plane);
-      const int r = (int)(P - (long)n * plane);
-      acc += dy[(long)n * dysn + (long)threadIdx.x * plane + r];
+    int n = (int)(r0 / d.OH), a = (int)(r0 - (long)n * d.OH);
+    for (long r = r0; r < r1; ++r) {
+      const float* dyr = dy + (long)n * dysn + (long)threadIdx.x * plane + (long)a * d.OW;
+      for (int b = 0; b < d.OW; ++b) acc += dyr[b];
+      if (++a == d.OH) { a = 0; ++n; }
     }
     atomicAdd(gb + threadIdx.x, acc);
   }
@@ -95,9 +109,9 @@ void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dy
   DBM_CHECK(d.Cout <= 256, "smallcin wgrad: Cout <= 256");
   const int K = d.Cin * d.KH * d.KW;
   const int nb = (d.Cout * K + 255) / 256;
-  long total = (long)d.N * d.OH * d.OW;
-  int split = (int)((2048 + nb - 1) / nb);
-  if (split > total / 16) split = (int)(total / 16);
+  const long rows = (long)d.N * d.OH;
+  int split = (int)((1024 + nb - 1) / nb);  // ~4 workgroups per CU in total
+  if (split > rows / 4) split = (int)(rows / 4);
   if (split < 1) split = 1;
   hipLaunchKernelGGL(smallcin_conv_wgrad_kernel, dim3(nb, split), dim3(256), 0, s, d, dy, dysn, gW, gb);
   DBM_HIP(hipGetLastError());
