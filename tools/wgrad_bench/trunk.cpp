@@ -49,7 +49,6 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nwg && i < 8192; ++i) for (int k = 0; k < 4; ++k) a[k] += (double)h[4 * i + k];
     printf("per task cycles: stage %.0f kloop %.0f epilogue %.0f total %.0f (n=%d)\n", a[0] / nwg, a[1] / nwg, a[2] / nwg, a[3] / nwg, nwg);
   }
-#endif
   printf("%d RDB: %d workgroups, %.1f us per launch, %.1f TFLOP/s\n", nrdb, b.total_wg[1] + b.total_wg[3] + b.total_wg[4], 1e3 * ms / reps, fl / (ms / reps * 1e-3) / 1e12);
   return 0;
 }
