@@ -179,10 +179,10 @@ def test_config2_generator_only_l1_16_rrdb(dbm):
     assert np.array_equal(y0, y1)
     loss0, gy = l1(y0, t)
     g.cleargrads(); g.backward(gy)
-    full = {k: p.grad.copy() for k, p in g._tensors.items() if p.grad is not None}
+    full = {k: p.grad.copy() for k, p in g._tensors.items() if p.kind == 0}
     half = gy.copy(); half[16:] = 0
     g.forward(*ins); g.cleargrads(); g.backward(half)
-    part = {k: p.grad.copy() for k, p in g._tensors.items() if p.grad is not None}
+    part = {k: p.grad.copy() for k, p in g._tensors.items() if p.kind == 0}
     other = gy.copy(); other[:16] = 0
     g.forward(*ins); g.cleargrads(); g.backward(other)
     gmax = max(float(np.abs(v).max()) for v in full.values())
@@ -339,6 +339,39 @@ def test_two_training_iterations_match_oracle(dbm):
     ref_e = otrain.train_eval_discriminator(arrays, og, od, train=False)
     got_e = dbm.train_eval_discriminator(arrays, g, d, train=False)
     assert np.allclose(got_e, ref_e, rtol=5e-3, atol=1e-5)
+
+
+def test_config3_full_batch_permutation_invariance(dbm):
+    """BASELINE.json config 3 at its full size (batch 64, 12 RRDB), where the oracle is too slow: the losses, metrics
+    and every gradient of a training iteration are invariant under a permutation of the minibatch (BatchNorm batch
+    statistics, RaGAN batch means and all reductions are symmetric in the samples) -- up to fp32 summation order."""
+    r = np.random.RandomState(123)
+    arrays = {k: r.rand(*shp).astype(np.float32) for k, shp in
+              (("X", (64, 1, 11, 11)), ("W1", (64, 1, 110, 110)), ("W2", (64, 2, 22, 22)), ("W3", (64, 1, 11, 11)),
+               ("Y", (64, 1, 36, 36)))}
+    perm = r.permutation(64)
+    np.random.seed(5)
+    g0 = dbm.GeneratorModel(num_residual_blocks=12)
+    d0 = dbm.DiscriminatorModel()
+    snap_g, snap_d = g0.serialize_dict(), d0.serialize_dict()
+    out = []
+    for p in (None, perm):
+        g = copy_params(dbm.GeneratorModel(num_residual_blocks=12, initialize=False), snap_g)
+        d = copy_params(dbm.DiscriminatorModel(initialize=False), snap_d, snap_d)
+        batch = dbm.device_batch({k: (v if p is None else v[p]) for k, v in arrays.items()})
+        d_opt = dbm.optimizers.Adam(alpha=0.0, eps=1e-8).setup(d)  # alpha = 0: gradients are computed, weights stay
+        g_opt = dbm.optimizers.Adam(alpha=0.0, eps=1e-8).setup(g)
+        m = list(dbm.train_eval_discriminator(batch, g, d, d_opt, prefetch_generator_forward=True))
+        gd = {k: t.grad.copy() for k, t in d._tensors.items() if t.kind == 0}
+        m += list(dbm.train_eval_generator(batch, g, d, g_opt))
+        gg = {k: t.grad.copy() for k, t in g._tensors.items() if t.kind == 0}
+        out.append((m, gd, gg))
+    (m0, gd0, gg0), (m1, gd1, gg1) = out
+    assert np.allclose(m0, m1, rtol=2e-5, atol=1e-6), (m0, m1)
+    for a, b in ((gd0, gd1), (gg0, gg1)):
+        gmax = max(float(np.abs(v).max()) for v in a.values())
+        for k in a:
+            assert np.abs(a[k] - b[k]).max() <= 1e-3 * max(float(np.abs(a[k]).max()), 1e-3 * gmax), k
 
 
 def test_npz_round_trip(dbm, tmp_path):  # srgan_train.py:1351-1361, deepbedmap.py:402-408
