@@ -15,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 DEVICE_PTRS = 1
 KEEP_GRAPH = 2
 BN_TRAIN = 4
+BF16 = 8
 
 c_float_p = C.POINTER(C.c_float)
 c_void_pp = C.POINTER(C.c_void_p)

@@ -323,6 +323,15 @@ int dbm_gen_forward(dbm_model* gm, int N, int H, int W, const float* x, const fl
   Generator* g = static_cast<Generator*>(gm);
   const bool keep = flags & DBM_KEEP_GRAPH;
   const size_t n = (size_t)N, hw = (size_t)H * W, P4 = 16 * (size_t)(H - 2) * (W - 2);
+  struct Bf16Scope {  // DBM_BF16: the convolution descriptors of this call point at the bf16 weight images
+    Generator* g;
+    Bf16Scope(Generator* gen, bool on) : g(on ? gen : nullptr) {
+      if (g) { g->ensure_packed_bf16(); g->use_bf16 = true; }
+    }
+    ~Bf16Scope() { if (g) g->use_bf16 = false; }
+  };
+  DBM_CHECK(!((flags & DBM_BF16) && keep), "dbm_gen_forward: DBM_BF16 is an inference mode (no DBM_KEEP_GRAPH)");
+  Bf16Scope bf16(g, (flags & DBM_BF16) != 0);
   if (flags & DBM_DEVICE_PTRS) {
     g->forward(N, H, W, x, w1, w2, w3, y, keep);
   } else {

@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // NPB > 0: the layer has at most NPB channel pairs per wavefront (the 9x9 trunk with 8/16-way split-K): ALL gathered
 // B operands of the wavefront's K slice are requested up front -- they are first-touch reads of activations another
@@ -133,6 +134,55 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
         }
 #pragma unroll
         for (int t = 0; t < T; ++t) av[t] = an[t];
+      }
+    }
+  } else if constexpr (NPB == -2) {
+    // bf16 multiply, fp32 accumulate (DBM_BF16 inference): v_mfma_f32_32x32x16_bf16 consumes sixteen input channels
+    // per instruction.  A lane's eight K values of the weight operand are ONE 16-byte load from the bf16 image; the
+    // activations stay fp32 in memory (eight gathers per MFMA, as in the fp32 path) and are rounded to nearest-even
+    // with v_cvt_pk_bf16_f32.  The matrix pipe is no longer the limit (32 instead of 512 cycles per sixteen
+    // channels); the vector L1 is.  Groups of sixteen channels are dealt round-robin to the wavefronts.
+    const int groups = d.Cin >> 4;
+    const bf16x8* w16 = reinterpret_cast<const bf16x8*>(d.wp16);
+    const float* xb = d.x + (long)n * d.xsn + (long)(8 * kh) * d.xsc;
+    const bf16x8* wb = w16 + (long)kh * d.CoutP + cout0 + j;
+    const long wt = (long)groups * 2 * d.CoutP;   // bf16x8 units between taps
+    const long wgs = 2L * d.CoutP;                // ... between channel groups
+    const long xgs = 16L * d.xsc;
+    // out-of-image taps read element 0 of the plane (always valid memory) and are zeroed after the load: no
+    // conditional loads in the loop; one (group, tap) step of software pipelining
+    float br[8], bn[8];
+    bf16x8 an;
+    int g = wave;
+    if (g < groups) {
+      const float* xc = xb + g * xgs;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bn[i] = xc[(long)i * d.xsc + xoff[0]];
+      an = wb[g * wgs];
+    }
+    for (; g < groups; g += WAVES) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const bf16x8 av = an;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) br[i] = bn[i];
+        // request the next step: tap t + 1 of this group, or tap 0 of this wavefront's next group
+        {
+          const bool last = (t == T - 1);
+          const int gn = last ? g + WAVES : g;
+          const int tn = last ? 0 : t + 1;
+          if (gn < groups) {
+            const float* xq = xb + gn * xgs + xoff[tn];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bn[i] = xq[(long)i * d.xsc];
+            an = wb[gn * wgs + tn * wt];
+          }
+        }
+        const bool ok = (okmask >> t) & 1u;
+        bf16x8 bv;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bv[i] = (__bf16)(ok ? br[i] : 0.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
       }
     }
   } else if constexpr (NPB < 0) {
@@ -309,6 +359,12 @@ constexpr int IGEMM_NPB = 6;  // channel pairs a wavefront may hold entirely in 
 
 template <int T, int WAVES, bool ROW>
 static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s) {
+  if constexpr (!ROW) {
+    if (d.wp16) {
+      hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -2, false>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+      return;
+    }
+  }
   const int npairs = d.Cin / (d.ksplit > 1 ? d.ksplit : 1) / WAVES / 2;
   if constexpr (T <= 9 && WAVES >= 8) {
     if (npairs <= IGEMM_NPB) {
@@ -332,7 +388,7 @@ static void launch_tw(const ConvDesc& d, dim3 grid, hipStream_t s) {
     const bool row = d.sin == 1 && d.ups == 0 && d.dy[0] == d.dy[1] && d.dy[1] == d.dy[2] && d.dx[1] == 0 &&
                      d.dx[0] == -d.dx[2] && (d.dx[0] == 1 || d.dx[0] == -1) && d.dy[3] == d.dy[5] && d.dy[6] == d.dy[8] &&
                      d.dx[3] == d.dx[0] && d.dx[6] == d.dx[0] && d.dx[4] == 0 && d.dx[7] == 0;
-    if (row) {
+    if (row && !d.wp16) {
       launch_twr<T, WAVES, true>(d, grid, s);
       return;
     }

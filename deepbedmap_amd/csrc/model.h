@@ -47,6 +47,7 @@ struct IgLayer {
   int Cview = 0, Kview = 0;  // the (C, K) the GEMM sees (deform_conv: C*9, 1)
   int CinP = 0, CoutP = 0;
   float* wf = nullptr;       // [T][CinP][CoutP]
+  void* wf16 = nullptr;      // bf16 [T][CinP/16][2][CoutP][8]: a lane's eight K values of one MFMA are one 16-byte load
   int OP = 0, CP = 0;
   float* wb[4] = {nullptr, nullptr, nullptr, nullptr};  // dgrad packs [Tb][OP][CP]
   int Tb = 0;
@@ -67,6 +68,9 @@ struct dbm_model {
   bool adam_ready = false;
   bool packed_dirty = true;
   long param_version = 0;  // bumped by every write to the parameter arena
+  long packed16_version = -1;  // param_version the bf16 forward images were built from
+  bool use_bf16 = false;       // fwd_desc hands out the bf16 images (set around a DBM_BF16 forward)
+  void ensure_packed_bf16();
   bool is_view = false;    // arenas and packed weight images belong to another model (Generator::twin)
   std::vector<IgLayer> layers;
   PackJob* d_pack_jobs = nullptr;  // device job table of the one-launch weight repack

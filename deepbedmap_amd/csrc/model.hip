@@ -45,6 +45,7 @@ dbm_model::~dbm_model() {
   if (is_view) return;  // nothing here is owned
   for (auto& L : layers) {
     if (L.wf) (void)hipFree(L.wf);
+    if (L.wf16) (void)hipFree(L.wf16);
     for (int i = 0; i < 4; ++i)
       if (L.wb[i]) (void)hipFree(L.wb[i]);
   }
@@ -180,6 +181,41 @@ void dbm_model::ensure_packed(hipStream_t on) {
   packed_dirty = false;
 }
 
+// bf16 forward images (DBM_BF16 inference): dst[t][g][kh][co][i] = bf16(W[co][cin = 16 g + 8 kh + i][tap t])
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int O, int Cview,
+                                                        int Kview, int CinP, int CoutP) {
+  const int T = Kview * Kview, G = CinP / 16;
+  const long total = (long)T * G * 2 * CoutP * 8;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int i = (int)(e & 7);
+    long r = e >> 3;
+    const int co = (int)(r % CoutP); r /= CoutP;
+    const int kh = (int)(r & 1); r >>= 1;
+    const int g = (int)(r % G);
+    const int t = (int)(r / G);
+    const int cin = 16 * g + 8 * kh + i;
+    float v = 0.f;
+    if (co < O && cin < Cview) v = w[((long)co * Cview + cin) * T + t];  // OIHW, taps fastest
+    dst[e] = (__bf16)v;
+  }
+}
+
+void dbm_model::ensure_packed_bf16() {
+  if (packed16_version == param_version) return;
+  hipStream_t s = ctx->stream;
+  for (auto& L : layers) {
+    const int T = L.Kview * L.Kview;
+    const size_t n = (size_t)T * L.CinP * L.CoutP;
+    if (!L.wf16) DBM_HIP(hipMalloc(&L.wf16, n * sizeof(__bf16)));
+    long nb = ((long)n + 2047) / 2048;
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, s, P(L.wi), (__bf16*)L.wf16, L.O, L.Cview, L.Kview, L.CinP,
+                       L.CoutP);
+  }
+  DBM_HIP(hipGetLastError());
+  packed16_version = param_version;
+}
+
 ConvDesc dbm_model::fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, float* y, long ysn,
                              int N) const {
   ConvDesc d;
@@ -194,6 +230,7 @@ ConvDesc dbm_model::fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin
     d.dx[t] = (signed char)(t % L.Kview - L.pad);
   }
   d.wp = L.wf; d.CoutP = L.CoutP; d.Cout = L.O;
+  d.wp16 = use_bf16 ? L.wf16 : nullptr;
   d.bias = L.bi >= 0 ? P(L.bi) : nullptr;
   d.y = y; d.ysn = ysn; d.ysc = OH * OW; d.OWp = OW; d.so = 1;
   d.s1 = 1.f; d.r1s = 1.f; d.s2 = 1.f; d.slope = 0.2f;

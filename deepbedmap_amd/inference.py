@@ -46,10 +46,11 @@ def crop_bounds(step: Shape, final_shape: Shape, ary_shape: Shape, xtrapad: Shap
 
 def predict_tiled(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=18000, x=22000),
                   ary_shape=Shape(y=1000, x=1000), stride=Shape(y=1000, x=1000), xtrapad=Shape(y=18, x=18), rank=0,
-                  world=1):
+                  world=1, dtype="float32"):
     """deepbedmap.py:689-741.  X (1,1,H,W), W1 (1,1,10H,10W), W2 (1,2,2H,2W), W3 (1,1,H,W) with
     (4H, 4W) == final_shape.  Returns Y_hat (1, 4H, 4W) float32, NaN where nothing was written (the outer frame and,
-    for world > 1, the tiles of the other ranks: tiles are dealt round-robin, no collective on the data path)."""
+    for world > 1, the tiles of the other ranks: tiles are dealt round-robin, no collective on the data path).
+    dtype="bfloat16": the convolutions multiply in bf16 (fp32 accumulation and storage), BASELINE.json config 5."""
     Y_hat = np.full(shape=(1, final_shape.y, final_shape.x), fill_value=np.nan, dtype=np.float32)
     steps = tile_steps(final_shape, stride)
     for i, step in enumerate(steps):
@@ -60,7 +61,7 @@ def predict_tiled(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=
         W1_crop = np.ascontiguousarray(W1_tile[:, :, y0 * 10:y1 * 10, x0 * 10:x1 * 10], dtype=np.float32)
         W2_crop = np.ascontiguousarray(W2_tile[:, :, y0 * 2:y1 * 2, x0 * 2:x1 * 2], dtype=np.float32)
         W3_crop = np.ascontiguousarray(W3_tile[:, :, y0:y1, x0:x1], dtype=np.float32)
-        with using_config(name="enable_backprop", value=False):
+        with using_config(name="enable_backprop", value=False), using_config(name="dtype", value=dtype):
             Y_pred = model.forward(x=X_crop, w1=W1_crop, w2=W2_crop, w3=W3_crop)
         y_slice = slice((y0 + xtrapad.y + 1) * 4, (y1 - xtrapad.y - 1) * 4)
         x_slice = slice((x0 + xtrapad.x + 1) * 4, (x1 - xtrapad.x - 1) * 4)
@@ -71,7 +72,7 @@ def predict_tiled(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=
 
 def predict_tiled_resident(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=18000, x=22000),
                            ary_shape=Shape(y=1000, x=1000), stride=Shape(y=1000, x=1000), xtrapad=Shape(y=18, x=18), rank=0,
-                           world=1, download=True):
+                           world=1, download=True, dtype="float32"):
     """predict_tiled with the grids resident in HBM.  Inputs are NumPy arrays (uploaded once) or DeviceArrays of the
     same shapes as for predict_tiled.  Returns Y_hat as a NumPy array (download=True) or as the device canvas."""
     ctx = model.ctx
@@ -98,7 +99,7 @@ def predict_tiled_resident(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape
             H, W = g.shape[2], g.shape[3]
             for c in range(g.shape[1]):
                 copy2d(b.ptr + 4 * c * (k * h) * (k * w), k * w, g.ptr + 4 * (c * H * W + (k * y0) * W + k * x0), W, k * w, k * h)
-        with using_config(name="enable_backprop", value=False):
+        with using_config(name="enable_backprop", value=False), using_config(name="dtype", value=dtype):
             Y_pred = model.forward(x=bufs[0], w1=bufs[1], w2=bufs[2], w3=bufs[3])
         Wo = 4 * (w - 2)
         rows = 4 * (h - 2) - 8 * xtrapad.y

@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 from . import _lib
-from ._lib import DbmError, KEEP_GRAPH, BN_TRAIN, DEVICE_PTRS
+from ._lib import BF16, DbmError, KEEP_GRAPH, BN_TRAIN, DEVICE_PTRS
 
 
 # --------------------------------------------------------------------------------------
@@ -28,6 +28,9 @@ class _Config:
     train = True
     enable_backprop = True
     ssim_window = "gaussian"  # unpinned by the reference: "gaussian" (sigma 1.5) or "uniform"
+    # "float32" (the reference's arithmetic) or "bfloat16": GeneratorModel.forward under enable_backprop=False multiplies
+    # in bf16 with fp32 accumulation and fp32 storage (area inference, BASELINE.json config 5)
+    dtype = "float32"
 
 
 global_config = _Config()
@@ -317,6 +320,12 @@ class GeneratorModel(_Link):
     def forward(self, x, w1, w2, w3):
         keep = bool(global_config.enable_backprop)
         flags = KEEP_GRAPH if keep else 0
+        if global_config.dtype == "bfloat16":
+            if keep:
+                raise ValueError("dtype bfloat16 is an inference mode: use using_config('enable_backprop', False)")
+            flags |= BF16
+        elif global_config.dtype != "float32":
+            raise ValueError(f"unknown dtype {global_config.dtype!r}")
         device = _is_device(x)
         n, _, h, w = x.shape
         exp = {"w1": (n, 1, 10 * h, 10 * w), "w2": (n, 2, 2 * h, 2 * w), "w3": (n, 1, h, w)}

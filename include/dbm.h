@@ -28,6 +28,8 @@ typedef struct dbm_model dbm_model;
 enum {
   DBM_DEVICE_PTRS = 1, /* array arguments are device pointers; call is asynchronous on the ctx stream */
   DBM_KEEP_GRAPH = 2,  /* retain activations for a following backward (Chainer: enable_backprop=True) */
+  DBM_BF16 = 8,        /* dbm_gen_forward without DBM_KEEP_GRAPH: the convolutions multiply in bf16 (operands rounded to
+                          nearest-even, fp32 accumulation, fp32 storage): the area-inference mode of BASELINE config 5 */
   DBM_BN_TRAIN = 4     /* discriminator BatchNorm uses batch statistics and updates running stats
                           (chainer.config.train=True, srgan_train.py:1125) */
 };
@@ -85,7 +87,7 @@ int dbm_model_params_changed(dbm_model* m);
 
 /* ---- forward / backward ---- */
 /* GeneratorModel.forward(x, w1, w2, w3): srgan_train.py:525-576.  x (N,1,H,W), w1 (N,1,10H,10W), w2 (N,2,2H,2W),
- * w3 (N,1,H,W) -> y (N,1,4(H-2),4(W-2)).  flags: DBM_DEVICE_PTRS, DBM_KEEP_GRAPH. */
+ * w3 (N,1,H,W) -> y (N,1,4(H-2),4(W-2)).  flags: DBM_DEVICE_PTRS, DBM_KEEP_GRAPH, DBM_BF16. */
 int dbm_gen_forward(dbm_model* g, int N, int H, int W, const float* x, const float* w1, const float* w2,
                     const float* w3, float* y, int flags);
 /* g_loss.backward() through the generator: srgan_train.py:1256.  gy (N,1,4(H-2),4(W-2)) = d loss / d y of the last

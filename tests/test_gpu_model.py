@@ -123,6 +123,27 @@ def test_generator_is_fully_convolutional(dbm):  # features/steps/test_deepbedma
     assert rel(y, ref) < TOL
 
 
+def test_generator_bf16_inference_mode(dbm):
+    """BASELINE.json config 5's arithmetic: convolutions multiply in bf16 (operands rounded to nearest-even), fp32
+    accumulation and storage.  Against the fp32 oracle the error is that of 8-bit significands (tolerance 3e-2 of
+    the output range, measured 1e-2); the mode is refused when a graph is to be retained."""
+    og = scaled_oracle_generator(12, 1.0)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=12, initialize=False), og.params)
+    ins = tile_inputs(2, 13)
+    ref = og.forward(*ins)
+    with dbm.using_config("enable_backprop", False), dbm.using_config("dtype", "bfloat16"):
+        y = g.forward(*ins).array
+        y2 = g.forward(*[dbm.to_device(a) for a in ins]).array.get()
+    with dbm.using_config("enable_backprop", False):
+        y32 = g.forward(*ins).array
+    assert np.isfinite(y).all() and np.array_equal(y, y2)
+    err = np.abs(y - ref).max() / np.abs(ref).max()
+    assert 1e-5 < err < 3e-2, err          # really a different arithmetic, and within bf16's reach
+    assert rel(y32, ref) < TOL               # the fp32 path is untouched by having built the bf16 images
+    with pytest.raises(ValueError), dbm.using_config("dtype", "bfloat16"):
+        g.forward(*ins)                      # enable_backprop is on
+
+
 def test_generator_rejects_bad_shapes(dbm):
     g = dbm.GeneratorModel(num_residual_blocks=1)
     x, w1, w2, w3 = tile_inputs(1, 0)
