@@ -22,7 +22,6 @@ void launch_deform_backward(const float* x, const float* off, const float* gcol,
 void launch_gemv_cols(const float* col, const float* w, const float* bias, float* y, int N, int K, int plane, hipStream_t s);
 void launch_gemv_cols_wgrad(const float* col, const float* gy, float* gw, float* gb, int N, int K, int plane, hipStream_t s);
 void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int H, int W, float slope, hipStream_t s);
-void launch_lrelu_bwd(const float* g, const float* mask, float* out, long total, float slope, hipStream_t s);
 
 // ---- norm_loss.hip ----
 // BatchNorm (training): per-channel batch statistics of z [N,C,plane]; writes mean/inv_std, updates running stats,

@@ -267,59 +267,6 @@ __global__ __launch_bounds__(256) void deform_backward_kernel(const float* __res
   gn[(long)(9 + t) * plane + p] = g.mv ? gv : 0.f;
 }
 
-// Training-tile variant (the whole image plane of CH channels fits in LDS): one workgroup owns (image n, CH channels).
-// The bilinear scatter goes to LDS with ds_add_f32 and leaves as plain coalesced stores -- no global atomics on gx, no
-// zero-fill of gx; only the 18 offset-gradient planes are folded across channel groups with global atomics.
-template <int CH>
-__global__ __launch_bounds__(1024) void deform_backward_lds_kernel(const float* __restrict__ x, const float* __restrict__ off,
-                                                                  const float* __restrict__ gcol,
-                                                                  const float* __restrict__ w1o,
-                                                                  const float* __restrict__ gy, float* __restrict__ gx,
-                                                                  float* goff, int N, int C, int H, int W, long offsn) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int plane = H * W;
-  float* sx = sm;
-  float* sg = sm + CH * plane;
-  const int n = blockIdx.x, c0 = blockIdx.y * CH, tid = threadIdx.x;
-  const float* xn = x + ((long)n * C + c0) * plane;
-  for (int e = tid; e < CH * plane; e += 1024) {
-    sx[e] = xn[e];
-    sg[e] = 0.f;
-  }
-  __syncthreads();
-  const float* on = off + (long)n * offsn;
-  float* gn = goff + (long)n * offsn;
-  for (int e = tid; e < 9 * plane; e += 1024) {
-    const int t = e / plane, p = e - t * plane;
-    const int a = p / W, b = p - a * W;
-    const DeformGeom g = deform_geom(on[(long)t * plane + p], on[(long)(9 + t) * plane + p], a, b, t / 3, t % 3, H, W, 1);
-    const int o1 = deform_corner(g.v0, g.u0, H, W, 1), o2 = deform_corner(g.v0, g.u0 + 1, H, W, 1);
-    const int o3 = deform_corner(g.v0 + 1, g.u0, H, W, 1), o4 = deform_corner(g.v0 + 1, g.u0 + 1, H, W, 1);
-    const float w1 = g.wu1 * g.wv1, w2 = g.wu0 * g.wv1, w3 = g.wu1 * g.wv0, w4 = g.wu0 * g.wv0;
-    const float gyv = gy ? gy[(long)n * plane + p] : 0.f;
-    float gu = 0.f, gv = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const float gq = gcol ? gcol[((long)n * C * 9 + (long)(c0 + c) * 9 + t) * plane + p] : w1o[(c0 + c) * 9 + t] * gyv;
-      const float* xc = sx + c * plane;
-      float* gc = sg + c * plane;
-      const float x1 = o1 >= 0 ? xc[o1] : 0.f, x2 = o2 >= 0 ? xc[o2] : 0.f;
-      const float x3 = o3 >= 0 ? xc[o3] : 0.f, x4 = o4 >= 0 ? xc[o4] : 0.f;
-      gu += gq * (-g.wv1 * x1 + g.wv1 * x2 - g.wv0 * x3 + g.wv0 * x4);
-      gv += gq * (-g.wu1 * x1 - g.wu0 * x2 + g.wu1 * x3 + g.wu0 * x4);
-      if (o1 >= 0) atomicAdd(gc + o1, gq * w1);
-      if (o2 >= 0) atomicAdd(gc + o2, gq * w2);
-      if (o3 >= 0) atomicAdd(gc + o3, gq * w3);
-      if (o4 >= 0) atomicAdd(gc + o4, gq * w4);
-    }
-    if (g.mu) atomicAdd(gn + (long)t * plane + p, gu);
-    if (g.mv) atomicAdd(gn + (long)(9 + t) * plane + p, gv);
-  }
-  __syncthreads();
-  float* gxn = gx + ((long)n * C + c0) * plane;
-  for (int e = tid; e < CH * plane; e += 1024) gxn[e] = sg[e];
-}
-
 // Same contract, without floating-point atomics on gx (ds_add_f32 retires about one lane per clock: the scatter
 // version keeps the LDS 100 % busy).  The sampling pattern of a tap is shared by all channels, so per (image, tap) the
 // workgroup builds the TRANSPOSED sparse sampling operator once -- a CSR list, per input pixel q, of the output
@@ -560,16 +507,3 @@ void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int
   DBM_HIP(hipGetLastError());
 }
 
-// out = g * lrelu'(mask)   (elementwise; used where the derivative cannot ride on a GEMM epilogue)
-__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ mask,
-                                                        float* __restrict__ out, long total, float slope) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  out[e] = mask[e] >= 0.f ? g[e] : slope * g[e];
-}
-
-void launch_lrelu_bwd(const float* g, const float* mask, float* out, long total, float slope, hipStream_t s) {
-  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, mask, out, total,
-                     slope);
-  DBM_HIP(hipGetLastError());
-}
