@@ -4,23 +4,29 @@
 // GEMM view: M = out channels, N = (in channel, tap), K = output positions.  The contiguous
 // memory axis (positions) is the MFMA K axis, which per-lane global loads cannot feed
 // efficiently (every lane would touch its own cache line), so operands are staged through LDS:
-// a workgroup stages, for one "band" (IB images x R output rows), the 32 x BP slab of dy and
-// the zero-padded, tap-ready input patch of up to 128 input channels, then each wavefront owns
-// one 32-channel input tile and keeps T (= taps) independent 32x32 accumulators, i.e. T
-// independent MFMA chains fed by 1 + 2/T LDS dwords per MFMA.
+// for one "band" of positions a 32 x BP slab of dy and the zero-framed, tap-ready input planes;
+// each wavefront owns one 32-channel input tile and keeps one 32x32 accumulator per tap, i.e.
+// T independent MFMA chains fed by 1 + 2/T LDS dwords per MFMA.
 //
 // One layer alone cannot fill 256 CUs (the trunk's weight matrices have 2..12 32x32 tiles), and
-// splitting K harder only multiplies the fp32 atomics that fold the partial sums.  So the launch
-// is BATCHED: a device-resident table of per-layer plans, one workgroup = (layer, input-channel
-// group, output tile, K split); all weight gradients of a backward pass with the same kernel size
-// go out in a single launch after the data-gradient chain (they do not depend on each other).
+// splitting K harder only multiplies the fp32 atomics that fold the partial sums.  So launches
+// are BATCHED: a device-resident table of per-layer plans, one workgroup = (layer, input-channel
+// group, output tile, K split); all weight gradients of a group of layers with the same kernel
+// form go out in a single launch (they do not depend on each other).
+//
+// Three kernel forms (WgradBatch::build picks per layer):
+//   wgrad_wave_dma_kernel   3x3 / stride 1 on small planes (the 9x9 trunk): whole-image bands, LDS-DMA staging,
+//                           two wavefronts = two input tiles sharing one dy slab
+//   wgrad_band_dma_kernel   3x3 / 4x4, any stride / folded resize, on large planes: row bands, dword LDS-DMA
+//   wgrad_kernel            general form (1x1 layers, 4x4 layers on tiny planes): four / eight wavefronts,
+//                           register-staged
 #include "dbm_internal.h"
 #include <algorithm>
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Phase timing of the wave-task kernels for the micro-benchmark under scratch/ (compiled out of the library).
+// Phase timing of the LDS-DMA kernels for tools/wgrad_bench/ (compiled out of the library).
 #ifdef DBM_WG_TIMING
 __device__ unsigned long long g_dbg[4 * 8192];
 #define WG_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
