@@ -75,6 +75,7 @@ struct ConvDesc {
   long masksn;
   int mask_c0;
   const float* zeros;  // >= 4 bytes of device zeros
+  unsigned planeM, owM; // set by the launcher: floor(2^32 / (OHl*OWl)), floor(2^32 / OWl) (division-free position decode)
   const void* wp16;    // bf16 forward image [T][Cin/16][2][CoutP][8] (null: fp32 MFMA path)
   int ksplit;          // set by the launcher: > 1 = blockIdx.z owns Cin / ksplit input channels and the plain result is
                        // folded into a pre-zeroed y with atomics (few-tile, long-K layers: the deep discriminator convs)

@@ -51,11 +51,16 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
   const long P = (long)blockIdx.x * 32 + j;
   const bool pv = P < (long)d.N * plane;
   int n = 0, a = 0, b = 0;
-  if (pv) {
-    n = (int)(P / plane);
-    const int r = (int)(P - (long)n * plane);
-    a = r / d.OWl;
-    b = r - a * d.OWl;
+  if (pv) {  // P < 2^31 (checked by the launcher): multiply-high estimates are at most one short
+    unsigned q = __umulhi((unsigned)P, d.planeM);
+    unsigned r = (unsigned)P - q * (unsigned)plane;
+    if (r >= (unsigned)plane) { ++q; r -= (unsigned)plane; }
+    n = (int)q;
+    unsigned qa = __umulhi(r, d.owM);
+    unsigned rb = r - qa * (unsigned)d.OWl;
+    if (rb >= (unsigned)d.OWl) { ++qa; rb -= (unsigned)d.OWl; }
+    a = (int)qa;
+    b = (int)rb;
   }
   const int cout0 = blockIdx.y * 32;
   const int ks = d.ksplit > 1 ? d.ksplit : 1;
@@ -406,6 +411,13 @@ static void launch_t(const ConvDesc& d, dim3 grid, int waves, hipStream_t s) {
 void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   ConvDesc d = d_in;
   d.ksplit = 1;
+  DBM_CHECK((long)d.N * d.OHl * d.OWl < (1L << 31), "igemm: more than 2^31 output positions");
+  auto magic = [](unsigned long long dv) {  // floor(2^32 / dv), saturated (dv == 1: the kernel's one-step correction still lands)
+    const unsigned long long m = 0x100000000ULL / dv;
+    return (unsigned)(m > 0xffffffffULL ? 0xffffffffULL : m);
+  };
+  d.planeM = magic((unsigned long long)d.OHl * d.OWl);
+  d.owM = magic((unsigned long long)d.OWl);
   DBM_CHECK(d.Cin % 32 == 0, "igemm: Cin must be a multiple of 32");
   DBM_CHECK(d.CoutP % 32 == 0 && d.Cout <= d.CoutP, "igemm: bad CoutP");
   DBM_CHECK(d.T == 1 || d.T == 4 || d.T == 9 || d.T == 16, "igemm: tap count must be 1, 4, 9 or 16");
