@@ -80,10 +80,10 @@ def main():
     comm = dbm.DataParallel() if world > 1 else None
     ctx = dbm.Context(local_rank)
     dbm._lib._default_ctx = ctx
-    # libdbm enqueues on torch's current stream: torch.cuda.synchronize() covers it, RCCL is ordered by stream events
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # multi-GPU: libdbm enqueues on the stream torch issues its RCCL collectives on (stream-ordered, no host waits);
+    # single GPU: the context's own stream (torch.cuda.synchronize() below is device-wide)
     if comm is not None:
-        comm._shared_stream.add(id(ctx))
+        comm.attach(ctx)
 
     np.random.seed(1234)  # identical initial weights on every rank (and broadcast below for good measure)
     g, g_opt, d, d_opt = dbm.compile_srgan_model(num_residual_blocks=N_RRDB, residual_scaling=0.1,

@@ -60,7 +60,15 @@ class DataParallel:
         """Run libdbm on torch's current HIP stream: torch then orders the RCCL collective after the backward
         kernels and the Adam kernel after the collective by stream events alone (no host synchronisation)."""
         if self.on_gpu:
-            ctx.set_stream(self.torch.cuda.current_stream().cuda_stream)
+            st = self.torch.cuda.current_stream()
+            if st.cuda_stream == 0:
+                # torch's default stream is the legacy NULL stream: it has no handle libdbm could be given
+                # (dbm_set_stream(ctx, NULL) means "the context's own stream").  Make a real stream current for this
+                # thread, so that the collectives torch issues and libdbm's kernels share one stream.
+                self._stream = self.torch.cuda.Stream(device=self.local_rank)
+                self.torch.cuda.set_stream(self._stream)
+                st = self._stream
+            ctx.set_stream(st.cuda_stream)
             self._shared_stream.add(id(ctx))
 
     def grad_view(self, model):
