@@ -45,8 +45,8 @@ class DataParallel:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.on_gpu = torch.cuda.is_available() if device is None else (device != "cpu")
-        if backend is None:
-            backend = "nccl" if self.on_gpu else "gloo"
+        if backend is None:  # DBM_DIST_BACKEND=gloo: e.g. several ranks on ONE GPU in a test (RCCL wants one device per rank)
+            backend = os.environ.get("DBM_DIST_BACKEND") or ("nccl" if self.on_gpu else "gloo")
         if self.on_gpu:
             torch.cuda.set_device(self.local_rank)
         if not dist.is_initialized():
