@@ -185,6 +185,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   // The 9x9 stage is a chain of ~180 short, latency-bound kernels (162-324 tiles each at batch 64).  The generator
   // has no cross-sample coupling, so the batch is cut into `nsplit` image ranges that run the same chain on
   // separate HIP streams: while one range's kernel is in its prologue / epilogue the other's feeds the MFMA pipes.
+  DBM_MARK(s, "  gen_forward:input_block");
   const int nsplit = std::min(trunk_split(N, hw), max_split);
   auto cn0 = [&](int c) { return (long)(((long)c * N) / nsplit); };          // first image of range c
   auto cnc = [&](int c) { return (int)(cn0(c + 1) - cn0(c)); };                // images in range c
@@ -229,6 +230,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     launch_igemm_conv(d, cstream(c));
   }
   for (int c = 1; c < nsplit; ++c) ctx->fork(cstream(c), s, 4 + c);
+  DBM_MARK(s, "  gen_forward:9x9_stage");
   // ---- nearest x2 + conv + LeakyReLU, twice; the resize is folded into the conv's gather (:556-568) ----
   {
     ConvDesc d = fwd_desc(layers[L_up1], a3.p, 64 * hw, h, w, 1, a41.p, 64 * 4 * hw, N);
