@@ -270,8 +270,10 @@ void Generator::backward(const float* gy) {
   const long hw = (long)h * w, P4 = 16 * hw;
   const int H4 = 4 * h, W4 = 4 * w, nrdb = 3 * n_rrdb;
   // ---- final_conv_layer2 (deformable, 64 -> 1) ----
+  // (its weight gradient only needs gy and the retained columns: side stream, underneath the sampler's backward)
+  ctx->fork_to_side(5);
+  launch_gemv_cols_wgrad(col2.p, gy, G(T_def2W), G(T_def2b), N, 576, (int)P4, ctx->side);
   launch_deform_backward(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, goff2.p, N, 64, H4, W4, 32 * P4, s);
-  launch_gemv_cols_wgrad(col2.p, gy, G(T_def2W), G(T_def2b), N, 576, (int)P4, s);
   {
     const IgLayer& L = layers[L_off2];
     run_wgrad(L, a51.p, 64 * P4, H4, W4, 0, goff2.p, 32 * P4, H4, W4, N, 1.f, &wbs[0]);
@@ -408,6 +410,8 @@ void Generator::backward(const float* gy) {
   join_chains();
   DBM_MARK(s, "G:backward_trunk_chain");
   // ---- pre_residual_conv_layer and the input block ----
+  SmallConvDesc small[4];
+  int small_i[4], nsmall = 0;
   {
     const IgLayer& L = layers[L_pre];
     run_wgrad(L, a0.p, 128 * hw, h, w, 0, dA[0].p, 192 * hw, h, w, N, 1.f, &wbs[6]);
@@ -431,7 +435,8 @@ void Generator::backward(const float* gy) {
         run_wgrad(L, (i == 1 ? colW1 : colW2).p, (long)L.CinP * hw, h, w, 0, g_a0.p + (long)i * 32 * hw, 128 * hw, h, w, N,
                   1.f, &wbs[6]);
       } else {
-        launch_smallcin_conv_wgrad(q, g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), s);
+        small[nsmall] = q;
+        small_i[nsmall++] = i;
       }
     }
   }
@@ -439,5 +444,9 @@ void Generator::backward(const float* gy) {
   ctx->fork_to_side(6);
   if (prev_grp >= 0) wbs[prev_grp].launch(ctx->side);
   wbs[6].launch(ctx->side);
+  for (int k = 0; k < nsmall; ++k) {  // the two single-channel 3x3 branches of the input block
+    const int i = small_i[k];
+    launch_smallcin_conv_wgrad(small[k], g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), ctx->side);
+  }
   ctx->join_side();  // the optimizer (and the next cleargrads) must see every gradient
 }
