@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="tiles per GPU (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="cudnn_deterministic=True (bitwise reproducible gradients; NOT the headline configuration)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not enqueue the G-step's generator forward underneath the D-step's discriminator passes")
     ap.add_argument("--share-generator-forward", action="store_true",
@@ -93,6 +95,7 @@ def main():
         comm.broadcast_params(d)
     batch = dbm.device_batch(synthetic_batch(args.batch, 42 + rank), ctx)  # inputs resident in HBM before timing
 
+    dbm.global_config.cudnn_deterministic = bool(args.deterministic)
     prefetch = not (args.share_generator_forward or args.no_prefetch)
 
     def step():  # one minibatch of deepbedmap_amd.trainer (srgan_train.py:1286-1309)
@@ -144,7 +147,8 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"dp{world}",
                        "generator_forwards_per_iteration": 1 if args.share_generator_forward else 2,
-                       "g_step_forward_prefetched_under_d_step": bool(prefetch)},
+                       "g_step_forward_prefetched_under_d_step": bool(prefetch),
+                       "cudnn_deterministic": bool(dbm.global_config.cudnn_deterministic)},
             "roofline": {
                 "bound": "mfma", "kernel": "igemm_conv_kernel (conv forward + data gradient, v_mfma_f32_32x32x2_f32)",
                 "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -26,6 +26,7 @@ SIGNATURES = {
     "dbm_shutdown": [C.c_void_p],
     "dbm_set_stream": [C.c_void_p, C.c_void_p],
     "dbm_synchronize": [C.c_void_p],
+    "dbm_set_deterministic": [C.c_void_p, C.c_int],
     "dbm_memcpy2d_d2d": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t],
     "dbm_fill_f32": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float],
     "dbm_profile_begin": [C.c_void_p],

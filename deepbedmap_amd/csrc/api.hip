@@ -22,9 +22,12 @@ static thread_local std::string g_last_error;
   }
 
 // metrics finalisation -----------------------------------------------------------------------------
-__global__ void gen_metrics_kernel(const float* sums, const float* adv, float* out, float nhw, float npool, float nwin,
+__global__ void gen_metrics_kernel(const float* part, int N, const float* adv, float* out, float nhw, float npool, float nwin,
                                    float cw, float aw, float tw, float sw) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float sums[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < N; ++n)  // per-tile partial sums of gen_loss_kernel, in tile order
+    for (int k = 0; k < 4; ++k) sums[k] += part[4 * n + k];
   const float content = sums[0] / nhw;
   const float topo = sums[1] / npool;
   const float ssim = sums[2] / nwin;
@@ -136,6 +139,12 @@ int dbm_synchronize(dbm_ctx* ctx) {
   DBM_API_BEGIN(ctx)
   DBM_HIP(hipStreamSynchronize(ctx->side));
   DBM_HIP(hipStreamSynchronize(ctx->stream));
+  DBM_API_END
+}
+
+int dbm_set_deterministic(dbm_ctx* ctx, int on) {
+  DBM_API_BEGIN(ctx)
+  g_wgrad_deterministic = on != 0;
   DBM_API_END
 }
 
@@ -413,11 +422,11 @@ static void gen_loss_device(dbm_ctx* ctx, const float* y, const float* t, const 
                             int win, float* out3, float* gy) {
   DBM_CHECK(win == 0 || win == 1, "ssim_window must be 0 (gaussian) or 1 (uniform)");
   hipStream_t s = ctx->stream;
-  ctx->loss_tmp.ensure(16 + (size_t)N);
-  float* sums = ctx->loss_tmp.p;       // [0..4]
+  ctx->loss_tmp.ensure(16 + 5 * (size_t)N);
   float* adv = ctx->loss_tmp.p + 8;    // [8..9]
   float* ones = ctx->loss_tmp.p + 16;  // N
-  DBM_HIP(hipMemsetAsync(sums, 0, 16 * sizeof(float), s));
+  float* sums = ones + N;              // 4 N per-tile partial sums
+  DBM_HIP(hipMemsetAsync(ctx->loss_tmp.p, 0, 16 * sizeof(float), s));
   if (!real_logits) {
     launch_fill(ones, N, 1.f, s);
     real_logits = ones;
@@ -426,7 +435,7 @@ static void gen_loss_device(dbm_ctx* ctx, const float* y, const float* t, const 
   launch_ragan_loss(real_logits, fake_logits, N, t_rf, t_fr, adv, nullptr, nullptr, s);
   launch_gen_loss(y, t, X, N, H, W, w[0], w[2], w[3], ctx->ssim_win[win], sums, gy, s);
   const float nhw = (float)N * H * W, npool = (float)N * (H / 4) * (W / 4), nwin = (float)N * (H - 8) * (W - 8);
-  hipLaunchKernelGGL(gen_metrics_kernel, dim3(1), dim3(64), 0, s, sums, adv, out3, nhw, npool, nwin, w[0], w[1], w[2], w[3]);
+  hipLaunchKernelGGL(gen_metrics_kernel, dim3(1), dim3(64), 0, s, sums, N, adv, out3, nhw, npool, nwin, w[0], w[1], w[2], w[3]);
   DBM_HIP(hipGetLastError());
 }
 
@@ -449,22 +458,28 @@ int dbm_generator_loss(dbm_ctx* ctx, const float* y_pred, const float* y_true, c
   DBM_API_END
 }
 
-__global__ void psnr_finish_kernel(float* acc, float n, float range) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) acc[1] = 20.f * log10f(range / sqrtf(acc[0] / n));
+__global__ void psnr_finish_kernel(const float* part, int blocks, float* out, float n, float range) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < blocks; ++i) s += part[i];
+  out[0] = 20.f * log10f(range / sqrtf(s / n));
 }
-__global__ void ssim_finish_kernel(const float* sums, float nwin, float* out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = sums[2] / nwin;
+__global__ void ssim_finish_kernel(const float* part, int N, float nwin, float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += part[4 * n + 2];
+  out[0] = s / nwin;
 }
 
 int dbm_psnr(dbm_ctx* ctx, const float* y_pred, const float* y_true, size_t n, double data_range, float* out, int flags) {
   DBM_API_BEGIN(ctx)
   const float* a = stage_in(ctx, 0, y_pred, n, flags);
   const float* b = stage_in(ctx, 1, y_true, n, flags);
-  ctx->loss_tmp.ensure(32);
+  const int blocks = sqdiff_blocks((long)n);
+  ctx->loss_tmp.ensure(32 + (size_t)blocks);
   float* acc = ctx->loss_tmp.p;
-  DBM_HIP(hipMemsetAsync(acc, 0, 8 * sizeof(float), ctx->stream));
-  launch_sqdiff(a, b, (long)n, acc, ctx->stream);
-  hipLaunchKernelGGL(psnr_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, acc, (float)n, (float)data_range);
+  launch_sqdiff(a, b, (long)n, acc + 32, ctx->stream);
+  hipLaunchKernelGGL(psnr_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, acc + 32, blocks, acc + 1, (float)n, (float)data_range);
   if (flags & DBM_DEVICE_PTRS) {
     DBM_HIP(hipMemcpyAsync(out, acc + 1, sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   } else {
@@ -482,11 +497,10 @@ int dbm_ssim(dbm_ctx* ctx, const float* y_pred, const float* y_true, int N, int 
   const float* a = stage_in(ctx, 0, y_pred, cnt, flags);
   const float* b = stage_in(ctx, 1, y_true, cnt, flags);
   float* dout = stage_out(ctx, 2, out, 1, flags);
-  ctx->loss_tmp.ensure(32);
-  float* sums = ctx->loss_tmp.p;
-  DBM_HIP(hipMemsetAsync(sums, 0, 8 * sizeof(float), ctx->stream));
+  ctx->loss_tmp.ensure(32 + 4 * (size_t)N);
+  float* sums = ctx->loss_tmp.p + 32;
   launch_gen_loss(a, b, nullptr, N, H, W, 0.f, 0.f, 0.f, ctx->ssim_win[ssim_window], sums, nullptr, ctx->stream);
-  hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, sums, (float)N * (H - 8) * (W - 8), dout);
+  hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, sums, N, (float)N * (H - 8) * (W - 8), dout);
   finish_out(ctx, 2, out, 1, flags);
   finish_sync(ctx, flags);
   DBM_API_END

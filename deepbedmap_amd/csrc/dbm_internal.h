@@ -147,7 +147,16 @@ struct WgradPlan {
   unsigned oplaneM;       // ceil(2^32 / (OH*OW))
   int wave_task;          // 0: wgrad_kernel (workgroup form), 2: wgrad_wave_dma_kernel, 3: wgrad_band_dma_kernel
   const float* zeros;     // >= 4 bytes of device zeros (out-of-image rows of the row-band DMA form)
+  // deterministic folding (no fp32 atomics): partial[slice][cout tile][group][wave][tap][16][64] in accumulator order,
+  // partial_b[slice][cout tile][32]; summed in slice order by wgrad_fold_kernel.  null = atomics.
+  float* partial;
+  float* partial_b;
+  int fold_start;         // first workgroup of this layer in the fold launch
+  // wavefront slot w of a workgroup owns input tile grp * fold_ctmul + (w % fold_cts) (if (w % fold_cts) < fold_ctmul) and
+  // the fold_tpw taps from (w / fold_cts) * fold_tpw
+  int fold_slots, fold_cts, fold_ctmul, fold_tpw;
 };
+extern bool g_wgrad_deterministic;  // dbm_set_deterministic: weight gradients are folded without fp32 atomics
 // fills p, returns the dynamic LDS bytes it needs (0: not eligible for the wave-task form)
 size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level = 0, int wave_task = 0, int S_fixed = 0);
 
@@ -156,11 +165,14 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level = 0, int wave_task
 struct WgradBatch {
   std::vector<WgradDesc> descs;
   bool built = false;
+  bool built_deterministic = false;
   static const int NCAT = 6;  // see WgradBatch::build
   WgradPlan* d_plans[NCAT] = {};
   int* d_starts[NCAT] = {};
   int nplans[NCAT] = {}, total_wg[NCAT] = {};
   size_t lds[NCAT] = {};
+  float* d_partial[NCAT] = {};   // scratch of the atomic-free folding (per category)
+  int fold_wgs[NCAT] = {};
   double flops[NCAT] = {};
   void add(const WgradDesc& d) { if (!built) descs.push_back(d); }
   void build();

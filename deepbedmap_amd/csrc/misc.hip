@@ -54,66 +54,54 @@ void launch_smallcin_conv_fwd(const SmallConvDesc& d, hipStream_t s) {
 }
 
 // gW[o][c][ky][kx] += sum_{n,a,b} dy[n][o][a][b] * x[n][c][a*s-p+ky][b*s-p+kx];  gb[o] += sum dy.
-// One thread per (o, c, ky, kx); whole output rows are split over gridDim.y workgroups (no integer division in the
-// loop, few partial sums per address: same-address fp32 atomics serialise in L2).
+// One WORKGROUP per weight element (and one per bias element): its 256 threads stride over the output positions
+// and the partial sums are folded by a fixed shuffle / LDS tree -- no K split across workgroups, so the one atomic
+// per element only orders separate launches (the two graphs of the discriminator: a + b == b + a).  Reproducible.
 __global__ __launch_bounds__(256) void smallcin_conv_wgrad_kernel(const SmallConvDesc d, const float* __restrict__ dy,
                                                                   long dysn, float* gW, float* gb) {
+  __shared__ float sh[4];
   const int K = d.Cin * d.KH * d.KW;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.x;
   const int plane = d.OH * d.OW;
-  const long rows = (long)d.N * d.OH;  // (n, a) pairs
-  const long chunk = (rows + gridDim.y - 1) / gridDim.y;
-  const long r0 = blockIdx.y * chunk, r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
-  if (e < d.Cout * K) {
-    const int o = e / K, k = e - o * K;
-    const int c = k / (d.KH * d.KW), kr = k - c * d.KH * d.KW;
-    const int ky = kr / d.KW, kx = kr - ky * d.KW;
-    // valid output columns for this tap: 0 <= b*stride - pad + kx < Win
-    int b0 = 0, b1 = d.OW;
-    while (b0 < b1 && b0 * d.stride - d.pad + kx < 0) ++b0;
-    while (b1 > b0 && (b1 - 1) * d.stride - d.pad + kx >= d.Win) --b1;
-    float acc = 0.f;
-    int n = (int)(r0 / d.OH), a = (int)(r0 - (long)n * d.OH);
-    for (long r = r0; r < r1; ++r) {
-      const int iy = a * d.stride - d.pad + ky;
-      if ((unsigned)iy < (unsigned)d.Hin) {
-        const float* dyr = dy + (long)n * dysn + (long)o * plane + (long)a * d.OW;
-        const float* xr = d.x + (long)n * d.xsn + (long)c * d.Hin * d.Win + (long)iy * d.Win - d.pad + kx;
-        float a0 = 0.f, a1 = 0.f;
-        int b = b0;
-        for (; b + 1 < b1; b += 2) {
-          a0 = fmaf(dyr[b], xr[b * d.stride], a0);
-          a1 = fmaf(dyr[b + 1], xr[(b + 1) * d.stride], a1);
-        }
-        if (b < b1) a0 = fmaf(dyr[b], xr[b * d.stride], a0);
-        acc += a0 + a1;
-      }
-      if (++a == d.OH) { a = 0; ++n; }
+  const bool bias = e >= d.Cout * K;
+  const int o = bias ? e - d.Cout * K : e / K;
+  const int k = bias ? 0 : e - o * K;
+  const int c = k / (d.KH * d.KW), kr = k - c * d.KH * d.KW;
+  const int ky = kr / d.KW, kx = kr - ky * d.KW;
+  // lanes run along the flattened (n, a, b) positions: coalesced dy reads; two multiply-high divisions per element
+  const unsigned total = (unsigned)d.N * (unsigned)plane;
+  const unsigned planeM = 0xffffffffu / (unsigned)plane, owM = 0xffffffffu / (unsigned)d.OW;  // floor((2^32-1)/d): <= 1 short
+  float acc = 0.f;
+  for (unsigned P = threadIdx.x; P < total; P += 256) {
+    unsigned n = __umulhi(P, planeM);
+    unsigned r = P - n * (unsigned)plane;
+    if (r >= (unsigned)plane) { ++n; r -= (unsigned)plane; }
+    const float g = dy[(long)n * dysn + (long)o * plane + r];
+    if (bias) {
+      acc += g;
+      continue;
     }
-    atomicAdd(gW + e, acc);
+    unsigned a = __umulhi(r, owM);
+    unsigned b = r - a * (unsigned)d.OW;
+    if (b >= (unsigned)d.OW) { ++a; b -= (unsigned)d.OW; }
+    const int iy = (int)a * d.stride - d.pad + ky, ix = (int)b * d.stride - d.pad + kx;
+    if ((unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
+      acc = fmaf(g, d.x[(long)n * d.xsn + (long)c * d.Hin * d.Win + (long)iy * d.Win + ix], acc);
   }
-  if (gb && blockIdx.x == 0 && threadIdx.x < d.Cout) {
-    float acc = 0.f;
-    int n = (int)(r0 / d.OH), a = (int)(r0 - (long)n * d.OH);
-    for (long r = r0; r < r1; ++r) {
-      const float* dyr = dy + (long)n * dysn + (long)threadIdx.x * plane + (long)a * d.OW;
-      for (int b = 0; b < d.OW; ++b) acc += dyr[b];
-      if (++a == d.OH) { a = 0; ++n; }
-    }
-    atomicAdd(gb + threadIdx.x, acc);
+  for (int s2 = 32; s2 > 0; s2 >>= 1) acc += __shfl_down(acc, s2, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float v = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (bias) atomicAdd(gb + o, v);
+    else atomicAdd(gW + e, v);
   }
 }
 
 void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dysn, float* gW, float* gb,
                                 hipStream_t s) {
-  DBM_CHECK(d.Cout <= 256, "smallcin wgrad: Cout <= 256");
   const int K = d.Cin * d.KH * d.KW;
-  const int nb = (d.Cout * K + 255) / 256;
-  const long rows = (long)d.N * d.OH;
-  int split = (int)((1024 + nb - 1) / nb);  // ~4 workgroups per CU in total
-  if (split > rows / 4) split = (int)(rows / 4);
-  if (split < 1) split = 1;
-  hipLaunchKernelGGL(smallcin_conv_wgrad_kernel, dim3(nb, split), dim3(256), 0, s, d, dy, dysn, gW, gb);
+  hipLaunchKernelGGL(smallcin_conv_wgrad_kernel, dim3(d.Cout * K + (gb ? d.Cout : 0)), dim3(256), 0, s, d, dy, dysn, gW, gb);
   DBM_HIP(hipGetLastError());
 }
 
@@ -272,7 +260,7 @@ __global__ __launch_bounds__(256) void deform_backward_kernel(const float* __res
 // workgroup builds the TRANSPOSED sparse sampling operator once -- a CSR list, per input pixel q, of the output
 // positions p and bilinear weights that touch q (counting sort with integer LDS atomics) -- and then every channel
 // GATHERS: gx[c][q] += sum_{(p,w) in list(q)} w * gcol[c][t][p], each q owned by one lane.
-template <int CH, int NT>
+template <int CH, int NT, bool DET>
 __global__ __launch_bounds__(NT) void deform_backward_csr_kernel(const float* __restrict__ x, const float* __restrict__ off,
                                                                   const float* __restrict__ gcol,
                                                                   const float* __restrict__ w1o,
@@ -348,29 +336,45 @@ __global__ __launch_bounds__(NT) void deform_backward_csr_kernel(const float* __
       if (o2 >= 0) { const int sl = atomicAdd(cur + o2, 1); ent_p[sl] = p; ent_w[sl] = w2; }
       if (o3 >= 0) { const int sl = atomicAdd(cur + o3, 1); ent_p[sl] = p; ent_w[sl] = w3; }
       if (o4 >= 0) { const int sl = atomicAdd(cur + o4, 1); ent_p[sl] = p; ent_w[sl] = w4; }
-      const float gyv = gy ? gy[(long)n * plane + p] : 0.f;
-      float gu = 0.f, gv = 0.f;
-      float gqs[CH];
-#pragma unroll
-      for (int c = 0; c < CH; ++c)
-        gqs[c] = gcol ? gcol[((long)n * C * 9 + (long)(c0 + c) * 9 + t) * plane + p] : w1o[(c0 + c) * 9 + t] * gyv;
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const float gq = gqs[c];
-        const float* xc = sx + c * plane;
-        const float x1 = o1 >= 0 ? xc[o1] : 0.f, x2 = o2 >= 0 ? xc[o2] : 0.f;
-        const float x3 = o3 >= 0 ? xc[o3] : 0.f, x4 = o4 >= 0 ? xc[o4] : 0.f;
-        gu += gq * (-g.wv1 * x1 + g.wv1 * x2 - g.wv0 * x3 + g.wv0 * x4);
-        gv += gq * (-g.wu1 * x1 - g.wu0 * x2 + g.wu1 * x3 + g.wu0 * x4);
+      if constexpr (!DET) {  // DET: the offset gradients come from deform_goff_kernel (no atomics across channel groups)
+        const float gyv = gy ? gy[(long)n * plane + p] : 0.f;
+        float gu = 0.f, gv = 0.f;
+        float gqs[CH];
+  #pragma unroll
+        for (int c = 0; c < CH; ++c)
+          gqs[c] = gcol ? gcol[((long)n * C * 9 + (long)(c0 + c) * 9 + t) * plane + p] : w1o[(c0 + c) * 9 + t] * gyv;
+  #pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const float gq = gqs[c];
+          const float* xc = sx + c * plane;
+          const float x1 = o1 >= 0 ? xc[o1] : 0.f, x2 = o2 >= 0 ? xc[o2] : 0.f;
+          const float x3 = o3 >= 0 ? xc[o3] : 0.f, x4 = o4 >= 0 ? xc[o4] : 0.f;
+          gu += gq * (-g.wv1 * x1 + g.wv1 * x2 - g.wv0 * x3 + g.wv0 * x4);
+          gv += gq * (-g.wu1 * x1 - g.wu0 * x2 + g.wu1 * x3 + g.wu0 * x4);
+        }
+        if (g.mu) atomicAdd(gn + (long)t * plane + p, gu);
+        if (g.mv) atomicAdd(gn + (long)(9 + t) * plane + p, gv);
       }
-      if (g.mu) atomicAdd(gn + (long)t * plane + p, gu);
-      if (g.mv) atomicAdd(gn + (long)(9 + t) * plane + p, gv);
     }
     __syncthreads();
     // ---- gather: every input pixel q sums its list, channel by channel ----
     // (entries outer, channels inner: the CH gathers of one list entry are independent loads in flight together)
     for (int q = tid; q < plane; q += NT) {
       const int s0 = offs[q], s1 = offs[q + 1];
+      if constexpr (DET) {  // the fill order (LDS cursor atomics) varies from run to run: sort the few entries by position
+        for (int i = s0 + 1; i < s1; ++i) {
+          const int kp = ent_p[i];
+          const float kw = ent_w[i];
+          int jj = i - 1;
+          while (jj >= s0 && ent_p[jj] > kp) {
+            ent_p[jj + 1] = ent_p[jj];
+            ent_w[jj + 1] = ent_w[jj];
+            --jj;
+          }
+          ent_p[jj + 1] = kp;
+          ent_w[jj + 1] = kw;
+        }
+      }
       float acc[CH];
 #pragma unroll
       for (int c = 0; c < CH; ++c) acc[c] = 0.f;
@@ -399,6 +403,39 @@ __global__ __launch_bounds__(NT) void deform_backward_csr_kernel(const float* __
   for (int e = tid; e < CH * plane; e += NT) gxn[e] = sg[e];
 }
 
+// Offset gradients without atomics (deterministic mode): one thread per (image, tap, position) walks all channels.
+__global__ __launch_bounds__(256) void deform_goff_kernel(const float* __restrict__ x, const float* __restrict__ off,
+                                                          const float* __restrict__ gcol, const float* __restrict__ w1o,
+                                                          const float* __restrict__ gy, float* __restrict__ goff, int N, int C,
+                                                          int H, int W, long offsn) {
+  const int plane = H * W;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * 9 * plane) return;
+  const int p = (int)(e % plane);
+  const int t = (int)((e / plane) % 9);
+  const int n = (int)(e / (9L * plane));
+  const int a = p / W, b = p - a * W;
+  const float* on = off + (long)n * offsn;
+  const DeformGeom g = deform_geom(on[(long)t * plane + p], on[(long)(9 + t) * plane + p], a, b, t / 3, t % 3, H, W, 1);
+  const int o1 = deform_corner(g.v0, g.u0, H, W, 1), o2 = deform_corner(g.v0, g.u0 + 1, H, W, 1);
+  const int o3 = deform_corner(g.v0 + 1, g.u0, H, W, 1), o4 = deform_corner(g.v0 + 1, g.u0 + 1, H, W, 1);
+  const float* xn = x + (long)n * C * plane;
+  const float gyv = gy ? gy[(long)n * plane + p] : 0.f;
+  float gu = 0.f, gv = 0.f;
+#pragma unroll 4
+  for (int c = 0; c < C; ++c) {
+    const float* xc = xn + (long)c * plane;
+    const float gq = gcol ? gcol[((long)n * C * 9 + (long)c * 9 + t) * plane + p] : w1o[c * 9 + t] * gyv;
+    const float x1 = o1 >= 0 ? xc[o1] : 0.f, x2 = o2 >= 0 ? xc[o2] : 0.f;
+    const float x3 = o3 >= 0 ? xc[o3] : 0.f, x4 = o4 >= 0 ? xc[o4] : 0.f;
+    gu += gq * (-g.wv1 * x1 + g.wv1 * x2 - g.wv0 * x3 + g.wv0 * x4);
+    gv += gq * (-g.wu1 * x1 - g.wu0 * x2 + g.wu1 * x3 + g.wu0 * x4);
+  }
+  float* gn = goff + (long)n * offsn;
+  gn[(long)t * plane + p] = g.mu ? gu : 0.f;
+  gn[(long)(9 + t) * plane + p] = g.mv ? gv : 0.f;
+}
+
 // gx is fully overwritten; goff[n][0:18] is overwritten (channels 18.. of a padded offset tensor are left alone).
 void launch_deform_backward(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy,
                             float* gx, float* goff, int N, int C, int H, int W, long offsn, hipStream_t s) {
@@ -408,13 +445,23 @@ void launch_deform_backward(const float* x, const float* off, const float* gcol,
   if (lds <= 150 * 1024 && C % CH == 0) {
     static bool attr_set = false;
     if (!attr_set) {
-      DBM_HIP(hipFuncSetAttribute((const void*)deform_backward_csr_kernel<CH, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  152 * 1024));
+      DBM_HIP(hipFuncSetAttribute((const void*)deform_backward_csr_kernel<CH, 1024, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+      DBM_HIP(hipFuncSetAttribute((const void*)deform_backward_csr_kernel<CH, 1024, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
       attr_set = true;
     }
-    DBM_HIP(hipMemset2DAsync(goff, sizeof(float) * offsn, 0, sizeof(float) * 18 * plane, N, s));
-    hipLaunchKernelGGL((deform_backward_csr_kernel<CH, 1024>), dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx, goff, N,
-                       C, H, W, offsn);
+    if (g_wgrad_deterministic) {
+      hipLaunchKernelGGL((deform_backward_csr_kernel<CH, 1024, true>), dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx,
+                         goff, N, C, H, W, offsn);
+      const long total = (long)N * 9 * plane;
+      hipLaunchKernelGGL(deform_goff_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, off, gcol, w1o, gy, goff, N, C,
+                         H, W, offsn);
+    } else {
+      DBM_HIP(hipMemset2DAsync(goff, sizeof(float) * offsn, 0, sizeof(float) * 18 * plane, N, s));
+      hipLaunchKernelGGL((deform_backward_csr_kernel<CH, 1024, false>), dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx,
+                         goff, N, C, H, W, offsn);
+    }
   } else {
     DBM_HIP(hipMemsetAsync(gx, 0, sizeof(float) * N * C * plane, s));
     const long total = (long)N * 9 * plane;
@@ -453,32 +500,34 @@ void launch_gemv_cols(const float* col, const float* w, const float* bias, float
 }
 
 // gw[k] += sum_{n,p} gy[n][p] * col[n][k][p];  gb += sum gy     (backward of the GEMV above)
-__global__ __launch_bounds__(256) void gemv_cols_wgrad_kernel(const float* __restrict__ col,
-                                                              const float* __restrict__ gy, float* gw, float* gb,
-                                                              int N, int K, int plane) {
-  __shared__ float part[4];
+// One 1024-thread workgroup per k: one wavefront per image at a time, lanes along the plane; fixed-order tree, no
+// fp32 atomics (reproducible).
+__global__ __launch_bounds__(1024) void gemv_cols_wgrad_kernel(const float* __restrict__ col,
+                                                               const float* __restrict__ gy, float* gw, float* gb,
+                                                               int N, int K, int plane) {
+  __shared__ float part[16];
   const int k = blockIdx.x;  // k == K computes the bias gradient
-  const long total = (long)N * plane;
-  const long chunk = (total + gridDim.y - 1) / gridDim.y;
-  const long e0 = blockIdx.y * chunk, e1 = (e0 + chunk < total) ? e0 + chunk : total;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc = 0.f;
-  for (long e = e0 + threadIdx.x; e < e1; e += 256) {
-    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);
-    acc += gy[e] * (k < K ? col[((long)n * K + k) * plane + p] : 1.f);
+  for (int n = wave; n < N; n += 16) {
+    const float* g = gy + (long)n * plane;
+    const float* c = col + ((long)n * K + (k < K ? k : 0)) * plane;
+    for (int p = lane; p < plane; p += 64) acc += g[p] * (k < K ? c[p] : 1.f);
   }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  if (lane == 0) part[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float v = (part[0] + part[1]) + (part[2] + part[3]);
-    if (k < K) atomicAdd(gw + k, v);
-    else if (gb) atomicAdd(gb, v);
+    float v = 0.f;
+    for (int w = 0; w < 16; ++w) v += part[w];
+    if (k < K) gw[k] += v;
+    else if (gb) gb[0] += v;
   }
 }
 
 void launch_gemv_cols_wgrad(const float* col, const float* gy, float* gw, float* gb, int N, int K, int plane,
                             hipStream_t s) {
-  hipLaunchKernelGGL(gemv_cols_wgrad_kernel, dim3(K + 1, 4), dim3(256), 0, s, col, gy, gw, gb, N, K, plane);
+  hipLaunchKernelGGL(gemv_cols_wgrad_kernel, dim3(K + 1), dim3(1024), 0, s, col, gy, gw, gb, N, K, plane);
   DBM_HIP(hipGetLastError());
 }
 

@@ -373,11 +373,11 @@ __global__ __launch_bounds__(256) void gen_loss_kernel(const float* __restrict__
   const float SQ = block_sum_256(sq, sh);
   const float SS = block_sum_256(ss, sh);
   const float TP = block_sum_256(tp, sh);
-  if (tid == 0) {
-    atomicAdd(sums + 0, L1);
-    atomicAdd(sums + 1, TP);
-    atomicAdd(sums + 2, SS);
-    atomicAdd(sums + 3, SQ);
+  if (tid == 0) {  // per-tile partial sums: the finishing kernels add them in tile order (no atomics: reproducible)
+    sums[4 * n + 0] = L1;
+    sums[4 * n + 1] = TP;
+    sums[4 * n + 2] = SS;
+    sums[4 * n + 3] = SQ;
   }
   if (gy == nullptr) return;
   __syncthreads();
@@ -490,12 +490,16 @@ __global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ a
     s += d * d;
   }
   const float t = block_sum_256(s, sh);
-  if (threadIdx.x == 0) atomicAdd(out, t);
+  if (threadIdx.x == 0) out[blockIdx.x] = t;  // per-block partial sums, added in order by the caller's finishing kernel
+}
+
+int sqdiff_blocks(long n) {
+  long blocks = (n + 255) / 256;
+  return (int)(blocks > 1024 ? 1024 : blocks);
 }
 
 void launch_sqdiff(const float* a, const float* b, long n, float* out, hipStream_t s) {
-  long blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
+  const long blocks = sqdiff_blocks(n);
   hipLaunchKernelGGL(sqdiff_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, n, out);
   DBM_HIP(hipGetLastError());
 }

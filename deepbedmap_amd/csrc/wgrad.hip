@@ -36,6 +36,20 @@ __device__ unsigned long long g_dbg[4 * 8192];
 #define WG_TACC(acc, a, b)
 #endif
 
+bool g_wgrad_deterministic = false;
+
+// Deterministic mode: a wavefront's accumulators go out in register order (256-byte stores) to its slot of the partial
+// buffer; wgrad_fold_kernel sums the K slices in order.
+template <int TPW>
+__device__ __forceinline__ void store_partial(const WgradPlan& p, int bz, int by, int grp, int slot, int lane, float scale,
+                                              const f32x16 (&acc)[TPW]) {
+  float* dst = p.partial + ((((long)bz * p.coutTiles + by) * p.groups + grp) * p.fold_slots + slot) * (TPW * 1024) + lane;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64] = scale * acc[t][r];
+}
+
 // TPW = taps per wavefront.  3x3 / 1x1: every wavefront keeps all T accumulators (TPW = T, 4 wavefronts, 256
 // registers -> two workgroups share a CU: one stages while the other feeds the MFMA pipe).  4x4: 16 accumulators are
 // 256 registers on their own, so the taps are split over two wavefronts per input tile (TPW = 8, 8 wavefronts).
@@ -286,6 +300,11 @@ __global__ __launch_bounds__(256 * (T / TPW), 2) void wgrad_kernel(const WgradPl
   // ---- fold the partial sums into gW[o][c][t] (t fastest).  A lane owns (o, c) pairs with a stride of T floats
   // between lanes, so direct atomics would touch a different cache line per lane; instead the wavefronts of one
   // input tile transpose 8 output rows at a time through LDS and issue the atomics over consecutive addresses. ----
+  if (p.partial) {
+    if (wave_active) store_partial<TPW>(p, bz, by, bx, wave, lane, d.scale, acc);
+    if (d.gb && bx == 0 && tid < 256 && (tid & 7) == 0) p.partial_b[((long)bz * p.coutTiles + by) * 32 + (tid >> 3)] = d.scale * bsum;
+    return;
+  }
   __syncthreads();  // staging buffers are dead: reuse the LDS
   {
     constexpr int ROWF = 32 * T;  // floats of one output row of a 32-channel input tile
@@ -462,6 +481,14 @@ __global__ __launch_bounds__(128, 2) void wgrad_wave_dma_kernel(const WgradPlan*
     WG_TACC(tK, tB, tC);
   }
   WG_T(tE);
+  if (p.partial) {
+    if (wave_active) store_partial<T>(p, bz, by, ct >> 1, wave, lane, d.scale, acc);
+    if (d.gb && ct == 0) {
+      bsum += __shfl_xor(bsum, 32, 64);
+      if (kh == 0) p.partial_b[((long)bz * p.coutTiles + by) * 32 + j] = d.scale * bsum;
+    }
+    return;
+  }
   __syncthreads();  // the slabs are dead: each wavefront transposes through its own piece of the LDS
   if (wave_active) {
     constexpr int ROWF = 32 * T;
@@ -669,6 +696,14 @@ __global__ __launch_bounds__(128, 2) void wgrad_band_dma_kernel(const WgradPlan*
     WG_TACC(tK, tB, tC);
   }
   WG_T(tE);
+  if (p.partial) {
+    if (wave_active) store_partial<TPW>(p, bz, by, (TG == 1) ? (ct >> 1) : ct, wave, lane, d.scale, acc);
+    if (d.gb && ct == 0 && tg == 0) {
+      bsum += __shfl_xor(bsum, 32, 64);
+      if (kh == 0) p.partial_b[((long)bz * p.coutTiles + by) * 32 + j] = d.scale * bsum;
+    }
+    return;
+  }
   // ---- fold into gW[o][c][t] (t fastest): 8 output rows at a time through LDS, atomics over consecutive addresses ----
   __syncthreads();
   {
@@ -706,6 +741,49 @@ __global__ __launch_bounds__(128, 2) void wgrad_band_dma_kernel(const WgradPlan*
     g_dbg[4 * blockIdx.x] = tS; g_dbg[4 * blockIdx.x + 1] = tK; g_dbg[4 * blockIdx.x + 2] = tZ - tE; g_dbg[4 * blockIdx.x + 3] = tZ - t00;
   }
 #endif
+}
+
+// Sums the K-slice partials of a weight-gradient launch in slice order and adds them to gW (OIHW) / gb: one workgroup per
+// 256 elements of one wavefront slot's tile.  No fp32 atomics on the K split (the one atomic per element below only
+// serialises the real- and the fake-batch graph of the discriminator: two contributions onto a cleared gradient, and
+// a + b == b + a), hence bitwise reproducible.
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ fstarts,
+                                                         int nplans) {
+  int lo = 0, hi = nplans - 1;
+  const int wg = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (fstarts[mid] <= wg) lo = mid; else hi = mid - 1;
+  }
+  const WgradPlan& p = plans[lo];
+  const WgradDesc& d = p.d;
+  const int T = d.KH * d.KW;
+  const int parts = p.fold_tpw * 4;  // 256-element pieces of a slot's fold_tpw * 1024 floats
+  int local = wg - fstarts[lo];
+  const int part = local % parts; local /= parts;
+  const int slot = local % p.fold_slots; local /= p.fold_slots;
+  const int grp = local % p.groups;
+  const int by = local / p.groups;
+  const int ctl = slot % p.fold_cts, tg = slot / p.fold_cts;
+  const int ct = grp * p.fold_ctmul + ctl;
+  const int cout0 = by * 32, cin_w = ct * 32;
+  if (d.gb && grp == 0 && slot == 0 && part == 0 && threadIdx.x < 32 && cout0 + (int)threadIdx.x < d.Cout) {
+    float v = 0.f;
+    for (int z = 0; z < p.S; ++z) v += p.partial_b[((long)z * p.coutTiles + by) * 32 + threadIdx.x];
+    atomicAdd(d.gb + cout0 + threadIdx.x, v);
+  }
+  if (ctl >= p.fold_ctmul || cin_w >= d.Cin) return;
+  const long tsz = (long)p.fold_tpw * 1024;
+  const long tile = (((long)by * p.groups + grp) * p.fold_slots + slot) * tsz;
+  const long sstride = (long)p.coutTiles * p.groups * p.fold_slots * tsz;
+  const int e = part * 256 + threadIdx.x;
+  float v = 0.f;
+#pragma unroll 4
+  for (int z = 0; z < p.S; ++z) v += p.partial[z * sstride + tile + e];
+  const int lane = e & 63, r = (e >> 6) & 15, t = tg * p.fold_tpw + (e >> 10);
+  const int o = cout0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  const int c = cin_w + (lane & 31);
+  if (o < d.Cout && c < d.Cin) atomicAdd(d.gW + ((long)o * d.Cin + c) * T + t, v);
 }
 
 static inline int odd_up(int v) { return v | 1; }
@@ -850,6 +928,9 @@ void WgradBatch::reset() {
   for (int g = 0; g < NCAT; ++g) {
     if (d_plans[g]) (void)hipFree(d_plans[g]);
     if (d_starts[g]) (void)hipFree(d_starts[g]);
+    if (d_partial[g]) (void)hipFree(d_partial[g]);
+    d_partial[g] = nullptr;
+    fold_wgs[g] = 0;
     d_plans[g] = nullptr;
     d_starts[g] = nullptr;
     nplans[g] = total_wg[g] = 0;
@@ -923,6 +1004,8 @@ void WgradBatch::build() {
         WgradPlan p;
         maxlds = std::max(maxlds, wgrad_plan(d, p, g >= 3 ? 0 : level, MODE[g], S_fixed));
         p.zeros = device_zeros();
+        p.partial = nullptr; p.partial_b = nullptr; p.fold_start = 0;
+        p.fold_slots = p.fold_cts = p.fold_ctmul = p.fold_tpw = 0;
         starts.push_back(total);
         total += p.wg_count;
         plans.push_back(p);
@@ -930,7 +1013,35 @@ void WgradBatch::build() {
       }
       if (total >= 448 || plans.empty() || g >= 3) break;
     }
-    starts.push_back(total);
+    std::vector<int> fstarts;
+    fold_wgs[g] = 0;
+    if (g_wgrad_deterministic && !plans.empty()) {
+      static const int SLOTS[NCAT] = {4, 4, 8, 2, 2, 2}, CTS[NCAT] = {4, 4, 4, 2, 2, 1}, TPWS[NCAT] = {1, 9, 8, 9, 9, 8};
+      size_t floats = 0, bfloats = 0;
+      int fw = 0;
+      for (auto& pl : plans) {
+        floats += (size_t)pl.S * pl.coutTiles * pl.groups * SLOTS[g] * TPWS[g] * 1024;
+        bfloats += (size_t)pl.S * pl.coutTiles * 32;
+      }
+      if (d_partial[g]) (void)hipFree(d_partial[g]);
+      DBM_HIP(hipMalloc((void**)&d_partial[g], (floats + bfloats) * sizeof(float)));
+      DBM_HIP(hipMemset(d_partial[g], 0, (floats + bfloats) * sizeof(float)));  // (inactive slots are never written)
+      float* base = d_partial[g];
+      float* bbase = base + floats;
+      for (auto& pl : plans) {
+        pl.partial = base; pl.partial_b = bbase;
+        pl.fold_slots = SLOTS[g]; pl.fold_cts = CTS[g]; pl.fold_tpw = TPWS[g];
+        pl.fold_ctmul = (g <= 2) ? pl.G : (g == 5 ? 1 : 2);
+        base += (size_t)pl.S * pl.coutTiles * pl.groups * SLOTS[g] * TPWS[g] * 1024;
+        bbase += (size_t)pl.S * pl.coutTiles * 32;
+        pl.fold_start = fw;
+        fstarts.push_back(fw);
+        fw += pl.coutTiles * pl.groups * SLOTS[g] * TPWS[g] * 4;
+      }
+      fold_wgs[g] = fw;
+      for (int v : fstarts) starts.push_back(v);  // the fold table rides behind the launch table
+    }
+    starts.insert(starts.begin() + (long)plans.size(), total);  // (prefix table of the launch: plans.size() + 1 entries)
     nplans[g] = (int)plans.size();
     total_wg[g] = total;
     lds[g] = maxlds;
@@ -943,6 +1054,7 @@ void WgradBatch::build() {
   }
   DBM_HIP(hipDeviceSynchronize());
   built = true;
+  built_deterministic = g_wgrad_deterministic;
 }
 
 template <typename K>
@@ -959,6 +1071,11 @@ static void launch_dma(K kernel, const WgradPlan* plans, const int* starts, int 
 }
 
 void WgradBatch::launch(hipStream_t s) {
+  if (built && built_deterministic != g_wgrad_deterministic) {  // mode switched: re-plan (keeps the descriptors)
+    std::vector<WgradDesc> keep = descs;
+    reset();
+    descs = keep;
+  }
   if (!built) build();
   for (int g = 0; g < NCAT; ++g) {
     if (nplans[g] == 0) continue;
@@ -969,6 +1086,10 @@ void WgradBatch::launch(hipStream_t s) {
     else if (g == 3) launch_dma(wgrad_wave_dma_kernel, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else if (g == 4) launch_dma(wgrad_band_dma_kernel<9, 9>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else launch_dma(wgrad_band_dma_kernel<16, 8>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    if (fold_wgs[g]) {
+      hipLaunchKernelGGL(wgrad_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);
+      DBM_HIP(hipGetLastError());
+    }
     if (g_profiler.enabled) g_profiler.end(s);
   }
 }

@@ -31,10 +31,24 @@ class _Config:
     # "float32" (the reference's arithmetic) or "bfloat16": GeneratorModel.forward under enable_backprop=False multiplies
     # in bf16 with fp32 accumulation and fp32 storage (area inference, BASELINE.json config 5)
     dtype = "float32"
+    # chainer.global_config.cudnn_deterministic (srgan_train.py:69): True = bitwise reproducible gradients (ordered folds
+    # instead of fp32 atomics), a few per cent slower.  Applied by the training / backward entry points.
+    cudnn_deterministic = False
 
 
 global_config = _Config()
 config = global_config
+
+
+_applied_deterministic = [None]
+
+
+def _apply_config(ctx):
+    """Push process-wide library switches that mirror chainer.global_config (cheap: only on change)."""
+    want = bool(global_config.cudnn_deterministic)
+    if _applied_deterministic[0] != want:
+        _lib.check(_lib.lib().dbm_set_deterministic(ctx.handle, int(want)), ctx.handle)
+        _applied_deterministic[0] = want
 
 
 @contextlib.contextmanager
@@ -354,6 +368,7 @@ class GeneratorModel(_Link):
 
     def backward(self, gy):
         """d loss / d output of the last retained forward -> parameter gradients (accumulated)."""
+        _apply_config(self.ctx)
         if _is_device(gy):
             _lib.check(_lib.lib().dbm_gen_backward(self._h, _dev_ptr(gy), DEVICE_PTRS), self.ctx.handle)
         else:
@@ -407,6 +422,7 @@ class DiscriminatorModel(_Link):
     __call__ = forward
 
     def backward(self, slot, glogits):
+        _apply_config(self.ctx)
         if _is_device(glogits):
             _lib.check(_lib.lib().dbm_disc_backward(self._h, slot, _dev_ptr(glogits), DEVICE_PTRS), self.ctx.handle)
         else:

@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from .srgan import (Adam, DeviceArray, DiscriminatorModel, GeneratorModel, global_config, save_npz, to_device,
-                    _dev_ptr, _is_device)
+                    _apply_config, _dev_ptr, _is_device)
 
 LOSS_WEIGHTS = (1e-2, 2e-2, 2e-3, 5.25e-0)  # calculate_generator_loss defaults (srgan_train.py:849-852)
 
@@ -71,6 +71,7 @@ def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, t
     dev = device_batch(input_arrays, g_model.ctx)
     n, h, w = _check_batch(dev)
     m = _metrics_buffer(g_model.ctx)
+    _apply_config(g_model.ctx)
     _lib.check(_lib.lib().dbm_discriminator_step(g_model._h, d_model._h, n, h, w, *[_dev_ptr(dev[k]) for k in _KEYS],
                                                  int(bool(train)) | (2 if share_generator_forward else 0) |
                                                  (4 if prefetch_generator_forward else 0) |
@@ -96,6 +97,7 @@ def train_eval_generator(input_arrays, g_model, d_model, g_optimizer=None, train
     m = _metrics_buffer(g_model.ctx)
     wts = (C.c_float * 4)(*LOSS_WEIGHTS)
     win = {"gaussian": 0, "uniform": 1}[global_config.ssim_window]
+    _apply_config(g_model.ctx)
     _lib.check(_lib.lib().dbm_generator_step(g_model._h, d_model._h, n, h, w, *[_dev_ptr(dev[k]) for k in _KEYS], wts,
                                              win, int(bool(train)) | (2 if share_generator_forward else 0), m.ptr),
                g_model.ctx.handle)

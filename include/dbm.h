@@ -41,6 +41,10 @@ int dbm_shutdown(dbm_ctx* ctx);
 const char* dbm_last_error(dbm_ctx* ctx);         /* ctx may be NULL (error of a failed dbm_init) */
 int dbm_set_stream(dbm_ctx* ctx, void* hip_stream); /* run on a caller-owned hipStream_t (NULL = the ctx's own) */
 int dbm_synchronize(dbm_ctx* ctx);
+/* chainer.global_config.cudnn_deterministic (srgan_train.py:69, deepbedmap.py:689).  on = 1: every gradient is folded in a
+ * fixed order (no fp32 atomics over a K split: partial sums + an ordered fold kernel, sorted sampling lists, a separate
+ * offset-gradient kernel), so a training run is bitwise reproducible; costs a few per cent.  Default 0.  Process-wide. */
+int dbm_set_deterministic(dbm_ctx* ctx, int on);
 /* measurement aid (bench.py roofline leg): while enabled, every launch of the two MFMA kernel families is bracketed
  * by hipEvents on the launch stream.  out = [ms, algorithmic FLOP, launches] for igemm_conv_kernel (forward + data
  * gradient), then the same three for wgrad_kernel. */

@@ -395,6 +395,46 @@ def test_config3_full_batch_permutation_invariance(dbm):
             assert np.abs(a[k] - b[k]).max() <= 1e-3 * max(float(np.abs(a[k]).max()), 1e-3 * gmax), k
 
 
+def test_cudnn_deterministic_training_is_bitwise_reproducible(dbm):
+    """chainer.global_config.cudnn_deterministic = True (srgan_train.py:69): with it, two training runs from the same
+    weights on the same minibatch end in bitwise identical weights, running statistics and metrics (ordered folds
+    instead of fp32 atomics); and the deterministic gradients agree with the default path to rounding."""
+    r = np.random.RandomState(31)
+    arrays = {k: r.rand(*shp).astype(np.float32) for k, shp in
+              (("X", (6, 1, 11, 11)), ("W1", (6, 1, 110, 110)), ("W2", (6, 2, 22, 22)), ("W3", (6, 1, 11, 11)),
+               ("Y", (6, 1, 36, 36)))}
+    batch = dbm.device_batch(arrays)
+    np.random.seed(9)
+    g0, d0 = dbm.GeneratorModel(num_residual_blocks=2), dbm.DiscriminatorModel()
+    snap_g, snap_d = g0.serialize_dict(), d0.serialize_dict()
+
+    def run(det, steps, alpha):
+        with dbm.using_config("cudnn_deterministic", det):
+            g = copy_params(dbm.GeneratorModel(num_residual_blocks=2, initialize=False), snap_g)
+            d = copy_params(dbm.DiscriminatorModel(initialize=False), snap_d, snap_d)
+            g_opt = dbm.optimizers.Adam(alpha=alpha, eps=1e-8).setup(g)
+            d_opt = dbm.optimizers.Adam(alpha=alpha, eps=1e-8).setup(d)
+            m = []
+            for _ in range(steps):
+                m += list(dbm.train_eval_discriminator(batch, g, d, d_opt, prefetch_generator_forward=True))
+                m += list(dbm.train_eval_generator(batch, g, d, g_opt))
+            grads = {"g/" + k: t.grad.copy() for k, t in g._tensors.items() if t.kind == 0}
+            return m, {**{"g/" + k: np.array(v) for k, v in g.serialize_dict().items()},
+                       **{"d/" + k: np.array(v) for k, v in d.serialize_dict().items()}}, grads
+
+    m1, w1, _ = run(True, 3, 1e-3)
+    m2, w2, _ = run(True, 3, 1e-3)
+    assert m1 == m2
+    for k in w1:
+        assert np.array_equal(w1[k], w2[k]), k
+    # same gradients as the default (atomic) path, up to summation order
+    _, _, gd = run(True, 1, 0.0)
+    _, _, ga = run(False, 1, 0.0)
+    gmax = max(float(np.abs(v).max()) for v in ga.values())
+    for k in ga:
+        assert np.abs(gd[k] - ga[k]).max() <= 1e-4 * max(float(np.abs(ga[k]).max()), 1e-3 * gmax), k
+
+
 def test_npz_round_trip(dbm, tmp_path):  # srgan_train.py:1351-1361, deepbedmap.py:402-408
     g = dbm.GeneratorModel(num_residual_blocks=1)
     d = dbm.DiscriminatorModel()
