@@ -1011,7 +1011,8 @@ void WgradBatch::build() {
         plans.push_back(p);
         fl += 2.0 * (double)d.N * d.OH * d.OW * d.Cout * d.Cin * TT[g];
       }
-      if (total >= 448 || plans.empty() || g >= 3) break;
+      // (deterministic mode: no finer K split than necessary -- every extra slice is a partial tile to write and fold)
+      if (total >= 448 || plans.empty() || g >= 3 || g_wgrad_deterministic) break;
     }
     std::vector<int> fstarts;
     fold_wgs[g] = 0;
@@ -1019,23 +1020,27 @@ void WgradBatch::build() {
       static const int SLOTS[NCAT] = {4, 4, 8, 2, 2, 2}, CTS[NCAT] = {4, 4, 4, 2, 2, 1}, TPWS[NCAT] = {1, 9, 8, 9, 9, 8};
       size_t floats = 0, bfloats = 0;
       int fw = 0;
+      // a layer without a K split needs no partials: its single contribution per launch goes out with the atomic
+      // epilogue (at most two launches' worth meet on a cleared gradient: still order-independent)
       for (auto& pl : plans) {
+        if (pl.S == 1) continue;
         floats += (size_t)pl.S * pl.coutTiles * pl.groups * SLOTS[g] * TPWS[g] * 1024;
         bfloats += (size_t)pl.S * pl.coutTiles * 32;
       }
       if (d_partial[g]) (void)hipFree(d_partial[g]);
-      DBM_HIP(hipMalloc((void**)&d_partial[g], (floats + bfloats) * sizeof(float)));
-      DBM_HIP(hipMemset(d_partial[g], 0, (floats + bfloats) * sizeof(float)));  // (inactive slots are never written)
+      DBM_HIP(hipMalloc((void**)&d_partial[g], (floats + bfloats + 1) * sizeof(float)));
+      DBM_HIP(hipMemset(d_partial[g], 0, (floats + bfloats + 1) * sizeof(float)));  // (inactive slots are never written)
       float* base = d_partial[g];
       float* bbase = base + floats;
       for (auto& pl : plans) {
+        pl.fold_start = fw;
+        fstarts.push_back(fw);
+        if (pl.S == 1) continue;  // (an empty range in the fold table)
         pl.partial = base; pl.partial_b = bbase;
         pl.fold_slots = SLOTS[g]; pl.fold_cts = CTS[g]; pl.fold_tpw = TPWS[g];
         pl.fold_ctmul = (g <= 2) ? pl.G : (g == 5 ? 1 : 2);
         base += (size_t)pl.S * pl.coutTiles * pl.groups * SLOTS[g] * TPWS[g] * 1024;
         bbase += (size_t)pl.S * pl.coutTiles * 32;
-        pl.fold_start = fw;
-        fstarts.push_back(fw);
         fw += pl.coutTiles * pl.groups * SLOTS[g] * TPWS[g] * 4;
       }
       fold_wgs[g] = fw;

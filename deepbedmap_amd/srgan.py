@@ -31,9 +31,10 @@ class _Config:
     # "float32" (the reference's arithmetic) or "bfloat16": GeneratorModel.forward under enable_backprop=False multiplies
     # in bf16 with fp32 accumulation and fp32 storage (area inference, BASELINE.json config 5)
     dtype = "float32"
-    # chainer.global_config.cudnn_deterministic (srgan_train.py:69): True = bitwise reproducible gradients (ordered folds
-    # instead of fp32 atomics), a few per cent slower.  Applied by the training / backward entry points.
-    cudnn_deterministic = False
+    # chainer.global_config.cudnn_deterministic, which srgan_train.py:69 sets to True at import: bitwise reproducible
+    # gradients (ordered folds instead of fp32 atomics).  False buys about 2 % of the step time.  Applied by the
+    # training / backward entry points.
+    cudnn_deterministic = True
 
 
 global_config = _Config()

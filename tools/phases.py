@@ -1,6 +1,6 @@
 """Where a training step goes: hipEvents at the phase boundaries of the main stream (dbm_phase_marks), unprofiled.
 
-    python tools/phases.py [prefetch|narrow|share]
+    python tools/phases.py [prefetch|narrow|share|atomics]   (atomics: prefetch with cudnn_deterministic=False)
 """
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -12,7 +12,8 @@ np.random.seed(1)
 g, go, d, do = dbm.compile_srgan_model(12, 0.1, 1.6e-4)
 batch = dbm.device_batch(synthetic_batch(64, 42), ctx)
 share = len(sys.argv) > 1 and sys.argv[1] == "share"
-prefetch = len(sys.argv) > 1 and sys.argv[1] in ("prefetch", "narrow")
+prefetch = len(sys.argv) > 1 and sys.argv[1] in ("prefetch", "narrow", "atomics")
+dbm.global_config.cudnn_deterministic = not (len(sys.argv) > 1 and sys.argv[1] == "atomics")
 class FakeComm:
     def allreduce_grads(self, model):
         return 1.0
