@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
   {
     static unsigned long long h[4 * 8192];
     hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg), sizeof(h));
-    const int nwg = b.total_wg[4] ? b.total_wg[4] : 1;
+    const int nwg = b.total_wg[3] ? b.total_wg[3] : 1;
     double a[4] = {0, 0, 0, 0};
     for (int i = 0; i < nwg && i < 8192; ++i) for (int k = 0; k < 4; ++k) a[k] += (double)h[4 * i + k];
     printf("per task cycles: stage %.0f kloop %.0f epilogue %.0f total %.0f (n=%d)\n", a[0] / nwg, a[1] / nwg, a[2] / nwg, a[3] / nwg, nwg);
