@@ -588,9 +588,6 @@ def test_shared_generator_forward_is_equivalent(dbm, mode):
             kw = {mode: share} if mode == "share_generator_forward" else {}
             out += list(dbm.train_eval_generator(arrays, g, d, g_opt, **kw))
         results.append(out)
-    assert results[0][:2] == results[1][:2]  # D-step of the first iteration: bitwise (same forward numbers)
-    # its G-step sees a discriminator whose update folded gradients with fp32 atomics (run-dependent order)
-    assert np.allclose(results[0][2:5], results[1][2:5], rtol=1e-4, atol=1e-6)
-    # second iteration: gradients were folded by fp32 atomics in a run-dependent order and went through Adam's
-    # sign-like first step, so only a loose agreement is meaningful
-    assert np.allclose(results[0], results[1], rtol=1e-2, atol=1e-4)
+    # cudnn_deterministic = True (the default): the scheduling variants run the same arithmetic in the same order, so
+    # every loss, accuracy and metric of both iterations is bitwise the one of the plain sequential path
+    assert results[0] == results[1]
