@@ -71,6 +71,12 @@ def main():
                     help="NOT the headline configuration: reuse the D-step's generator forward in the G-step")
     args = ap.parse_args()
 
+    # Contract: rank 0 prints ONE JSON line on stdout.  Libraries write banners to file descriptor 1 from C (RCCL prints its
+    # version block when the first communicator is created): everything that is not the result goes to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     import deepbedmap_amd as dbm
@@ -168,7 +174,7 @@ def main():
             pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()
 
