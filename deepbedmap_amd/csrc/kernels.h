@@ -18,7 +18,7 @@ void launch_im2col(const float* x, float* col, int N, int Cin, int Hin, int Win,
                    int KP, hipStream_t s);
 void launch_deform_sample(const float* x, const float* off, float* col, int N, int C, int H, int W, long offsn, hipStream_t s);
 void launch_deform_backward(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy,
-                            float* gx, float* goff, int N, int C, int H, int W, long offsn, hipStream_t s);
+                            float* gx, float* goff, int N, int C, int H, int W, long offsn, hipStream_t s, hipStream_t aux = nullptr, hipEvent_t* ev = nullptr);
 void launch_gemv_cols(const float* col, const float* w, const float* bias, float* y, int N, int K, int plane, hipStream_t s);
 void launch_gemv_cols_wgrad(const float* col, const float* gy, float* gw, float* gb, int N, int K, int plane, hipStream_t s);
 void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int H, int W, float slope, hipStream_t s);

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void deform_goff_kernel(const float* __restric
 
 // gx is fully overwritten; goff[n][0:18] is overwritten (channels 18.. of a padded offset tensor are left alone).
 void launch_deform_backward(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy,
-                            float* gx, float* goff, int N, int C, int H, int W, long offsn, hipStream_t s) {
+                            float* gx, float* goff, int N, int C, int H, int W, long offsn, hipStream_t s, hipStream_t aux, hipEvent_t* ev) {
   const long plane = (long)H * W;
   constexpr int CH = 8;
   const size_t lds = sizeof(float) * ((size_t)2 * CH * plane + 10 * plane + 1);
@@ -452,11 +452,21 @@ void launch_deform_backward(const float* x, const float* off, const float* gcol,
       attr_set = true;
     }
     if (g_wgrad_deterministic) {
+      // the offset gradients read the same inputs and write a different output: on `aux` (when the caller has a free
+      // stream and two events) they run next to the gather kernel instead of behind it
+      const long total = (long)N * 9 * plane;
+      hipStream_t sg = s;
+      if (aux && ev) {
+        DBM_HIP(hipEventRecord(ev[0], s));
+        DBM_HIP(hipStreamWaitEvent(aux, ev[0], 0));
+        sg = aux;
+      }
+      hipLaunchKernelGGL(deform_goff_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sg, x, off, gcol, w1o, gy, goff, N, C,
+                         H, W, offsn);
+      if (sg != s) DBM_HIP(hipEventRecord(ev[1], aux));
       hipLaunchKernelGGL((deform_backward_csr_kernel<CH, 1024, true>), dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx,
                          goff, N, C, H, W, offsn);
-      const long total = (long)N * 9 * plane;
-      hipLaunchKernelGGL(deform_goff_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, off, gcol, w1o, gy, goff, N, C,
-                         H, W, offsn);
+      if (sg != s) DBM_HIP(hipStreamWaitEvent(s, ev[1], 0));
     } else {
       DBM_HIP(hipMemset2DAsync(goff, sizeof(float) * offsn, 0, sizeof(float) * 18 * plane, N, s));
       hipLaunchKernelGGL((deform_backward_csr_kernel<CH, 1024, false>), dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx,
