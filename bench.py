@@ -29,6 +29,15 @@ BATCH_PER_GPU = 64
 N_RRDB = 12
 
 
+def baseline_metric():
+    """BASELINE.json's metric string (the file ships with the repository)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "DEM tiles/sec (fwd+bwd, gen+disc) at batch 64, 1/2/4/8 MI355X"
+
+
 def synthetic_batch(n, seed):
     r = lambda *s: np.random.RandomState(seed=seed).rand(*s).astype(np.float32)  # noqa: E731
     return {"X": r(n, 1, 11, 11), "W1": r(n, 1, 110, 110), "W2": r(n, 2, 22, 22), "W3": r(n, 1, 11, 11),
@@ -137,7 +146,7 @@ def main():
         tiles = args.batch * world * args.steps
         achieved = ig_flop / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
         out = {
-            "metric": "DEM tiles/sec (fwd+bwd, gen+disc) at batch 64",
+            "metric": baseline_metric(),
             "value": tiles / dt,
             "unit": "tiles/s",
             "n_gpus": world,
