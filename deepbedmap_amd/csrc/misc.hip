@@ -269,8 +269,8 @@ __global__ __launch_bounds__(NT) void deform_backward_csr_kernel(const float* __
   extern __shared__ __attribute__((aligned(16))) float sm[];
   __shared__ int wtot[NT / 64];
   const int plane = H * W;
-  float* sx = sm;                              // CH * plane
-  float* sg = sx + CH * plane;                 // CH * plane
+  float* sx = sm;                              // CH * plane (not in the DET variant: the offset gradients, the only
+  float* sg = DET ? sm : sx + CH * plane;      // CH * plane   reader of x, are computed by deform_goff_kernel)
   int* offs = (int*)(sg + CH * plane);         // plane + 1  (counts, then exclusive offsets)
   int* cur = offs + plane + 1;                 // plane      (fill cursors)
   int* ent_p = cur + plane;                    // 4 * plane
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NT) void deform_backward_csr_kernel(const float* __
   const int lane = tid & 63, wave = tid >> 6;
   const float* xn = x + ((long)n * C + c0) * plane;
   for (int e = tid; e < CH * plane; e += NT) {
-    sx[e] = xn[e];
+    if constexpr (!DET) sx[e] = xn[e];
     sg[e] = 0.f;
   }
   const float* on = off + (long)n * offsn;
@@ -443,11 +443,18 @@ void launch_deform_backward(const float* x, const float* off, const float* gcol,
   constexpr int CH = 8;
   const size_t lds = sizeof(float) * ((size_t)2 * CH * plane + 10 * plane + 1);
   if (lds <= 150 * 1024 && C % CH == 0) {
+    // deterministic variant: x is not staged, which leaves room for 16 channels per workgroup -- one round of N * C / 16
+    // workgroups, the sampling lists built half as often, sixteen gathers in flight per list entry
+    constexpr int CHD = 16;
+    const bool wide = C % CHD == 0 && sizeof(float) * ((size_t)CHD * plane + 10 * plane + 1) <= 150 * 1024;
+    const size_t lds_det = sizeof(float) * ((size_t)(wide ? CHD : CH) * plane + 10 * plane + 1);
     static bool attr_set = false;
     if (!attr_set) {
       DBM_HIP(hipFuncSetAttribute((const void*)deform_backward_csr_kernel<CH, 1024, false>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
       DBM_HIP(hipFuncSetAttribute((const void*)deform_backward_csr_kernel<CH, 1024, true>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+      DBM_HIP(hipFuncSetAttribute((const void*)deform_backward_csr_kernel<CHD, 1024, true>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
       attr_set = true;
     }
@@ -464,8 +471,12 @@ void launch_deform_backward(const float* x, const float* off, const float* gcol,
       hipLaunchKernelGGL(deform_goff_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, sg, x, off, gcol, w1o, gy, goff, N, C,
                          H, W, offsn);
       if (sg != s) DBM_HIP(hipEventRecord(ev[1], aux));
-      hipLaunchKernelGGL((deform_backward_csr_kernel<CH, 1024, true>), dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx,
-                         goff, N, C, H, W, offsn);
+      if (wide)
+        hipLaunchKernelGGL((deform_backward_csr_kernel<CHD, 1024, true>), dim3(N, C / CHD), dim3(1024), lds_det, s, x, off, gcol, w1o,
+                           gy, gx, goff, N, C, H, W, offsn);
+      else
+        hipLaunchKernelGGL((deform_backward_csr_kernel<CH, 1024, true>), dim3(N, C / CH), dim3(1024), lds_det, s, x, off, gcol, w1o,
+                           gy, gx, goff, N, C, H, W, offsn);
       if (sg != s) DBM_HIP(hipStreamWaitEvent(s, ev[1], 0));
     } else {
       DBM_HIP(hipMemset2DAsync(goff, sizeof(float) * offsn, 0, sizeof(float) * 18 * plane, N, s));
