@@ -8,6 +8,10 @@ static thread_local std::string g_last_error;
   dbm_ctx* _ectx = (ctxptr);  \
   try {
 #define DBM_API_END                                   \
+  if (_ectx && _ectx->dev_err && *(volatile int*)_ectx->dev_err) {                                    \
+    *(volatile int*)_ectx->dev_err = 0;                                                               \
+    throw DbmError(5, "a persistent kernel gave up waiting for a neighbouring workgroup (results of the last calls are invalid)"); \
+  }                                                   \
   return 0;                                           \
   }                                                   \
   catch (const DbmError& e) {                         \
@@ -95,6 +99,9 @@ int dbm_init(int hip_device, dbm_ctx** out) {
   for (auto& st : c->chain) DBM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   for (auto& e : c->ev_fork) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   DBM_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  DBM_HIP(hipHostMalloc((void**)&c->dev_err, sizeof(int), hipHostMallocMapped));
+  *c->dev_err = 0;
+  DBM_HIP(hipHostGetDevicePointer((void**)&c->dev_err_d, c->dev_err, 0));
   DBM_HIP(hipMalloc((void**)&c->zeros, 256));
   DBM_HIP(hipMemset(c->zeros, 0, 256));
   float w[9];
@@ -115,6 +122,7 @@ int dbm_shutdown(dbm_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->zeros);
+  if (ctx->dev_err) (void)hipHostFree(ctx->dev_err);
   (void)hipFree(ctx->ssim_win[0]);
   (void)hipFree(ctx->ssim_win[1]);
   ctx->loss_tmp.release();

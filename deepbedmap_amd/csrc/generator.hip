@@ -60,6 +60,40 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
 Generator::~Generator() {
   if (twin) delete twin;
   if (ev_prefetch) (void)hipEventDestroy(ev_prefetch);
+  if (!is_view) {
+    (void)hipFree(tf_wstream); (void)hipFree(tf_bstream); (void)hipFree((void*)tf_wsrc); (void)hipFree((void*)tf_bsrc);
+  }
+  (void)hipFree(tf_inbox); (void)hipFree((void*)tf_cat);
+}
+
+// ---- fused 9x9 trunk forward (trunk_fused.hip) ----
+static bool trunk_fused_enabled() {
+  static const bool on = !(getenv("DBM_TRUNK_FUSED") && atoi(getenv("DBM_TRUNK_FUSED")) == 0);
+  return on;
+}
+
+bool Generator::trunk_fused_ok(int h, int w) const { return h == 9 && w == 9 && !use_bf16 && trunk_fused_enabled(); }
+
+void Generator::pack_extra(hipStream_t s) {
+  if (is_view || !trunk_fused_enabled()) return;
+  const int nrdb = 3 * n_rrdb;
+  if (!tf_wstream) {
+    const size_t nw = trunk_fused_stream_floats(nrdb);
+    DBM_HIP(hipMalloc((void**)&tf_wstream, nw * sizeof(float)));
+    DBM_HIP(hipMemset(tf_wstream, 0, nw * sizeof(float)));
+    DBM_HIP(hipMalloc((void**)&tf_bstream, (size_t)nrdb * 192 * sizeof(float)));
+    std::vector<const float*> ws(nrdb * 5), bs(nrdb * 5);
+    for (int i = 0; i < nrdb * 5; ++i) {
+      ws[i] = P(layers[L_rdb[i]].wi);
+      bs[i] = P(layers[L_rdb[i]].bi);
+    }
+    DBM_HIP(hipMalloc((void**)&tf_wsrc, ws.size() * sizeof(float*)));
+    DBM_HIP(hipMalloc((void**)&tf_bsrc, bs.size() * sizeof(float*)));
+    DBM_HIP(hipMemcpy((void*)tf_wsrc, ws.data(), ws.size() * sizeof(float*), hipMemcpyHostToDevice));
+    DBM_HIP(hipMemcpy((void*)tf_bsrc, bs.data(), bs.size() * sizeof(float*), hipMemcpyHostToDevice));
+    DBM_HIP(hipDeviceSynchronize());
+  }
+  launch_pack_trunk_fused(tf_wsrc, tf_bsrc, tf_wstream, tf_bstream, nrdb, s);
 }
 
 Generator* Generator::get_twin() {
@@ -75,6 +109,7 @@ Generator* Generator::get_twin() {
   t->layers = layers;
   t->params = params; t->grads = grads; t->adam_m = adam_m; t->adam_v = adam_v; t->pers = pers;
   t->is_view = true;
+  t->owner = this;
   t->packed_dirty = false;
   t->chain_base = 0;  // its main stream is chain[1] (set by the caller); the second image range shares chain[0]
   twin = t;
@@ -145,6 +180,7 @@ void Generator::ensure_ws(int N, int H, int W, bool train) {
     }
     have_graph = false;
   }
+  if (!same || tr != wsTrain) tf_cat_valid = false;
   if (!same || tr != wsTrain)
     for (auto& b : wbs) b.reset();  // buffers may have moved: re-plan the batched weight gradients
   wsN = N; wsH = H; wsW = W; wsTrain = tr;
@@ -186,7 +222,8 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   // has no cross-sample coupling, so the batch is cut into `nsplit` image ranges that run the same chain on
   // separate HIP streams: while one range's kernel is in its prologue / epilogue the other's feeds the MFMA pipes.
   DBM_MARK(s, "  gen_forward:input_block");
-  const int nsplit = std::min(trunk_split(N, hw), max_split);
+  const bool fused = trunk_fused_ok(h, w);  // the whole trunk as one persistent launch (trunk_fused.hip)
+  const int nsplit = fused ? 1 : std::min(trunk_split(N, hw), max_split);
   auto cn0 = [&](int c) { return (long)(((long)c * N) / nsplit); };          // first image of range c
   auto cnc = [&](int c) { return (int)(cn0(c + 1) - cn0(c)); };                // images in range c
   auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[chain_base + c - 1]; };
@@ -199,7 +236,33 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     launch_igemm_conv(d, cstream(c));
   }
   // ---- RRDB trunk (:546; RDB :333-360, RRDB :393-404) ----
-  for (int j = 0; j < nrdb; ++j) {
+  if (fused) {
+    const Generator* src = owner ? owner : this;
+    DBM_CHECK(src->tf_wstream != nullptr, "fused trunk: weight streams not packed");
+    const int IMGS = 64;  // 192 workgroups: resident at once on 256 CUs
+    if (!tf_inbox) {
+      DBM_HIP(hipMalloc((void**)&tf_inbox, trunk_fused_inbox_bytes(IMGS)));
+      DBM_HIP(hipMemsetAsync(tf_inbox, 0, trunk_fused_inbox_bytes(IMGS), s));
+    }
+    if (keep && !tf_cat_valid) {
+      std::vector<float*> ptrs(nrdb + 1);
+      for (int i = 0; i <= nrdb; ++i) ptrs[i] = cat[i].p;
+      if (!tf_cat) DBM_HIP(hipMalloc((void**)&tf_cat, ptrs.size() * sizeof(float*)));
+      DBM_HIP(hipMemcpyAsync((void*)tf_cat, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice, s));
+      DBM_HIP(hipStreamSynchronize(s));  // `ptrs` is pageable host memory
+      tf_cat_valid = true;
+    }
+    for (int i0 = 0; i0 < N; i0 += IMGS) {
+      TrunkFusedLaunch L;
+      L.wstream = src->tf_wstream; L.bstream = src->tf_bstream; L.in = cat[0].p;
+      L.cat = keep ? tf_cat : nullptr; L.out = cat[slot(nrdb)].p;
+      L.inbox = tf_inbox; L.err = ctx->dev_err_d;
+      L.nrdb = nrdb; L.nimg = std::min(IMGS, N - i0); L.img0 = i0; L.epoch = ++tf_epoch;
+      L.rs = rs; L.slope = SLOPE;
+      launch_trunk_fused(L, s);
+    }
+  }
+  for (int j = 0; j < (fused ? 0 : nrdb); ++j) {
     for (int c = 0; c < nsplit; ++c) {  // one dense block per range at a time: fewer stream switches on the host
       for (int k = 0; k < 5; ++k) {
         const long n0 = cn0(c) * 192 * hw;

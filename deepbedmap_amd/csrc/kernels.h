@@ -60,3 +60,21 @@ void launch_adam(float* p, const float* g, float* m, float* v, long n, float alp
 void launch_fill(float* p, long n, float v, hipStream_t s);
 int sqdiff_blocks(long n);  // partial sums launch_sqdiff writes to out[0..blocks)
 void launch_sqdiff(const float* a, const float* b, long n, float* out, hipStream_t s);
+
+// ---- fused RRDB trunk forward on 9x9 planes (trunk_fused.hip) ----
+struct TrunkFusedLaunch {
+  const float* wstream;  // trunk_fused_stream_floats(nrdb) floats, written by launch_pack_trunk_fused
+  const float* bstream;  // nrdb * 192 floats
+  const float* in;       // (N, 192, 81) concat buffer whose channels 0..63 hold the trunk input
+  float* const* cat;     // device table of nrdb + 1 concat buffers (training: every layer output is kept), or null
+  float* out;            // cat == null: concat buffer receiving the trunk output in channels 0..63
+  unsigned long long* inbox;  // trunk_fused_inbox_bytes(images per launch)
+  int* err;              // device word raised when a neighbour never answered (bounded spins)
+  int nrdb, nimg, img0, epoch;
+  float rs, slope;
+};
+size_t trunk_fused_stream_floats(int nrdb);
+size_t trunk_fused_inbox_bytes(int nimg);
+void launch_pack_trunk_fused(const float* const* d_wsrc, const float* const* d_bsrc, float* wstream, float* bstream, int nrdb,
+                             hipStream_t s);
+void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s);

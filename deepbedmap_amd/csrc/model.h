@@ -25,6 +25,8 @@ struct dbm_ctx {
   void fork_to_side(int k);          // side waits for everything enqueued on `stream` so far
   void join_side();                  // `stream` waits for everything enqueued on `side` so far
   std::string err;
+  int* dev_err = nullptr;     // host-mapped word a persistent kernel raises when a bounded spin runs out (checked by every API call)
+  int* dev_err_d = nullptr;   // its device address
   float* zeros = nullptr;     // 256 B of zeros (igemm out-of-image taps)
   float* ssim_win[2] = {nullptr, nullptr};  // 9-tap 1-D windows: gaussian(1.5), uniform
   DevBuf loss_tmp;            // scratch for the loss entry points
@@ -84,6 +86,7 @@ struct dbm_model {
   int tid(const std::string& key) const;
   int add_iglayer(const std::string& name, int O, int C, int K, int stride, int pad, bool bias, bool as_1x1 = false);
   void ensure_packed(hipStream_t on = nullptr);  // rebuild the packed weight images if the parameters changed
+  virtual void pack_extra(hipStream_t) {}        // model-specific images, same launch point
   // helpers building descriptors
   ConvDesc fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, float* y, long ysn, int N) const;
   void run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_fwd, hipStream_t s = nullptr) const;
@@ -121,9 +124,21 @@ struct Generator : dbm_model {
   // chain[0], chain[1]): with a fifth, streams share a hardware queue and independent chains serialise (measured:
   // every phase of the step 2x slower).
   Generator* twin = nullptr;
+  Generator* owner = nullptr;  // twin only: the model whose arenas and weight images it aliases
   int chain_base = 0;
   int max_split = 2;  // image ranges the 9x9 stage may be cut into (1: everything on the caller's stream)
   hipEvent_t ev_prefetch = nullptr;
+  // fused 9x9 trunk forward (trunk_fused.hip): per-wavefront weight streams (owner only), per-workspace hand-off granules
+  float* tf_wstream = nullptr;
+  float* tf_bstream = nullptr;
+  const float** tf_wsrc = nullptr;   // device tables of the trunk layers' W / b
+  const float** tf_bsrc = nullptr;
+  unsigned long long* tf_inbox = nullptr;
+  float** tf_cat = nullptr;          // device table of the concat buffers (training workspace)
+  bool tf_cat_valid = false;
+  int tf_epoch = 0;
+  void pack_extra(hipStream_t s) override;
+  bool trunk_fused_ok(int h, int w) const;
   Generator* get_twin();
   ~Generator() override;
   Generator(dbm_ctx* c, int n, float r, int oc);

@@ -178,6 +178,7 @@ void dbm_model::ensure_packed(hipStream_t on) {
     }
   }
   launch_pack_jobs(d_pack_jobs, n_pack_jobs, n_pack_blocks, s);
+  pack_extra(s);
   packed_dirty = false;
 }
 
