@@ -63,7 +63,7 @@ Generator::~Generator() {
   if (!is_view) {
     (void)hipFree(tf_wstream); (void)hipFree(tf_bstream); (void)hipFree((void*)tf_wsrc); (void)hipFree((void*)tf_bsrc);
   }
-  (void)hipFree(tf_inbox); (void)hipFree((void*)tf_cat);
+  (void)hipFree(tf_inbox);
 }
 
 // ---- fused 9x9 trunk forward (trunk_fused.hip) ----
@@ -72,7 +72,9 @@ static bool trunk_fused_enabled() {
   return on;
 }
 
-bool Generator::trunk_fused_ok(int h, int w) const { return h == 9 && w == 9 && !use_bf16 && trunk_fused_enabled(); }
+bool Generator::trunk_fused_ok(int h, int w) const {
+  return h == 9 && w == 9 && !use_bf16 && 3 * n_rrdb + 1 <= TRUNK_FUSED_MAXCAT && trunk_fused_enabled();
+}
 
 void Generator::pack_extra(hipStream_t s) {
   if (is_view || !trunk_fused_enabled()) return;
@@ -180,7 +182,6 @@ void Generator::ensure_ws(int N, int H, int W, bool train) {
     }
     have_graph = false;
   }
-  if (!same || tr != wsTrain) tf_cat_valid = false;
   if (!same || tr != wsTrain)
     for (auto& b : wbs) b.reset();  // buffers may have moved: re-plan the batched weight gradients
   wsN = N; wsH = H; wsW = W; wsTrain = tr;
@@ -244,18 +245,12 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       DBM_HIP(hipMalloc((void**)&tf_inbox, trunk_fused_inbox_bytes(IMGS)));
       DBM_HIP(hipMemsetAsync(tf_inbox, 0, trunk_fused_inbox_bytes(IMGS), s));
     }
-    if (keep && !tf_cat_valid) {
-      std::vector<float*> ptrs(nrdb + 1);
-      for (int i = 0; i <= nrdb; ++i) ptrs[i] = cat[i].p;
-      if (!tf_cat) DBM_HIP(hipMalloc((void**)&tf_cat, ptrs.size() * sizeof(float*)));
-      DBM_HIP(hipMemcpyAsync((void*)tf_cat, ptrs.data(), ptrs.size() * sizeof(float*), hipMemcpyHostToDevice, s));
-      DBM_HIP(hipStreamSynchronize(s));  // `ptrs` is pageable host memory
-      tf_cat_valid = true;
-    }
+    std::vector<float*> ptrs(nrdb + 1);
+    for (int i = 0; i <= nrdb && keep; ++i) ptrs[i] = cat[i].p;
     for (int i0 = 0; i0 < N; i0 += IMGS) {
       TrunkFusedLaunch L;
       L.wstream = src->tf_wstream; L.bstream = src->tf_bstream; L.in = cat[0].p;
-      L.cat = keep ? tf_cat : nullptr; L.out = cat[slot(nrdb)].p;
+      L.cat = keep ? ptrs.data() : nullptr; L.out = cat[slot(nrdb)].p;
       L.inbox = tf_inbox; L.err = ctx->dev_err_d;
       L.nrdb = nrdb; L.nimg = std::min(IMGS, N - i0); L.img0 = i0; L.epoch = ++tf_epoch;
       L.rs = rs; L.slope = SLOPE;

@@ -62,11 +62,12 @@ int sqdiff_blocks(long n);  // partial sums launch_sqdiff writes to out[0..block
 void launch_sqdiff(const float* a, const float* b, long n, float* out, hipStream_t s);
 
 // ---- fused RRDB trunk forward on 9x9 planes (trunk_fused.hip) ----
+#define TRUNK_FUSED_MAXCAT 64
 struct TrunkFusedLaunch {
   const float* wstream;  // trunk_fused_stream_floats(nrdb) floats, written by launch_pack_trunk_fused
   const float* bstream;  // nrdb * 192 floats
   const float* in;       // (N, 192, 81) concat buffer whose channels 0..63 hold the trunk input
-  float* const* cat;     // device table of nrdb + 1 concat buffers (training: every layer output is kept), or null
+  float* const* cat;     // HOST table of nrdb + 1 concat buffers (training: every layer output is kept), or null
   float* out;            // cat == null: concat buffer receiving the trunk output in channels 0..63
   unsigned long long* inbox;  // trunk_fused_inbox_bytes(images per launch)
   int* err;              // device word raised when a neighbour never answered (bounded spins)

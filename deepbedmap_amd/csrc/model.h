@@ -134,8 +134,6 @@ struct Generator : dbm_model {
   const float** tf_wsrc = nullptr;   // device tables of the trunk layers' W / b
   const float** tf_bsrc = nullptr;
   unsigned long long* tf_inbox = nullptr;
-  float** tf_cat = nullptr;          // device table of the concat buffers (training workspace)
-  bool tf_cat_valid = false;
   int tf_epoch = 0;
   void pack_extra(hipStream_t s) override;
   bool trunk_fused_ok(int h, int w) const;

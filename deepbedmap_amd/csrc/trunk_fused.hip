@@ -40,12 +40,15 @@ struct Args {
   const float* wstream;   // [wave][rdb][26][UNIT]: every wavefront reads one contiguous stream
   const float* bstream;   // [rdb][192]: conv1..4 (32 each), conv5 (64)
   const float* in;        // (N, 192, 81) concat buffer of dense block 0; channels 0..63 hold the trunk input
-  float* const* cat;      // training: nrdb + 1 concat buffers (cat[0] == in); null in inference
+  float* cat[TRUNK_FUSED_MAXCAT];  // training: nrdb + 1 concat buffers (cat[0] == in), in the kernel arguments: a
+                          // pointer table in global memory costs a dependent vector load per epilogue
+  int store_all;
   float* out;             // inference: concat buffer receiving the trunk output in channels 0..63
   unsigned long long* inbox;  // [3 * images][2][2][64][9] granules {value, tag}
   int* err;
   int nrdb, nimg, img0, epoch;
   float rs, slope;
+  int abl;
 };
 
 struct Wave {
@@ -56,6 +59,13 @@ struct Wave {
   int pofs;                // 11 + position offset (own row cell of a plane), valid for n < 27
   const float* wp;         // next weight block of this wavefront
   float xres[4];           // RRDB input at this thread's four conv5 outputs
+  // epilogue constants of this thread's first output (register r = 2 w, tile 0); the others add immediates
+  unsigned ep_l;           // LDS cell of (channel m0, own position)
+  unsigned ep_g;           // element offset inside a concat buffer: (img * 192 + m0) * 81 + band * 27 + n
+  unsigned ep_up, ep_dn;   // granule index inside the upper / lower neighbour's inbox (parity 0, channel m0)
+  unsigned hl_g[2];        // halo fetch: granule index of slot s = lane (+64) inside my inbox (parity 0, channel 0)
+  int hl_l[2];             // ... and its LDS cell relative to the quad's first plane (-1: nothing to fetch)
+  bool st_ok, up_ok, dn_ok;
 };
 
 #define DI __device__ __forceinline__
@@ -74,14 +84,14 @@ template <int NM> DI void issue_loads(float (&A)[36], const float* p, int lane) 
 }
 
 // SEL 0: all nine taps; 1: the middle kernel row (needs no halo row); 2: the outer kernel rows
-template <int NM, int SEL> DI void mma_taps(const float (&A)[36], int b, f16v (&acc)[2]) {
+template <int NM, int SEL, int ABL = 0> DI void mma_taps(const float (&A)[36], int b, f16v (&acc)[2]) {
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     if (SEL == 1 && tap / 3 != 1) continue;
     if (SEL == 2 && tap / 3 == 1) continue;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const float bv = lds[b + ks * 2 * CS + (tap / 3) * 10 + tap % 3];
+      const float bv = (ABL & 1) ? __int_as_float(b) : lds[b + ks * 2 * CS + (tap / 3) * 10 + tap % 3];
 #pragma unroll
       for (int mt = 0; mt < NM; ++mt)
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mt * 18 + tap * 2 + ks], bv, acc[mt], 0, 0, 0);
@@ -100,7 +110,7 @@ DI void granule_store(unsigned long long* p, float v, unsigned tag) {
 }  // namespace
 
 // One layer of a dense block.  K = 0..4 (conv_layer1..5).  A0 / A1: the weight ping-pong (static parity per dense block).
-template <int K>
+template <int K, int ABL>
 __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int j, bool last_rdb) {
   constexpr int NM = K == 4 ? 2 : 1;
   constexpr int U = 2 + K;
@@ -111,27 +121,43 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
   const int par_in = (serial - 1) & 1;
   const bool need_halo = serial > 0;                 // the first layer's halo rows came with the input load
 
-  // ---- request the halo granules of this wavefront's newest quads now; they are checked just before use ----
+  // hipcc's waitcnt bookkeeping does not survive branches (epilogue stores, the rare spin path): wherever it is unsure it
+  // emits vmcnt(0).  So every unit first takes the wait for ITS weights (issued one unit ago), and only then issues the
+  // next unit's loads: a conservative vmcnt(0) never sits behind a freshly issued prefetch.
+  {
+    float (&first)[36] = (base & 1) ? A1 : A0;
+#pragma unroll
+    for (int i = 0; i < 18 * NM; ++i) asm volatile("" ::"v"(first[i]));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- layer-start requests, pinned here: the halo granules of this wavefront's newest quads (checked just before
+  // use) and the biases of this thread's epilogue outputs.  Every lane loads (lanes without a granule re-read slot 0).
   // granule slot s (0..71) of a quad: channel e = s / 18, side = (s / 9) & 1 (0: row above, 1: row below), column s % 9
   constexpr int NQ = K == 0 ? 2 : 1;                 // newest quads of this wavefront
   const unsigned long long* gp[NQ][2];
   unsigned long long gv[NQ][2];
   int gdst[NQ][2];
+  {
+    const unsigned long long* inb = a.inbox + (par_in ? 2 * 64 * 9 : 0);
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int quad = K == 0 ? w + 8 * q : w + 8 * (1 + K);
-    const int pch = K == 0 ? 4 * (w + 8 * q) : 4 * w;  // channel of the producing layer's output
+    for (int q = 0; q < NQ; ++q) {
+      const int quad = K == 0 ? w + 8 * q : w + 8 * (1 + K);
+      const int pch = K == 0 ? 4 * (w + 8 * q) : 4 * w;  // channel of the producing layer's output
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int s = lane + 64 * r;
-      const int e = s / 18, side = (s / 9) & 1, c = s % 9;
-      const bool have = need_halo && s < 72 && (side == 0 ? W.band > 0 : W.band < 2);
-      gdst[q][r] = have ? (quad * 4 + e) * CS + (side ? 40 : 0) + c + 1 : -1;
-      gp[q][r] = a.inbox + ((((size_t)(W.cl * 3 + W.band) * 2 + par_in) * 2 + side) * 64 + pch + e) * 9 + c;
-      gv[q][r] = 0;
-      if (have) gv[q][r] = granule_load(gp[q][r]);
+      for (int r = 0; r < 2; ++r) {
+        gdst[q][r] = (need_halo && W.hl_l[r] >= 0) ? W.hl_l[r] + quad * 4 * CS : -1;
+        gp[q][r] = inb + (W.hl_g[r] + pch * 9);
+        gv[q][r] = granule_load(gp[q][r]);
+      }
     }
   }
+  float bias[2 * NM];
+#pragma unroll
+  for (int k = 0; k < 2 * NM; ++k) {
+    const int r = 2 * w + (k & 1);
+    bias[k] = a.bstream[j * 192 + (K < 4 ? 32 * K : 128) + (k >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+  }
+  __builtin_amdgcn_sched_barrier(0);
 
   f16v acc[2];
 #pragma unroll
@@ -144,78 +170,98 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
     float (&nxt)[36] = par ? A0 : A1;
     // the next unit of this wavefront's stream (next layer / next dense block included; the stream is padded at its end)
     const bool next_is_nm2 = (u + 1 < U) ? (K == 4) : (K == 3);
+    if (u > 0) {
+#pragma unroll
+      for (int i = 0; i < 18 * NM; ++i) asm volatile("" ::"v"(cur[i]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (next_is_nm2) { issue_loads<2>(nxt, W.wp, lane); W.wp += 2 * UNIT; }
     else { issue_loads<1>(nxt, W.wp, lane); W.wp += UNIT; }
+    __builtin_amdgcn_sched_barrier(0);  // hipcc otherwise sinks the prefetch to just before its first use
     const int b = W.bofs + (w + 8 * u) * 4 * CS;
     const bool newest = (K == 0) || (u == U - 1);
     if (!newest) {
-      mma_taps<NM, 0>(cur, b, acc);
+      mma_taps<NM, 0, ABL>(cur, b, acc);
     } else {
-      mma_taps<NM, 1>(cur, b, acc);
+      mma_taps<NM, 1, ABL>(cur, b, acc);
       // pin the middle-row MFMAs BEFORE the wait (hipcc otherwise sinks them below the spin loop: they are pure)
       asm volatile("" : "+v"(acc[0]));
       if (NM == 2) asm volatile("" : "+v"(acc[1]));
       const int q = K == 0 ? u : 0;
+      bool ok = true;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        if (gdst[q][r] >= 0) {
-          unsigned long long g = gv[q][r];
-          int spins = 0;
+      for (int r = 0; r < 2; ++r) ok = ok && (gdst[q][r] < 0 || (unsigned)(gv[q][r] >> 32) == tag_in);
+      if (!__all(ok) && !(a.abl & 1)) {  // rare: the neighbour is behind
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          if (gdst[q][r] >= 0) {
+            int spins = 0;
 #pragma nounroll
-          while ((unsigned)(g >> 32) != tag_in) {
-            __builtin_amdgcn_s_sleep(1);
-            g = granule_load(gp[q][r]);
-            if (++spins > SPIN_LIMIT) { *a.err = 1; break; }
+            while ((unsigned)(gv[q][r] >> 32) != tag_in) {
+              __builtin_amdgcn_s_sleep(1);
+              gv[q][r] = granule_load(gp[q][r]);
+              if (++spins > SPIN_LIMIT) { *a.err = 1; break; }
+            }
           }
-          lds[gdst[q][r]] = __uint_as_float((unsigned)g);
         }
       }
-      mma_taps<NM, 2>(cur, b, acc);
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (gdst[q][r] >= 0) lds[gdst[q][r]] = __uint_as_float((unsigned)gv[q][r]);
+      mma_taps<NM, 2, ABL>(cur, b, acc);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
-
   // ---- split-K reduction over the eight wavefronts + epilogue, one 32-channel tile at a time ----
   const unsigned tag_out = ((unsigned)a.epoch << 12) | (unsigned)(serial + 1);
   const int par_out = serial & 1;
-  const int n = W.n;
+  if (ABL & 2) { asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(bias[0])); return; }
+  // uniform bases of this layer's outputs
+  float* gbase = nullptr;
+  if (K < 4) { if (a.store_all) gbase = a.cat[j] + (64 + 32 * K) * 81; }
+  else { gbase = a.store_all ? a.cat[j + 1] : (last_rdb ? a.out : nullptr); }
+  unsigned long long* obox = a.inbox + (par_out ? 2 * 64 * 9 : 0);
+  const bool publish = !(K == 4 && last_rdb);
+  constexpr int LCH = K < 4 ? (64 + 32 * K) * CS : 0;  // first LDS plane of this layer's output
 #pragma unroll
   for (int mt = 0; mt < NM; ++mt) {
     if (mt) __syncthreads();  // the previous tile's sums have been read
 #pragma unroll
     for (int r = 0; r < 16; ++r) lds[RED0 + (w * 16 + r) * 64 + lane] = acc[mt][r];
     __syncthreads();
+    float v[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = 2 * w + i;
-      float v = 0.f;
+      float t = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < NWAVE; ++ww) v += lds[RED0 + (ww * 16 + r) * 64 + lane];
-      const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);  // output channel of this layer
-      if (n < 27) {
-        int ch;  // plane the value goes to
-        float* gdst_p = nullptr;
-        if (K < 4) {
-          v += a.bstream[j * 192 + 32 * K + m];
-          v = v >= 0.f ? v : a.slope * v;
-          ch = 64 + 32 * K + m;
-          if (a.cat) gdst_p = a.cat[j];
-        } else {
-          v = a.rs * (v + a.bstream[j * 192 + 128 + m]) + lds[m * CS + W.pofs];  // a5 * rs + a0  (:358)
-          if (j % 3 == 2) {                                                          // a3 * rs + x   (:402)
-            v = a.rs * v + W.xres[mt * 2 + i];
-            W.xres[mt * 2 + i] = v;
-          }
-          ch = m;
-          if (a.cat) gdst_p = a.cat[j + 1];
-          else if (last_rdb) gdst_p = a.out;
+      for (int ww = 0; ww < NWAVE; ++ww) t += lds[RED0 + (ww * 16 + r) * 64 + lane];
+      t += bias[mt * 2 + i];
+      if (K < 4) {
+        t = t >= 0.f ? t : a.slope * t;
+      } else {
+        t = a.rs * t + lds[W.ep_l + (mt * 32 + i) * CS];  // a5 * rs + a0  (:358)
+        if (j % 3 == 2) {                                 // a3 * rs + x   (:402)
+          t = a.rs * t + W.xres[mt * 2 + i];
+          W.xres[mt * 2 + i] = t;
         }
-        lds[ch * CS + W.pofs] = v;
-        if (gdst_p) gdst_p[((size_t)W.img * 192 + ch) * 81 + W.band * 27 + n] = v;
-        if (!(K == 4 && last_rdb)) {
-          if (n < 9 && W.band > 0)  // my top row is the bottom halo of the band above
-            granule_store(a.inbox + ((((size_t)(W.cl * 3 + W.band - 1) * 2 + par_out) * 2 + 1) * 64 + m) * 9 + n, v, tag_out);
-          if (n >= 18 && W.band < 2)
-            granule_store(a.inbox + ((((size_t)(W.cl * 3 + W.band + 1) * 2 + par_out) * 2 + 0) * 64 + m) * 9 + (n - 18), v, tag_out);
+      }
+      v[i] = t;
+    }
+    if (W.st_ok) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        lds[LCH + W.ep_l + (mt * 32 + i) * CS] = v[i];
+        if (gbase) gbase[W.ep_g + (mt * 32 + i) * 81] = v[i];
+      }
+      if (publish) {
+        if (W.up_ok) {  // my top row is the bottom halo of the band above
+#pragma unroll
+          for (int i = 0; i < 2; ++i) granule_store(obox + (W.ep_up + (mt * 32 + i) * 9), v[i], tag_out);
+        }
+        if (W.dn_ok) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) granule_store(obox + (W.ep_dn + (mt * 32 + i) * 9), v[i], tag_out);
         }
       }
     }
@@ -223,6 +269,7 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
   __syncthreads();  // planes written: the next layer may read them
 }
 
+template <int ABL>
 __global__ __launch_bounds__(512) void trunk_fused_kernel(Args a) {
   Wave W;
   W.t = threadIdx.x; W.lane = W.t & 63; W.w = W.t >> 6;
@@ -240,6 +287,26 @@ __global__ __launch_bounds__(512) void trunk_fused_kernel(Args a) {
     W.pofs = 11 + po;
   }
   W.wp = a.wstream + (size_t)W.w * a.nrdb * WAVE_RDB;
+  {
+    const int m0 = ((2 * W.w) & 3) + 8 * ((2 * W.w) >> 2) + 4 * (W.lane >> 5), n = W.n;
+    const unsigned me = (unsigned)(W.cl * 3 + W.band);
+    W.st_ok = n < 27;
+    W.up_ok = n < 9 && W.band > 0;
+    W.dn_ok = n >= 18 && n < 27 && W.band < 2;
+    W.ep_l = (unsigned)(m0 * CS + W.pofs);
+    W.ep_g = (unsigned)((W.img * 192 + m0) * 81 + W.band * 27 + n);
+    W.ep_up = (((me - 1) * 2) * 2 + 1) * 576 + m0 * 9 + n;        // [wg][parity][side][64][9]
+    W.ep_dn = (((me + 1) * 2) * 2 + 0) * 576 + m0 * 9 + (n - 18);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int s0 = W.lane + 64 * r;
+      const int sl = s0 < 72 ? s0 : 0;
+      const int e = sl / 18, side = (sl / 9) & 1, c = sl % 9;
+      const bool have = s0 < 72 && (side == 0 ? W.band > 0 : W.band < 2);
+      W.hl_g[r] = ((me * 2) * 2 + side) * 576 + e * 9 + c;
+      W.hl_l[r] = have ? e * CS + (side ? 40 : 0) + c + 1 : -1;
+    }
+  }
 
   for (int i = W.t; i < 192 * CS; i += NTHREADS) lds[i] = 0.f;
   __syncthreads();
@@ -263,11 +330,11 @@ __global__ __launch_bounds__(512) void trunk_fused_kernel(Args a) {
   W.wp += UNIT;
   for (int j = 0; j < a.nrdb; ++j) {
     const bool last = j == a.nrdb - 1;
-    dense_layer<0>(a, W, A0, A1, j, last);
-    dense_layer<1>(a, W, A0, A1, j, last);
-    dense_layer<2>(a, W, A0, A1, j, last);
-    dense_layer<3>(a, W, A0, A1, j, last);
-    dense_layer<4>(a, W, A0, A1, j, last);
+    dense_layer<0, ABL>(a, W, A0, A1, j, last);
+    dense_layer<1, ABL>(a, W, A0, A1, j, last);
+    dense_layer<2, ABL>(a, W, A0, A1, j, last);
+    dense_layer<3, ABL>(a, W, A0, A1, j, last);
+    dense_layer<4, ABL>(a, W, A0, A1, j, last);
   }
 }
 
@@ -316,13 +383,26 @@ void launch_pack_trunk_fused(const float* const* d_wsrc, const float* const* d_b
 void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     attr = true;
   }
   Args a;
-  a.wstream = L.wstream; a.bstream = L.bstream; a.in = L.in; a.cat = L.cat; a.out = L.out; a.inbox = L.inbox; a.err = L.err;
+  a.wstream = L.wstream; a.bstream = L.bstream; a.in = L.in; a.out = L.out;
+  a.store_all = L.cat != nullptr;
+  for (int i = 0; i < TRUNK_FUSED_MAXCAT; ++i) a.cat[i] = (L.cat && i <= L.nrdb) ? L.cat[i] : nullptr;
+  DBM_CHECK(L.nrdb + 1 <= TRUNK_FUSED_MAXCAT, "fused trunk: too many dense blocks");
+  a.inbox = L.inbox; a.err = L.err;
+  static const int abl = getenv("DBM_TF_ABL") ? atoi(getenv("DBM_TF_ABL")) : 0;
+  a.abl = abl;
   a.nrdb = L.nrdb; a.nimg = L.nimg; a.img0 = L.img0; a.epoch = L.epoch & 0xFFFFF; a.rs = L.rs; a.slope = L.slope;
   const int grid = ((L.nimg + 7) / 8) * 24;
-  hipLaunchKernelGGL(trunk_fused_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+  static const int ablk = getenv("DBM_TF_ABLK") ? atoi(getenv("DBM_TF_ABLK")) : 0;
+  if (ablk == 1) hipLaunchKernelGGL(trunk_fused_kernel<1>, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+  else if (ablk == 2) hipLaunchKernelGGL(trunk_fused_kernel<2>, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+  else if (ablk == 3) hipLaunchKernelGGL(trunk_fused_kernel<3>, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+  else hipLaunchKernelGGL(trunk_fused_kernel<0>, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
   DBM_HIP(hipGetLastError());
 }
