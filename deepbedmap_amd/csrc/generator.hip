@@ -61,7 +61,7 @@ Generator::~Generator() {
   if (twin) delete twin;
   if (ev_prefetch) (void)hipEventDestroy(ev_prefetch);
   if (!is_view) {
-    (void)hipFree(tf_wstream); (void)hipFree(tf_bstream); (void)hipFree((void*)tf_wsrc); (void)hipFree((void*)tf_bsrc);
+    (void)hipFree(tf_wstream); (void)hipFree(tf_bstream); (void)hipFree(tf_bwd_wstream); (void)hipFree((void*)tf_wsrc); (void)hipFree((void*)tf_bsrc);
   }
   (void)hipFree(tf_inbox);
 }
@@ -84,6 +84,9 @@ void Generator::pack_extra(hipStream_t s) {
     DBM_HIP(hipMalloc((void**)&tf_wstream, nw * sizeof(float)));
     DBM_HIP(hipMemset(tf_wstream, 0, nw * sizeof(float)));
     DBM_HIP(hipMalloc((void**)&tf_bstream, (size_t)nrdb * 192 * sizeof(float)));
+    const size_t nb = trunk_fused_bwd_stream_floats(nrdb);
+    DBM_HIP(hipMalloc((void**)&tf_bwd_wstream, nb * sizeof(float)));
+    DBM_HIP(hipMemset(tf_bwd_wstream, 0, nb * sizeof(float)));
     std::vector<const float*> ws(nrdb * 5), bs(nrdb * 5);
     for (int i = 0; i < nrdb * 5; ++i) {
       ws[i] = P(layers[L_rdb[i]].wi);
@@ -96,6 +99,7 @@ void Generator::pack_extra(hipStream_t s) {
     DBM_HIP(hipDeviceSynchronize());
   }
   launch_pack_trunk_fused(tf_wsrc, tf_bsrc, tf_wstream, tf_bstream, nrdb, s);
+  launch_pack_trunk_fused_bwd(tf_wsrc, tf_bwd_wstream, nrdb, s);
 }
 
 Generator* Generator::get_twin() {
@@ -402,8 +406,55 @@ void Generator::backward(const float* gy) {
   DBM_MARK(s, "G:backward_tail_layers");
   ctx->fork_to_side(0);
   wbs[0].launch(ctx->side);
-  // ---- trunk, last dense block first; like the forward, as `nsplit` image ranges on separate streams ----
-  const int nsplit = std::min(trunk_split(N, hw), max_split);
+  // ---- trunk, last dense block first ----
+  const bool fused = trunk_fused_ok(h, w) && !(getenv("DBM_TRUNK_FUSED_BWD") && atoi(getenv("DBM_TRUNK_FUSED_BWD")) == 0);
+  auto group_of = [&](int j) {
+    // groups of residual-in-residual blocks, shrinking towards the end of the chain: what is still to do once the
+    // data-gradient chain has finished (the last group + the pre-residual / input-block batch) is exposed time
+    const int r = j / 3;
+    return r == 0 ? 5 : r == 1 ? 4 : r <= 3 ? 3 : (r >= 4 + (n_rrdb - 3) / 2 ? 1 : 2);
+  };
+  if (fused) {  // one persistent launch per group (trunk_fused_bwd.hip); the group's weight gradients follow on the side stream
+    const Generator* src = owner ? owner : this;
+    DBM_CHECK(src->tf_bwd_wstream != nullptr, "fused trunk: weight streams not packed");
+    const int IMGS = 64;
+    if (!tf_inbox) {
+      DBM_HIP(hipMalloc((void**)&tf_inbox, trunk_fused_inbox_bytes(IMGS)));
+      DBM_HIP(hipMemsetAsync(tf_inbox, 0, trunk_fused_inbox_bytes(IMGS), s));
+    }
+    std::vector<float*> dAp(nrdb);
+    std::vector<const float*> catp(nrdb);
+    for (int i = 0; i < nrdb; ++i) { dAp[i] = dA[i].p; catp[i] = cat[i].p; }
+    int prev = -1;
+    for (int j = nrdb - 1; j >= 0; --j) {
+      const int grp = group_of(j);
+      if (grp != prev) {
+        if (prev >= 0) { ctx->fork_to_side(prev); wbs[prev].launch(ctx->side); }
+        int jlo = j;
+        while (jlo > 0 && group_of(jlo - 1) == grp) --jlo;
+        for (int i0 = 0; i0 < N; i0 += IMGS) {
+          TrunkFusedBwdLaunch L;
+          L.wstream = src->tf_bwd_wstream;
+          L.gin = dA[j + 1].p; L.gin_sn = (j + 1 == nrdb) ? 64 * hw : 192 * hw;
+          L.dA = dAp.data(); L.cat = catp.data(); L.g_a3 = g_a3.p;
+          L.inbox = tf_inbox; L.err = ctx->dev_err_d;
+          L.nrdb = nrdb; L.j0 = jlo; L.j1 = j + 1; L.nimg = std::min(IMGS, N - i0); L.img0 = i0; L.epoch = ++tf_epoch;
+          L.rs = rs; L.slope = SLOPE;
+          launch_trunk_fused_bwd(L, s);
+        }
+        prev = grp;
+      }
+      // the weight gradients of this dense block (descriptors only; launched with the group)
+      const float* Gout = dA[j + 1].p;
+      const long gsn = (j + 1 == nrdb) ? 64 * hw : 192 * hw;
+      const float sc = (j % 3 == 2) ? rs * rs : rs;
+      run_wgrad(layers[L_rdb[j * 5 + 4]], cat[j].p, 192 * hw, h, w, 0, Gout, gsn, h, w, N, sc, &wbs[grp]);
+      for (int k = 3; k >= 0; --k)
+        run_wgrad(layers[L_rdb[j * 5 + k]], cat[j].p, 192 * hw, h, w, 0, dA[j].p + (long)(64 + 32 * k) * hw, 192 * hw, h, w, N,
+                  1.f, &wbs[grp]);
+    }
+  }
+  const int nsplit = fused ? 1 : std::min(trunk_split(N, hw), max_split);
   auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[chain_base + c - 1]; };
   auto chunk = [&](ConvDesc d, int c) {  // descriptor restricted to image range c
     const long n0 = ((long)c * N) / nsplit;
@@ -415,8 +466,8 @@ void Generator::backward(const float* gy) {
   };
   auto join_chains = [&]() { for (int c = 1; c < nsplit; ++c) ctx->fork(cstream(c), s, 7); };
   for (int c = 1; c < nsplit; ++c) ctx->fork(s, cstream(c), 7);
-  int prev_grp = -1;
-  for (int j = nrdb - 1; j >= 0; --j) {
+  int prev_grp = fused ? 5 : -1;  // (fused: the last group is still to be launched below)
+  for (int j = fused ? -1 : nrdb - 1; j >= 0; --j) {
     // groups of residual-in-residual blocks, shrinking towards the end of the chain: what is still to do once the
     // data-gradient chain has finished (the last group + the pre-residual / input-block batch) is exposed time
     const int r = j / 3;

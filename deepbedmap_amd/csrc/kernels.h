@@ -79,3 +79,21 @@ size_t trunk_fused_inbox_bytes(int nimg);
 void launch_pack_trunk_fused(const float* const* d_wsrc, const float* const* d_bsrc, float* wstream, float* bstream, int nrdb,
                              hipStream_t s);
 void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s);
+
+// ---- fused data-gradient chain of the RRDB trunk on 9x9 planes (trunk_fused_bwd.hip) ----
+struct TrunkFusedBwdLaunch {
+  const float* wstream;      // trunk_fused_bwd_stream_floats(nrdb), written by launch_pack_trunk_fused_bwd
+  const float* gin;          // gradient w.r.t. the output of dense block j1 - 1 (channels 0..63), image stride gin_sn
+  long gin_sn;
+  float* const* dA;          // HOST table: dA[j] (N, 192, 81), j < nrdb
+  const float* const* cat;   // HOST table: forward concat buffers
+  const float* g_a3;         // (N, 64, 81): added to the trunk input gradient at j == 0
+  unsigned long long* inbox;
+  int* err;
+  int nrdb, j0, j1;          // dense blocks j1 - 1 ... j0 (both multiples of 3)
+  int nimg, img0, epoch;
+  float rs, slope;
+};
+size_t trunk_fused_bwd_stream_floats(int nrdb);
+void launch_pack_trunk_fused_bwd(const float* const* d_wsrc, float* wstream, int nrdb, hipStream_t s);
+void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s);

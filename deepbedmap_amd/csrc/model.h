@@ -131,6 +131,7 @@ struct Generator : dbm_model {
   // fused 9x9 trunk forward (trunk_fused.hip): per-wavefront weight streams (owner only), per-workspace hand-off granules
   float* tf_wstream = nullptr;
   float* tf_bstream = nullptr;
+  float* tf_bwd_wstream = nullptr;   // transposed / tap-flipped streams of the fused data-gradient chain
   const float** tf_wsrc = nullptr;   // device tables of the trunk layers' W / b
   const float** tf_bsrc = nullptr;
   unsigned long long* tf_inbox = nullptr;

@@ -1,0 +1,338 @@
+// Data-gradient chain of the RRDB trunk (backward of srgan_train.py:333-360 / :393-404) on 9x9 planes as persistent
+// launches, one per group of residual-in-residual blocks (the weight-gradient batches of a group go to the side stream
+// as soon as its launch is enqueued behind it).
+//
+// Same decomposition as trunk_fused.hip: a workgroup owns three rows of one image, the gradient of the dense block's
+// concat (192 channels) lives in LDS, zero-framed; the three workgroups of an image exchange the boundary rows of every
+// finished 32-channel gradient block through data-tagged granules.  Differences:
+//  * a layer's data gradient has FEW input channels (K = 32 x 9, conv_layer5: 64 x 9) and MANY outputs (64..192): the
+//    output is cut into 16-channel x 16-position sub-tiles (v_mfma_f32_16x16x4_f32), sub-tile i belongs to wavefront
+//    i % 8 and is computed over the whole K by that wavefront alone -- no split-K, no reduction; the epilogue is a
+//    read-modify-write of the wavefront's own LDS cells;
+//  * partial sums (the accumulated gradient of channels that still receive contributions) never leave LDS; a 32-channel
+//    block goes to global memory once, when it is final (masked with lrelu'), which is also when its boundary rows are
+//    published.  The layer-by-layer path reads and re-writes the whole concat gradient in every launch.
+// Every spin is bounded (ctx error word).
+#include "model.h"
+
+namespace {
+
+constexpr int CS = 56;
+constexpr int NWAVE = 8;
+constexpr int NTHREADS = NWAVE * 64;
+constexpr int BUNIT = 36 * 64;       // floats per weight unit: one lane's 4 input-channel quads x 9 taps
+constexpr int UNITS_HI = 28, UNITS_LO = 24;  // units per dense block for wavefronts 0..3 / 4..7 (see pack kernel)
+constexpr int SPIN_LIMIT = 1 << 21;
+constexpr int P0 = 0, P1 = 64 * CS, Q0 = 128 * CS;  // LDS plane regions: two 64-channel banks (Gout / D[0:64]), D[64:192]
+constexpr size_t LDS_BYTES = (size_t)256 * CS * sizeof(float);
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+extern __shared__ float lds[];
+
+struct Args {
+  const float* wstream;
+  const float* gin;        // gradient w.r.t. the output of dense block j1 - 1: (N, *, 81), channels 0..63
+  long gin_sn;
+  float* dA[TRUNK_FUSED_MAXCAT];         // dA[j], (N, 192, 81)
+  const float* cat[TRUNK_FUSED_MAXCAT];  // forward concat buffers (LeakyReLU masks)
+  const float* g_a3;       // (N, 64, 81), added at j == 0
+  unsigned long long* inbox;
+  int* err;
+  int nrdb, j0, j1, nimg, img0, epoch;
+  float rs, slope;
+};
+
+struct Wave {
+  int lane, w, t;
+  int img, band, cl;
+  int nh;           // position half of this wavefront's sub-tiles
+  int pos;          // position 0..31 of this lane's column (>= 27: padding)
+  int bofs;         // B operand lane base: (lane >> 4) * CS + position offset
+  int pofs;         // 11 + position offset: own cell inside a plane
+  bool st_ok, up_ok, dn_ok;
+  unsigned me;      // inbox slot of this workgroup
+  const float* wp;
+  float skipv[4];   // gradient of the RRDB output at this thread's conv_layer1 outputs (the `x` skip of :402)
+};
+
+#define DI __device__ __forceinline__
+
+DI void issue_unit(float (&A)[36], const float* p, int lane) {
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const f4v v = *reinterpret_cast<const f4v*>(p + c * 256 + lane * 4);
+    A[4 * c + 0] = v.x; A[4 * c + 1] = v.y; A[4 * c + 2] = v.z; A[4 * c + 3] = v.w;
+  }
+}
+
+DI void mma_unit(const float (&A)[36], int b, f4v (&acc)[2]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float bv = lds[b + q * 4 * CS + (tap / 3) * 10 + tap % 3];
+      acc[(q * 9 + tap) & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q * 9 + tap], bv, acc[(q * 9 + tap) & 1], 0, 0, 0);
+    }
+  }
+}
+
+DI unsigned long long granule_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DI void granule_store(unsigned long long* p, float v, unsigned tag) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// fetch the halo rows of NCH freshly finished channels (planes from `plane0`) from the neighbours' granules
+template <int NCH> DI void fetch_halo(const Args& a, const Wave& W, int plane0, int par, unsigned tag) {
+  const unsigned long long* inb = a.inbox + ((size_t)W.me * 2 + par) * 2 * 576;
+#pragma unroll
+  for (int r = 0; r < (NCH * 18 + NTHREADS - 1) / NTHREADS; ++r) {
+    const int g = W.t + NTHREADS * r;
+    const int ch = g / 18, side = (g / 9) & 1, c = g % 9;
+    const bool have = g < NCH * 18 && (side == 0 ? W.band > 0 : W.band < 2);
+    if (have) {
+      const unsigned long long* p = inb + (side * 64 + ch) * 9 + c;
+      unsigned long long v = granule_load(p);
+      int spins = 0;
+#pragma nounroll
+      while ((unsigned)(v >> 32) != tag) {
+        __builtin_amdgcn_s_sleep(1);
+        v = granule_load(p);
+        if (++spins > SPIN_LIMIT) { *a.err = 1; break; }
+      }
+      lds[plane0 + ch * CS + (side ? 40 : 0) + c + 1] = __uint_as_float((unsigned)v);
+    }
+  }
+}
+
+// One sub-tile (16 output channels x 16 positions) of one layer's data gradient.
+//  KL: 4 = conv_layer5 (input Gout, 64 channels, NU = 4 units), 3..0 = conv_layer4..1 (32 input channels, NU = 2)
+template <int KL>
+DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s, int j, int gin_region, int dlow_region,
+                 int serial) {
+  constexpr int NU = KL == 4 ? 4 : 2;
+  constexpr int fin0 = KL == 4 ? 160 : KL == 3 ? 128 : KL == 2 ? 96 : KL == 1 ? 64 : 0;  // first channel that is final
+  const int lane = W.lane;
+  const int mt = (W.w >> 1) + 4 * s;           // 16-channel output tile
+  const int ch0 = 16 * mt + 4 * (lane >> 4);   // this lane's four output channels ch0 .. ch0 + 3
+  const bool fin = 16 * mt >= fin0;            // wave-uniform
+  const bool third = (j % 3 == 2), first = (j % 3 == 0);
+  // B operand planes: Gout bank (conv5) or D[64 + 32 KL ...]
+  const int breg = (KL == 4 ? gin_region : Q0 + 32 * KL * CS) + W.bofs;
+
+  float maskv[4] = {1.f, 1.f, 1.f, 1.f}, extra[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool use_mask = fin && (KL > 0 || j == 0);
+  const unsigned gofs = (unsigned)((W.img * 192 + ch0) * 81 + W.band * 27 + W.pos);
+
+  f4v acc[2];
+  acc[0] = (f4v){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    float (&cur)[36] = (u & 1) ? A1 : A0;
+    float (&nxt)[36] = (u & 1) ? A0 : A1;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) asm volatile("" ::"v"(cur[i]));  // the wait for this unit's weights, BEFORE the next issue
+    __builtin_amdgcn_sched_barrier(0);
+    if (u == 0 && W.st_ok) {  // what the epilogue reads from global memory: masks of final channels, the j == 0 extras
+      if (use_mask) {
+        const float* C = a.cat[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) maskv[r] = C[gofs + r * 81];
+      }
+      if (KL == 0 && j == 0) {
+        const unsigned go = (unsigned)((W.img * 64 + ch0) * 81 + W.band * 27 + W.pos);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) extra[r] = a.g_a3[go + r * 81];
+      }
+    }
+    issue_unit(nxt, W.wp, lane);
+    W.wp += BUNIT;
+    __builtin_amdgcn_sched_barrier(0);
+    mma_unit(cur, breg + u * 16 * CS, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue: this lane's four cells ----
+  const float sc = third ? a.rs * a.rs : a.rs;
+  const float r1s = third ? a.rs : 1.f;
+  const unsigned tag_out = ((unsigned)a.epoch << 12) | (unsigned)(serial + 1);
+  if (W.st_ok) {
+    float* gdst = a.dA[j];
+    unsigned long long* obox = a.inbox + ((serial & 1) ? 2 * 576 : 0);
+    const bool publish = fin && !(KL == 0 && j == a.j0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = ch0 + r;
+      const int cell = (ch < 64 ? dlow_region + ch * CS : Q0 + (ch - 64) * CS) + W.pofs;
+      float v = acc[0][r] + acc[1][r];
+      if (KL == 4) {
+        v *= sc;
+        if (ch < 64) v += r1s * lds[gin_region + ch * CS + W.pofs];  // d out / d a0  (:358, :402)
+      } else {
+        if (KL == 0) {
+          if (first) v += W.skipv[r];          // d (RRDB out) / d x  (:402)
+          if (j == 0) v += extra[r];           // a3 = a1 + ...  (:551)
+        }
+        v += lds[cell];
+      }
+      if (use_mask) v = maskv[r] >= 0.f ? v : a.slope * v;
+      lds[cell] = v;
+      if (KL == 0 && first) W.skipv[r] = v;
+      if (fin) {
+        gdst[gofs + r * 81] = v;
+        if (publish) {
+          const int pch = ch - fin0;
+          if (W.up_ok) granule_store(obox + ((size_t)(W.me - 1) * 4 + 1) * 576 + pch * 9 + W.pos, v, tag_out);
+          if (W.dn_ok) granule_store(obox + ((size_t)(W.me + 1) * 4 + 0) * 576 + pch * 9 + (W.pos - 18), v, tag_out);
+        }
+      }
+    }
+  }
+}
+
+template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int j, int gin_region, int dlow_region,
+                               int serial) {
+  // sub-tiles of this layer: 2 * (64 + 32 KL) / 16 = 24, 20, 16, 12, 8; wavefront w owns w, w + 8, w + 16
+  constexpr int S = (64 + 32 * KL) / 8;
+  constexpr int SMAX = (S + 7) / 8;
+  // keep hipcc from hoisting every address of every (layer, sub-tile, register) out of the dense-block loop (it spills)
+  asm volatile("" : "+v"(W.pos), "+v"(W.bofs), "+v"(W.pofs), "+v"(W.lane));
+#pragma unroll
+  for (int s = 0; s < SMAX; ++s) {
+    if (W.w + 8 * s < S) sub_tile<KL>(a, W, A0, A1, s, j, gin_region, dlow_region, serial);
+  }
+  // the block that just became final feeds the next layer: fetch its halo rows, then one barrier
+  constexpr int NCH = KL == 0 ? 64 : 32;
+  const int plane0 = KL == 0 ? dlow_region : Q0 + 32 * (KL - 1) * CS;
+  if (!(KL == 0 && j == a.j0)) {
+    const unsigned tag = ((unsigned)a.epoch << 12) | (unsigned)(serial + 1);
+    fetch_halo<NCH>(a, W, plane0, serial & 1, tag);
+  }
+  __syncthreads();
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void trunk_fused_bwd_kernel(Args a) {
+  Wave W;
+  W.t = threadIdx.x; W.lane = W.t & 63; W.w = W.t >> 6;
+  const int B = blockIdx.x;
+  W.cl = (B / 24) * 8 + (B % 8);
+  W.band = (B / 8) % 3;
+  if (W.cl >= a.nimg) return;
+  W.img = a.img0 + W.cl;
+  W.me = (unsigned)(W.cl * 3 + W.band);
+  W.nh = W.w & 1;
+  W.pos = W.nh * 16 + (W.lane & 15);
+  {
+    const int n = W.pos;
+    const int po = n < 27 ? (n / 9) * 10 + n % 9 : (n == 27 ? 9 : n == 28 ? 19 : 29 + (n - 29));
+    W.bofs = (W.lane >> 4) * CS + po;
+    W.pofs = 11 + po;
+    W.st_ok = n < 27;
+    W.up_ok = n < 9 && W.band > 0;
+    W.dn_ok = n >= 18 && n < 27 && W.band < 2;
+  }
+  {
+    const int nblk = a.nrdb - a.j1;  // dense blocks already done by earlier launches
+    const size_t per = (size_t)a.nrdb * BUNIT;
+    const size_t base = W.w < 4 ? per * UNITS_HI * W.w : per * (UNITS_HI * 4 + UNITS_LO * (W.w - 4));
+    W.wp = a.wstream + base + (size_t)nblk * BUNIT * (W.w < 4 ? UNITS_HI : UNITS_LO);
+  }
+  for (int i = W.t; i < 256 * CS; i += NTHREADS) lds[i] = 0.f;
+  __syncthreads();
+  // Gout of the first dense block of this launch: channels 0..63, rows 3*band-1 .. 3*band+3, into bank P0
+  const float* gin = a.gin + (size_t)W.img * a.gin_sn;
+  for (int i = W.t; i < 64 * 45; i += NTHREADS) {
+    const int ch = i / 45, rc = i % 45, r = rc / 9, c = rc % 9;
+    const int row = 3 * W.band - 1 + r;
+    if (row >= 0 && row < 9) lds[P0 + ch * CS + r * 10 + c + 1] = gin[ch * 81 + row * 9 + c];
+  }
+  {  // launches cover whole RRDBs: the skip source of the first RRDB is the launch's Gout itself
+    const int ch0 = 16 * (W.w >> 1) + 4 * (W.lane >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) W.skipv[r] = W.st_ok ? gin[(ch0 + r) * 81 + W.band * 27 + W.pos] : 0.f;
+  }
+  __syncthreads();
+
+  float A0[36], A1[36];
+  issue_unit(A0, W.wp, W.lane);
+  W.wp += BUNIT;
+  int serial = 0;
+  int par = 0;  // Gout bank
+  for (int j = a.j1 - 1; j >= a.j0; --j) {
+    const int gin_region = par ? P1 : P0, dlow_region = par ? P0 : P1;
+    layer<4>(a, W, A0, A1, j, gin_region, dlow_region, serial + 0);
+    layer<3>(a, W, A0, A1, j, gin_region, dlow_region, serial + 1);
+    layer<2>(a, W, A0, A1, j, gin_region, dlow_region, serial + 2);
+    layer<1>(a, W, A0, A1, j, gin_region, dlow_region, serial + 3);
+    layer<0>(a, W, A0, A1, j, gin_region, dlow_region, serial + 4);
+    serial += 5;
+    par ^= 1;
+  }
+}
+
+// dst-driven gather of the transposed, tap-flipped trunk weights into the per-wavefront streams
+__global__ void pack_trunk_fused_bwd_kernel(const float* const* wsrc, float* wstream, int nrdb) {
+  const long per = (long)nrdb * BUNIT;
+  const long total = per * (UNITS_HI * 4 + UNITS_LO * 4);
+  for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
+    int w;
+    long rem;
+    if (f < per * UNITS_HI * 4) { w = (int)(f / (per * UNITS_HI)); rem = f % (per * UNITS_HI); }
+    else { const long g = f - per * UNITS_HI * 4; w = 4 + (int)(g / (per * UNITS_LO)); rem = g % (per * UNITS_LO); }
+    const int upr = w < 4 ? UNITS_HI : UNITS_LO;
+    const int rblk = (int)(rem / ((long)upr * BUNIT));     // dense blocks in processing order: j = nrdb - 1 - rblk
+    int ui = (int)((rem / BUNIT) % upr);
+    const int x = (int)(rem % BUNIT);
+    const int j = nrdb - 1 - rblk;
+    // unit -> (layer, sub-tile s, unit u)
+    const int nsub[5] = {3, w < 4 ? 3 : 2, 2, w < 4 ? 2 : 1, 1};  // conv5, conv4, conv3, conv2, conv1
+    int KL = 4, s = 0, u = 0;
+    for (int l = 0; l < 5; ++l) {
+      const int nu = l == 0 ? 4 : 2;
+      if (ui < nsub[l] * nu) { KL = 4 - l; s = ui / nu; u = ui % nu; break; }
+      ui -= nsub[l] * nu;
+    }
+    const int lane = (x % 256) / 4, i = 4 * (x / 256) + x % 4;
+    const int q = i / 9, tap = i % 9;
+    const int mt = (w >> 1) + 4 * s;
+    const int ci = 16 * mt + (lane & 15);                   // forward input channel = gradient output channel
+    const int co = 4 * (4 * u + q) + (lane >> 4);           // forward output channel = K index
+    const int Cin = 64 + 32 * KL;
+    wstream[f] = wsrc[j * 5 + KL][((long)co * Cin + ci) * 9 + (8 - tap)];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+size_t trunk_fused_bwd_stream_floats(int nrdb) { return (size_t)nrdb * BUNIT * (UNITS_HI * 4 + UNITS_LO * 4) + 4 * BUNIT; }
+
+void launch_pack_trunk_fused_bwd(const float* const* d_wsrc, float* wstream, int nrdb, hipStream_t s) {
+  hipLaunchKernelGGL(pack_trunk_fused_bwd_kernel, dim3(2048), dim3(256), 0, s, d_wsrc, wstream, nrdb);
+  DBM_HIP(hipGetLastError());
+}
+
+void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    attr = true;
+  }
+  DBM_CHECK(L.nrdb + 1 <= TRUNK_FUSED_MAXCAT, "fused trunk: too many dense blocks");
+  DBM_CHECK(L.j0 % 3 == 0 && L.j1 % 3 == 0 && L.j0 < L.j1 && L.j1 <= L.nrdb, "fused trunk backward: launches cover whole RRDBs");
+  Args a;
+  a.wstream = L.wstream; a.gin = L.gin; a.gin_sn = L.gin_sn; a.g_a3 = L.g_a3; a.inbox = L.inbox; a.err = L.err;
+  for (int i = 0; i < TRUNK_FUSED_MAXCAT; ++i) {
+    a.dA[i] = i < L.nrdb ? L.dA[i] : nullptr;
+    a.cat[i] = i < L.nrdb ? L.cat[i] : nullptr;
+  }
+  a.nrdb = L.nrdb; a.j0 = L.j0; a.j1 = L.j1; a.nimg = L.nimg; a.img0 = L.img0; a.epoch = L.epoch & 0xFFFFF;
+  a.rs = L.rs; a.slope = L.slope;
+  const int grid = ((L.nimg + 7) / 8) * 24;
+  hipLaunchKernelGGL(trunk_fused_bwd_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+  DBM_HIP(hipGetLastError());
+}
