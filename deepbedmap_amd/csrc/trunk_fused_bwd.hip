@@ -27,6 +27,7 @@ constexpr int P0 = 0, P1 = 64 * CS, Q0 = 128 * CS;  // LDS plane regions: two 64
 constexpr size_t LDS_BYTES = (size_t)256 * CS * sizeof(float);
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+constexpr int NACC = 4;  // independent accumulator chains of a sub-tile (summed in the epilogue)
 
 extern __shared__ float lds[];
 
@@ -41,6 +42,7 @@ struct Args {
   int* err;
   int nrdb, j0, j1, nimg, img0, epoch;
   float rs, slope;
+  int abl;  // measurement aid (DBM_TFB_ABL): 1 = no halo exchange, 2 = no epilogue (results are then wrong)
 };
 
 struct Wave {
@@ -66,14 +68,24 @@ DI void issue_unit(float (&A)[36], const float* p, int lane) {
   }
 }
 
-DI void mma_unit(const float (&A)[36], int b, f4v (&acc)[2]) {
+// 36 MFMAs of one unit.  The B operands of quad q + 1 are requested before the MFMAs of quad q and pinned there
+// (hipcc otherwise puts every ds_read right in front of its MFMA: one exposed LDS latency per pair of MFMAs).
+DI void mma_unit(const float (&A)[36], int b, f4v (&acc)[NACC]) {
+  float bq[2][9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) bq[0][tap] = lds[b + (tap / 3) * 10 + tap % 3];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
+    if (q < 3) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const float bv = lds[b + q * 4 * CS + (tap / 3) * 10 + tap % 3];
-      acc[(q * 9 + tap) & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q * 9 + tap], bv, acc[(q * 9 + tap) & 1], 0, 0, 0);
+      for (int tap = 0; tap < 9; ++tap) bq[(q + 1) & 1][tap] = lds[b + (q + 1) * 4 * CS + (tap / 3) * 10 + tap % 3];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      acc[(q * 9 + tap) % NACC] =
+          __builtin_amdgcn_mfma_f32_16x16x4f32(A[q * 9 + tap], bq[q & 1][tap], acc[(q * 9 + tap) % NACC], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -85,17 +97,34 @@ DI void granule_store(unsigned long long* p, float v, unsigned tag) {
                      __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// fetch the halo rows of NCH freshly finished channels (planes from `plane0`) from the neighbours' granules
-template <int NCH> DI void fetch_halo(const Args& a, const Wave& W, int plane0, int par, unsigned tag) {
-  const unsigned long long* inb = a.inbox + ((size_t)W.me * 2 + par) * 2 * 576;
+// Halo rows of NCH freshly finished channels (planes from `plane0`) come from the neighbours' granules.  The loads are
+// issued before the wavefront's last sub-tile of the layer (the final block is computed FIRST, so the neighbours have
+// usually published by then) and checked after it.
+template <int NCH> struct HaloReq {
+  static constexpr int R = (NCH * 18 + NTHREADS - 1) / NTHREADS;
+  unsigned long long v[R];
+};
+template <int NCH> DI const unsigned long long* halo_ptr(const Args& a, const Wave& W, int par, int r, int& dst, int plane0) {
+  const int g = W.t + NTHREADS * r;
+  const int ch = g / 18, side = (g / 9) & 1, c = g % 9;
+  const bool have = g < NCH * 18 && (side == 0 ? W.band > 0 : W.band < 2);
+  dst = have ? plane0 + ch * CS + (side ? 40 : 0) + c + 1 : -1;
+  return a.inbox + ((size_t)W.me * 2 + par) * 2 * 576 + (side * 64 + (have ? ch : 0)) * 9 + c;
+}
+template <int NCH> DI void halo_issue(const Args& a, const Wave& W, int par, HaloReq<NCH>& q) {
 #pragma unroll
-  for (int r = 0; r < (NCH * 18 + NTHREADS - 1) / NTHREADS; ++r) {
-    const int g = W.t + NTHREADS * r;
-    const int ch = g / 18, side = (g / 9) & 1, c = g % 9;
-    const bool have = g < NCH * 18 && (side == 0 ? W.band > 0 : W.band < 2);
-    if (have) {
-      const unsigned long long* p = inb + (side * 64 + ch) * 9 + c;
-      unsigned long long v = granule_load(p);
+  for (int r = 0; r < HaloReq<NCH>::R; ++r) {
+    int dst;
+    q.v[r] = granule_load(halo_ptr<NCH>(a, W, par, r, dst, 0));
+  }
+}
+template <int NCH> DI void halo_finish(const Args& a, const Wave& W, int plane0, int par, unsigned tag, HaloReq<NCH>& q) {
+#pragma unroll
+  for (int r = 0; r < HaloReq<NCH>::R; ++r) {
+    int dst;
+    const unsigned long long* p = halo_ptr<NCH>(a, W, par, r, dst, plane0);
+    if (dst >= 0) {
+      unsigned long long v = q.v[r];
       int spins = 0;
 #pragma nounroll
       while ((unsigned)(v >> 32) != tag) {
@@ -103,7 +132,7 @@ template <int NCH> DI void fetch_halo(const Args& a, const Wave& W, int plane0, 
         v = granule_load(p);
         if (++spins > SPIN_LIMIT) { *a.err = 1; break; }
       }
-      lds[plane0 + ch * CS + (side ? 40 : 0) + c + 1] = __uint_as_float((unsigned)v);
+      lds[dst] = __uint_as_float((unsigned)v);
     }
   }
 }
@@ -127,9 +156,9 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s
   const bool use_mask = fin && (KL > 0 || j == 0);
   const unsigned gofs = (unsigned)((W.img * 192 + ch0) * 81 + W.band * 27 + W.pos);
 
-  f4v acc[2];
-  acc[0] = (f4v){0.f, 0.f, 0.f, 0.f};
-  acc[1] = (f4v){0.f, 0.f, 0.f, 0.f};
+  f4v acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (f4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     float (&cur)[36] = (u & 1) ? A1 : A0;
@@ -157,6 +186,7 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s
   }
 
   // ---- epilogue: this lane's four cells ----
+  if (a.abl & 2) { asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); return; }
   const float sc = third ? a.rs * a.rs : a.rs;
   const float r1s = third ? a.rs : 1.f;
   const unsigned tag_out = ((unsigned)a.epoch << 12) | (unsigned)(serial + 1);
@@ -168,7 +198,7 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s
     for (int r = 0; r < 4; ++r) {
       const int ch = ch0 + r;
       const int cell = (ch < 64 ? dlow_region + ch * CS : Q0 + (ch - 64) * CS) + W.pofs;
-      float v = acc[0][r] + acc[1][r];
+      float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
       if (KL == 4) {
         v *= sc;
         if (ch < 64) v += r1s * lds[gin_region + ch * CS + W.pofs];  // d out / d a0  (:358, :402)
@@ -201,17 +231,20 @@ template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[36], float (
   constexpr int SMAX = (S + 7) / 8;
   // keep hipcc from hoisting every address of every (layer, sub-tile, register) out of the dense-block loop (it spills)
   asm volatile("" : "+v"(W.pos), "+v"(W.bofs), "+v"(W.pofs), "+v"(W.lane));
-#pragma unroll
-  for (int s = 0; s < SMAX; ++s) {
-    if (W.w + 8 * s < S) sub_tile<KL>(a, W, A0, A1, s, j, gin_region, dlow_region, serial);
-  }
-  // the block that just became final feeds the next layer: fetch its halo rows, then one barrier
+  // the block that becomes final in this layer feeds the next one: its sub-tiles (the highest channels) go first
   constexpr int NCH = KL == 0 ? 64 : 32;
   const int plane0 = KL == 0 ? dlow_region : Q0 + 32 * (KL - 1) * CS;
-  if (!(KL == 0 && j == a.j0)) {
-    const unsigned tag = ((unsigned)a.epoch << 12) | (unsigned)(serial + 1);
-    fetch_halo<NCH>(a, W, plane0, serial & 1, tag);
+  const bool fetch = !(KL == 0 && j == a.j0) && !(a.abl & 1);
+  HaloReq<NCH> hq;
+#pragma unroll
+  for (int s = SMAX - 1; s >= 0; --s) {
+    if (s == 0 && fetch) {
+      halo_issue<NCH>(a, W, serial & 1, hq);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (W.w + 8 * s < S) sub_tile<KL>(a, W, A0, A1, s, j, gin_region, dlow_region, serial);
   }
+  if (fetch) halo_finish<NCH>(a, W, plane0, serial & 1, ((unsigned)a.epoch << 12) | (unsigned)(serial + 1), hq);
   __syncthreads();
 }
 
@@ -295,7 +328,7 @@ __global__ void pack_trunk_fused_bwd_kernel(const float* const* wsrc, float* wst
     int KL = 4, s = 0, u = 0;
     for (int l = 0; l < 5; ++l) {
       const int nu = l == 0 ? 4 : 2;
-      if (ui < nsub[l] * nu) { KL = 4 - l; s = ui / nu; u = ui % nu; break; }
+      if (ui < nsub[l] * nu) { KL = 4 - l; s = nsub[l] - 1 - ui / nu; u = ui % nu; break; }  // highest sub-tile first
       ui -= nsub[l] * nu;
     }
     const int lane = (x % 256) / 4, i = 4 * (x / 256) + x % 4;
@@ -332,6 +365,8 @@ void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s) {
   }
   a.nrdb = L.nrdb; a.j0 = L.j0; a.j1 = L.j1; a.nimg = L.nimg; a.img0 = L.img0; a.epoch = L.epoch & 0xFFFFF;
   a.rs = L.rs; a.slope = L.slope;
+  static const int abl = getenv("DBM_TFB_ABL") ? atoi(getenv("DBM_TFB_ABL")) : 0;
+  a.abl = abl;
   const int grid = ((L.nimg + 7) / 8) * 24;
   hipLaunchKernelGGL(trunk_fused_bwd_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
   DBM_HIP(hipGetLastError());

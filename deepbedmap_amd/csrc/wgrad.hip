@@ -1076,6 +1076,9 @@ static void launch_dma(K kernel, const WgradPlan* plans, const int* starts, int 
 }
 
 void WgradBatch::launch(hipStream_t s) {
+  // measurement aid (tools/phases.py): DBM_NO_WGRAD=1 times the data-gradient chains alone (gradients are then wrong)
+  static const bool skip_all = getenv("DBM_NO_WGRAD") && atoi(getenv("DBM_NO_WGRAD")) != 0;
+  if (skip_all) return;
   if (built && built_deterministic != g_wgrad_deterministic) {  // mode switched: re-plan (keeps the descriptors)
     std::vector<WgradDesc> keep = descs;
     reset();
