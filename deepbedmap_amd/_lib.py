@@ -31,6 +31,7 @@ SIGNATURES = {
     "dbm_fill_f32": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float],
     "dbm_profile_begin": [C.c_void_p],
     "dbm_profile_end": [C.c_void_p, C.POINTER(C.c_double)],
+    "dbm_profile_end_ex": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
     "dbm_phase_marks": [C.c_void_p, C.c_int, C.c_char_p, C.c_int],
     "dbm_malloc": [C.c_void_p, C.c_size_t, c_void_pp],
     "dbm_free": [C.c_void_p, C.c_void_p],

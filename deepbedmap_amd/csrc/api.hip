@@ -159,8 +159,8 @@ int dbm_set_deterministic(dbm_ctx* ctx, int on) {
 int dbm_profile_begin(dbm_ctx* ctx) {
   DBM_API_BEGIN(ctx)
   DBM_HIP(hipStreamSynchronize(ctx->stream));
-  double junk[8];
-  g_profiler.collect(junk);
+  double junk[12];
+  g_profiler.collect(junk, 4);
   g_profiler.enabled = true;
   DBM_API_END
 }
@@ -169,7 +169,19 @@ int dbm_profile_end(dbm_ctx* ctx, double out[8]) {
   DBM_API_BEGIN(ctx)
   g_profiler.enabled = false;
   DBM_HIP(hipStreamSynchronize(ctx->stream));
-  g_profiler.collect(out);
+  double all[12];
+  g_profiler.collect(all, 4);
+  for (int i = 0; i < 6; ++i) out[i] = all[i];
+  out[6] = out[7] = 0.0;
+  DBM_API_END
+}
+
+int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(out != nullptr && nfam >= 1 && nfam <= 4, "dbm_profile_end_ex: nfam must be 1..4");
+  g_profiler.enabled = false;
+  DBM_HIP(hipStreamSynchronize(ctx->stream));
+  g_profiler.collect(out, nfam);
   DBM_API_END
 }
 

@@ -84,14 +84,15 @@ struct ConvDesc {
 void launch_igemm_conv(const ConvDesc& d, hipStream_t s);
 
 // Per-kernel-family timing with HIP events on the launch stream (bench.py's roofline leg).
-// family 0 = igemm_conv_kernel (forward + data gradient), 1 = wgrad_kernel.
+// family 0 = igemm_conv_kernel (forward + data gradient), 1 = weight-gradient kernels, 2 = trunk_fused_kernel,
+// 3 = trunk_fused_bwd_kernel.
 struct KernelProfiler {
   bool enabled = false;
   struct Rec { hipEvent_t a, b; double flops; int family; };
   std::vector<Rec> recs;
   void begin(hipStream_t s, int family, double flops);
   void end(hipStream_t s);
-  void collect(double out[8]);  // [ms, flops, launches] per family, then clears
+  void collect(double* out, int nfam);  // [ms, flops, launches] for families 0 .. nfam-1, then clears
   // phase marks: one event per named point of a training step on the main stream (dbm_phase_marks)
   bool marks_enabled = false;
   std::vector<std::pair<std::string, hipEvent_t>> marks;

@@ -323,15 +323,17 @@ void KernelProfiler::begin(hipStream_t s, int family, double flops) {
 
 void KernelProfiler::end(hipStream_t s) { DBM_HIP(hipEventRecord(recs.back().b, s)); }
 
-void KernelProfiler::collect(double out[8]) {
-  for (int i = 0; i < 8; ++i) out[i] = 0.0;
+void KernelProfiler::collect(double* out, int nfam) {
+  for (int i = 0; i < 3 * nfam; ++i) out[i] = 0.0;
   for (auto& r : recs) {
     DBM_HIP(hipEventSynchronize(r.b));
     float ms = 0.f;
     DBM_HIP(hipEventElapsedTime(&ms, r.a, r.b));
-    out[r.family * 3 + 0] += ms;
-    out[r.family * 3 + 1] += r.flops;
-    out[r.family * 3 + 2] += 1.0;
+    if (r.family < nfam) {
+      out[r.family * 3 + 0] += ms;
+      out[r.family * 3 + 1] += r.flops;
+      out[r.family * 3 + 2] += 1.0;
+    }
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }

@@ -48,7 +48,6 @@ struct Args {
   int* err;
   int nrdb, nimg, img0, epoch;
   float rs, slope;
-  int abl;
 };
 
 struct Wave {
@@ -84,14 +83,14 @@ template <int NM> DI void issue_loads(float (&A)[36], const float* p, int lane) 
 }
 
 // SEL 0: all nine taps; 1: the middle kernel row (needs no halo row); 2: the outer kernel rows
-template <int NM, int SEL, int ABL = 0> DI void mma_taps(const float (&A)[36], int b, f16v (&acc)[2]) {
+template <int NM, int SEL> DI void mma_taps(const float (&A)[36], int b, f16v (&acc)[2]) {
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     if (SEL == 1 && tap / 3 != 1) continue;
     if (SEL == 2 && tap / 3 == 1) continue;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const float bv = (ABL & 1) ? __int_as_float(b) : lds[b + ks * 2 * CS + (tap / 3) * 10 + tap % 3];
+      const float bv = lds[b + ks * 2 * CS + (tap / 3) * 10 + tap % 3];
 #pragma unroll
       for (int mt = 0; mt < NM; ++mt)
         acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[mt * 18 + tap * 2 + ks], bv, acc[mt], 0, 0, 0);
@@ -110,7 +109,7 @@ DI void granule_store(unsigned long long* p, float v, unsigned tag) {
 }  // namespace
 
 // One layer of a dense block.  K = 0..4 (conv_layer1..5).  A0 / A1: the weight ping-pong (static parity per dense block).
-template <int K, int ABL>
+template <int K>
 __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int j, bool last_rdb) {
   constexpr int NM = K == 4 ? 2 : 1;
   constexpr int U = 2 + K;
@@ -181,9 +180,9 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
     const int b = W.bofs + (w + 8 * u) * 4 * CS;
     const bool newest = (K == 0) || (u == U - 1);
     if (!newest) {
-      mma_taps<NM, 0, ABL>(cur, b, acc);
+      mma_taps<NM, 0>(cur, b, acc);
     } else {
-      mma_taps<NM, 1, ABL>(cur, b, acc);
+      mma_taps<NM, 1>(cur, b, acc);
       // pin the middle-row MFMAs BEFORE the wait (hipcc otherwise sinks them below the spin loop: they are pure)
       asm volatile("" : "+v"(acc[0]));
       if (NM == 2) asm volatile("" : "+v"(acc[1]));
@@ -191,7 +190,7 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
       bool ok = true;
 #pragma unroll
       for (int r = 0; r < 2; ++r) ok = ok && (gdst[q][r] < 0 || (unsigned)(gv[q][r] >> 32) == tag_in);
-      if (!__all(ok) && !(a.abl & 1)) {  // rare: the neighbour is behind
+      if (!__all(ok)) {  // rare: the neighbour is behind
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           if (gdst[q][r] >= 0) {
@@ -208,14 +207,13 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
 #pragma unroll
       for (int r = 0; r < 2; ++r)
         if (gdst[q][r] >= 0) lds[gdst[q][r]] = __uint_as_float((unsigned)gv[q][r]);
-      mma_taps<NM, 2, ABL>(cur, b, acc);
+      mma_taps<NM, 2>(cur, b, acc);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   // ---- split-K reduction over the eight wavefronts + epilogue, one 32-channel tile at a time ----
   const unsigned tag_out = ((unsigned)a.epoch << 12) | (unsigned)(serial + 1);
   const int par_out = serial & 1;
-  if (ABL & 2) { asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(bias[0])); return; }
   // uniform bases of this layer's outputs
   float* gbase = nullptr;
   if (K < 4) { if (a.store_all) gbase = a.cat[j] + (64 + 32 * K) * 81; }
@@ -269,7 +267,6 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
   __syncthreads();  // planes written: the next layer may read them
 }
 
-template <int ABL>
 __global__ __launch_bounds__(512) void trunk_fused_kernel(Args a) {
   Wave W;
   W.t = threadIdx.x; W.lane = W.t & 63; W.w = W.t >> 6;
@@ -330,11 +327,11 @@ __global__ __launch_bounds__(512) void trunk_fused_kernel(Args a) {
   W.wp += UNIT;
   for (int j = 0; j < a.nrdb; ++j) {
     const bool last = j == a.nrdb - 1;
-    dense_layer<0, ABL>(a, W, A0, A1, j, last);
-    dense_layer<1, ABL>(a, W, A0, A1, j, last);
-    dense_layer<2, ABL>(a, W, A0, A1, j, last);
-    dense_layer<3, ABL>(a, W, A0, A1, j, last);
-    dense_layer<4, ABL>(a, W, A0, A1, j, last);
+    dense_layer<0>(a, W, A0, A1, j, last);
+    dense_layer<1>(a, W, A0, A1, j, last);
+    dense_layer<2>(a, W, A0, A1, j, last);
+    dense_layer<3>(a, W, A0, A1, j, last);
+    dense_layer<4>(a, W, A0, A1, j, last);
   }
 }
 
@@ -383,10 +380,7 @@ void launch_pack_trunk_fused(const float* const* d_wsrc, const float* const* d_b
 void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    DBM_HIP(hipFuncSetAttribute((const void*)trunk_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     attr = true;
   }
   Args a;
@@ -395,14 +389,11 @@ void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
   for (int i = 0; i < TRUNK_FUSED_MAXCAT; ++i) a.cat[i] = (L.cat && i <= L.nrdb) ? L.cat[i] : nullptr;
   DBM_CHECK(L.nrdb + 1 <= TRUNK_FUSED_MAXCAT, "fused trunk: too many dense blocks");
   a.inbox = L.inbox; a.err = L.err;
-  static const int abl = getenv("DBM_TF_ABL") ? atoi(getenv("DBM_TF_ABL")) : 0;
-  a.abl = abl;
   a.nrdb = L.nrdb; a.nimg = L.nimg; a.img0 = L.img0; a.epoch = L.epoch & 0xFFFFF; a.rs = L.rs; a.slope = L.slope;
   const int grid = ((L.nimg + 7) / 8) * 24;
-  static const int ablk = getenv("DBM_TF_ABLK") ? atoi(getenv("DBM_TF_ABLK")) : 0;
-  if (ablk == 1) hipLaunchKernelGGL(trunk_fused_kernel<1>, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
-  else if (ablk == 2) hipLaunchKernelGGL(trunk_fused_kernel<2>, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
-  else if (ablk == 3) hipLaunchKernelGGL(trunk_fused_kernel<3>, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
-  else hipLaunchKernelGGL(trunk_fused_kernel<0>, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+  const double flop = 2.0 * 19408896.0 * L.nrdb * L.nimg;  // 19 408 896 MAC per dense block and tile
+  if (g_profiler.enabled) g_profiler.begin(s, 2, flop);
+  hipLaunchKernelGGL(trunk_fused_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+  if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
 }

@@ -368,6 +368,8 @@ void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s) {
   static const int abl = getenv("DBM_TFB_ABL") ? atoi(getenv("DBM_TFB_ABL")) : 0;
   a.abl = abl;
   const int grid = ((L.nimg + 7) / 8) * 24;
+  if (g_profiler.enabled) g_profiler.begin(s, 3, 2.0 * 19408896.0 * (L.j1 - L.j0) * L.nimg);
   hipLaunchKernelGGL(trunk_fused_bwd_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
+  if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
 }

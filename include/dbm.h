@@ -50,6 +50,9 @@ int dbm_set_deterministic(dbm_ctx* ctx, int on);
  * gradient), then the same three for wgrad_kernel. */
 int dbm_profile_begin(dbm_ctx* ctx);
 int dbm_profile_end(dbm_ctx* ctx, double out[8]);
+/* the same for nfam <= 4 kernel families, three values each: igemm_conv_kernel, the weight-gradient kernels,
+ * trunk_fused_kernel (RRDB trunk forward, srgan_train.py:546), trunk_fused_bwd_kernel (its data-gradient chain) */
+int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam);
 /* measurement aid: while enabled, the step entry points record one hipEvent per phase boundary on the main stream;
  * enable = 0 stops, synchronises and writes "name milliseconds-since-the-first-mark" lines into out (cap bytes). */
 int dbm_phase_marks(dbm_ctx* ctx, int enable, char* out, int cap);

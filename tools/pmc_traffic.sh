@@ -19,7 +19,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f"{out}/{c}_counter_collection.csv")):
         if r["Counter_Name"] != c:
             continue
-        k = "igemm_conv_kernel" if "igemm_conv_kernel" in r["Kernel_Name"] else ("wgrad_kernel" if "wgrad_" in r["Kernel_Name"] else None)
+        kn = r["Kernel_Name"]
+        k = ("igemm_conv_kernel" if "igemm_conv_kernel" in kn else "trunk_fused_bwd_kernel" if "trunk_fused_bwd_kernel" in kn
+             else "trunk_fused_kernel" if "trunk_fused_kernel" in kn and "pack" not in kn else "wgrad_kernel" if "wgrad_" in kn else None)
         if k:
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     for k, (s, n) in acc.items():
