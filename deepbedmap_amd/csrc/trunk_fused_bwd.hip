@@ -27,7 +27,7 @@ constexpr int P0 = 0, P1 = 64 * CS, Q0 = 128 * CS;  // LDS plane regions: two 64
 constexpr size_t LDS_BYTES = (size_t)256 * CS * sizeof(float);
 
 typedef float f4v __attribute__((ext_vector_type(4)));
-constexpr int NACC = 4;  // independent accumulator chains of a sub-tile (summed in the epilogue)
+constexpr int NACC = 2;  // independent accumulator chains of a sub-tile (summed in the epilogue)
 
 extern __shared__ float lds[];
 
@@ -152,7 +152,7 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s
   // B operand planes: Gout bank (conv5) or D[64 + 32 KL ...]
   const int breg = (KL == 4 ? gin_region : Q0 + 32 * KL * CS) + W.bofs;
 
-  float maskv[4] = {1.f, 1.f, 1.f, 1.f}, extra[4] = {0.f, 0.f, 0.f, 0.f};
+  float maskv[4] = {1.f, 1.f, 1.f, 1.f};
   const bool use_mask = fin && (KL > 0 || j == 0);
   const unsigned gofs = (unsigned)((W.img * 192 + ch0) * 81 + W.band * 27 + W.pos);
 
@@ -172,11 +172,6 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s
 #pragma unroll
         for (int r = 0; r < 4; ++r) maskv[r] = C[gofs + r * 81];
       }
-      if (KL == 0 && j == 0) {
-        const unsigned go = (unsigned)((W.img * 64 + ch0) * 81 + W.band * 27 + W.pos);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) extra[r] = a.g_a3[go + r * 81];
-      }
     }
     issue_unit(nxt, W.wp, lane);
     W.wp += BUNIT;
@@ -186,7 +181,7 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s
   }
 
   // ---- epilogue: this lane's four cells ----
-  if (a.abl & 2) { asm volatile("" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3])); return; }
+  if (a.abl & 2) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); return; }
   const float sc = third ? a.rs * a.rs : a.rs;
   const float r1s = third ? a.rs : 1.f;
   const unsigned tag_out = ((unsigned)a.epoch << 12) | (unsigned)(serial + 1);
@@ -198,14 +193,14 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s
     for (int r = 0; r < 4; ++r) {
       const int ch = ch0 + r;
       const int cell = (ch < 64 ? dlow_region + ch * CS : Q0 + (ch - 64) * CS) + W.pofs;
-      float v = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+      float v = acc[0][r] + acc[1][r];
       if (KL == 4) {
         v *= sc;
         if (ch < 64) v += r1s * lds[gin_region + ch * CS + W.pofs];  // d out / d a0  (:358, :402)
       } else {
         if (KL == 0) {
           if (first) v += W.skipv[r];          // d (RRDB out) / d x  (:402)
-          if (j == 0) v += extra[r];           // a3 = a1 + ...  (:551)
+          if (j == 0) v += a.g_a3[(unsigned)((W.img * 64 + ch) * 81 + W.band * 27 + W.pos)];  // a3 = a1 + ...  (:551)
         }
         v += lds[cell];
       }

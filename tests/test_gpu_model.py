@@ -591,3 +591,63 @@ def test_shared_generator_forward_is_equivalent(dbm, mode):
     # cudnn_deterministic = True (the default): the scheduling variants run the same arithmetic in the same order, so
     # every loss, accuracy and metric of both iterations is bitwise the one of the plain sequential path
     assert results[0] == results[1]
+
+
+# ---- the persistent RRDB-trunk kernels (trunk_fused.hip / trunk_fused_bwd.hip: 9x9 planes only) ----
+@pytest.mark.parametrize("n_blocks,n,rs", [(3, 5, 0.3), (1, 1, 0.1), (2, 9, 0.2)])
+def test_fused_trunk_forward_backward_parity(dbm, n_blocks, n, rs):
+    """11x11 tiles -> 9x9 trunk planes: forward and every gradient against the oracle.  Odd batch sizes leave image
+    clusters partly empty, several RRDBs exercise the `a3*rs + x` skip across launches' internal state, j == 0 the
+    pre-residual mask / g_a3 path (srgan_train.py:333-360, 393-404, 541-551)."""
+    og = scaled_oracle_generator(n_blocks, 1.5, rs=rs)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=n_blocks, residual_scaling=rs, initialize=False), og.params)
+    ins = tile_inputs(n, 11)
+    ref = og.forward(*ins, keep=True)
+    y = g.forward(*ins)
+    assert rel(y.array, ref) < TOL
+    gy = np.random.RandomState(3).normal(size=ref.shape).astype(np.float32)
+    G = og.backward(gy)
+    g.cleargrads()
+    g.backward(gy)
+    worst = grad_errors(g, G)[0]
+    assert worst[0] < 5e-4, worst
+
+
+_FUSED_AB_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import deepbedmap_amd as d
+n = int(sys.argv[3])
+np.random.seed(7)
+g = d.GeneratorModel(num_residual_blocks=2)
+rs = np.random.RandomState(5)
+ins = [rs.rand(n, 1, 11, 11), rs.rand(n, 1, 110, 110), rs.rand(n, 2, 22, 22), rs.rand(n, 1, 11, 11)]
+ins = [a.astype(np.float32) for a in ins]
+with d.using_config("enable_backprop", False):
+    y0 = g.forward(*ins).array
+y = g.forward(*ins)
+gy = rs.normal(size=y.array.shape).astype(np.float32)
+g.cleargrads()
+g.backward(gy)
+grads = np.concatenate([np.asarray(p.grad).ravel() for p in g.params()])
+np.savez(sys.argv[2], y0=np.asarray(y0), y=np.asarray(y.array), grads=grads)
+"""
+
+
+def test_fused_trunk_matches_layerwise_path(dbm, tmp_path):
+    """The same forward / backward with DBM_TRUNK_FUSED=0 (one launch per layer) in a second process: the two paths
+    only differ in summation order.  70 tiles: more than one 64-image launch of the persistent kernels."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ab.py"
+    script.write_text(_FUSED_AB_SCRIPT)
+    outs = {}
+    for fused in ("1", "0"):
+        env = dict(os.environ, DBM_TRUNK_FUSED=fused)
+        out = str(tmp_path / f"o{fused}.npz")
+        subprocess.run([sys.executable, str(script), root, out, "70"], check=True, env=env, timeout=600)
+        outs[fused] = np.load(out)
+    for k in ("y0", "y", "grads"):
+        assert rel(outs["1"][k], outs["0"][k]) < 2e-5, k
