@@ -2,6 +2,7 @@
 #include "model.h"
 
 static const float SLOPE = 0.2f;
+static bool trunk_fused_enabled();
 
 Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
   ctx = c;
@@ -54,6 +55,9 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
   conv("final_conv_layer2/deform_conv", oc, 64, 3, 3);
   T_def2W = tid("final_conv_layer2/deform_conv/W");
   T_def2b = tid("final_conv_layer2/deform_conv/b");
+  // the persistent trunk kernels read their own weight streams: the trunk's per-layer images are built on demand only
+  if (trunk_fused_enabled() && 3 * n + 1 <= TRUNK_FUSED_MAXCAT)
+    for (int i : L_rdb) layers[i].lazy = true;
   alloc_arenas();
 }
 
@@ -261,6 +265,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       launch_trunk_fused(L, s);
     }
   }
+  if (!fused) (owner ? owner : this)->ensure_packed_lazy();
   for (int j = 0; j < (fused ? 0 : nrdb); ++j) {
     for (int c = 0; c < nsplit; ++c) {  // one dense block per range at a time: fewer stream switches on the host
       for (int k = 0; k < 5; ++k) {
@@ -460,6 +465,7 @@ void Generator::backward(const float* gy) {
                   1.f, &wbs[grp]);
     }
   }
+  if (!fused) (owner ? owner : this)->ensure_packed_lazy();
   const int nsplit = fused ? 1 : std::min(trunk_split(N, hw), max_split);
   auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[chain_base + c - 1]; };
   auto chunk = [&](ConvDesc d, int c) {  // descriptor restricted to image range c

@@ -53,6 +53,7 @@ struct IgLayer {
   int OP = 0, CP = 0;
   float* wb[4] = {nullptr, nullptr, nullptr, nullptr};  // dgrad packs [Tb][OP][CP]
   int Tb = 0;
+  bool lazy = false;  // packed on demand only (dbm_model::ensure_packed_lazy)
   signed char bky[4][DBM_MAX_TAPS], bkx[4][DBM_MAX_TAPS], bdy[4][DBM_MAX_TAPS], bdx[4][DBM_MAX_TAPS];
 };
 
@@ -77,6 +78,10 @@ struct dbm_model {
   std::vector<IgLayer> layers;
   PackJob* d_pack_jobs = nullptr;  // device job table of the one-launch weight repack
   int n_pack_jobs = 0, n_pack_blocks = 0;
+  PackJob* d_lazy_jobs = nullptr;  // the same for the layers marked lazy
+  int n_lazy_jobs = 0, n_lazy_blocks = 0;
+  bool pack_tables_built = false;
+  long lazy_version = -1;          // param_version the lazy layers' images were built from
   virtual ~dbm_model();
   int add_tensor(const std::string& key, std::vector<int64_t> shape, int kind);
   void alloc_arenas();
@@ -86,6 +91,7 @@ struct dbm_model {
   int tid(const std::string& key) const;
   int add_iglayer(const std::string& name, int O, int C, int K, int stride, int pad, bool bias, bool as_1x1 = false);
   void ensure_packed(hipStream_t on = nullptr);  // rebuild the packed weight images if the parameters changed
+  void ensure_packed_lazy(hipStream_t on = nullptr);  // ... including the layers marked lazy
   virtual void pack_extra(hipStream_t) {}        // model-specific images, same launch point
   // helpers building descriptors
   ConvDesc fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin, int Win, int ups, float* y, long ysn, int N) const;

@@ -55,6 +55,7 @@ dbm_model::~dbm_model() {
   if (adam_v) (void)hipFree(adam_v);
   if (pers) (void)hipFree(pers);
   if (d_pack_jobs) (void)hipFree(d_pack_jobs);
+  if (d_lazy_jobs) (void)hipFree(d_lazy_jobs);
 }
 
 int dbm_model::add_tensor(const std::string& key, std::vector<int64_t> shape, int kind) {
@@ -141,45 +142,62 @@ int dbm_model::add_iglayer(const std::string& name, int O, int C, int K, int str
   return (int)layers.size() - 1;
 }
 
+// job table of the one-launch repack for the layers with lazy == want_lazy
+static void build_pack_table(const dbm_model& m, bool want_lazy, PackJob** d_jobs, int* njobs, int* nblocks) {
+  std::vector<PackJob> jobs;
+  int blocks = 0;
+  auto add = [&](const IgLayer& L, int T, const signed char* ky, const signed char* kx, int transpose, int KP, int MP,
+                 float* dst) {
+    PackJob j;
+    memset(&j, 0, sizeof(j));
+    j.w = m.P(L.wi); j.dst = dst; j.O = L.O; j.C = L.Cview; j.KH = L.Kview; j.KW = L.Kview; j.T = T;
+    j.transpose = transpose; j.KP = KP; j.MP = MP;
+    for (int t = 0; t < T; ++t) { j.ky[t] = ky[t]; j.kx[t] = kx[t]; }
+    const long total = (long)T * KP * MP;
+    long nb = (total + 2047) / 2048;  // 8 elements per thread
+    if (nb > 64) nb = 64;
+    j.block_start = blocks; j.block_count = (int)nb;
+    blocks += (int)nb;
+    jobs.push_back(j);
+  };
+  for (auto& L : m.layers) {
+    if (L.lazy != want_lazy) continue;
+    const int T = L.Kview * L.Kview;
+    signed char ky[DBM_MAX_TAPS], kx[DBM_MAX_TAPS];
+    for (int t = 0; t < T; ++t) { ky[t] = (signed char)(t / L.Kview); kx[t] = (signed char)(t % L.Kview); }
+    add(L, T, ky, kx, 0, L.CinP, L.CoutP, L.wf);
+    const int nph = L.stride == 1 ? 1 : 4;
+    for (int ph = 0; ph < nph; ++ph) add(L, L.Tb, L.bky[ph], L.bkx[ph], 1, L.OP, L.CP, L.wb[ph]);
+  }
+  *njobs = (int)jobs.size();
+  *nblocks = blocks;
+  if (!jobs.empty()) {
+    DBM_HIP(hipMalloc((void**)d_jobs, jobs.size() * sizeof(PackJob)));
+    DBM_HIP(hipMemcpy(*d_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+    DBM_HIP(hipDeviceSynchronize());
+  }
+}
+
 void dbm_model::ensure_packed(hipStream_t on) {
   if (!packed_dirty) return;
   hipStream_t s = on ? on : ctx->stream;
-  if (!d_pack_jobs) {  // the job table only depends on the layer list: build and upload it once
-    std::vector<PackJob> jobs;
-    int blocks = 0;
-    auto add = [&](const IgLayer& L, int T, const signed char* ky, const signed char* kx, int transpose, int KP, int MP,
-                   float* dst) {
-      PackJob j;
-      memset(&j, 0, sizeof(j));
-      j.w = P(L.wi); j.dst = dst; j.O = L.O; j.C = L.Cview; j.KH = L.Kview; j.KW = L.Kview; j.T = T;
-      j.transpose = transpose; j.KP = KP; j.MP = MP;
-      for (int t = 0; t < T; ++t) { j.ky[t] = ky[t]; j.kx[t] = kx[t]; }
-      const long total = (long)T * KP * MP;
-      long nb = (total + 2047) / 2048;  // 8 elements per thread
-      if (nb > 64) nb = 64;
-      j.block_start = blocks; j.block_count = (int)nb;
-      blocks += (int)nb;
-      jobs.push_back(j);
-    };
-    for (auto& L : layers) {
-      const int T = L.Kview * L.Kview;
-      signed char ky[DBM_MAX_TAPS], kx[DBM_MAX_TAPS];
-      for (int t = 0; t < T; ++t) { ky[t] = (signed char)(t / L.Kview); kx[t] = (signed char)(t % L.Kview); }
-      add(L, T, ky, kx, 0, L.CinP, L.CoutP, L.wf);
-      const int nph = L.stride == 1 ? 1 : 4;
-      for (int ph = 0; ph < nph; ++ph) add(L, L.Tb, L.bky[ph], L.bkx[ph], 1, L.OP, L.CP, L.wb[ph]);
-    }
-    n_pack_jobs = (int)jobs.size();
-    n_pack_blocks = blocks;
-    if (n_pack_jobs) {
-      DBM_HIP(hipMalloc((void**)&d_pack_jobs, jobs.size() * sizeof(PackJob)));
-      DBM_HIP(hipMemcpy(d_pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
-      DBM_HIP(hipDeviceSynchronize());
-    }
+  if (!pack_tables_built) {  // the job tables only depend on the layer list: build and upload them once
+    build_pack_table(*this, false, &d_pack_jobs, &n_pack_jobs, &n_pack_blocks);
+    build_pack_table(*this, true, &d_lazy_jobs, &n_lazy_jobs, &n_lazy_blocks);
+    pack_tables_built = true;
   }
-  launch_pack_jobs(d_pack_jobs, n_pack_jobs, n_pack_blocks, s);
+  if (n_pack_jobs) launch_pack_jobs(d_pack_jobs, n_pack_jobs, n_pack_blocks, s);
   pack_extra(s);
   packed_dirty = false;
+}
+
+// Layers marked lazy (the generator's trunk when the persistent kernels serve it) keep their per-layer images only for
+// the callers that still need them: other plane sizes than 9x9, DBM_TRUNK_FUSED=0.
+void dbm_model::ensure_packed_lazy(hipStream_t on) {
+  ensure_packed(on);
+  if (lazy_version == param_version || !n_lazy_jobs) return;
+  launch_pack_jobs(d_lazy_jobs, n_lazy_jobs, n_lazy_blocks, on ? on : ctx->stream);
+  lazy_version = param_version;
 }
 
 // bf16 forward images (DBM_BF16 inference): dst[t][g][kh][co][i] = bf16(W[co][cin = 16 g + 8 kh + i][tap t])

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Runs on the GPU box: per-kernel STANDALONE durations (rocprofv3 --pmc serialises the dispatches: no two kernels overlap),
+# i.e. the chip time each kernel family costs per training step when nothing shares the GPU with it.
+# usage: tools/serial_kernel_times.sh <tag>
+set -e
+TAG=${1:-serial}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --stats -f csv -d "$OUT" -o ser -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 1 > "$OUT/bench.log" 2>&1
+rm -f "$OUT"/ser_kernel_trace.csv "$OUT"/ser_counter_collection.csv
+ls "$OUT"
