@@ -193,6 +193,18 @@ int dbm_memcpy2d_d2d(dbm_ctx* ctx, void* dst, size_t dpitch, const void* src, si
   DBM_API_END
 }
 
+int dbm_gather_rows(dbm_ctx* ctx, void* dst, const void* src, const int* idx_host, int n, size_t row_bytes) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(n >= 0 && row_bytes % 4 == 0, "dbm_gather_rows: rows must be whole float32 elements");
+  if (n && row_bytes) {
+    DBM_CHECK(idx_host != nullptr, "dbm_gather_rows: idx is NULL");
+    ctx->stage[7].ensure((size_t)n);  // (floats: 4 bytes each, like the int indices)
+    DBM_HIP(hipMemcpyAsync(ctx->stage[7].p, idx_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    launch_gather_rows(src, dst, (const int*)ctx->stage[7].p, n, row_bytes, ctx->stream);
+  }
+  DBM_API_END
+}
+
 int dbm_fill_f32(dbm_ctx* ctx, float* dst, size_t n, float value) {
   DBM_API_BEGIN(ctx)
   if (n) launch_fill(dst, (long)n, value, ctx->stream);

@@ -58,6 +58,7 @@ void launch_gen_loss(const float* y, const float* t, const float* X, int N, int 
 void launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha_t, float one_minus_beta1,
                  float one_minus_beta2, float eps, float gscale, hipStream_t s);
 void launch_fill(float* p, long n, float v, hipStream_t s);
+void launch_gather_rows(const void* src, void* dst, const int* d_idx, int n, size_t row_bytes, hipStream_t s);
 int sqdiff_blocks(long n);  // partial sums launch_sqdiff writes to out[0..blocks)
 void launch_sqdiff(const float* a, const float* b, long n, float* out, hipStream_t s);
 

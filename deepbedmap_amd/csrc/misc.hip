@@ -577,3 +577,26 @@ void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int
   DBM_HIP(hipGetLastError());
 }
 
+
+// chainer.dataset.concat_examples on a device-resident dataset: dst row i = src row idx[i] (rows of `row` elements of V)
+template <typename V>
+__global__ void gather_rows_kernel(const V* __restrict__ src, V* __restrict__ dst, const int* __restrict__ idx, long row) {
+  const long i = blockIdx.y;
+  const V* s = src + (long)idx[i] * row;
+  V* d = dst + i * row;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < row; k += (long)gridDim.x * blockDim.x) d[k] = s[k];
+}
+
+void launch_gather_rows(const void* src, void* dst, const int* d_idx, int n, size_t row_bytes, hipStream_t s) {
+  const bool wide = row_bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0;
+  const long row = (long)(row_bytes / (wide ? 16 : 4));
+  long gx = (row + 255) / 256;
+  if (gx > 64) gx = 64;
+  if (wide)
+    hipLaunchKernelGGL(gather_rows_kernel<float4>, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, (const float4*)src, (float4*)dst,
+                       d_idx, row);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<float>, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, s, (const float*)src, (float*)dst,
+                       d_idx, row);
+  DBM_HIP(hipGetLastError());
+}

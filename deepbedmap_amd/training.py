@@ -155,8 +155,49 @@ class SerialIterator:
 
 
 def concat_examples(dataset, batch):
-    """Gather the rows `batch` (index array) of every array in the dataset dict."""
-    return {k: np.ascontiguousarray(v[batch]) for k, v in dataset.items()}
+    """Gather the rows `batch` (index array) of every array in the dataset dict (chainer.dataset.concat_examples,
+    srgan_train.py:1286-1288).  Arrays that live on the device (the reference moves the whole dataset `to_gpu`,
+    srgan_train.py:107-121) are gathered there -- one kernel per array, no host round trip -- and stay there."""
+    out = {}
+    idx = None
+    for k, v in dataset.items():
+        if _is_device(v):
+            if idx is None:
+                idx = np.ascontiguousarray(batch, dtype=np.int32)
+                if idx.size and (idx.min() < 0 or idx.max() >= len(v)):
+                    raise IndexError("concat_examples: index out of range")
+            dst = DeviceArray((len(idx),) + tuple(v.shape[1:]), v.ctx)
+            row_bytes = 4 * int(np.prod(v.shape[1:]))
+            _lib.check(_lib.lib().dbm_gather_rows(v.ctx.handle, C.c_void_p(dst.ptr), C.c_void_p(v.ptr),
+                                                  idx.ctypes.data_as(C.POINTER(C.c_int)), len(idx), row_bytes), v.ctx.handle)
+            out[k] = dst
+        else:
+            out[k] = np.ascontiguousarray(v[batch])
+    return out
+
+
+def dataset_to_device(dataset, ctx=None):
+    """`chainer.backend.cuda.to_gpu` over the five arrays of the DictDataset (srgan_train.py:107-121)."""
+    return {k: (v if _is_device(v) else to_device(v, ctx)) for k, v in dataset.items()}
+
+
+def split_dataset_random(dataset, first_size: int, seed=None):
+    """chainer.datasets.split_dataset_random: one seeded permutation, the first `first_size` examples and the rest."""
+    n = len(next(iter(dataset.values())))
+    if not 0 <= first_size <= n:
+        raise ValueError("first_size must be in [0, len(dataset)]")
+    order = np.random.RandomState(seed).permutation(n)
+    return concat_examples(dataset, order[:first_size]), concat_examples(dataset, order[first_size:])
+
+
+def get_train_dev_iterators(dataset, first_size: int, batch_size: int = 128, seed: int = 42):
+    """srgan_train.py:132-166: seeded random train / dev split, a shuffling and a sequential repeating iterator."""
+    train_set, dev_set = split_dataset_random(dataset, first_size=first_size, seed=seed)
+    train_iter = SerialIterator(dataset=train_set, batch_size=batch_size, repeat=True, shuffle=True)
+    dev_iter = SerialIterator(dataset=dev_set, batch_size=batch_size, repeat=True, shuffle=False)
+    n_train, n_dev = train_iter.n, dev_iter.n
+    print(f"Training dataset: {n_train} tiles,", f"Development dataset: {n_dev} tiles")
+    return train_iter, n_train, dev_iter, n_dev
 
 
 def trainer(i: int, columns: list, train_iter, dev_iter, g_model, g_optimizer, d_model, d_optimizer, comm=None):

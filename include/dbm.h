@@ -66,6 +66,9 @@ int dbm_memcpy_d2h(dbm_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
 int dbm_memcpy2d_d2d(dbm_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_dev, size_t src_pitch,
                      size_t width_bytes, size_t height);
 int dbm_fill_f32(dbm_ctx* ctx, float* dst_dev, size_t n, float value);
+/* chainer.dataset.concat_examples over a dataset that lives on the device (srgan_train.py:107-121 `to_gpu`, 1286-1288):
+ * dst row i = src row idx[i], rows of row_bytes (a multiple of 4) bytes; idx is a HOST array of n ints.  Asynchronous. */
+int dbm_gather_rows(dbm_ctx* ctx, void* dst_dev, const void* src_dev, const int* idx_host, int n, size_t row_bytes);
 
 /* ---- models ---- */
 /* GeneratorModel.__init__(num_residual_blocks=12, residual_scaling=0.1, out_channels=1): srgan_train.py:450-523.

@@ -651,3 +651,34 @@ def test_fused_trunk_matches_layerwise_path(dbm, tmp_path):
         outs[fused] = np.load(out)
     for k in ("y0", "y", "grads"):
         assert rel(outs["1"][k], outs["0"][k]) < 2e-5, k
+
+
+def test_device_resident_dataset_gather_and_epoch(dbm):
+    """The reference moves the whole DictDataset to the GPU and gathers minibatches there (srgan_train.py:107-121,
+    1286-1288): dbm_gather_rows against NumPy fancy indexing (484-byte rows take the 4-byte path, the others 16-byte),
+    and one `trainer` epoch over device-resident iterators == the same epoch over host arrays."""
+    r = np.random.RandomState(8)
+    n = 24
+    ds = {"X": r.rand(n, 1, 11, 11), "W1": r.rand(n, 1, 110, 110), "W2": r.rand(n, 2, 22, 22), "W3": r.rand(n, 1, 11, 11),
+          "Y": r.rand(n, 1, 36, 36)}
+    ds = {k: v.astype(np.float32) for k, v in ds.items()}
+    dds = dbm.dataset_to_device(ds)
+    idx = np.array([5, 0, 23, 5, 11, 7, 2], dtype=np.int64)
+    got = dbm.concat_examples(dds, idx)
+    for k in ds:
+        np.testing.assert_array_equal(got[k].get(), ds[k][idx])
+    with pytest.raises(IndexError):
+        dbm.concat_examples(dds, np.array([n]))
+    cols = ["discriminator_loss", "discriminator_accu", "generator_loss", "generator_psnr", "generator_ssim",
+            "val_discriminator_loss", "val_discriminator_accu", "val_generator_loss", "val_generator_psnr", "val_generator_ssim"]
+    results = []
+    for data in (ds, dds):
+        np.random.seed(11)
+        g, go, d, do = dbm.compile_srgan_model(num_residual_blocks=1, residual_scaling=0.3, learning_rate=5e-4)
+        train_iter, n_train, dev_iter, n_dev = dbm.get_train_dev_iterators(data, first_size=16, batch_size=8, seed=42)
+        train_iter._rng = np.random.RandomState(3); train_iter.reset()
+        results.append(dbm.trainer(0, cols, train_iter, dev_iter, g, go, d, do))
+        assert (n_train, n_dev) == (16, 8)
+    for c in cols:
+        assert len(results[0][c]) > 0 and np.isfinite(results[0][c]).all()
+        np.testing.assert_array_equal(results[0][c], results[1][c])

@@ -1,6 +1,7 @@
 """CPU tests of the host-side logic that needs no GPU: iterator semantics (srgan_train.py:132-166, 1286-1288,
 1311-1313), tiling index arithmetic (deepbedmap.py:689-741), Chainer parameter ordering, config flags."""
 import numpy as np
+import pytest
 
 import deepbedmap_amd as dbm
 from deepbedmap_amd.srgan import _chainer_order
@@ -72,3 +73,22 @@ def test_residual_scaling_and_blocks_are_plain_attributes():
     # deepbedmap.py:402-405 / srgan_train.py:1577-1578 read them back; they are not serialized
     shapes = omodel.generator_param_shapes(3)
     assert not any("residual_scaling" in k or "num_residual_blocks" in k for k in shapes)
+
+
+def test_get_train_dev_iterators_split_semantics():
+    """srgan_train.py:132-166 / chainer.datasets.split_dataset_random: one seeded permutation, disjoint and complete."""
+    import deepbedmap_amd.training as tr
+
+    n = 40
+    ds = {"X": np.arange(n, dtype=np.float32).reshape(n, 1, 1, 1), "Y": 10 * np.arange(n, dtype=np.float32).reshape(n, 1, 1, 1)}
+    train_iter, n_train, dev_iter, n_dev = tr.get_train_dev_iterators(ds, first_size=int(n * 0.95), batch_size=8, seed=42)
+    assert (n_train, n_dev) == (38, 2)
+    order = np.random.RandomState(42).permutation(n)
+    np.testing.assert_array_equal(train_iter.dataset["X"].ravel(), order[:38].astype(np.float32))
+    np.testing.assert_array_equal(dev_iter.dataset["X"].ravel(), order[38:].astype(np.float32))
+    np.testing.assert_array_equal(train_iter.dataset["Y"].ravel(), 10 * train_iter.dataset["X"].ravel())  # rows stay paired
+    assert train_iter.shuffle and not dev_iter.shuffle and train_iter.repeat and dev_iter.repeat
+    # the dev iterator walks its two tiles in order, wrapping around to fill the batch of 8
+    np.testing.assert_array_equal(dev_iter.next()[:2], [0, 1])
+    with pytest.raises(ValueError):
+        tr.split_dataset_random(ds, first_size=n + 1, seed=0)
