@@ -18,15 +18,31 @@
 namespace {
 
 constexpr int CS = 56;
-constexpr int NWAVE = 8;
+#ifndef TFB_NWAVE
+#define TFB_NWAVE 8
+#endif
+constexpr int NWAVE = TFB_NWAVE;     // 8 or 16 (16 wavefronts, four per SIMD at <= 128 VGPRs: measured 8 % SLOWER)
 constexpr int NTHREADS = NWAVE * 64;
-constexpr int BUNIT = 36 * 64;       // floats per weight unit: one lane's 4 input-channel quads x 9 taps
-constexpr int UNITS_HI = 28, UNITS_LO = 24;  // units per dense block for wavefronts 0..3 / 4..7 (see pack kernel)
+constexpr int QU = NWAVE == 16 ? 2 : 4;  // input-channel quads per weight unit
+constexpr int AU = QU * 9;           // floats per lane per unit: QU quads x 9 taps
+constexpr int BUNIT = AU * 64;       // floats per weight unit
+// sub-tiles of conv_layer5 .. conv_layer1's data gradient (2 * output channels / 16); wavefront w owns w, w + NWAVE, ...
+__host__ __device__ constexpr int layer_subtiles(int l) { return l == 0 ? 24 : l == 1 ? 20 : l == 2 ? 16 : l == 3 ? 12 : 8; }
+__host__ __device__ constexpr int wave_subtiles(int l, int w) {
+  return layer_subtiles(l) > w ? (layer_subtiles(l) - w + NWAVE - 1) / NWAVE : 0;
+}
+__host__ __device__ constexpr int layer_units(int l) { return (l == 0 ? 16 : 8) / QU; }  // units per sub-tile
+__host__ __device__ inline int wave_units(int w) {  // weight units of wavefront w per dense block
+  int n = 0;
+  for (int l = 0; l < 5; ++l) n += wave_subtiles(l, w) * layer_units(l);
+  return n;
+}
 constexpr int SPIN_LIMIT = 1 << 21;
 constexpr int P0 = 0, P1 = 64 * CS, Q0 = 128 * CS;  // LDS plane regions: two 64-channel banks (Gout / D[0:64]), D[64:192]
 constexpr size_t LDS_BYTES = (size_t)256 * CS * sizeof(float);
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 constexpr int NACC = 2;  // independent accumulator chains of a sub-tile (summed in the epilogue)
 
 extern __shared__ float lds[];
@@ -60,23 +76,27 @@ struct Wave {
 
 #define DI __device__ __forceinline__
 
-DI void issue_unit(float (&A)[36], const float* p, int lane) {
+DI void issue_unit(float (&A)[AU], const float* p, int lane) {
 #pragma unroll
-  for (int c = 0; c < 9; ++c) {
+  for (int c = 0; c < AU / 4; ++c) {
     const f4v v = *reinterpret_cast<const f4v*>(p + c * 256 + lane * 4);
     A[4 * c + 0] = v.x; A[4 * c + 1] = v.y; A[4 * c + 2] = v.z; A[4 * c + 3] = v.w;
   }
+  if (AU % 4) {
+    const f2v v = *reinterpret_cast<const f2v*>(p + (AU / 4) * 256 + lane * 2);
+    A[AU - 2] = v.x; A[AU - 1] = v.y;
+  }
 }
 
-// 36 MFMAs of one unit.  The B operands of quad q + 1 are requested before the MFMAs of quad q and pinned there
+// The QU * 9 MFMAs of one unit.  The B operands of quad q + 1 are requested before the MFMAs of quad q and pinned there
 // (hipcc otherwise puts every ds_read right in front of its MFMA: one exposed LDS latency per pair of MFMAs).
-DI void mma_unit(const float (&A)[36], int b, f4v (&acc)[NACC]) {
+DI void mma_unit(const float (&A)[AU], int b, f4v (&acc)[NACC]) {
   float bq[2][9];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) bq[0][tap] = lds[b + (tap / 3) * 10 + tap % 3];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (q < 3) {
+  for (int q = 0; q < QU; ++q) {
+    if (q < QU - 1) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) bq[(q + 1) & 1][tap] = lds[b + (q + 1) * 4 * CS + (tap / 3) * 10 + tap % 3];
     }
@@ -140,12 +160,12 @@ template <int NCH> DI void halo_finish(const Args& a, const Wave& W, int plane0,
 // One sub-tile (16 output channels x 16 positions) of one layer's data gradient.
 //  KL: 4 = conv_layer5 (input Gout, 64 channels, NU = 4 units), 3..0 = conv_layer4..1 (32 input channels, NU = 2)
 template <int KL>
-DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s, int j, int gin_region, int dlow_region,
+DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s, int j, int gin_region, int dlow_region,
                  int serial) {
-  constexpr int NU = KL == 4 ? 4 : 2;
+  constexpr int NU = (KL == 4 ? 16 : 8) / QU;
   constexpr int fin0 = KL == 4 ? 160 : KL == 3 ? 128 : KL == 2 ? 96 : KL == 1 ? 64 : 0;  // first channel that is final
   const int lane = W.lane;
-  const int mt = (W.w >> 1) + 4 * s;           // 16-channel output tile
+  const int mt = (W.w >> 1) + (NWAVE / 2) * s;  // 16-channel output tile
   const int ch0 = 16 * mt + 4 * (lane >> 4);   // this lane's four output channels ch0 .. ch0 + 3
   const bool fin = 16 * mt >= fin0;            // wave-uniform
   const bool third = (j % 3 == 2), first = (j % 3 == 0);
@@ -161,10 +181,10 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s
   for (int i = 0; i < NACC; ++i) acc[i] = (f4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    float (&cur)[36] = (u & 1) ? A1 : A0;
-    float (&nxt)[36] = (u & 1) ? A0 : A1;
+    float (&cur)[AU] = (u & 1) ? A1 : A0;
+    float (&nxt)[AU] = (u & 1) ? A0 : A1;
 #pragma unroll
-    for (int i = 0; i < 36; ++i) asm volatile("" ::"v"(cur[i]));  // the wait for this unit's weights, BEFORE the next issue
+    for (int i = 0; i < AU; ++i) asm volatile("" ::"v"(cur[i]));  // the wait for this unit's weights, BEFORE the next issue
     __builtin_amdgcn_sched_barrier(0);
     if (u == 0 && W.st_ok) {  // what the epilogue reads from global memory: masks of final channels, the j == 0 extras
       if (use_mask) {
@@ -176,7 +196,7 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s
     issue_unit(nxt, W.wp, lane);
     W.wp += BUNIT;
     __builtin_amdgcn_sched_barrier(0);
-    mma_unit(cur, breg + u * 16 * CS, acc);
+    mma_unit(cur, breg + u * QU * 4 * CS, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -219,11 +239,11 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int s
   }
 }
 
-template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[36], float (&A1)[36], int j, int gin_region, int dlow_region,
+template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int j, int gin_region, int dlow_region,
                                int serial) {
   // sub-tiles of this layer: 2 * (64 + 32 KL) / 16 = 24, 20, 16, 12, 8; wavefront w owns w, w + 8, w + 16
   constexpr int S = (64 + 32 * KL) / 8;
-  constexpr int SMAX = (S + 7) / 8;
+  constexpr int SMAX = (S + NWAVE - 1) / NWAVE;
   // keep hipcc from hoisting every address of every (layer, sub-tile, register) out of the dense-block loop (it spills)
   asm volatile("" : "+v"(W.pos), "+v"(W.bofs), "+v"(W.pofs), "+v"(W.lane));
   // the block that becomes final in this layer feeds the next one: its sub-tiles (the highest channels) go first
@@ -237,7 +257,7 @@ template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[36], float (
       halo_issue<NCH>(a, W, serial & 1, hq);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (W.w + 8 * s < S) sub_tile<KL>(a, W, A0, A1, s, j, gin_region, dlow_region, serial);
+    if (W.w + NWAVE * s < S) sub_tile<KL>(a, W, A0, A1, s, j, gin_region, dlow_region, serial);
   }
   if (fetch) halo_finish<NCH>(a, W, plane0, serial & 1, ((unsigned)a.epoch << 12) | (unsigned)(serial + 1), hq);
   __syncthreads();
@@ -245,7 +265,7 @@ template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[36], float (
 
 }  // namespace
 
-__global__ __launch_bounds__(512) void trunk_fused_bwd_kernel(Args a) {
+__global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
   Wave W;
   W.t = threadIdx.x; W.lane = W.t & 63; W.w = W.t >> 6;
   const int B = blockIdx.x;
@@ -267,9 +287,9 @@ __global__ __launch_bounds__(512) void trunk_fused_bwd_kernel(Args a) {
   }
   {
     const int nblk = a.nrdb - a.j1;  // dense blocks already done by earlier launches
-    const size_t per = (size_t)a.nrdb * BUNIT;
-    const size_t base = W.w < 4 ? per * UNITS_HI * W.w : per * (UNITS_HI * 4 + UNITS_LO * (W.w - 4));
-    W.wp = a.wstream + base + (size_t)nblk * BUNIT * (W.w < 4 ? UNITS_HI : UNITS_LO);
+    size_t before = 0;
+    for (int w = 0; w < W.w; ++w) before += wave_units(w);
+    W.wp = a.wstream + ((size_t)a.nrdb * before + (size_t)nblk * wave_units(W.w)) * BUNIT;
   }
   for (int i = W.t; i < 256 * CS; i += NTHREADS) lds[i] = 0.f;
   __syncthreads();
@@ -283,11 +303,12 @@ __global__ __launch_bounds__(512) void trunk_fused_bwd_kernel(Args a) {
   {  // launches cover whole RRDBs: the skip source of the first RRDB is the launch's Gout itself
     const int ch0 = 16 * (W.w >> 1) + 4 * (W.lane >> 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) W.skipv[r] = W.st_ok ? gin[(ch0 + r) * 81 + W.band * 27 + W.pos] : 0.f;
+    for (int r = 0; r < 4; ++r)  // (only the wavefronts that own conv_layer1 sub-tiles: channels < 64)
+      W.skipv[r] = (W.st_ok && ch0 < 64) ? gin[(ch0 + r) * 81 + W.band * 27 + W.pos] : 0.f;
   }
   __syncthreads();
 
-  float A0[36], A1[36];
+  float A0[AU], A1[AU];
   issue_unit(A0, W.wp, W.lane);
   W.wp += BUNIT;
   int serial = 0;
@@ -306,38 +327,42 @@ __global__ __launch_bounds__(512) void trunk_fused_bwd_kernel(Args a) {
 
 // dst-driven gather of the transposed, tap-flipped trunk weights into the per-wavefront streams
 __global__ void pack_trunk_fused_bwd_kernel(const float* const* wsrc, float* wstream, int nrdb) {
-  const long per = (long)nrdb * BUNIT;
-  const long total = per * (UNITS_HI * 4 + UNITS_LO * 4);
+  long total = 0;
+  for (int w = 0; w < NWAVE; ++w) total += (long)nrdb * wave_units(w) * BUNIT;
   for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
-    int w;
-    long rem;
-    if (f < per * UNITS_HI * 4) { w = (int)(f / (per * UNITS_HI)); rem = f % (per * UNITS_HI); }
-    else { const long g = f - per * UNITS_HI * 4; w = 4 + (int)(g / (per * UNITS_LO)); rem = g % (per * UNITS_LO); }
-    const int upr = w < 4 ? UNITS_HI : UNITS_LO;
+    int w = 0;
+    long rem = f;
+    while (rem >= (long)nrdb * wave_units(w) * BUNIT) { rem -= (long)nrdb * wave_units(w) * BUNIT; ++w; }
+    const int upr = wave_units(w);
     const int rblk = (int)(rem / ((long)upr * BUNIT));     // dense blocks in processing order: j = nrdb - 1 - rblk
     int ui = (int)((rem / BUNIT) % upr);
     const int x = (int)(rem % BUNIT);
     const int j = nrdb - 1 - rblk;
-    // unit -> (layer, sub-tile s, unit u)
-    const int nsub[5] = {3, w < 4 ? 3 : 2, 2, w < 4 ? 2 : 1, 1};  // conv5, conv4, conv3, conv2, conv1
+    // unit -> (layer, sub-tile s, unit u); the wavefront walks its sub-tiles from the highest channels down
     int KL = 4, s = 0, u = 0;
     for (int l = 0; l < 5; ++l) {
-      const int nu = l == 0 ? 4 : 2;
-      if (ui < nsub[l] * nu) { KL = 4 - l; s = nsub[l] - 1 - ui / nu; u = ui % nu; break; }  // highest sub-tile first
-      ui -= nsub[l] * nu;
+      const int nu = layer_units(l), ns = wave_subtiles(l, w);
+      if (ui < ns * nu) { KL = 4 - l; s = ns - 1 - ui / nu; u = ui % nu; break; }
+      ui -= ns * nu;
     }
-    const int lane = (x % 256) / 4, i = 4 * (x / 256) + x % 4;
+    int lane, i;
+    if (x < (AU / 4) * 256) { lane = (x % 256) / 4; i = 4 * (x / 256) + x % 4; }
+    else { lane = (x - (AU / 4) * 256) / 2; i = (AU / 4) * 4 + (x - (AU / 4) * 256) % 2; }
     const int q = i / 9, tap = i % 9;
-    const int mt = (w >> 1) + 4 * s;
+    const int mt = (w >> 1) + (NWAVE / 2) * s;
     const int ci = 16 * mt + (lane & 15);                   // forward input channel = gradient output channel
-    const int co = 4 * (4 * u + q) + (lane >> 4);           // forward output channel = K index
+    const int co = 4 * (QU * u + q) + (lane >> 4);          // forward output channel = K index
     const int Cin = 64 + 32 * KL;
     wstream[f] = wsrc[j * 5 + KL][((long)co * Cin + ci) * 9 + (8 - tap)];
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-size_t trunk_fused_bwd_stream_floats(int nrdb) { return (size_t)nrdb * BUNIT * (UNITS_HI * 4 + UNITS_LO * 4) + 4 * BUNIT; }
+size_t trunk_fused_bwd_stream_floats(int nrdb) {
+  size_t units = 0;
+  for (int w = 0; w < NWAVE; ++w) units += wave_units(w);
+  return (size_t)nrdb * units * BUNIT + 4 * BUNIT;
+}
 
 void launch_pack_trunk_fused_bwd(const float* const* d_wsrc, float* wstream, int nrdb, hipStream_t s) {
   hipLaunchKernelGGL(pack_trunk_fused_bwd_kernel, dim3(2048), dim3(256), 0, s, d_wsrc, wstream, nrdb);
