@@ -326,25 +326,30 @@ __global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
 }
 
 // dst-driven gather of the transposed, tap-flipped trunk weights into the per-wavefront streams
-__global__ void pack_trunk_fused_bwd_kernel(const float* const* wsrc, float* wstream, int nrdb) {
-  long total = 0;
-  for (int w = 0; w < NWAVE; ++w) total += (long)nrdb * wave_units(w) * BUNIT;
+struct PackTab {
+  long base[NWAVE + 1];   // first float of wavefront w's stream
+  int upr[NWAVE];         // its units per dense block
+  int cum[NWAVE][6];      // ... and where conv_layer5 .. conv_layer1 start inside them
+  int nsub[NWAVE][5];
+};
+__global__ void pack_trunk_fused_bwd_kernel(const float* const* wsrc, float* wstream, int nrdb, PackTab tab) {
+  const long total = tab.base[NWAVE];
   for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
     int w = 0;
-    long rem = f;
-    while (rem >= (long)nrdb * wave_units(w) * BUNIT) { rem -= (long)nrdb * wave_units(w) * BUNIT; ++w; }
-    const int upr = wave_units(w);
+#pragma unroll
+    for (int k = 1; k < NWAVE; ++k) w += f >= tab.base[k] ? 1 : 0;
+    const long rem = f - tab.base[w];
+    const int upr = tab.upr[w];
     const int rblk = (int)(rem / ((long)upr * BUNIT));     // dense blocks in processing order: j = nrdb - 1 - rblk
-    int ui = (int)((rem / BUNIT) % upr);
+    const int ui = (int)((rem / BUNIT) % upr);
     const int x = (int)(rem % BUNIT);
     const int j = nrdb - 1 - rblk;
     // unit -> (layer, sub-tile s, unit u); the wavefront walks its sub-tiles from the highest channels down
-    int KL = 4, s = 0, u = 0;
-    for (int l = 0; l < 5; ++l) {
-      const int nu = layer_units(l), ns = wave_subtiles(l, w);
-      if (ui < ns * nu) { KL = 4 - l; s = ns - 1 - ui / nu; u = ui % nu; break; }
-      ui -= ns * nu;
-    }
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k) l += ui >= tab.cum[w][k] ? 1 : 0;
+    const int KL = 4 - l, nu = layer_units(l), ul = ui - tab.cum[w][l];
+    const int s = tab.nsub[w][l] - 1 - ul / nu, u = ul % nu;
     int lane, i;
     if (x < (AU / 4) * 256) { lane = (x % 256) / 4; i = 4 * (x / 256) + x % 4; }
     else { lane = (x - (AU / 4) * 256) / 2; i = (AU / 4) * 4 + (x - (AU / 4) * 256) % 2; }
@@ -365,7 +370,22 @@ size_t trunk_fused_bwd_stream_floats(int nrdb) {
 }
 
 void launch_pack_trunk_fused_bwd(const float* const* d_wsrc, float* wstream, int nrdb, hipStream_t s) {
-  hipLaunchKernelGGL(pack_trunk_fused_bwd_kernel, dim3(2048), dim3(256), 0, s, d_wsrc, wstream, nrdb);
+  PackTab tab;
+  long base = 0;
+  for (int w = 0; w < NWAVE; ++w) {
+    tab.base[w] = base;
+    tab.upr[w] = wave_units(w);
+    int c = 0;
+    for (int l = 0; l < 5; ++l) {
+      tab.cum[w][l] = c;
+      tab.nsub[w][l] = wave_subtiles(l, w);
+      c += wave_subtiles(l, w) * layer_units(l);
+    }
+    tab.cum[w][5] = c;
+    base += (long)nrdb * tab.upr[w] * BUNIT;
+  }
+  tab.base[NWAVE] = base;
+  hipLaunchKernelGGL(pack_trunk_fused_bwd_kernel, dim3(2048), dim3(256), 0, s, d_wsrc, wstream, nrdb, tab);
   DBM_HIP(hipGetLastError());
 }
 
