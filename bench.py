@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--no-deterministic", action="store_true",
                     help="cudnn_deterministic=False: fp32 atomics instead of ordered gradient folds (the reference trains "
                          "with cudnn_deterministic=True, srgan_train.py:69, and so does the headline configuration)")
+    ap.add_argument("--sync-batch-stats", action="store_true",
+                    help="N > 1: BatchNorm / RaGAN statistics over the global batch (exactly one process at batch N*64; slower)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="do not enqueue the G-step's generator forward underneath the D-step's discriminator passes")
     ap.add_argument("--share-generator-forward", action="store_true",
@@ -95,7 +97,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     torch.cuda.set_device(local_rank)
-    comm = dbm.DataParallel() if world > 1 else None
+    comm = dbm.DataParallel(sync_batch_stats=args.sync_batch_stats) if world > 1 else None
     ctx = dbm.Context(local_rank)
     dbm._lib._default_ctx = ctx
     # multi-GPU: libdbm enqueues on the stream torch issues its RCCL collectives on (stream-ordered, no host waits);
@@ -175,7 +177,8 @@ def main():
                        "parallelism": f"dp{world}",
                        "generator_forwards_per_iteration": 1 if args.share_generator_forward else 2,
                        "g_step_forward_prefetched_under_d_step": bool(prefetch),
-                       "cudnn_deterministic": bool(dbm.global_config.cudnn_deterministic)},
+                       "cudnn_deterministic": bool(dbm.global_config.cudnn_deterministic),
+                       "sync_batch_stats": bool(args.sync_batch_stats and world > 1)},
             "roofline": {
                 "bound": "mfma", "kernel": dom["kernel"],
                 "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

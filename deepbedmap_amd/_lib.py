@@ -21,6 +21,9 @@ c_float_p = C.POINTER(C.c_float)
 c_void_pp = C.POINTER(C.c_void_p)
 
 # name -> (argtypes) ; every function returns int except dbm_last_error
+# void allreduce_sum(void* user, float* dev, int n): the sync_batch_stats hook (dbm_set_sync_batch_stats)
+ALLREDUCE_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
+
 SIGNATURES = {
     "dbm_init": [C.c_int, c_void_pp],
     "dbm_shutdown": [C.c_void_p],
@@ -33,6 +36,7 @@ SIGNATURES = {
     "dbm_profile_begin": [C.c_void_p],
     "dbm_profile_end": [C.c_void_p, C.POINTER(C.c_double)],
     "dbm_profile_end_ex": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
+    "dbm_set_sync_batch_stats": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "dbm_phase_marks": [C.c_void_p, C.c_int, C.c_char_p, C.c_int],
     "dbm_malloc": [C.c_void_p, C.c_size_t, c_void_pp],
     "dbm_free": [C.c_void_p, C.c_void_p],

@@ -156,6 +156,16 @@ int dbm_set_deterministic(dbm_ctx* ctx, int on) {
   DBM_API_END
 }
 
+int dbm_set_sync_batch_stats(dbm_ctx* ctx, int world, void (*allreduce_sum)(void* user, float* dev, int n), void* user) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(world >= 1, "dbm_set_sync_batch_stats: world must be >= 1");
+  DBM_CHECK(world == 1 || allreduce_sum != nullptr, "dbm_set_sync_batch_stats: a hook is required for world > 1");
+  ctx->sync_world = world;
+  ctx->sync_fn = world > 1 ? allreduce_sum : nullptr;
+  ctx->sync_user = user;
+  DBM_API_END
+}
+
 int dbm_profile_begin(dbm_ctx* ctx) {
   DBM_API_BEGIN(ctx)
   DBM_HIP(hipStreamSynchronize(ctx->stream));
@@ -595,10 +605,13 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   // forward.  D(fake) starts only after it has finished, so the two BatchNorm running-average updates keep the
   // reference's order (real, then fake: srgan_train.py:1145-1146).
   DBM_MARK(s, "D:begin");
+  // sync_batch_stats: the statistics hooks enqueue their collectives on the main stream, so every discriminator pass
+  // stays there (no side / chain streams for them)
+  const bool sync = c->sync_stats() && train;
   c->fork_to_side(0);
   {
     hipStream_t main_stream = c->stream;
-    c->stream = c->side;
+    if (!sync) c->stream = c->side;
     try {
       d->forward(N, H4, W4, Y, lr, train, train, 0);  // real batch (:1145)
     } catch (...) {
@@ -634,14 +647,23 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   }
   c->join_side();
   d->forward(N, H4, W4, g->yout.p, lf, train, train, 1);   // fake batch (:1146) -- separate BatchNorm statistics
-  launch_ragan_loss(lr, lf, N, 1, 0, metrics, train ? gr : nullptr, train ? gf : nullptr, s);
+  if (sync) {  // relativistic means over the global batch (:995-1004)
+    float* sb = c->sync_buf.p + 3 * 512;
+    launch_ragan_sync_sums(lr, lf, N, sb, s);
+    c->allreduce(sb, 2);
+    launch_ragan_sync_loss(lr, lf, N, c->sync_world, 1, 0, sb, metrics, s);
+    c->allreduce(sb + 2, 2);
+    launch_ragan_sync_grad(lr, lf, N, c->sync_world, 1, 0, sb, gr, gf, s);
+  } else {
+    launch_ragan_loss(lr, lf, N, 1, 0, metrics, train ? gr : nullptr, train ? gf : nullptr, s);
+  }
   DBM_MARK(s, "D:disc_forward_fake+loss");
   if (train) {
     DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));  // cleargrads (:1162)
     // d_loss.backward() (:1163): the real- and the fake-batch graphs are independent (gradients are accumulated
     // with atomics), so the fake batch's pass runs on a second stream; both hand their weight gradients to the side stream
     // (while a prefetched generator forward owns chain[0] / chain[1], both passes stay on the main stream)
-    const bool two_streams = !(prefetch && train);
+    const bool two_streams = !(prefetch && train) && !sync;
     if (two_streams) {
       c->fork(s, c->chain[0], 7);
       c->stream = c->chain[0];

@@ -81,7 +81,13 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
     c.istd[i].ensure(DC_O[i]);
     ConvDesc d = fwd_desc(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, c.z[i].p, (long)DC_O[i] * ho * wo, N);
     launch_igemm_conv(d, s);
-    if (bn_train)
+    if (bn_train && ctx->sync_stats()) {  // statistics of the global batch: local sums -> all-reduce -> apply
+      ctx->sync_buf.ensure(3 * 512 + 4);
+      launch_bn_sync_stats(c.z[i].p, ctx->sync_buf.p, N, DC_O[i], ho * wo, s);
+      ctx->allreduce(ctx->sync_buf.p, 3 * DC_O[i]);
+      launch_bn_sync_fwd_apply(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), ctx->sync_buf.p, c.mean[i].p, c.istd[i].p,
+                               S(T_bn[i][2]), S(T_bn[i][3]), N, DC_O[i], ho * wo, ctx->sync_world, 1e-5f, 0.9f, SLOPE, s);
+    } else if (bn_train)
       launch_bn_train_fwd(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, S(T_bn[i][2]),
                           S(T_bn[i][3]), N, DC_O[i], ho * wo, 1e-5f, 0.9f, SLOPE, s);
     else
@@ -143,8 +149,16 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
   for (int i = 9; i >= 1; --i) {
     const IgLayer& L = layers[L_conv[i]];
     const int hin = hs[i], win = ws[i], ho = hs[i + 1], wo = ws[i + 1];
-    launch_bn_train_bwd(c.z[i].p, gh, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, g_z[slot][i].p, G(T_bn[i][0]),
-                        G(T_bn[i][1]), nullptr, N, DC_O[i], ho * wo, SLOPE, s);
+    if (ctx->sync_stats()) {
+      ctx->sync_buf.ensure(3 * 512 + 4);
+      launch_bn_sync_bwd_sums(c.z[i].p, gh, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, ctx->sync_buf.p,
+                              G(T_bn[i][0]), G(T_bn[i][1]), N, DC_O[i], ho * wo, SLOPE, s);
+      ctx->allreduce(ctx->sync_buf.p, 2 * DC_O[i]);
+      launch_bn_sync_bwd_apply(c.z[i].p, gh, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, ctx->sync_buf.p,
+                               g_z[slot][i].p, N, DC_O[i], ho * wo, ctx->sync_world, SLOPE, s);
+    } else
+      launch_bn_train_bwd(c.z[i].p, gh, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, g_z[slot][i].p, G(T_bn[i][0]),
+                          G(T_bn[i][1]), nullptr, N, DC_O[i], ho * wo, SLOPE, s);
     run_wgrad(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, g_z[slot][i].p, (long)DC_O[i] * ho * wo, ho, wo, N, 1.f,
               merge_slots ? &wbm[wgroup(i)] : &wb[slot][wgroup(i)]);
     ConvDesc d;

@@ -98,3 +98,20 @@ struct TrunkFusedBwdLaunch {
 size_t trunk_fused_bwd_stream_floats(int nrdb);
 void launch_pack_trunk_fused_bwd(const float* const* d_wsrc, float* wstream, int nrdb, hipStream_t s);
 void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s);
+
+// ---- sync_batch_stats (norm_loss.hip): BatchNorm / RaGAN statistics over the global batch of a data-parallel run ----
+void launch_bn_sync_stats(const float* z, float* buf, int N, int C, int plane, hipStream_t s);
+void launch_bn_sync_fwd_apply(const float* z, float* y, const float* gamma, const float* beta, const float* buf, float* mean,
+                              float* inv_std, float* avg_mean, float* avg_var, int N, int C, int plane, int world, float eps,
+                              float decay, float slope, hipStream_t s);
+void launch_bn_sync_bwd_sums(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
+                             const float* inv_std, float* buf, float* ggamma, float* gbeta, int N, int C, int plane, float slope,
+                             hipStream_t s);
+void launch_bn_sync_bwd_apply(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
+                              const float* inv_std, const float* buf, float* gz, int N, int C, int plane, int world, float slope,
+                              hipStream_t s);
+void launch_ragan_sync_sums(const float* real, const float* fake, int N, float* buf, hipStream_t s);
+void launch_ragan_sync_loss(const float* real, const float* fake, int N, int world, int real_target, int fake_target, float* buf,
+                            float* out, hipStream_t s);
+void launch_ragan_sync_grad(const float* real, const float* fake, int N, int world, int real_target, int fake_target,
+                            const float* buf, float* g_real, float* g_fake, hipStream_t s);

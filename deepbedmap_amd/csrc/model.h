@@ -25,6 +25,14 @@ struct dbm_ctx {
   void fork_to_side(int k);          // side waits for everything enqueued on `stream` so far
   void join_side();                  // `stream` waits for everything enqueued on `side` so far
   std::string err;
+  // sync_batch_stats (dbm_set_sync_batch_stats): > 1 = BatchNorm / RaGAN statistics are summed over `sync_world` ranks by
+  // the caller's hook, which must enqueue the collective on `stream`
+  int sync_world = 1;
+  void (*sync_fn)(void* user, float* dev, int n) = nullptr;
+  void* sync_user = nullptr;
+  bool sync_stats() const { return sync_world > 1 && sync_fn != nullptr; }
+  void allreduce(float* dev, int n) { sync_fn(sync_user, dev, n); }
+  DevBuf sync_buf;            // 3 x 512 floats of per-channel sums + 4 for the loss
   int* dev_err = nullptr;     // host-mapped word a persistent kernel raises when a bounded spin runs out (checked by every API call)
   int* dev_err_d = nullptr;   // its device address
   float* zeros = nullptr;     // 256 B of zeros (igemm out-of-image taps)

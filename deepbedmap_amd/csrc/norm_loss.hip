@@ -167,6 +167,114 @@ void launch_bn_train_bwd(const float* z, const float* gh, const float* gamma, co
 }
 
 // ----------------------------------------------------------------------------------------------
+// sync_batch_stats: BatchNorm over the GLOBAL batch of a data-parallel run.  Each pass is cut where the
+// per-channel sums cross ranks: local statistics -> all-reduce (the caller's hook) -> apply.  Local means / M2 are
+// combined Chan-style (sum of means, of M2 and of squared means: equal counts per rank), so the variance keeps the
+// two-pass accuracy of the single-process kernel.
+// ----------------------------------------------------------------------------------------------
+#define BN_SYNC_FOR_EACH(body)                                              \
+  for (long e = threadIdx.x; e < m; e += 256) {                             \
+    const int n = (int)(e / plane), p = (int)(e - (long)n * plane);         \
+    const long idx = ((long)n * C + c) * plane + p;                         \
+    body                                                                    \
+  }
+
+__global__ __launch_bounds__(256) void bn_sync_stats_kernel(const float* __restrict__ z, float* buf, int N, int C, int plane) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x;
+  const long m = (long)N * plane;
+  float s = 0.f;
+  BN_SYNC_FOR_EACH(s += z[idx];)
+  const float mean = block_sum<256>(s, sh) / (float)m;
+  float q = 0.f;
+  BN_SYNC_FOR_EACH(const float d = z[idx] - mean; q += d * d;)
+  const float M2 = block_sum<256>(q, sh);
+  if (threadIdx.x == 0) { buf[c] = mean; buf[C + c] = M2; buf[2 * C + c] = mean * mean; }
+}
+
+__global__ __launch_bounds__(256) void bn_sync_fwd_apply_kernel(const float* __restrict__ z, float* __restrict__ y,
+                                                                const float* gamma, const float* beta, const float* buf,
+                                                                float* mean_o, float* istd_o, float* avg_mean, float* avg_var,
+                                                                int N, int C, int plane, int world, float eps, float decay,
+                                                                float slope) {
+  const int c = blockIdx.x;
+  const long m = (long)N * plane;
+  const double mg = (double)m * world;
+  const float mean = buf[c] / (float)world;
+  const float M2 = buf[C + c] + (float)m * (buf[2 * C + c] - (float)world * mean * mean);
+  const float var = fmaxf(M2, 0.f) / (float)mg;
+  const float istd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_o[c] = mean;
+    istd_o[c] = istd;
+    const float adjust = (float)(mg / (mg - 1 > 1 ? mg - 1 : 1.0));
+    avg_mean[c] = avg_mean[c] * decay + (1.f - decay) * mean;
+    avg_var[c] = avg_var[c] * decay + ((1.f - decay) * adjust) * var;
+  }
+  const float g = gamma[c], b = beta[c];
+  BN_SYNC_FOR_EACH(const float v = g * ((z[idx] - mean) * istd) + b; y[idx] = v >= 0.f ? v : slope * v;)
+}
+
+__global__ __launch_bounds__(256) void bn_sync_bwd_sums_kernel(const float* __restrict__ z, const float* __restrict__ gh,
+                                                               const float* gamma, const float* beta, const float* mean_i,
+                                                               const float* istd_i, float* buf, float* ggamma, float* gbeta,
+                                                               int N, int C, int plane, float slope) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x;
+  const long m = (long)N * plane;
+  const float mean = mean_i[c], istd = istd_i[c], g = gamma[c], b = beta[c];
+  float s1 = 0.f, s2 = 0.f;
+  BN_SYNC_FOR_EACH(const float xh = (z[idx] - mean) * istd; const float yv = g * xh + b;
+                   const float gt = yv >= 0.f ? gh[idx] : slope * gh[idx]; s1 += gt; s2 += gt * xh;)
+  const float sg = block_sum<256>(s1, sh);
+  const float sgx = block_sum<256>(s2, sh);
+  if (threadIdx.x == 0) {
+    buf[c] = sg; buf[C + c] = sgx;
+    atomicAdd(ggamma + c, sgx);  // this rank's share: the gradient all-reduce sums the ranks
+    atomicAdd(gbeta + c, sg);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_sync_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ gh,
+                                                                const float* gamma, const float* beta, const float* mean_i,
+                                                                const float* istd_i, const float* buf, float* __restrict__ gz,
+                                                                int N, int C, int plane, int world, float slope) {
+  const int c = blockIdx.x;
+  const long m = (long)N * plane;
+  const float mean = mean_i[c], istd = istd_i[c], g = gamma[c], b = beta[c];
+  const float sg = buf[c], sgx = buf[C + c];
+  const float k = g * istd, im = 1.f / ((float)m * (float)world);
+  BN_SYNC_FOR_EACH(const float xh = (z[idx] - mean) * istd; const float yv = g * xh + b;
+                   const float gt = yv >= 0.f ? gh[idx] : slope * gh[idx]; gz[idx] = k * (gt - (sg + xh * sgx) * im);)
+}
+
+void launch_bn_sync_stats(const float* z, float* buf, int N, int C, int plane, hipStream_t s) {
+  hipLaunchKernelGGL(bn_sync_stats_kernel, dim3(C), dim3(256), 0, s, z, buf, N, C, plane);
+  DBM_HIP(hipGetLastError());
+}
+void launch_bn_sync_fwd_apply(const float* z, float* y, const float* gamma, const float* beta, const float* buf, float* mean,
+                              float* inv_std, float* avg_mean, float* avg_var, int N, int C, int plane, int world, float eps,
+                              float decay, float slope, hipStream_t s) {
+  hipLaunchKernelGGL(bn_sync_fwd_apply_kernel, dim3(C), dim3(256), 0, s, z, y, gamma, beta, buf, mean, inv_std, avg_mean, avg_var,
+                     N, C, plane, world, eps, decay, slope);
+  DBM_HIP(hipGetLastError());
+}
+void launch_bn_sync_bwd_sums(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
+                             const float* inv_std, float* buf, float* ggamma, float* gbeta, int N, int C, int plane, float slope,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(bn_sync_bwd_sums_kernel, dim3(C), dim3(256), 0, s, z, gh, gamma, beta, mean, inv_std, buf, ggamma, gbeta, N,
+                     C, plane, slope);
+  DBM_HIP(hipGetLastError());
+}
+void launch_bn_sync_bwd_apply(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
+                              const float* inv_std, const float* buf, float* gz, int N, int C, int plane, int world, float slope,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(bn_sync_bwd_apply_kernel, dim3(C), dim3(256), 0, s, z, gh, gamma, beta, mean, inv_std, buf, gz, N, C, plane,
+                     world, slope);
+  DBM_HIP(hipGetLastError());
+}
+
+// ----------------------------------------------------------------------------------------------
 // L.Linear head of the discriminator (srgan_train.py:646-647, 693-696).  51 300 + 101 parameters.
 // ----------------------------------------------------------------------------------------------
 // one wavefront per output element: both rows are read coalesced, then a shuffle reduction
@@ -276,6 +384,62 @@ __global__ __launch_bounds__(256) void ragan_loss_kernel(const float* __restrict
       g_fake[i] = (1.f / (1.f + expf(-xf)) - tf) / (float)N - S1 / (float)N;
     }
   }
+}
+
+// sync_batch_stats form of the relativistic-average loss: the means of the other class's logits are GLOBAL-batch means
+// (srgan_train.py:995-1004 at the global batch).  buf[0..1] = sums of the logits (all-reduced by the caller), then
+// buf[2..3] = this rank's sums of the sigmoid residuals (all-reduced), then the gradients.
+__global__ __launch_bounds__(256) void ragan_sync_sums_kernel(const float* real, const float* fake, int N, float* buf) {
+  __shared__ float sh[4];
+  float sr = 0.f, sf = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) { sr += real[i]; sf += fake[i]; }
+  const float a = block_sum_256(sr, sh), b = block_sum_256(sf, sh);
+  if (threadIdx.x == 0) { buf[0] = a; buf[1] = b; }
+}
+__global__ __launch_bounds__(256) void ragan_sync_loss_kernel(const float* real, const float* fake, int N, int world, float tr,
+                                                              float tf, float* buf, float* out) {
+  __shared__ float sh[4];
+  const float ng = (float)N * (float)world;
+  const float mr = buf[0] / ng, mf = buf[1] / ng;
+  float l = 0.f, acc = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float xr = real[i] - mf, xf = fake[i] - mr;
+    l += sce_elem(xr, tr) + sce_elem(xf, tf);
+    acc += (real[i] >= 0.f ? 1.f : 0.f) + (fake[i] >= 0.f ? 0.f : 1.f);
+    s1 += (1.f / (1.f + expf(-xr)) - tr) / (float)N;
+    s2 += (1.f / (1.f + expf(-xf)) - tf) / (float)N;
+  }
+  const float L = block_sum_256(l, sh) / (float)N;
+  const float A = block_sum_256(acc, sh) / (float)(2 * N);
+  const float S1 = block_sum_256(s1, sh), S2 = block_sum_256(s2, sh);
+  if (threadIdx.x == 0) { out[0] = L; out[1] = A; buf[2] = S1; buf[3] = S2; }
+}
+__global__ __launch_bounds__(256) void ragan_sync_grad_kernel(const float* real, const float* fake, int N, int world, float tr,
+                                                              float tf, const float* buf, float* g_real, float* g_fake) {
+  const float ng = (float)N * (float)world;
+  const float mr = buf[0] / ng, mf = buf[1] / ng;
+  const float S1 = buf[2] / (float)world, S2 = buf[3] / (float)world;  // mean over ranks of the per-rank sums
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float xr = real[i] - mf, xf = fake[i] - mr;
+    g_real[i] = (1.f / (1.f + expf(-xr)) - tr) / (float)N - S2 / (float)N;
+    g_fake[i] = (1.f / (1.f + expf(-xf)) - tf) / (float)N - S1 / (float)N;
+  }
+}
+void launch_ragan_sync_sums(const float* real, const float* fake, int N, float* buf, hipStream_t s) {
+  hipLaunchKernelGGL(ragan_sync_sums_kernel, dim3(1), dim3(256), 0, s, real, fake, N, buf);
+  DBM_HIP(hipGetLastError());
+}
+void launch_ragan_sync_loss(const float* real, const float* fake, int N, int world, int real_target, int fake_target, float* buf,
+                            float* out, hipStream_t s) {
+  hipLaunchKernelGGL(ragan_sync_loss_kernel, dim3(1), dim3(256), 0, s, real, fake, N, world, (float)real_target,
+                     (float)fake_target, buf, out);
+  DBM_HIP(hipGetLastError());
+}
+void launch_ragan_sync_grad(const float* real, const float* fake, int N, int world, int real_target, int fake_target,
+                            const float* buf, float* g_real, float* g_fake, hipStream_t s) {
+  hipLaunchKernelGGL(ragan_sync_grad_kernel, dim3(1), dim3(256), 0, s, real, fake, N, world, (float)real_target,
+                     (float)fake_target, buf, g_real, g_fake);
+  DBM_HIP(hipGetLastError());
 }
 
 void launch_ragan_loss(const float* real, const float* fake, int N, int real_target, int fake_target, float* out,

@@ -36,7 +36,10 @@ class _ForeignCuda:
 class DataParallel:
     """comm object accepted by train_eval_discriminator / train_eval_generator (`comm=`)."""
 
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, sync_batch_stats=False):
+        """sync_batch_stats=True: the discriminator's BatchNorm statistics and the relativistic-average means are taken
+        over the GLOBAL batch: world x N tiles then train exactly like one process at batch world*N (up to fp32
+        summation order), at the price of ~40 small all-reduces per D-step.  Default False: per-rank statistics."""
         import torch
         import torch.distributed as dist
 
@@ -55,6 +58,8 @@ class DataParallel:
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
         self._views = {}
         self._shared_stream = set()
+        self.sync_batch_stats = bool(sync_batch_stats)
+        self._hooks = {}
 
     def attach(self, ctx):
         """Run libdbm on torch's current HIP stream: torch then orders the RCCL collective after the backward
@@ -70,6 +75,25 @@ class DataParallel:
                 st = self._stream
             ctx.set_stream(st.cuda_stream)
             self._shared_stream.add(id(ctx))
+        if self.sync_batch_stats and self.on_gpu and self.world > 1:
+            self._install_sync_hook(ctx)
+
+    def _install_sync_hook(self, ctx):
+        """dbm_set_sync_batch_stats: libdbm calls back with a small device buffer of per-rank sums; the collective goes
+        onto the stream libdbm shares with torch (attach), so nothing synchronises the host."""
+        import ctypes as C
+
+        from . import _lib
+
+        dev = f"cuda:{self.local_rank}"
+
+        def hook(user, ptr, n):
+            t = self.torch.as_tensor(_ForeignCuda(ptr, n), device=dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+        cb = _lib.ALLREDUCE_HOOK(hook)
+        self._hooks[id(ctx)] = cb  # keep the trampoline alive as long as the context may call it
+        _lib.check(_lib.lib().dbm_set_sync_batch_stats(ctx.handle, self.world, C.cast(cb, C.c_void_p), None), ctx.handle)
 
     def grad_view(self, model):
         """torch view of the model's flat gradient arena (device memory owned by libdbm)."""

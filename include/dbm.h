@@ -45,6 +45,13 @@ int dbm_synchronize(dbm_ctx* ctx);
  * fixed order (no fp32 atomics over a K split: partial sums + an ordered fold kernel, sorted sampling lists, a separate
  * offset-gradient kernel), so a training run is bitwise reproducible; costs a few per cent.  Default 0.  Process-wide. */
 int dbm_set_deterministic(dbm_ctx* ctx, int on);
+/* sync_batch_stats (data-parallel training that must equal ONE process at the global batch): with world > 1 the
+ * discriminator's training-mode BatchNorm layers (srgan_train.py:636-644, 663-689) use the statistics of the global batch in
+ * forward and backward, and calculate_discriminator_loss (srgan_train.py:995-1004) the global-batch means of the logits.
+ * The library computes per-rank sums into a small device buffer and calls allreduce_sum(user, dev, n), which must enqueue
+ * an in-place SUM all-reduce of n floats on the context's stream (RCCL / torch.distributed on the shared stream).
+ * world = 1 (or a NULL hook) restores per-rank statistics, the default. */
+int dbm_set_sync_batch_stats(dbm_ctx* ctx, int world, void (*allreduce_sum)(void* user, float* dev, int n), void* user);
 /* measurement aid (bench.py roofline leg): while enabled, every launch of the two MFMA kernel families is bracketed
  * by hipEvents on the launch stream.  out = [ms, algorithmic FLOP, launches] for igemm_conv_kernel (forward + data
  * gradient), then the same three for wgrad_kernel. */
