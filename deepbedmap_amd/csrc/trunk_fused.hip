@@ -16,7 +16,8 @@
 //  * split-K partial tiles are reduced through LDS; the epilogue (bias, LeakyReLU, `a5*rs + a0`, `a3*rs + x`) writes the
 //    LDS planes, the global concat buffers the backward pass reads (training) and the neighbours' granules.
 // Every spin is bounded (an error word is raised instead of a hang); workgroups never wait for anything but the two
-// neighbours of their own image, 75 KB of LDS lets two workgroups share a CU, so a 192-workgroup launch is resident at once.
+// neighbours of their own image.  241 VGPRs: one workgroup per CU, a 64-image launch (192 workgroups) is resident at once on
+// the 256 CUs; kernels of other streams only delay it (they finish).
 #include "model.h"
 
 namespace {
