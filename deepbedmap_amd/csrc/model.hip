@@ -155,7 +155,7 @@ static void build_pack_table(const dbm_model& m, bool want_lazy, PackJob** d_job
     for (int t = 0; t < T; ++t) { j.ky[t] = ky[t]; j.kx[t] = kx[t]; }
     const long total = (long)T * KP * MP;
     long nb = (total + 2047) / 2048;  // 8 elements per thread
-    if (nb > 64) nb = 64;
+    if (nb > 512) nb = 512;
     j.block_start = blocks; j.block_count = (int)nb;
     blocks += (int)nb;
     jobs.push_back(j);
