@@ -177,7 +177,8 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
     memset(&q, 0, sizeof(q));
     q.x = c.img.p; q.xsn = (long)c.H * c.W; q.Cin = 1; q.Hin = c.H; q.Win = c.W;
     q.Cout = 64; q.OH = c.H; q.OW = c.W; q.KH = q.KW = 3; q.stride = 1; q.pad = 1; q.N = N;
-    launch_smallcin_conv_wgrad(q, gh, 64L * c.H * c.W, G(T_c0W), G(T_c0b), s);
+    c0_scratch[slot].ensure(smallcin_wgrad_scratch_floats(64));
+    launch_smallcin_conv_wgrad(q, gh, 64L * c.H * c.W, G(T_c0W), G(T_c0b), s, c0_scratch[slot].p);
   }
   // conv_layer1..9 weight gradients: one launch per kernel size and half of the stack, on the side stream (they
   // overlap the data-gradient chain and the other batch's backward pass); each slot has its own slabs g_z[slot][*]

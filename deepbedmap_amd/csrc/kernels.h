@@ -12,7 +12,10 @@ struct SmallConvDesc {
   int act; float slope;
 };
 void launch_smallcin_conv_fwd(const SmallConvDesc& d, hipStream_t s);
-void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dysn, float* gW, float* gb, hipStream_t s);
+// scratch (optional, smallcin_wgrad_scratch_floats(Cout) floats, private to the launch): the read-dy-once form for <= 9 taps
+void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dysn, float* gW, float* gb, hipStream_t s,
+                                float* scratch = nullptr);
+size_t smallcin_wgrad_scratch_floats(int Cout);
 
 void launch_im2col(const float* x, float* col, int N, int Cin, int Hin, int Win, int KH, int KW, int stride, int OH, int OW,
                    int KP, hipStream_t s);
