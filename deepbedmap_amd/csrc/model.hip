@@ -153,11 +153,13 @@ static void build_pack_table(const dbm_model& m, bool want_lazy, PackJob** d_job
     j.w = m.P(L.wi); j.dst = dst; j.O = L.O; j.C = L.Cview; j.KH = L.Kview; j.KW = L.Kview; j.T = T;
     j.transpose = transpose; j.KP = KP; j.MP = MP;
     for (int t = 0; t < T; ++t) { j.ky[t] = ky[t]; j.kx[t] = kx[t]; }
-    const long total = (long)T * KP * MP;
-    long nb = (total + 2047) / 2048;  // 8 elements per thread
-    if (nb > 512) nb = 512;
-    j.block_start = blocks; j.block_count = (int)nb;
-    blocks += (int)nb;
+    // one workgroup per 32 x TC tile of the (out, in) plane (pack_weights_kernel)
+    const int taps = L.Kview * L.Kview, TC = taps > 9 ? 16 : 32;
+    DBM_CHECK(taps <= 16 && KP % 32 == 0 && MP % 32 == 0, "pack_weights_kernel: unsupported layer geometry");
+    const int oR = transpose ? KP : MP, cR = transpose ? MP : KP;
+    const int nb = (oR / 32) * (cR / TC);
+    j.block_start = blocks; j.block_count = nb;
+    blocks += nb;
     jobs.push_back(j);
   };
   for (auto& L : m.layers) {
