@@ -663,7 +663,9 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     // d_loss.backward() (:1163): the real- and the fake-batch graphs are independent (gradients are accumulated
     // with atomics), so the fake batch's pass runs on a second stream; both hand their weight gradients to the side stream
     // (while a prefetched generator forward owns chain[0] / chain[1], both passes stay on the main stream)
-    const bool two_streams = !(prefetch && train) && !sync;
+    // (with the persistent trunk kernel the prefetched forward occupies ONE stream, chain[1]: chain[0] is free again)
+    const bool twin_one_stream = !narrow && g->trunk_fused_ok(H - 2, W - 2);
+    const bool two_streams = (!(prefetch && train) || twin_one_stream) && !sync;
     if (two_streams) {
       c->fork(s, c->chain[0], 7);
       c->stream = c->chain[0];
