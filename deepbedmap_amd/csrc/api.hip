@@ -459,26 +459,43 @@ int dbm_discriminator_loss(dbm_ctx* ctx, const float* real, const float* fake, i
 }
 
 // device-side generator loss; all pointers are device pointers.  out3: [g_loss, psnr, ssim].
-static void gen_loss_device(dbm_ctx* ctx, const float* y, const float* t, const float* X, const float* real_logits,
-                            const float* fake_logits, int N, int H, int W, const float w[4], int t_rf, int t_fr,
-                            int win, float* out3, float* gy) {
+// Two halves, because the adversarial term is DETACHED from the generator (srgan_train.py:1229-1237): the gradient gy only
+// needs the content / topographic / SSIM terms (gen_loss_terms), the discriminator's logits only enter the loss VALUE
+// (gen_loss_finish) -- the G-step runs its discriminator forward beside the generator's backward pass.
+static void gen_loss_terms(dbm_ctx* ctx, const float* y, const float* t, const float* X, int N, int H, int W, const float w[4],
+                           int win, float* gy) {
   DBM_CHECK(win == 0 || win == 1, "ssim_window must be 0 (gaussian) or 1 (uniform)");
   hipStream_t s = ctx->stream;
   ctx->loss_tmp.ensure(16 + 5 * (size_t)N);
+  float* sums = ctx->loss_tmp.p + 16 + N;  // 4 N per-tile partial sums
+  DBM_HIP(hipMemsetAsync(ctx->loss_tmp.p, 0, 16 * sizeof(float), s));
+  launch_gen_loss(y, t, X, N, H, W, w[0], w[2], w[3], ctx->ssim_win[win], sums, gy, s);
+}
+// adversarial term: calculate_discriminator_loss(real=ones, fake=D(fake) detached, targets swapped) (:874-879, :1233-1237)
+static void gen_loss_adv(dbm_ctx* ctx, const float* real_logits, const float* fake_logits, int N, int t_rf, int t_fr) {
+  hipStream_t s = ctx->stream;
   float* adv = ctx->loss_tmp.p + 8;    // [8..9]
   float* ones = ctx->loss_tmp.p + 16;  // N
-  float* sums = ones + N;              // 4 N per-tile partial sums
-  DBM_HIP(hipMemsetAsync(ctx->loss_tmp.p, 0, 16 * sizeof(float), s));
   if (!real_logits) {
     launch_fill(ones, N, 1.f, s);
     real_logits = ones;
   }
-  // adversarial term: calculate_discriminator_loss(real=ones, fake=D(fake) detached, targets swapped) (:874-879, :1233-1237)
   launch_ragan_loss(real_logits, fake_logits, N, t_rf, t_fr, adv, nullptr, nullptr, s);
-  launch_gen_loss(y, t, X, N, H, W, w[0], w[2], w[3], ctx->ssim_win[win], sums, gy, s);
+}
+static void gen_loss_finish(dbm_ctx* ctx, int N, int H, int W, const float w[4], float* out3) {
+  hipStream_t s = ctx->stream;
+  const float* adv = ctx->loss_tmp.p + 8;
+  const float* sums = ctx->loss_tmp.p + 16 + N;
   const float nhw = (float)N * H * W, npool = (float)N * (H / 4) * (W / 4), nwin = (float)N * (H - 8) * (W - 8);
   hipLaunchKernelGGL(gen_metrics_kernel, dim3(1), dim3(64), 0, s, sums, N, adv, out3, nhw, npool, nwin, w[0], w[1], w[2], w[3]);
   DBM_HIP(hipGetLastError());
+}
+static void gen_loss_device(dbm_ctx* ctx, const float* y, const float* t, const float* X, const float* real_logits,
+                            const float* fake_logits, int N, int H, int W, const float w[4], int t_rf, int t_fr,
+                            int win, float* out3, float* gy) {
+  gen_loss_terms(ctx, y, t, X, N, H, W, w, win, gy);
+  gen_loss_adv(ctx, real_logits, fake_logits, N, t_rf, t_fr);
+  gen_loss_finish(ctx, N, H, W, w, out3);
 }
 
 int dbm_generator_loss(dbm_ctx* ctx, const float* y_pred, const float* y_true, const float* x, const float* real_logits,
@@ -593,7 +610,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   const bool prefetch = (train & 4) != 0 && !share;
   // bit 8: the caller runs collectives on a stream of its own (RCCL): the prefetched forward then stays on ONE library
   // stream so that, with the caller's two, no more than four are ever busy (see Generator::twin)
-  const bool narrow = (train & 8) != 0;
+  const bool narrow = (train & 8) != 0 && !g->trunk_fused_ok(H - 2, W - 2);  // (a fused pass is one stream anyway)
   train &= 1;
   g->ensure_ws(N, H, W, share && train);
   d->g_out.ensure(4 * (size_t)N);
@@ -664,7 +681,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     // with atomics), so the fake batch's pass runs on a second stream; both hand their weight gradients to the side stream
     // (while a prefetched generator forward owns chain[0] / chain[1], both passes stay on the main stream)
     // (with the persistent trunk kernel the prefetched forward occupies ONE stream, chain[1]: chain[0] is free again)
-    const bool twin_one_stream = !narrow && g->trunk_fused_ok(H - 2, W - 2);
+    const bool twin_one_stream = g->trunk_fused_ok(H - 2, W - 2);
     const bool two_streams = (!(prefetch && train) || twin_one_stream) && !sync;
     if (two_streams) {
       c->fork(s, c->chain[0], 7);
@@ -713,13 +730,16 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
                           t->wsH == H && t->wsW == W && t->graph_in[0] == X && t->graph_in[1] == W1 && t->graph_in[2] == W2 &&
                           t->graph_in[3] == W3;
   Generator* gg = prefetched ? t : g;  // the workspace that holds this step's graph
-  const bool pack_aside = d->packed_dirty && !reuse && !prefetched;
+  const bool pack_aside = d->packed_dirty && !reuse && !prefetched && !train;
   if (pack_aside) {  // the discriminator's weight images (stale since its Adam step) are rebuilt under the generator forward
     c->fork_to_side(5);
     d->ensure_packed(c->side);
   }
+  // Training: the discriminator's eval-mode forward on the fakes only feeds the loss VALUE (detached, :1229-1237), so it
+  // runs on chain[1] -- weight repack included -- beside the generator's backward pass; main joins it for the metrics.
+  const bool overlap_d = train && !reuse;
   if (prefetched) {
-    d->ensure_packed();  // (the main stream has nothing else to do until the prefetched forward has finished)
+    if (!overlap_d) d->ensure_packed();
     DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));
     t->graph_version = -1;  // consumed
   } else if (!reuse) {
@@ -730,14 +750,35 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
   if (pack_aside) c->join_side();
   d->g_out.ensure(4 * (size_t)N);
   float* lf = d->g_out.p;
-  d->forward(N, H4, W4, gg->yout.p, lf, false, false, 1);  // eval-mode BatchNorm, detached (:1228-1229)
-  gen_loss_device(c, gg->yout.p, Y, X, nullptr, lf, N, H4, W4, weights, 0, 1, ssim_window, metrics + 2,
-                  train ? gg->g_y.p : nullptr);
-  DBM_MARK(s, "G:disc_forward+loss");
-  if (train) {
+  if (overlap_d) {
+    gen_loss_terms(c, gg->yout.p, Y, X, N, H4, W4, weights, ssim_window, gg->g_y.p);
+    hipStream_t aux = c->chain[1];
+    c->fork(s, aux, 11);  // fakes, the discriminator's updated weights and the cleared loss scratch are final on `s`
+    c->stream = aux;
+    try {
+      d->forward(N, H4, W4, gg->yout.p, lf, false, false, 1);  // eval-mode BatchNorm, detached (:1228-1229)
+      gen_loss_adv(c, nullptr, lf, N, 0, 1);
+    } catch (...) {
+      c->stream = s;
+      throw;
+    }
+    c->stream = s;
+    DBM_MARK(s, "G:disc_forward+loss");
     DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), s));  // cleargrads (:1255)
     gg->backward(gg->g_y.p);                                             // g_loss.backward() (:1256)
+    c->fork(aux, s, 12);
+    gen_loss_finish(c, N, H4, W4, weights, metrics + 2);
     DBM_MARK(s, "G:generator_backward_joined");
+  } else {
+    d->forward(N, H4, W4, gg->yout.p, lf, false, false, 1);  // eval-mode BatchNorm, detached (:1228-1229)
+    gen_loss_device(c, gg->yout.p, Y, X, nullptr, lf, N, H4, W4, weights, 0, 1, ssim_window, metrics + 2,
+                    train ? gg->g_y.p : nullptr);
+    DBM_MARK(s, "G:disc_forward+loss");
+    if (train) {
+      DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), s));  // cleargrads (:1255)
+      gg->backward(gg->g_y.p);                                             // g_loss.backward() (:1256)
+      DBM_MARK(s, "G:generator_backward_joined");
+    }
   }
   DBM_API_END
 }
