@@ -90,15 +90,20 @@ DI void issue_unit(float (&A)[AU], const float* p, int lane) {
 
 // The QU * 9 MFMAs of one unit.  The B operands of quad q + 1 are requested before the MFMAs of quad q and pinned there
 // (hipcc otherwise puts every ds_read right in front of its MFMA: one exposed LDS latency per pair of MFMAs).
-DI void mma_unit(const float (&A)[AU], int b, f4v (&acc)[NACC]) {
+DI void mma_unit(const float (&A)[AU], int b, int b_next, float (&bq0)[9], f4v (&acc)[NACC]) {
+  // bq0 holds the operands of this unit's first quad (requested during the previous unit); on return those of the next
+  // unit's first quad (b_next < 0: there is none)
   float bq[2][9];
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) bq[0][tap] = lds[b + (tap / 3) * 10 + tap % 3];
+  for (int tap = 0; tap < 9; ++tap) bq[0][tap] = bq0[tap];
 #pragma unroll
   for (int q = 0; q < QU; ++q) {
     if (q < QU - 1) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) bq[(q + 1) & 1][tap] = lds[b + (q + 1) * 4 * CS + (tap / 3) * 10 + tap % 3];
+    } else if (b_next >= 0) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) bq0[tap] = lds[b_next + (tap / 3) * 10 + tap % 3];
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -161,7 +166,7 @@ template <int NCH> DI void halo_finish(const Args& a, const Wave& W, int plane0,
 //  KL: 4 = conv_layer5 (input Gout, 64 channels, NU = 4 units), 3..0 = conv_layer4..1 (32 input channels, NU = 2)
 template <int KL>
 DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s, int j, int gin_region, int dlow_region,
-                 int serial) {
+                 int serial, const float (&bfirst)[9]) {
   constexpr int NU = (KL == 4 ? 16 : 8) / QU;
   constexpr int fin0 = KL == 4 ? 160 : KL == 3 ? 128 : KL == 2 ? 96 : KL == 1 ? 64 : 0;  // first channel that is final
   const int lane = W.lane;
@@ -179,6 +184,9 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
   f4v acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = (f4v){0.f, 0.f, 0.f, 0.f};
+  float bq0[9];  // B operands of the next quad to be multiplied; every sub-tile of a layer starts with the same nine
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) bq0[tap] = bfirst[tap];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     float (&cur)[AU] = (u & 1) ? A1 : A0;
@@ -196,7 +204,7 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
     issue_unit(nxt, W.wp, lane);
     W.wp += BUNIT;
     __builtin_amdgcn_sched_barrier(0);
-    mma_unit(cur, breg + u * QU * 4 * CS, acc);
+    mma_unit(cur, breg + u * QU * 4 * CS, u + 1 < NU ? breg + (u + 1) * QU * 4 * CS : -1, bq0, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -251,13 +259,20 @@ template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[AU], float (
   const int plane0 = KL == 0 ? dlow_region : Q0 + 32 * (KL - 1) * CS;
   const bool fetch = !(KL == 0 && j == a.j0) && !(a.abl & 1);
   HaloReq<NCH> hq;
+  // the first quad's nine B operands are the same for all of this wavefront's sub-tiles of the layer: requested once
+  float bfirst[9];
+  {
+    const int b0 = (KL == 4 ? gin_region : Q0 + 32 * KL * CS) + W.bofs;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) bfirst[tap] = lds[b0 + (tap / 3) * 10 + tap % 3];
+  }
 #pragma unroll
   for (int s = SMAX - 1; s >= 0; --s) {
     if (s == 0 && fetch) {
       halo_issue<NCH>(a, W, serial & 1, hq);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (W.w + NWAVE * s < S) sub_tile<KL>(a, W, A0, A1, s, j, gin_region, dlow_region, serial);
+    if (W.w + NWAVE * s < S) sub_tile<KL>(a, W, A0, A1, s, j, gin_region, dlow_region, serial, bfirst);
   }
   if (fetch) halo_finish<NCH>(a, W, plane0, serial & 1, ((unsigned)a.epoch << 12) | (unsigned)(serial + 1), hq);
   __syncthreads();
