@@ -21,7 +21,8 @@ constexpr int CS = 56;
 #ifndef TFB_NWAVE
 #define TFB_NWAVE 8
 #endif
-constexpr int NWAVE = TFB_NWAVE;     // 8 or 16 (16 wavefronts, four per SIMD at <= 128 VGPRs: measured 8 % SLOWER)
+constexpr int NWAVE = TFB_NWAVE;     // 8 or 16 (16 wavefronts, four per SIMD at <= 128 VGPRs: measured 8 % SLOWER; 4 would
+                                     // need a second skipv set: conv_layer1 then has two sub-tiles per wavefront)
 constexpr int NTHREADS = NWAVE * 64;
 constexpr int QU = NWAVE == 16 ? 2 : 4;  // input-channel quads per weight unit
 constexpr int AU = QU * 9;           // floats per lane per unit: QU quads x 9 taps
