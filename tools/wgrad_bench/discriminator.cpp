@@ -4,7 +4,7 @@
 KernelProfiler g_profiler;
 void KernelProfiler::begin(hipStream_t, int, double) {}
 void KernelProfiler::end(hipStream_t) {}
-void KernelProfiler::collect(double*) {}
+void KernelProfiler::collect(double*, int) {}
 int main(int argc, char** argv) {
   const int N = 64;
   static const int O[10] = {64, 64, 128, 128, 128, 256, 256, 512, 512, 512};

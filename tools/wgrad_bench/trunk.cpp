@@ -4,7 +4,7 @@
 KernelProfiler g_profiler;
 void KernelProfiler::begin(hipStream_t, int, double) {}
 void KernelProfiler::end(hipStream_t) {}
-void KernelProfiler::collect(double*) {}
+void KernelProfiler::collect(double*, int) {}
 int main(int argc, char** argv) {
   const int N = 64, h = 9, w = 9, hw = 81;
   const int nrdb = argc > 1 ? atoi(argv[1]) : 12;
