@@ -765,7 +765,9 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
     c->stream = s;
     DBM_MARK(s, "G:disc_forward+loss");
     DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), s));  // cleargrads (:1255)
+    gg->grads_cleared = true;  // (the memset above: two-slice weight gradients may fold with atomics, bit for bit)
     gg->backward(gg->g_y.p);                                             // g_loss.backward() (:1256)
+    gg->grads_cleared = false;
     c->fork(aux, s, 12);
     gen_loss_finish(c, N, H4, W4, weights, metrics + 2);
     DBM_MARK(s, "G:generator_backward_joined");
@@ -776,7 +778,9 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
     DBM_MARK(s, "G:disc_forward+loss");
     if (train) {
       DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), s));  // cleargrads (:1255)
+      gg->grads_cleared = true;
       gg->backward(gg->g_y.p);                                             // g_loss.backward() (:1256)
+      gg->grads_cleared = false;
       DBM_MARK(s, "G:generator_backward_joined");
     }
   }

@@ -167,6 +167,10 @@ struct WgradBatch {
   std::vector<WgradDesc> descs;
   bool built = false;
   bool built_deterministic = false;
+  // The caller guarantees that every gW / gb of this batch is ZERO when the batch runs and receives nothing else (the
+  // training step: cleargrads, then one backward pass).  Two K slices may then fold with atomics even in deterministic
+  // mode: (0 + a) + b == (0 + b) + a bit for bit -- no partial tiles, no fold kernel for those layers.
+  bool cleared_target = false, built_cleared = false;
   static const int NCAT = 6;  // see WgradBatch::build
   WgradPlan* d_plans[NCAT] = {};
   int* d_starts[NCAT] = {};

@@ -336,6 +336,7 @@ void Generator::backward(const float* gy) {
   const int N = wsN, H = wsH, W = wsW, h = H - 2, w = W - 2;
   const long hw = (long)h * w, P4 = 16 * hw;
   const int H4 = 4 * h, W4 = 4 * w, nrdb = 3 * n_rrdb;
+  for (auto& b : wbs) b.cleared_target = grads_cleared;
   // ---- final_conv_layer2 (deformable, 64 -> 1) ----
   // (its weight gradient only needs gy and the retained columns: side stream, underneath the sampler's backward)
   ctx->fork_to_side(5);

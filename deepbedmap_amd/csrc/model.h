@@ -128,6 +128,7 @@ struct Generator : dbm_model {
   const float* graph_in[4] = {nullptr, nullptr, nullptr, nullptr};
   const float* bw_in[4] = {nullptr, nullptr, nullptr, nullptr};  // forward inputs, needed by the input-block wgrad
   static const int NWB = 7;
+  bool grads_cleared = false;  // set by dbm_generator_step around backward(): cleargrads has just run (WgradBatch::cleared_target)
   WgradBatch wbs[NWB];  // batched weight gradients: tail, 5 trunk groups, pre-residual + input block (launched on the side stream)
   std::vector<DevBuf> cat, dA;
   DevBuf in_x, in_w1, in_w2, in_w3, a0, a3, a41, a42, off1, off2, col1, col2, a51, yout;

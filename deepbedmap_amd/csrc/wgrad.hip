@@ -1023,7 +1023,7 @@ void WgradBatch::build() {
       // a layer without a K split needs no partials: its single contribution per launch goes out with the atomic
       // epilogue (at most two launches' worth meet on a cleared gradient: still order-independent)
       for (auto& pl : plans) {
-        if (pl.S == 1) continue;
+        if (pl.S <= (cleared_target ? 2 : 1)) continue;
         floats += (size_t)pl.S * pl.coutTiles * pl.groups * SLOTS[g] * TPWS[g] * 1024;
         bfloats += (size_t)pl.S * pl.coutTiles * 32;
       }
@@ -1035,7 +1035,7 @@ void WgradBatch::build() {
       for (auto& pl : plans) {
         pl.fold_start = fw;
         fstarts.push_back(fw);
-        if (pl.S == 1) continue;  // (an empty range in the fold table)
+        if (pl.S <= (cleared_target ? 2 : 1)) continue;  // (an empty range in the fold table)
         pl.partial = base; pl.partial_b = bbase;
         pl.fold_slots = SLOTS[g]; pl.fold_cts = CTS[g]; pl.fold_tpw = TPWS[g];
         pl.fold_ctmul = (g <= 2) ? pl.G : (g == 5 ? 1 : 2);
@@ -1060,6 +1060,7 @@ void WgradBatch::build() {
   DBM_HIP(hipDeviceSynchronize());
   built = true;
   built_deterministic = g_wgrad_deterministic;
+  built_cleared = cleared_target;
 }
 
 template <typename K>
@@ -1079,7 +1080,7 @@ void WgradBatch::launch(hipStream_t s) {
   // measurement aid (tools/phases.py): DBM_NO_WGRAD=1 times the data-gradient chains alone (gradients are then wrong)
   static const bool skip_all = getenv("DBM_NO_WGRAD") && atoi(getenv("DBM_NO_WGRAD")) != 0;
   if (skip_all) return;
-  if (built && built_deterministic != g_wgrad_deterministic) {  // mode switched: re-plan (keeps the descriptors)
+  if (built && (built_deterministic != g_wgrad_deterministic || built_cleared != cleared_target)) {  // mode switched: re-plan (keeps the descriptors)
     std::vector<WgradDesc> keep = descs;
     reset();
     descs = keep;
