@@ -156,6 +156,12 @@ struct WgradPlan {
   // wavefront slot w of a workgroup owns input tile grp * fold_ctmul + (w % fold_cts) (if (w % fold_cts) < fold_ctmul) and
   // the fold_tpw taps from (w / fold_cts) * fold_tpw
   int fold_slots, fold_cts, fold_ctmul, fold_tpw;
+  // Pair buffers (the other deterministic folding): K slices 2k and 2k + 1 add with atomics into buffer k, which is
+  // zero and has gW's own layout (+ Cout bias floats): two contributions commute bit for bit.  pair_direct: pair 0 goes
+  // straight to gW / gb (the gradient is known to be zero).  wgrad_pair_fold_kernel adds the buffers in order, clears them.
+  float* pairW;
+  long pair_stride;   // floats per buffer: Cout * Cin * T, then Cout
+  int pair_n, pair_direct;
 };
 extern bool g_wgrad_deterministic;  // dbm_set_deterministic: weight gradients are folded without fp32 atomics
 // fills p, returns the dynamic LDS bytes it needs (0: not eligible for the wave-task form)
@@ -178,6 +184,7 @@ struct WgradBatch {
   size_t lds[NCAT] = {};
   float* d_partial[NCAT] = {};   // scratch of the atomic-free folding (per category)
   int fold_wgs[NCAT] = {};
+  bool pair_mode[NCAT] = {};     // deterministic folding through pair buffers (WgradPlan::pairW)
   double flops[NCAT] = {};
   void add(const WgradDesc& d) { if (!built) descs.push_back(d); }
   void build();

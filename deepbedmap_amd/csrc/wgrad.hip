@@ -40,6 +40,18 @@ bool g_wgrad_deterministic = false;
 
 // Deterministic mode: a wavefront's accumulators go out in register order (256-byte stores) to its slot of the partial
 // buffer; wgrad_fold_kernel sums the K slices in order.
+// gradient targets of K slice bz: gW / gb themselves, or a pair buffer
+__device__ __forceinline__ void pair_targets(const WgradPlan& p, int bz, float*& gW, float*& gb) {
+  gW = p.d.gW; gb = p.d.gb;
+  if (p.pairW) {
+    const int k = (bz >> 1) - p.pair_direct;
+    if (k >= 0) {
+      gW = p.pairW + (long)k * p.pair_stride;
+      gb = gb ? gW + (p.pair_stride - p.d.Cout) : nullptr;
+    }
+  }
+}
+
 template <int TPW>
 __device__ __forceinline__ void store_partial(const WgradPlan& p, int bz, int by, int grp, int slot, int lane, float scale,
                                               const f32x16 (&acc)[TPW]) {
@@ -305,6 +317,8 @@ __global__ __launch_bounds__(256 * (T / TPW), 2) void wgrad_kernel(const WgradPl
     if (d.gb && bx == 0 && tid < 256 && (tid & 7) == 0) p.partial_b[((long)bz * p.coutTiles + by) * 32 + (tid >> 3)] = d.scale * bsum;
     return;
   }
+  float *gWt, *gbt;
+  pair_targets(p, bz, gWt, gbt);
   __syncthreads();  // staging buffers are dead: reuse the LDS
   {
     constexpr int ROWF = 32 * T;  // floats of one output row of a 32-channel input tile
@@ -325,14 +339,14 @@ __global__ __launch_bounds__(256 * (T / TPW), 2) void wgrad_kernel(const WgradPl
           const int rem = e - rl * ROWF;
           const int o = cout0 + 8 * q + rl;
           const int c = cin_w + rem / T;
-          if (o < d.Cout && c < d.Cin) atomicAdd(d.gW + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
+          if (o < d.Cout && c < d.Cin) atomicAdd(gWt + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
         }
       }
       __syncthreads();
     }
   }
   if (d.gb && bx == 0 && tid < 256 && (tid & 7) == 0 && cout0 + (tid >> 3) < d.Cout)
-    atomicAdd(d.gb + cout0 + (tid >> 3), d.scale * bsum);
+    atomicAdd(gbt + cout0 + (tid >> 3), d.scale * bsum);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -489,6 +503,8 @@ __global__ __launch_bounds__(128, 2) void wgrad_wave_dma_kernel(const WgradPlan*
     }
     return;
   }
+  float *gWt, *gbt;
+  pair_targets(p, bz, gWt, gbt);
   __syncthreads();  // the slabs are dead: each wavefront transposes through its own piece of the LDS
   if (wave_active) {
     constexpr int ROWF = 32 * T;
@@ -505,14 +521,14 @@ __global__ __launch_bounds__(128, 2) void wgrad_wave_dma_kernel(const WgradPlan*
         const int rem = e - rl * ROWF;
         const int o = cout0 + 8 * q + rl;
         const int c = cin_w + rem / T;
-        if (o < d.Cout && c < d.Cin) atomicAdd(d.gW + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
+        if (o < d.Cout && c < d.Cin) atomicAdd(gWt + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
       }
       __builtin_amdgcn_wave_barrier();
     }
   }
   if (d.gb && ct == 0) {
     bsum += __shfl_xor(bsum, 32, 64);
-    if (kh == 0 && cout0 + j < d.Cout) atomicAdd(d.gb + cout0 + j, d.scale * bsum);
+    if (kh == 0 && cout0 + j < d.Cout) atomicAdd(gbt + cout0 + j, d.scale * bsum);
   }
 #ifdef DBM_WG_TIMING
   __builtin_amdgcn_s_waitcnt(0);
@@ -704,6 +720,8 @@ __global__ __launch_bounds__(128, 2) void wgrad_band_dma_kernel(const WgradPlan*
     }
     return;
   }
+  float *gWt, *gbt;
+  pair_targets(p, bz, gWt, gbt);
   // ---- fold into gW[o][c][t] (t fastest): 8 output rows at a time through LDS, atomics over consecutive addresses ----
   __syncthreads();
   {
@@ -724,7 +742,7 @@ __global__ __launch_bounds__(128, 2) void wgrad_band_dma_kernel(const WgradPlan*
           const int rem = e - rl * ROWF;
           const int o = cout0 + 8 * q + rl;
           const int c = cin_w + rem / T;
-          if (o < d.Cout && c < d.Cin) atomicAdd(d.gW + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
+          if (o < d.Cout && c < d.Cin) atomicAdd(gWt + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
         }
       }
       if (TG == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
@@ -732,7 +750,7 @@ __global__ __launch_bounds__(128, 2) void wgrad_band_dma_kernel(const WgradPlan*
   }
   if (d.gb && ct == 0 && tg == 0) {
     bsum += __shfl_xor(bsum, 32, 64);
-    if (kh == 0 && cout0 + j < d.Cout) atomicAdd(d.gb + cout0 + j, d.scale * bsum);
+    if (kh == 0 && cout0 + j < d.Cout) atomicAdd(gbt + cout0 + j, d.scale * bsum);
   }
 #ifdef DBM_WG_TIMING
   __builtin_amdgcn_s_waitcnt(0);
@@ -787,6 +805,31 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradPlan* __rest
 }
 
 static inline int odd_up(int v) { return v | 1; }
+
+// The other deterministic folding (pair buffers, see WgradPlan::pairW): gW += buffers in order, the buffers are cleared for
+// the next launch.  Elementwise and coalesced: the buffers have gW's layout.
+__global__ __launch_bounds__(256) void wgrad_pair_fold_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ fstarts,
+                                                              int nplans) {
+  int lo = 0, hi = nplans - 1;
+  const int wg = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (fstarts[mid] <= wg) lo = mid; else hi = mid - 1;
+  }
+  const WgradPlan& p = plans[lo];
+  if (!p.pairW || p.pair_n == 0) return;
+  const long wsize = p.pair_stride - p.d.Cout;
+  const long i = (long)(wg - fstarts[lo]) * 256 + threadIdx.x;
+  if (i >= p.pair_stride) return;
+  float v = 0.f;
+  for (int k = 0; k < p.pair_n; ++k) {
+    float* q = p.pairW + (long)k * p.pair_stride + i;
+    v += *q;
+    *q = 0.f;
+  }
+  if (i < wsize) atomicAdd(p.d.gW + i, v);
+  else if (p.d.gb) atomicAdd(p.d.gb + (i - wsize), v);
+}
 
 static size_t band_plan(const WgradDesc& d, WgradPlan& p, int S_fixed) {
   // row-band LDS-DMA form (wgrad_band_dma_kernel): the largest band of R output rows whose slabs fit half a CU's LDS
@@ -1005,6 +1048,7 @@ void WgradBatch::build() {
         maxlds = std::max(maxlds, wgrad_plan(d, p, g >= 3 ? 0 : level, MODE[g], S_fixed));
         p.zeros = device_zeros();
         p.partial = nullptr; p.partial_b = nullptr; p.fold_start = 0;
+        p.pairW = nullptr; p.pair_n = 0; p.pair_direct = 0; p.pair_stride = 0;
         p.fold_slots = p.fold_cts = p.fold_ctmul = p.fold_tpw = 0;
         starts.push_back(total);
         total += p.wg_count;
@@ -1018,11 +1062,39 @@ void WgradBatch::build() {
     fold_wgs[g] = 0;
     if (g_wgrad_deterministic && !plans.empty()) {
       static const int SLOTS[NCAT] = {4, 4, 8, 2, 2, 2}, CTS[NCAT] = {4, 4, 4, 2, 2, 1}, TPWS[NCAT] = {1, 9, 8, 9, 9, 8};
+      static const int pairs_env = getenv("DBM_WGRAD_PAIRS") ? atoi(getenv("DBM_WGRAD_PAIRS")) : 1;
+      pair_mode[g] = pairs_env != 0;
       size_t floats = 0, bfloats = 0;
       int fw = 0;
+      if (pair_mode[g]) {
+        // pair buffers: slices 2k, 2k + 1 -> buffer k (pair 0 straight to the gradient when it is known to be zero)
+        for (auto& pl : plans) {
+          const int npair = (pl.S + 1) / 2, direct = cleared_target ? 1 : 0;
+          const long stride = (((long)pl.d.Cout * pl.d.Cin * pl.d.KH * pl.d.KW + pl.d.Cout) + 3) & ~3L;
+          if (pl.S > 1 && npair - direct > 0) floats += (size_t)(npair - direct) * stride;
+        }
+        if (d_partial[g]) (void)hipFree(d_partial[g]);
+        DBM_HIP(hipMalloc((void**)&d_partial[g], (floats + 4) * sizeof(float)));
+        DBM_HIP(hipMemset(d_partial[g], 0, (floats + 4) * sizeof(float)));
+        float* base = d_partial[g];
+        for (auto& pl : plans) {
+          pl.fold_start = fw;
+          fstarts.push_back(fw);
+          pl.pairW = nullptr; pl.pair_n = 0; pl.pair_direct = 0; pl.pair_stride = 0;
+          if (pl.S <= 1) continue;
+          const int npair = (pl.S + 1) / 2, direct = cleared_target ? 1 : 0;
+          if (npair - direct <= 0) continue;  // two slices onto a cleared gradient: plain atomics commute
+          // (the stride is the exact tensor size + bias; the arena offset is rounded up to four floats)
+          pl.pair_stride = (long)pl.d.Cout * pl.d.Cin * pl.d.KH * pl.d.KW + pl.d.Cout;
+          pl.pairW = base; pl.pair_n = npair - direct; pl.pair_direct = direct;
+          base += (size_t)pl.pair_n * ((pl.pair_stride + 3) & ~3L);
+          fw += (int)((pl.pair_stride + 255) / 256);
+        }
+      } else {
       // a layer without a K split needs no partials: its single contribution per launch goes out with the atomic
       // epilogue (at most two launches' worth meet on a cleared gradient: still order-independent)
       for (auto& pl : plans) {
+        pl.pairW = nullptr; pl.pair_n = 0; pl.pair_direct = 0; pl.pair_stride = 0;
         if (pl.S <= (cleared_target ? 2 : 1)) continue;
         floats += (size_t)pl.S * pl.coutTiles * pl.groups * SLOTS[g] * TPWS[g] * 1024;
         bfloats += (size_t)pl.S * pl.coutTiles * 32;
@@ -1042,6 +1114,7 @@ void WgradBatch::build() {
         base += (size_t)pl.S * pl.coutTiles * pl.groups * SLOTS[g] * TPWS[g] * 1024;
         bbase += (size_t)pl.S * pl.coutTiles * 32;
         fw += pl.coutTiles * pl.groups * SLOTS[g] * TPWS[g] * 4;
+      }
       }
       fold_wgs[g] = fw;
       for (int v : fstarts) starts.push_back(v);  // the fold table rides behind the launch table
@@ -1096,7 +1169,10 @@ void WgradBatch::launch(hipStream_t s) {
     else if (g == 4) launch_dma(wgrad_band_dma_kernel<9, 9>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else launch_dma(wgrad_band_dma_kernel<16, 8>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     if (fold_wgs[g]) {
-      hipLaunchKernelGGL(wgrad_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);
+      if (pair_mode[g])
+        hipLaunchKernelGGL(wgrad_pair_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);
+      else
+        hipLaunchKernelGGL(wgrad_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);
       DBM_HIP(hipGetLastError());
     }
     if (g_profiler.enabled) g_profiler.end(s);
