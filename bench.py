@@ -23,10 +23,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r1", "traffic_pmc.json")  # tools/pmc_traffic.sh (separate --pmc passes)
+def _traffic_json():  # tools/pmc_traffic.sh (separate --pmc passes); the newest round's file
+    for r in ("r2", "r1"):
+        p = os.path.join(ROOT, "profiles", r, "traffic_pmc.json")
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "r1", "traffic_pmc.json")
+
+
+TRAFFIC_JSON = _traffic_json()
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BATCH_PER_GPU = 64
 N_RRDB = 12
+GFLOP_PER_TILE = 8.43  # 2 G-fwd + 3 D-fwd + G-bwd + 2 D-bwd ~ 4 G_f + 7 D_f at 12 RRDB
 
 
 def baseline_metric():
@@ -44,31 +53,123 @@ def synthetic_batch(n, seed):
             "Y": r(n, 1, 36, 36)}
 
 
-def cpu_baseline(sample_tiles=8):
-    """The oracle (NumPy restatement of the Chainer CPU path: im2col + BLAS sgemm) on this box's host cores, on a
-    bounded sample of the same workload: one full D-step + G-step at batch `sample_tiles`, 12 RRDB."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(threads=None):
+    """The oracle (NumPy restatement of the Chainer CPU path: im2col + BLAS sgemm) on this box's host cores, on a bounded
+    sample of the same workload: the full D-step + G-step (forward, backward, Adam), 12 RRDB, at batch 8 (one warm-up,
+    median of three) and batch 16 (once); the cost model t(N) = a + b N through those two points gives the batch-64 rate
+    (the oracle's batch-64 iteration itself takes minutes on most hosts).  Beside it the same iteration in torch-CPU
+    fp32 (oneDNN convolutions, autograd), a strong-CPU yardstick.  BLAS / torch threads are pinned and reported."""
+    import statistics
+
     from oracle import model as omodel
     from oracle import train as otrain
 
-    arrays = synthetic_batch(sample_tiles, 42)
-    og = omodel.GeneratorModel(num_residual_blocks=N_RRDB, seed=1)
-    od = omodel.DiscriminatorModel(seed=2)
-    g_opt = otrain.Adam(og.params, alpha=1.6e-4)
-    d_opt = otrain.Adam(od.params, alpha=1.6e-4)
-    t0 = time.perf_counter()
-    otrain.train_eval_discriminator(arrays, og, od, d_opt)
-    otrain.train_eval_generator(arrays, og, od, g_opt)
-    dt = time.perf_counter() - t0
-    return {"value": sample_tiles / dt, "unit": "tiles/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"1 full D-step+G-step (fwd+bwd+Adam) at batch {sample_tiles}, 12 RRDB, NumPy/BLAS oracle, "
-                      f"{dt:.1f} s wall"}
+    ncpu = os.cpu_count() or 1
+    threads = threads or min(ncpu, 64)
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=threads)
+    except Exception:
+        limit = None
+
+    def port_step(n):
+        arrays = synthetic_batch(n, 42)
+        og = omodel.GeneratorModel(num_residual_blocks=N_RRDB, seed=1)
+        od = omodel.DiscriminatorModel(seed=2)
+        g_opt = otrain.Adam(og.params, alpha=1.6e-4)
+        d_opt = otrain.Adam(od.params, alpha=1.6e-4)
+        t0 = time.perf_counter()
+        otrain.train_eval_discriminator(arrays, og, od, d_opt)
+        otrain.train_eval_generator(arrays, og, od, g_opt)
+        return time.perf_counter() - t0
+
+    t_all = time.perf_counter()
+    port_step(8)  # warm-up: BLAS thread pool, page faults of the im2col buffers
+    t8 = statistics.median(port_step(8) for _ in range(3))
+    t16 = port_step(16)
+    b = max((t16 - t8) / 8.0, 1e-9)
+    a = max(t8 - 8.0 * b, 0.0)
+    out = {"value": 64.0 / (a + 64.0 * b), "unit": "tiles/s", "cores": threads, "kind": "port",
+           "host_cpus": ncpu, "cpu_model": _cpu_model(), "blas_threads": threads,
+           "measured": {"batch8_s_median_of_3": t8, "batch16_s": t16, "tiles_per_s_at_batch8": 8.0 / t8,
+                        "tiles_per_s_at_batch16": 16.0 / t16},
+           "sample": f"full D-step+G-step (fwd+bwd+Adam), 12 RRDB, NumPy/BLAS oracle: 1 warm-up + median of 3 at batch 8 "
+                     f"({t8:.1f} s), 1 at batch 16 ({t16:.1f} s); value = batch-64 rate from t(N) = {a:.2f} + {b:.3f} N s"}
+    try:  # torch-CPU (oneDNN) fp32, same iteration at batch 8
+        import torch
+
+        from oracle import torch_ref as tr
+
+        torch.set_num_threads(threads)
+        og = omodel.GeneratorModel(num_residual_blocks=N_RRDB, seed=1)
+        od = omodel.DiscriminatorModel(seed=2)
+        Pg, Pd = tr.tp(og.params, torch.float32), tr.tp(od.params, torch.float32)
+        Sd = {k: torch.tensor(np.asarray(v, np.float32)) for k, v in od.persistent.items() if not k.endswith("/N")}
+        arrays = {k: torch.tensor(v) for k, v in synthetic_batch(8, 42).items()}
+
+        def torch_step():
+            t0 = time.perf_counter()
+            tr.training_iteration(Pg, Pd, Sd, arrays, n_blocks=N_RRDB)
+            return time.perf_counter() - t0
+
+        torch_step()
+        tt = statistics.median(torch_step() for _ in range(3))
+        out["torch_cpu"] = {"value": 8.0 / tt, "unit": "tiles/s", "threads": threads,
+                            "sample": f"same iteration, torch {torch.__version__} CPU fp32 (oneDNN, autograd), batch 8, "
+                                      f"1 warm-up + median of 3 ({tt:.2f} s)"}
+    except Exception as e:  # pragma: no cover
+        out["torch_cpu"] = {"error": repr(e)}
+    if limit is not None:
+        limit.restore_original_limits() if hasattr(limit, "restore_original_limits") else None
+    out["wall_s"] = time.perf_counter() - t_all
+    return out
+
+
+def spawn_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher: this process has not touched the GPU (torch is not even imported
+    yet), so it starts N fresh children -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, exactly what `python -m torch.distributed.run --nproc-per-node N` would set -- waits for them and
+    forwards rank 0's JSON line.  Nothing is exec'ed or re-exec'ed.  Returns the exit code."""
+    import socket
+    import subprocess
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="tiles per GPU (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-deterministic", action="store_true",
@@ -80,7 +181,13 @@ def main():
                     help="do not enqueue the G-step's generator forward underneath the D-step's discriminator passes")
     ap.add_argument("--share-generator-forward", action="store_true",
                     help="NOT the headline configuration: reuse the D-step's generator forward in the G-step")
+    ap.add_argument("--dist-backend", default=None, choices=["rccl", "nccl", "gloo"],
+                    help="N > 1: rccl (default) = libdbm's native communicator, gradient buckets overlapped with the backward "
+                         "passes; nccl = torch.distributed's RCCL, one all-reduce after each backward (round-1 form)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     # Contract: rank 0 prints ONE JSON line on stdout.  Libraries write banners to file descriptor 1 from C (RCCL prints its
     # version block when the first communicator is created): everything that is not the result goes to stderr.
@@ -95,9 +202,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
-    comm = dbm.DataParallel(sync_batch_stats=args.sync_batch_stats) if world > 1 else None
+    comm = dbm.DataParallel(backend=args.dist_backend, sync_batch_stats=args.sync_batch_stats) if world > 1 else None
     ctx = dbm.Context(local_rank)
     dbm._lib._default_ctx = ctx
     # multi-GPU: libdbm enqueues on the stream torch issues its RCCL collectives on (stream-ordered, no host waits);
@@ -121,23 +229,33 @@ def main():
                                      prefetch_generator_forward=prefetch)
         dbm.train_eval_generator(batch, g, d, g_opt, comm=comm, share_generator_forward=args.share_generator_forward)
 
+    lib = dbm._lib.lib()
     for _ in range(args.warmup):
         step()
     if comm is not None:
         comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    dbm._lib.check(lib.dbm_timer(ctx.handle, 0, None), ctx.handle)  # HIP events on the library's main stream as well
     for _ in range(args.steps):
         step()
+    dbm._lib.check(lib.dbm_timer(ctx.handle, 1, None), ctx.handle)
     torch.cuda.synchronize()
     if comm is not None:
         comm.barrier()
     dt = time.perf_counter() - t0
+    ev_ms = C.c_double(0.0)
+    dbm._lib.check(lib.dbm_timer(ctx.handle, 2, C.byref(ev_ms)), ctx.handle)
     if comm is not None:
         dt = comm.max_over_ranks(dt)
+    comm_stats = None
+    if comm is not None:
+        cw, cb, cc = C.c_int(0), C.c_size_t(0), C.c_size_t(0)
+        dbm._lib.check(lib.dbm_comm_stats(ctx.handle, C.byref(cw), C.byref(cb), C.byref(cc), 0), ctx.handle)
+        comm_stats = {"backend": comm.backend, "world": cw.value, "bytes_per_step": cb.value / max(args.steps + args.warmup, 1),
+                      "collectives_per_step": cc.value / max(args.steps + args.warmup, 1)}
 
     # ---- roofline leg (outside the timed region): hipEvent-bracketed launches of the dominant kernel ----
-    lib = dbm._lib.lib()
     prof = (C.c_double * 12)()
     dbm._lib.check(lib.dbm_profile_begin(ctx.handle), ctx.handle)
     step()
@@ -166,6 +284,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_hip_events": ev_ms.value / args.steps,  # start .. stop events on the main stream (rank 0)
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -183,6 +302,9 @@ def main():
                 "bound": "mfma", "kernel": dom["kernel"],
                 "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                # the whole step against the same roof: SURVEY 8d's 8.43 GFLOP per tile (4 G_f + 7 D_f at 12 RRDB)
+                "step_algorithmic_gflop": GFLOP_PER_TILE * args.batch,
+                "frac_step": GFLOP_PER_TILE * args.batch * world / (dt / args.steps) / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world),
                 "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                 "algorithmic_gflop_per_launch": dom["algorithmic_gflop_per_launch"],
                 "other_kernels": [{k: f[k] for k in ("kernel", "achieved", "ms_per_step", "launches_per_step", "avg_launch_us")}
@@ -192,9 +314,12 @@ def main():
         try:  # HBM bytes per launch of the dominant kernel: PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, from the committed pass
             with open(TRAFFIC_JSON) as f:
                 out["roofline"]["traffic"] = json.load(f)[dom["key"]]["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r1/traffic_pmc.json (rocprofv3 --pmc, separate passes)"
+                out["roofline"]["traffic_source"] = ("static: " + os.path.relpath(TRAFFIC_JSON, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / "
+                                                     "WRITE_SIZE in separate passes of this command; not measured in this run)")
         except Exception:
             pass
+        if comm_stats is not None:
+            out["config"]["gradient_exchange"] = comm_stats
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -24,7 +24,18 @@ c_void_pp = C.POINTER(C.c_void_p)
 # void allreduce_sum(void* user, float* dev, int n): the sync_batch_stats hook (dbm_set_sync_batch_stats)
 ALLREDUCE_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
 
+# void allreduce_sum(void* user, float* dev, size_t n, void* hip_stream): the gradient-exchange hook (dbm_comm_set_hook)
+COMM_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
 SIGNATURES = {
+    "dbm_comm_unique_id": [C.c_void_p],
+    "dbm_comm_init": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "dbm_comm_set_hook": [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "dbm_comm_destroy": [C.c_void_p],
+    "dbm_comm_broadcast": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int],
+    "dbm_comm_allreduce": [C.c_void_p, C.c_void_p, C.c_size_t],
+    "dbm_comm_stats": [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int],
+    "dbm_allreduce_grads": [C.c_void_p, C.POINTER(C.c_double)],
     "dbm_init": [C.c_int, c_void_pp],
     "dbm_shutdown": [C.c_void_p],
     "dbm_set_stream": [C.c_void_p, C.c_void_p],
@@ -37,6 +48,7 @@ SIGNATURES = {
     "dbm_profile_end": [C.c_void_p, C.POINTER(C.c_double)],
     "dbm_profile_end_ex": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
     "dbm_set_sync_batch_stats": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    "dbm_timer": [C.c_void_p, C.c_int, C.POINTER(C.c_double)],
     "dbm_phase_marks": [C.c_void_p, C.c_int, C.c_char_p, C.c_int],
     "dbm_malloc": [C.c_void_p, C.c_size_t, c_void_pp],
     "dbm_free": [C.c_void_p, C.c_void_p],

@@ -125,6 +125,11 @@ int dbm_shutdown(dbm_ctx* ctx) {
   if (ctx->dev_err) (void)hipHostFree(ctx->dev_err);
   (void)hipFree(ctx->ssim_win[0]);
   (void)hipFree(ctx->ssim_win[1]);
+  ctx->comm_destroy();
+  for (auto& e : ctx->ev_timer)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->ev_comm) (void)hipEventDestroy(ctx->ev_comm);
+  if (ctx->ev_comm_done) (void)hipEventDestroy(ctx->ev_comm_done);
   ctx->loss_tmp.release();
   for (auto& b : ctx->stage) b.release();
   (void)hipStreamSynchronize(ctx->side);
@@ -159,10 +164,62 @@ int dbm_set_deterministic(dbm_ctx* ctx, int on) {
 int dbm_set_sync_batch_stats(dbm_ctx* ctx, int world, void (*allreduce_sum)(void* user, float* dev, int n), void* user) {
   DBM_API_BEGIN(ctx)
   DBM_CHECK(world >= 1, "dbm_set_sync_batch_stats: world must be >= 1");
-  DBM_CHECK(world == 1 || allreduce_sum != nullptr, "dbm_set_sync_batch_stats: a hook is required for world > 1");
+  DBM_CHECK(world == 1 || allreduce_sum != nullptr || (ctx->nccl_comm != nullptr && ctx->comm_world == world),
+            "dbm_set_sync_batch_stats: world > 1 needs a hook or the native communicator (dbm_comm_init) of the same world");
   ctx->sync_world = world;
   ctx->sync_fn = world > 1 ? allreduce_sum : nullptr;
   ctx->sync_user = user;
+  DBM_API_END
+}
+
+// ---- gradient exchange (comm.hip) ----
+int dbm_comm_unique_id(void* out128) {
+  DBM_API_BEGIN(nullptr)
+  DBM_CHECK(out128 != nullptr, "dbm_comm_unique_id: out is NULL");
+  dbm_comm_unique_id_impl(out128);
+  DBM_API_END
+}
+int dbm_comm_init(dbm_ctx* ctx, int rank, int world, const void* id128) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(id128 != nullptr, "dbm_comm_init: id is NULL");
+  ctx->comm_init(rank, world, id128);
+  DBM_API_END
+}
+int dbm_comm_set_hook(dbm_ctx* ctx, int rank, int world,
+                      void (*allreduce_sum)(void* user, float* dev, size_t n, void* hip_stream), void* user) {
+  DBM_API_BEGIN(ctx)
+  ctx->comm_set_hook(rank, world, allreduce_sum, user);
+  DBM_API_END
+}
+int dbm_comm_destroy(dbm_ctx* ctx) {
+  DBM_API_BEGIN(ctx)
+  ctx->comm_destroy();
+  DBM_API_END
+}
+int dbm_comm_broadcast(dbm_ctx* ctx, float* dev, size_t nfloats, int root) {
+  DBM_API_BEGIN(ctx)
+  ctx->comm_broadcast(dev, nfloats, root, ctx->stream);
+  DBM_API_END
+}
+int dbm_comm_allreduce(dbm_ctx* ctx, float* dev, size_t nfloats) {
+  DBM_API_BEGIN(ctx)
+  ctx->comm_allreduce(&dev, &nfloats, 1, ctx->stream);
+  DBM_API_END
+}
+int dbm_comm_stats(dbm_ctx* ctx, int* world, size_t* bytes, size_t* calls, int reset) {
+  DBM_API_BEGIN(ctx)
+  if (world) *world = ctx->comm_active() ? ctx->comm_world : 1;
+  if (bytes) *bytes = ctx->comm_bytes;
+  if (calls) *calls = ctx->comm_calls;
+  if (reset) ctx->comm_bytes = ctx->comm_calls = 0;
+  DBM_API_END
+}
+int dbm_allreduce_grads(dbm_model* m, double* grad_scale) {
+  DBM_API_BEGIN(m->ctx)
+  float* p = m->grads;
+  size_t n = m->nparam;
+  m->ctx->comm_allreduce(&p, &n, 1, m->ctx->stream);
+  if (grad_scale) *grad_scale = m->ctx->comm_active() ? 1.0 / m->ctx->comm_world : 1.0;
   DBM_API_END
 }
 
@@ -218,6 +275,24 @@ int dbm_gather_rows(dbm_ctx* ctx, void* dst, const void* src, const int* idx_hos
 int dbm_fill_f32(dbm_ctx* ctx, float* dst, size_t n, float value) {
   DBM_API_BEGIN(ctx)
   if (n) launch_fill(dst, (long)n, value, ctx->stream);
+  DBM_API_END
+}
+
+int dbm_timer(dbm_ctx* ctx, int op, double* ms) {
+  DBM_API_BEGIN(ctx)
+  for (auto& e : ctx->ev_timer)
+    if (!e) DBM_HIP(hipEventCreate(&e));
+  if (op == 0) {
+    DBM_HIP(hipEventRecord(ctx->ev_timer[0], ctx->stream));
+  } else if (op == 1) {
+    DBM_HIP(hipEventRecord(ctx->ev_timer[1], ctx->stream));
+  } else {
+    DBM_CHECK(ms != nullptr, "dbm_timer: ms is NULL");
+    DBM_HIP(hipEventSynchronize(ctx->ev_timer[1]));
+    float t = 0.f;
+    DBM_HIP(hipEventElapsedTime(&t, ctx->ev_timer[0], ctx->ev_timer[1]));
+    *ms = (double)t;
+  }
   DBM_API_END
 }
 
@@ -611,6 +686,13 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   // bit 8: the caller runs collectives on a stream of its own (RCCL): the prefetched forward then stays on ONE library
   // stream so that, with the caller's two, no more than four are ever busy (see Generator::twin)
   const bool narrow = (train & 8) != 0 && !g->trunk_fused_ok(H - 2, W - 2);  // (a fused pass is one stream anyway)
+  // data-parallel run with a communicator on the context (dbm_comm_init / dbm_comm_set_hook): the gradient buckets are
+  // summed over ranks inside this call, overlapped with the backward passes; bit 4 (16) leaves the exchange to the caller
+  struct CommScope {
+    dbm_ctx* c;
+    CommScope(dbm_ctx* ctx, bool on) : c(ctx) { c->comm_in_step = on; }
+    ~CommScope() { c->comm_in_step = false; }
+  } comm_scope(c, (train & 1) && !(train & 16) && c->comm_active());
   train &= 1;
   g->ensure_ws(N, H, W, share && train);
   d->g_out.ensure(4 * (size_t)N);
@@ -688,6 +770,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
       c->stream = c->chain[0];
     }
     d->merge_slots = true;  // one weight-gradient launch per layer group for both graphs
+    d->comm_sent_lo = d->comm_sent_hi = 0;
     try {
       d->backward(1, gf, false);
       c->stream = s;
@@ -703,6 +786,14 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     DBM_MARK(s, "D:disc_backward_fake_chain_joined");
     c->join_side();
     DBM_MARK(s, "D:weight_gradients_joined");
+    if (c->comm_in_step) {  // what launch_group has not sent yet: [0, lo) and [hi, nparam) in one fused group
+      float* p[2] = {d->grads, d->grads + d->comm_sent_hi};
+      size_t n[2] = {d->comm_sent_lo, d->nparam - d->comm_sent_hi};
+      if (d->comm_sent_hi == 0) { n[0] = d->nparam; n[1] = 0; }
+      c->comm_bucket(p, n, n[1] ? 2 : 1, s);
+      c->comm_join(s);
+      DBM_MARK(s, "D:gradients_exchanged");
+    }
   }
   DBM_API_END
 }
@@ -718,6 +809,11 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
   hipStream_t s = c->stream;
   const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
   const bool share = (train & 2) != 0;
+  struct CommScope {
+    dbm_ctx* c;
+    CommScope(dbm_ctx* ctx, bool on) : c(ctx) { c->comm_in_step = on; }
+    ~CommScope() { c->comm_in_step = false; }
+  } comm_scope(c, (train & 1) && !(train & 16) && c->comm_active());
   train &= 1;
   // Opt-in: the generator and its inputs are unchanged since the D-step of this iteration, so that step's forward
   // (bitwise the same numbers) is reused instead of recomputed.  Off by default: the reference runs it twice.
@@ -768,7 +864,7 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
     gg->grads_cleared = true;  // (the memset above: two-slice weight gradients may fold with atomics, bit for bit)
     gg->backward(gg->g_y.p);                                             // g_loss.backward() (:1256)
     gg->grads_cleared = false;
-    c->fork(aux, s, 12);
+    c->fork(aux, s, 12);  // (chain[1] also carried the gradient exchange of a data-parallel run)
     gen_loss_finish(c, N, H4, W4, weights, metrics + 2);
     DBM_MARK(s, "G:generator_backward_joined");
   } else {
@@ -781,6 +877,7 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
       gg->grads_cleared = true;
       gg->backward(gg->g_y.p);                                             // g_loss.backward() (:1256)
       gg->grads_cleared = false;
+      c->comm_join(s);
       DBM_MARK(s, "G:generator_backward_joined");
     }
   }

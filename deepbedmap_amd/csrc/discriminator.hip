@@ -124,6 +124,13 @@ void Discriminator::launch_group(int slot, int g) {
     DBM_HIP(hipStreamWaitEvent(ctx->side, ev_grp[0][g], 0));
     if (ev_grp[1][g]) DBM_HIP(hipStreamWaitEvent(ctx->side, ev_grp[1][g], 0));
     wbm[g].launch(ctx->side);
+    // Data-parallel run: group 0 = conv_layer6..9 is 89 % of the discriminator's parameters, one contiguous range of the
+    // gradient arena, and final as soon as this launch is: its all-reduce runs underneath the rest of the backward pass.
+    if (g == 0 && ctx->comm_in_step) {
+      const size_t lo = tensors[layers[L_conv[6]].wi].off, hi = tensors[layers[L_conv[9]].wi].off + tensors[layers[L_conv[9]].wi].n;
+      ctx->comm_bucket(grads + lo, hi - lo, ctx->side);
+      comm_sent_lo = lo; comm_sent_hi = hi;
+    }
   }
 }
 

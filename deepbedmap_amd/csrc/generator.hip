@@ -412,10 +412,22 @@ void Generator::backward(const float* gy) {
   DBM_MARK(s, "G:backward_tail_layers");
   ctx->fork_to_side(0);
   wbs[0].launch(ctx->side);
+  // Data-parallel run: the gradient arena is in construction order (input block | pre | trunk | tail), and the backward
+  // pass finishes it from the end: every group of weight gradients that has been enqueued on the side stream is a
+  // contiguous range that can be summed over ranks (chain[1]) while the rest of the pass still runs.
+  auto rdb_off = [&](int j) { return j >= nrdb ? tensors[layers[L_post].wi].off : tensors[layers[L_rdb[j * 5]].wi].off; };
+  if (ctx->comm_in_step) ctx->comm_bucket(grads + rdb_off(nrdb), nparam - rdb_off(nrdb), ctx->side);
   // ---- trunk, last dense block first ----
   const bool fused = trunk_fused_ok(h, w) && !(getenv("DBM_TRUNK_FUSED_BWD") && atoi(getenv("DBM_TRUNK_FUSED_BWD")) == 0);
+  int final_hi = nrdb;  // dense blocks [0, final_hi): the trunk group whose weight gradients go out last, with the input block's
   // fused chain: two equal groups measured best (1: 12.19, 2: 12.14, 3: 12.23, 4: 12.17 ms per step, shrinking groups 12.49)
-  static const int ngroups_env = getenv("DBM_BWD_GROUPS") ? atoi(getenv("DBM_BWD_GROUPS")) : 2;
+  // (data-parallel: four groups, so that the last, exposed, gradient bucket is a quarter of the trunk instead of half)
+  static const int ngroups_forced = getenv("DBM_BWD_GROUPS") ? atoi(getenv("DBM_BWD_GROUPS")) : -1;
+  const int ngroups_env = ngroups_forced >= 0 ? ngroups_forced : (ctx->comm_in_step ? 4 : 2);
+  if (ngroups_env != wbs_groups) {
+    for (int i = 1; i <= 5; ++i) wbs[i].reset();
+    wbs_groups = ngroups_env;
+  }
   auto group_of = [&](int j) {
     // groups of residual-in-residual blocks, shrinking towards the end of the chain: what is still to do once the
     // data-gradient chain has finished (the last group + the pre-residual / input-block batch) is exposed time
@@ -437,11 +449,15 @@ void Generator::backward(const float* gy) {
     std::vector<float*> dAp(nrdb);
     std::vector<const float*> catp(nrdb);
     for (int i = 0; i < nrdb; ++i) { dAp[i] = dA[i].p; catp[i] = cat[i].p; }
-    int prev = -1;
+    int prev = -1, prev_lo = 0, prev_hi = 0;
     for (int j = nrdb - 1; j >= 0; --j) {
       const int grp = group_of(j);
       if (grp != prev) {
-        if (prev >= 0) { ctx->fork_to_side(prev); wbs[prev].launch(ctx->side); }
+        if (prev >= 0) {
+          ctx->fork_to_side(prev);
+          wbs[prev].launch(ctx->side);
+          if (ctx->comm_in_step) ctx->comm_bucket(grads + rdb_off(prev_lo), rdb_off(prev_hi) - rdb_off(prev_lo), ctx->side);
+        }
         int jlo = j;
         while (jlo > 0 && group_of(jlo - 1) == grp) --jlo;
         for (int i0 = 0; i0 < N; i0 += IMGS) {
@@ -455,6 +471,8 @@ void Generator::backward(const float* gy) {
           launch_trunk_fused_bwd(L, s);
         }
         prev = grp;
+        prev_lo = jlo; prev_hi = j + 1;
+        final_hi = j + 1;
       }
       // the weight gradients of this dense block (descriptors only; launched with the group)
       const float* Gout = dA[j + 1].p;
@@ -572,5 +590,7 @@ void Generator::backward(const float* gy) {
     const int i = small_i[k];
     launch_smallcin_conv_wgrad(small[k], g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), ctx->side);
   }
+  // input block, pre-residual conv and the trunk group launched last (layer-wise trunk path: the whole trunk)
+  if (ctx->comm_in_step) ctx->comm_bucket(grads, rdb_off(final_hi), ctx->side);
   ctx->join_side();  // the optimizer (and the next cleargrads) must see every gradient
 }

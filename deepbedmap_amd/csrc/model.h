@@ -30,9 +30,27 @@ struct dbm_ctx {
   int sync_world = 1;
   void (*sync_fn)(void* user, float* dev, int n) = nullptr;
   void* sync_user = nullptr;
-  bool sync_stats() const { return sync_world > 1 && sync_fn != nullptr; }
-  void allreduce(float* dev, int n) { sync_fn(sync_user, dev, n); }
+  bool sync_stats() const { return sync_world > 1 && (sync_fn != nullptr || nccl_comm != nullptr); }
+  void allreduce(float* dev, int n);  // statistics collective on `stream`: the hook, or the native communicator
   DevBuf sync_buf;            // 3 x 512 floats of per-channel sums + 4 for the loss
+  // ---- gradient exchange of a data-parallel run (comm.hip): native RCCL communicator, or a caller hook ----
+  void* nccl_comm = nullptr;  // ncclComm_t (dbm_comm_init)
+  int comm_rank = 0, comm_world = 1;
+  void (*comm_hook)(void* user, float* dev, size_t n, void* hip_stream) = nullptr;  // dbm_comm_set_hook
+  void* comm_user = nullptr;
+  bool comm_in_step = false;  // set by the fused steps: the backward passes hand finished buckets to comm_bucket
+  hipEvent_t ev_comm = nullptr, ev_comm_done = nullptr;
+  hipEvent_t ev_timer[2] = {nullptr, nullptr};  // dbm_timer
+  size_t comm_bytes = 0, comm_calls = 0;  // statistics (dbm_comm_stats)
+  bool comm_active() const { return comm_world > 1 && (nccl_comm != nullptr || comm_hook != nullptr); }
+  void comm_init(int rank, int world, const void* id128);
+  void comm_set_hook(int rank, int world, void (*fn)(void*, float*, size_t, void*), void* user);
+  void comm_destroy();
+  void comm_allreduce(float* const* p, const size_t* n, int nranges, hipStream_t on);
+  void comm_broadcast(float* p, size_t n, int root, hipStream_t on);
+  void comm_bucket(float* const* p, const size_t* n, int nranges, hipStream_t producer);
+  void comm_bucket(float* p, size_t n, hipStream_t producer) { comm_bucket(&p, &n, 1, producer); }
+  void comm_join(hipStream_t consumer);
   int* dev_err = nullptr;     // host-mapped word a persistent kernel raises when a bounded spin runs out (checked by every API call)
   int* dev_err_d = nullptr;   // its device address
   float* zeros = nullptr;     // 256 B of zeros (igemm out-of-image taps)
@@ -40,6 +58,8 @@ struct dbm_ctx {
   DevBuf loss_tmp;            // scratch for the loss entry points
   DevBuf stage[8];            // host<->device staging for the non-DEVICE_PTRS entry points
 };
+
+void dbm_comm_unique_id_impl(void* out128);  // comm.hip: ncclGetUniqueId
 
 struct Tensor {
   std::string key;
@@ -129,6 +149,7 @@ struct Generator : dbm_model {
   const float* bw_in[4] = {nullptr, nullptr, nullptr, nullptr};  // forward inputs, needed by the input-block wgrad
   static const int NWB = 7;
   bool grads_cleared = false;  // set by dbm_generator_step around backward(): cleargrads has just run (WgradBatch::cleared_target)
+  int wbs_groups = -1;  // trunk groups the batches below were planned for
   WgradBatch wbs[NWB];  // batched weight gradients: tail, 5 trunk groups, pre-residual + input block (launched on the side stream)
   std::vector<DevBuf> cat, dA;
   DevBuf in_x, in_w1, in_w2, in_w3, a0, a3, a41, a42, off1, off2, col1, col2, a51, yout;
@@ -175,6 +196,7 @@ struct Discriminator : dbm_model {
   static const int NWG = 4;
   WgradBatch wbm[NWG];     // the same for BOTH graphs in one launch per group (the fused D-step: twice the work per launch)
   hipEvent_t ev_grp[2][NWG] = {};
+  size_t comm_sent_lo = 0, comm_sent_hi = 0;  // gradient range already handed to the exchange by launch_group (this step)
   bool merge_slots = false;  // set by dbm_discriminator_step around its two backward calls (fake first, then real)
   void launch_group(int slot, int g);
   WgradBatch wb[2][NWG];  // batched weight gradients per retained graph (real / fake batch): layers 9..6, 5..4, 3..2, 1

@@ -1,6 +1,7 @@
 """Data parallelism over the GPUs of one node: one process per GPU, tile minibatches sharded by rank,
-one sum all-reduce of the flat gradient arena per optimizer step (RCCL over xGMI through
-torch.distributed, backend "nccl"; "gloo" on CPU for the tests).  The reference trains on a single
+the flat gradient arena is summed over ranks once per optimizer step -- by libdbm's native RCCL communicator
+(dbm_comm_init: librccl over xGMI), bucket by bucket underneath the backward passes; torch.distributed ("gloo") is only
+the host-side rendezvous.  The reference trains on a single
 GPU (srgan_train.py:58-61, 1039-1040); this is new design.
 
 No collective touches the data path: each rank runs the whole D-step/G-step on its own tiles; only
@@ -34,7 +35,19 @@ class _ForeignCuda:
 
 
 class DataParallel:
-    """comm object accepted by train_eval_discriminator / train_eval_generator (`comm=`)."""
+    """comm object accepted by train_eval_discriminator / train_eval_generator (`comm=`).
+
+    Three transports, chosen by `backend` (default: environment DBM_DIST_BACKEND, else "rccl" on a GPU, "gloo" on CPU):
+
+    * "rccl"  (the product path) -- libdbm's NATIVE communicator (dbm_comm_init: librccl over xGMI).  The fused steps
+      sum their gradient buckets over ranks themselves, underneath the backward passes, on a library stream; torch is
+      only the host-side rendezvous (a gloo process group carries the 128-byte id, barriers and the timing maximum).
+    * "gloo" with device arrays -- the same in-step bucket schedule, but every bucket goes through a Python hook
+      (dbm_comm_set_hook) that synchronises the stream and reduces with gloo: for tests with several ranks on ONE GPU,
+      where RCCL refuses to build a communicator.
+    * "nccl" -- torch.distributed's RCCL on a stream shared with libdbm: one whole-arena all-reduce after each backward
+      (round-1 behaviour, kept for comparison); and "gloo" on CPU tensors for the host-logic tests.
+    """
 
     def __init__(self, backend=None, device=None, sync_batch_stats=False):
         """sync_batch_stats=True: the discriminator's BatchNorm statistics and the relativistic-average means are taken
@@ -48,22 +61,62 @@ class DataParallel:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.on_gpu = torch.cuda.is_available() if device is None else (device != "cpu")
-        if backend is None:  # DBM_DIST_BACKEND=gloo: e.g. several ranks on ONE GPU in a test (RCCL wants one device per rank)
-            backend = os.environ.get("DBM_DIST_BACKEND") or ("nccl" if self.on_gpu else "gloo")
+        if backend is None:
+            backend = os.environ.get("DBM_DIST_BACKEND") or ("rccl" if self.on_gpu else "gloo")
+        self.backend = backend
+        self.native = self.on_gpu and backend == "rccl"        # libdbm's own RCCL communicator
+        self.hooked = self.on_gpu and backend == "gloo"        # in-step buckets through a gloo hook
         if self.on_gpu:
             torch.cuda.set_device(self.local_rank)
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            dist.init_process_group(backend="gloo" if backend == "rccl" else backend, rank=self.rank, world_size=self.world)
         self._views = {}
         self._shared_stream = set()
+        self._in_step = set()   # contexts whose fused steps exchange the gradients themselves
         self.sync_batch_stats = bool(sync_batch_stats)
         self._hooks = {}
 
+    # ---- wiring a context ----
     def attach(self, ctx):
-        """Run libdbm on torch's current HIP stream: torch then orders the RCCL collective after the backward
-        kernels and the Adam kernel after the collective by stream events alone (no host synchronisation)."""
+        """Give `ctx` its communicator.  rccl: dbm_comm_init (collective: every rank must call it).  gloo on a GPU: the
+        bucket hook.  nccl: libdbm runs on torch's current HIP stream, so that torch orders the RCCL collective after the
+        backward kernels and the Adam kernel after the collective by stream order alone (no host synchronisation)."""
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.lib()
+        if self.native:
+            ident = [None]
+            if self.rank == 0:
+                buf = C.create_string_buffer(128)
+                _lib.check(lib.dbm_comm_unique_id(buf), None)
+                ident[0] = buf.raw
+            if self.world > 1:
+                self.dist.broadcast_object_list(ident, src=0)
+            _lib.check(lib.dbm_comm_init(ctx.handle, self.rank, self.world, C.c_char_p(ident[0])), ctx.handle)
+            self._in_step.add(id(ctx))
+            if self.sync_batch_stats and self.world > 1:
+                _lib.check(lib.dbm_set_sync_batch_stats(ctx.handle, self.world, None, None), ctx.handle)
+            return
+        if self.hooked:
+            dev = f"cuda:{self.local_rank}"
+
+            def bucket_hook(user, ptr, n, stream):  # blocking: everything enqueued so far, then a host-side sum
+                self.torch.cuda.synchronize()
+                t = self.torch.as_tensor(_ForeignCuda(ptr, n), device=dev)
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+                self.torch.cuda.synchronize()
+
+            cb = _lib.COMM_HOOK(bucket_hook)
+            self._hooks[("grad", id(ctx))] = cb
+            _lib.check(lib.dbm_comm_set_hook(ctx.handle, self.rank, self.world, C.cast(cb, C.c_void_p), None), ctx.handle)
+            self._in_step.add(id(ctx))
+            if self.sync_batch_stats and self.world > 1:
+                self._install_sync_hook(ctx)
+            return
         if self.on_gpu:
             st = self.torch.cuda.current_stream()
             if st.cuda_stream == 0:
@@ -78,6 +131,14 @@ class DataParallel:
         if self.sync_batch_stats and self.on_gpu and self.world > 1:
             self._install_sync_hook(ctx)
 
+    def exchanges_in_step(self, ctx):
+        """True when dbm_discriminator_step / dbm_generator_step on `ctx` sum the gradients over ranks themselves."""
+        return id(ctx) in self._in_step
+
+    def step_flags(self, ctx):
+        """Extra `train` bits of the fused steps: 8 = the caller's collectives run on a stream of their own (torch's RCCL)."""
+        return 8 if (self.on_gpu and not self.exchanges_in_step(ctx)) else 0
+
     def _install_sync_hook(self, ctx):
         """dbm_set_sync_batch_stats: libdbm calls back with a small device buffer of per-rank sums; the collective goes
         onto the stream libdbm shares with torch (attach), so nothing synchronises the host."""
@@ -88,13 +149,25 @@ class DataParallel:
         dev = f"cuda:{self.local_rank}"
 
         def hook(user, ptr, n):
+            if self.hooked:
+                self.torch.cuda.synchronize()
             t = self.torch.as_tensor(_ForeignCuda(ptr, n), device=dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            if self.hooked:
+                self.torch.cuda.synchronize()
 
         cb = _lib.ALLREDUCE_HOOK(hook)
         self._hooks[id(ctx)] = cb  # keep the trampoline alive as long as the context may call it
         _lib.check(_lib.lib().dbm_set_sync_batch_stats(ctx.handle, self.world, C.cast(cb, C.c_void_p), None), ctx.handle)
 
+    def detach(self, ctx):
+        from . import _lib
+
+        if id(ctx) in self._in_step:
+            _lib.check(_lib.lib().dbm_comm_destroy(ctx.handle), ctx.handle)
+            self._in_step.discard(id(ctx))
+
+    # ---- collectives ----
     def grad_view(self, model):
         """torch view of the model's flat gradient arena (device memory owned by libdbm)."""
         key = id(model)
@@ -109,8 +182,10 @@ class DataParallel:
         return self._views[key]
 
     def allreduce_grads(self, model):
-        """Sum the gradient arena over ranks; returns the scale (1/world) the optimizer applies."""
-        if self.world > 1:
+        """Sum the gradient arena over ranks; returns the scale (1/world) the optimizer applies.  After a fused step on a
+        context with its own communicator there is nothing left to do: the step has exchanged every bucket."""
+        ctx = getattr(model, "ctx", None)
+        if self.world > 1 and not (ctx is not None and self.exchanges_in_step(ctx)):
             t = self.grad_view(model)
             shared = (not self.on_gpu) or id(model.ctx) in self._shared_stream
             if self.on_gpu and not shared:
@@ -120,10 +195,33 @@ class DataParallel:
                 self.torch.cuda.current_stream().synchronize()
         return 1.0 / self.world
 
+    def allreduce_grads_now(self, model):
+        """Whole-arena exchange for callers that ran model.backward() themselves (no fused step): dbm_allreduce_grads."""
+        import ctypes as C
+
+        from . import _lib
+
+        ctx = getattr(model, "ctx", None)
+        if ctx is not None and self.exchanges_in_step(ctx):
+            scale = C.c_double(1.0)
+            _lib.check(_lib.lib().dbm_allreduce_grads(model._h, C.byref(scale)), ctx.handle)
+            return float(scale.value)
+        return self.allreduce_grads(model)
+
     def broadcast_params(self, model, src=0):
         """Make every rank start from rank `src`'s parameters."""
         if self.world > 1:
             arena = model.param_arena()
+            ctx = getattr(model, "ctx", None)
+            if self.native and ctx is not None and self.exchanges_in_step(ctx):
+                import ctypes as C
+
+                from . import _lib
+
+                _lib.check(_lib.lib().dbm_comm_broadcast(ctx.handle, C.c_void_p(arena.ptr), arena.size, int(src)), ctx.handle)
+                ctx.synchronize()
+                model.mark_params_changed()
+                return
             t = arena if isinstance(arena, self.torch.Tensor) else self.torch.as_tensor(
                 _ForeignCuda(arena.ptr, arena.size), device=f"cuda:{self.local_rank}")
             if self.on_gpu:
@@ -141,6 +239,7 @@ class DataParallel:
     def max_over_ranks(self, value):
         if self.world == 1:
             return value
-        t = self.torch.tensor([value], dtype=self.torch.float64, device=f"cuda:{self.local_rank}" if self.on_gpu else "cpu")
+        on_dev = self.on_gpu and self.backend == "nccl"  # the gloo control group reduces host tensors
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=f"cuda:{self.local_rank}" if on_dev else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())

@@ -75,7 +75,8 @@ def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, t
     _lib.check(_lib.lib().dbm_discriminator_step(g_model._h, d_model._h, n, h, w, *[_dev_ptr(dev[k]) for k in _KEYS],
                                                  int(bool(train)) | (2 if share_generator_forward else 0) |
                                                  (4 if prefetch_generator_forward else 0) |
-                                                 (8 if comm is not None else 0), m.ptr),
+                                                 (comm.step_flags(g_model.ctx) if hasattr(comm, "step_flags") else
+                                                  (8 if comm is not None else 0)), m.ptr),
                g_model.ctx.handle)
     if train is True:
         scale = comm.allreduce_grads(d_model) if comm is not None else 1.0

@@ -50,8 +50,33 @@ int dbm_set_deterministic(dbm_ctx* ctx, int on);
  * forward and backward, and calculate_discriminator_loss (srgan_train.py:995-1004) the global-batch means of the logits.
  * The library computes per-rank sums into a small device buffer and calls allreduce_sum(user, dev, n), which must enqueue
  * an in-place SUM all-reduce of n floats on the context's stream (RCCL / torch.distributed on the shared stream).
- * world = 1 (or a NULL hook) restores per-rank statistics, the default. */
+ * With a native communicator of the same world (dbm_comm_init) the hook may be NULL: the sums go through RCCL.
+ * world = 1 restores per-rank statistics, the default. */
 int dbm_set_sync_batch_stats(dbm_ctx* ctx, int world, void (*allreduce_sum)(void* user, float* dev, int n), void* user);
+/* ---- gradient exchange of a data-parallel run (one process / one dbm_ctx per GPU) ----
+ * The reference trains on ONE GPU (srgan_train.py:58-61, 1039-1040: `model.to_gpu()` of a single device); these entry
+ * points are what a multi-GPU `trainer` (srgan_train.py:1267-1329) calls between `backward()` and `optimizer.update()`
+ * (:1163-1164, :1256-1257).  Native path: RCCL over xGMI, opened at run time (librccl.so.1), no torch involved.
+ * dbm_comm_unique_id: rank 0 creates the 128-byte rendezvous id (ncclGetUniqueId) and hands it to the other ranks by
+ * any host channel; dbm_comm_init: every rank joins (collective call; world = 1 is allowed and makes everything below a
+ * no-op).  With a communicator on the context, dbm_discriminator_step / dbm_generator_step sum their gradient arenas
+ * over ranks THEMSELVES, bucket by bucket underneath the backward passes (D: conv_layer6..9 = 89 % of the bytes as soon
+ * as their weight gradients are enqueued, the rest at the end; G: tail, trunk groups, input block), on a library
+ * stream; the caller then runs dbm_adam_update(m, 1.0 / world).  Bit 4 (16) of `train` leaves the exchange to the caller.
+ * dbm_comm_set_hook replaces RCCL by a callback (tests: several ranks on one GPU, where RCCL refuses to run): it must
+ * enqueue an in-place SUM all-reduce of n floats ordered after the work already enqueued on hip_stream and before
+ * work enqueued there later (a blocking implementation may synchronise that stream and reduce on the host). */
+int dbm_comm_unique_id(void* out128);
+int dbm_comm_init(dbm_ctx* ctx, int rank, int world, const void* id128);
+int dbm_comm_set_hook(dbm_ctx* ctx, int rank, int world,
+                      void (*allreduce_sum)(void* user, float* dev, size_t n, void* hip_stream), void* user);
+int dbm_comm_destroy(dbm_ctx* ctx);
+/* in-place broadcast / sum all-reduce of device floats on the context's stream (parameter broadcast at start-up; metrics) */
+int dbm_comm_broadcast(dbm_ctx* ctx, float* dev, size_t nfloats, int root);
+int dbm_comm_allreduce(dbm_ctx* ctx, float* dev, size_t nfloats);
+/* bytes / collective calls issued so far on this context's communicator (reset != 0 clears the counters) */
+int dbm_comm_stats(dbm_ctx* ctx, int* world, size_t* bytes, size_t* calls, int reset);
+
 /* measurement aid (bench.py roofline leg): while enabled, every launch of the two MFMA kernel families is bracketed
  * by hipEvents on the launch stream.  out = [ms, algorithmic FLOP, launches] for igemm_conv_kernel (forward + data
  * gradient), then the same three for wgrad_kernel. */
@@ -60,6 +85,9 @@ int dbm_profile_end(dbm_ctx* ctx, double out[8]);
 /* the same for nfam <= 4 kernel families, three values each: igemm_conv_kernel, the weight-gradient kernels,
  * trunk_fused_kernel (RRDB trunk forward, srgan_train.py:546), trunk_fused_bwd_kernel (its data-gradient chain) */
 int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam);
+/* measurement aid: HIP-event stopwatch on the context's stream.  op 0 = record the start event, 1 = record the stop
+ * event (both asynchronous), 2 = wait for the stop event and write the elapsed milliseconds to *ms. */
+int dbm_timer(dbm_ctx* ctx, int op, double* ms);
 /* measurement aid: while enabled, the step entry points record one hipEvent per phase boundary on the main stream;
  * enable = 0 stops, synchronises and writes "name milliseconds-since-the-first-mark" lines into out (cap bytes). */
 int dbm_phase_marks(dbm_ctx* ctx, int enable, char* out, int cap);
@@ -147,6 +175,10 @@ int dbm_adam_setup(dbm_model* m, double alpha, double beta1, double beta2, doubl
  * sum all-reduce). */
 int dbm_adam_update(dbm_model* m, double grad_scale);
 
+/* Whole-arena gradient all-reduce on the context's stream for callers that drive dbm_gen_backward / dbm_disc_backward
+ * themselves (no overlap); *grad_scale (may be NULL) receives 1 / world for dbm_adam_update. */
+int dbm_allreduce_grads(dbm_model* m, double* grad_scale);
+
 /* ---- fused steps (device-resident inputs, asynchronous) ---- */
 /* train_eval_discriminator: srgan_train.py:1084-1166 up to and including d_loss.backward() (update = dbm_adam_update).
  * arrays are DEVICE pointers: X (N,1,11,11), W1 (N,1,110,110), W2 (N,2,22,22), W3 (N,1,11,11), Y (N,1,36,36).
@@ -156,7 +188,8 @@ int dbm_adam_update(dbm_model* m, double grad_scale);
  * then skips its own forward: NOT what the reference does, off by default); bit 2 (4) = the following
  * dbm_generator_step's forward is enqueued now, in its own workspace and on separate streams, underneath this
  * step's discriminator passes (the trainer's pattern; discarded if the next call does not match); bit 3 (8) = the
- * caller runs collectives on a stream of its own: the prefetched forward stays on one library stream. */
+ * caller runs collectives on a stream of its own: the prefetched forward stays on one library stream; bit 4 (16) = do
+ * not exchange gradients inside the call although the context has a communicator (dbm_comm_init). */
 int dbm_discriminator_step(dbm_model* g, dbm_model* d, int N, int H, int W, const float* X, const float* W1,
                            const float* W2, const float* W3, const float* Y, int train, float* metrics_dev);
 /* train_eval_generator: srgan_train.py:1170-1263 up to and including g_loss.backward().

@@ -30,4 +30,4 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 package -- always as the checker, never as the product path.  The product
 (deepbedmap_amd) never imports it and fails loudly when its HIP library is missing.
 """
-from . import ops, model, train  # noqa: F401
+from . import ops, model, train  # noqa: F401  (torch_ref is imported on demand: it needs torch)

@@ -1,7 +1,10 @@
-"""Independent torch-CPU (autograd) restatement of the hot path, used ONLY to cross-check the
-NumPy oracle's forward and hand-written backward (tests/test_oracle_vs_torch.py).
-It is written from the same semantics sheet but shares no code with
-oracle/: convs go through torch.nn.functional (oneDNN), gradients through autograd."""
+"""Independent torch-CPU (autograd) restatement of the hot path -- TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+Two uses: cross-checking the NumPy oracle's forward and hand-written backward in float64
+(tests/test_oracle_vs_torch.py), and the "torch_cpu" figure of bench.py's cpu_baseline leg (the same training
+iteration in float32 through oneDNN: a strong-CPU yardstick next to the NumPy/BLAS port).
+It is written from the same semantics sheet but shares no code with the NumPy modules:
+convs go through torch.nn.functional (oneDNN), gradients through autograd."""
 import math
 
 import torch
@@ -138,3 +141,33 @@ def g_loss(y_pred, y_true, fake_labels, x_topo, kind="gaussian"):
     content = (y_pred - y_true).abs().mean()
     topo = (F.avg_pool2d(y_pred, 4) - x_topo).abs().mean()
     return 1e-2 * content + 2e-2 * adv + 2e-3 * topo + 5.25 * (1 - ssim(y_pred, y_true, 9, kind))
+
+
+def training_iteration(Pg, Pd, Sd, arrays, n_blocks=12, rs=0.1, lr=1.6e-4):
+    """One D-step + G-step (srgan_train.py:1084-1263) through autograd: what bench.py times on the host cores.  The
+    update is a sign step (what Adam's first step amounts to); the optimizer is a negligible part of the iteration."""
+    X, W1, W2, W3, Y = (arrays[k] for k in ("X", "W1", "W2", "W3", "Y"))
+    for p in list(Pg.values()) + list(Pd.values()):
+        p.grad = None
+    # D-step (:1131-1164): fakes under no_grad, two training-mode BatchNorm batches, RaGAN loss, backward
+    with torch.no_grad():
+        fake = generator_forward(Pg, X, W1, W2, W3, n_blocks, rs)
+    real_pred = discriminator_forward(Pd, Sd, Y, train=True)
+    fake_pred = discriminator_forward(Pd, Sd, fake, train=True)
+    dl = d_loss(real_pred, fake_pred)
+    dl.backward()
+    with torch.no_grad():
+        for p in Pd.values():
+            p -= lr * torch.sign(p.grad)
+    # G-step (:1222-1257): forward with graph, eval-mode detached discriminator, four-term loss, backward
+    for p in Pg.values():
+        p.grad = None
+    fake = generator_forward(Pg, X, W1, W2, W3, n_blocks, rs)
+    with torch.no_grad():
+        fake_labels = discriminator_forward(Pd, Sd, fake, train=False)
+    gl = g_loss(fake, Y, fake_labels, X[:, :, 1:-1, 1:-1])
+    gl.backward()
+    with torch.no_grad():
+        for p in Pg.values():
+            p -= lr * torch.sign(p.grad)
+    return float(dl.detach()), float(gl.detach())

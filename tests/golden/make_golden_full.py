@@ -1,0 +1,193 @@
+"""Regenerates tests/golden/esrgan_full.npz: oracle outputs at BASELINE.json's FULL configuration sizes.
+
+    python tests/golden/make_golden_full.py            # ~5 minutes on 8 cores, ~12 GB peak
+
+The reference's numerics live in Chainer, which cannot be imported in this image, so -- like
+esrgan_small.npz -- these vectors come from the repo's own oracle (pinned by the reference's known answers,
+tests/test_oracle_kats.py).  What they add: the HIP path is compared with the oracle at the sizes the benchmark runs
+(192 resident workgroups of the persistent trunk kernels, three bands per image, prefetched forward, merged
+discriminator weight-gradient launches), where running the oracle inside the GPU test would take minutes.
+
+  c3  BASELINE config 3: full ESRGAN iteration, batch 64, 12 RRDB (srgan_train.py:1084-1263): generator forward,
+      D-step [loss, accuracy], G-step [loss, psnr, ssim], every gradient of both models;
+  c2  BASELINE config 2: generator only, 16 RRDB, batch 32, pixel-L1 loss (F.mean_absolute_error): forward, loss,
+      every gradient;
+  c5  BASELINE config 5: ONE interior 288 x 288 crop of the continent sweep (deepbedmap.py:706-728) -> 1144 x 1144,
+      fp32 forward (the reference for the bf16 sweep mode as well).
+
+Large tensors are stored as a digest: a seeded sample of entries, the l2 norm, the largest magnitude and four random
++-1 projections in float64 (a projection error relative to the l2 norm IS the relative rms error of the tensor, and
+any misplaced / missing block of contributions shows up in it).  Weights and inputs are NOT stored: they are seeded
+(`models_c3` ..., `arrays`) and rebuilt by the test through the same functions.
+"""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from oracle import model as omodel  # noqa: E402
+from oracle import train as otrain  # noqa: E402
+
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "esrgan_full.npz")
+NSAMPLE = 512   # entries kept per tensor (whole tensor if smaller)
+NPROJ = 4
+ALPHA, EPS = 1e-4, 1e-8
+
+
+# ---- seeded inputs and weights (shared with tests/test_gpu_fullsize.py) ----
+def arrays(n, seed, h=11, w=11):
+    """One independent stream per array (the reference's own fixture seeds all five alike, srgan_train.py:1101-1105,
+    which makes X == W3: useless for catching a swapped branch)."""
+    r = [np.random.RandomState(seed + i) for i in range(5)]
+    f = np.float32
+    return {"X": r[0].rand(n, 1, h, w).astype(f), "W1": r[1].rand(n, 1, 10 * h, 10 * w).astype(f),
+            "W2": r[2].rand(n, 2, 2 * h, 2 * w).astype(f), "W3": r[3].rand(n, 1, h, w).astype(f),
+            "Y": r[4].rand(n, 1, 4 * (h - 2), 4 * (w - 2)).astype(f)}
+
+
+def oracle_generator(n_blocks, seed, bias_noise=0.1):
+    """The reference's initialisation (HeNormal(0.1), srgan_train.py:220) plus non-zero biases."""
+    g = omodel.GeneratorModel(num_residual_blocks=n_blocks, seed=seed)
+    r = np.random.RandomState(seed + 1)
+    for k in sorted(g.params):
+        if not k.endswith("/W"):
+            g.params[k] += r.normal(0, bias_noise, g.params[k].shape).astype(np.float32)
+    return g
+
+
+def oracle_discriminator(seed):
+    d = omodel.DiscriminatorModel(seed=seed)
+    r = np.random.RandomState(seed + 1)
+    for k in sorted(d.params):
+        if k.endswith("/W"):
+            d.params[k] *= np.float32(3.0)  # logits of an untrained D are ~1e-3 otherwise
+        elif k.endswith("gamma"):
+            d.params[k] += r.normal(0, 0.2, d.params[k].shape).astype(np.float32)
+        else:
+            d.params[k] += r.normal(0, 0.1, d.params[k].shape).astype(np.float32)
+    return d
+
+
+def models_c3():
+    return oracle_generator(12, 101), oracle_discriminator(202)
+
+
+def models_c2():
+    return oracle_generator(16, 303)
+
+
+def models_c5():
+    return oracle_generator(12, 404)
+
+
+def target_c2():
+    return np.random.RandomState(77).rand(32, 1, 36, 36).astype(np.float32)
+
+
+# ---- digests ----
+def _rng(name):
+    return np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+
+
+def digest(name, a):
+    """(sample values float32[min(size, NSAMPLE)], stats float64[2 + NPROJ] = l2, max|.|, projections)."""
+    a = np.asarray(a)
+    flat = a.reshape(-1)
+    r = _rng(name)
+    idx = np.arange(flat.size) if flat.size <= NSAMPLE else np.sort(r.choice(flat.size, NSAMPLE, replace=False))
+    f64 = flat.astype(np.float64)
+    stats = [float(np.sqrt((f64 * f64).sum())), float(np.abs(f64).max())]
+    for _ in range(NPROJ):
+        sign = r.randint(0, 2, flat.size).astype(np.float64) * 2.0 - 1.0
+        stats.append(float((f64 * sign).sum()))
+    return flat[idx].astype(np.float32), np.array(stats, np.float64)
+
+
+def digest_dict(prefix, tensors):
+    """name-sorted digests of a dict of arrays, packed into two arrays (+ the offsets of each tensor's sample)."""
+    samples, stats, offs = [], [], [0]
+    for k in sorted(tensors):
+        s, st = digest(prefix + k, tensors[k])
+        samples.append(s)
+        stats.append(st)
+        offs.append(offs[-1] + s.size)
+    return {prefix + "samples": np.concatenate(samples), prefix + "stats": np.stack(stats),
+            prefix + "offsets": np.array(offs, np.int64)}
+
+
+def check_digest_dict(gold, prefix, tensors, tol_sample, tol_proj, floor=1e-6):
+    """Compares a dict of arrays with a stored digest_dict.  Returns the worst (error / tolerance, name, what).
+    A tensor's errors are relative to its own largest magnitude, but never finer than `floor` x the largest magnitude
+    of the whole dict (gradients that are exactly zero in theory only carry rounding noise)."""
+    names = sorted(tensors)
+    stats, offs, samples = gold[prefix + "stats"], gold[prefix + "offsets"], gold[prefix + "samples"]
+    assert len(names) == len(stats), (len(names), len(stats))
+    gmax = float(stats[:, 1].max())
+    worst = (0.0, "", "")
+    for i, k in enumerate(names):
+        s, st = digest(prefix + k, tensors[k])
+        ref_s = samples[offs[i]:offs[i + 1]]
+        assert s.shape == ref_s.shape, k
+        scale = max(float(stats[i, 1]), floor * gmax)
+        e_s = float(np.abs(s.astype(np.float64) - ref_s).max()) / scale / tol_sample
+        # a projection of n entries with independent errors of relative size e has an error of e * l2
+        l2 = max(float(stats[i, 0]), floor * gmax * np.sqrt(np.asarray(tensors[k]).size))
+        e_p = float(np.abs(st[2:] - stats[i, 2:]).max()) / l2 / tol_proj
+        e_n = abs(st[0] - stats[i, 0]) / l2 / tol_proj
+        for e, what in ((e_s, "sample"), (e_p, "projection"), (e_n, "l2")):
+            if e > worst[0]:
+                worst = (e, k, what)
+    return worst
+
+
+# ---- the three configurations ----
+def compute_c3():
+    a = arrays(64, 4200)
+    g, d = models_c3()
+    out = {"c3/g_forward": g.forward(a["X"], a["W1"], a["W2"], a["W3"])}
+    out["c3/d_step"] = np.array(otrain.train_eval_discriminator(a, g, d, otrain.Adam(d.params, alpha=ALPHA, eps=EPS)), np.float64)
+    out.update(digest_dict("c3/gradD/", d.grads))
+    out.update(digest_dict("c3/persD/", {k: v for k, v in d.persistent.items() if not k.endswith("/N")}))
+    out["c3/g_step"] = np.array(otrain.train_eval_generator(a, g, d, otrain.Adam(g.params, alpha=ALPHA, eps=EPS)), np.float64)
+    out.update(digest_dict("c3/gradG/", g.grads))
+    return out
+
+
+def compute_c2():
+    a = arrays(32, 3100)
+    g = models_c2()
+    t = target_c2()
+    y = g.forward(a["X"], a["W1"], a["W2"], a["W3"], keep=True)
+    out = {"c2/g_forward": y, "c2/loss": np.array(float(np.abs(y - t).mean()), np.float64)}
+    gy = (np.sign(y - t) / np.float32(y.size)).astype(np.float32)  # F.mean_absolute_error backward
+    out.update(digest_dict("c2/gradG/", g.backward(gy)))
+    return out
+
+
+C5_STRIDE, C5_BLOCK = 8, 64
+
+
+def compute_c5():
+    a = arrays(1, 5100, h=288, w=288)
+    g = models_c5()
+    y = g.forward(a["X"], a["W1"], a["W2"], a["W3"])  # (1, 1, 1144, 1144)
+    s, st = digest("c5/y", y)
+    c = y.shape[2] // 2 - C5_BLOCK // 2
+    return {"c5/grid": y[0, 0, ::C5_STRIDE, ::C5_STRIDE].copy(), "c5/centre": y[0, 0, c:c + C5_BLOCK, c:c + C5_BLOCK].copy(),
+            "c5/samples": s, "c5/stats": st, "c5/shape": np.array(y.shape, np.int64)}
+
+
+if __name__ == "__main__":
+    import time
+
+    out = {}
+    for fn in (compute_c3, compute_c2, compute_c5):
+        t0 = time.time()
+        out.update(fn())
+        print(fn.__name__, f"{time.time() - t0:.0f} s", flush=True)
+    np.savez_compressed(PATH, **out)
+    print("wrote", PATH, os.path.getsize(PATH), "bytes")

@@ -1,0 +1,185 @@
+"""-m gpu: the HIP path at BASELINE.json's FULL configuration sizes against oracle outputs committed as
+tests/golden/esrgan_full.npz (made by tests/golden/make_golden_full.py; the oracle needs minutes at these sizes).
+
+This is the regime the benchmark runs: 64 images = 192 resident workgroups of the persistent trunk kernels with
+three bands per image and granule hand-offs, the prefetched G-step forward, merged discriminator weight-gradient
+launches, the ordered (cudnn_deterministic) gradient folds.  Tolerances: 1e-4 forward (BASELINE north_star),
+5e-4 gradients (sums over 64 x 81 .. 64 x 1296 positions in another order than BLAS), 3e-2 bf16.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden_full as mgf  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL_FWD, TOL_GRAD, TOL_BF16 = 1e-4, 5e-4, 3e-2
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(mgf.PATH))
+
+
+@pytest.fixture(scope="module")
+def dbm():
+    import deepbedmap_amd as d
+
+    return d
+
+
+@pytest.fixture(autouse=True)
+def _reset_config(dbm):
+    dbm.global_config.train = True
+    dbm.global_config.enable_backprop = True
+    dbm.global_config.ssim_window = "gaussian"
+    dbm.global_config.cudnn_deterministic = True
+    yield
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def copy_params(dst, src_params, persistent=None):
+    for name, p in dst._tensors.items():
+        if name in src_params:
+            p.array = src_params[name]
+        elif persistent is not None and name in persistent:
+            p.array = np.asarray(persistent[name], dtype=np.float32)
+    return dst
+
+
+def grads_of(model):
+    return {k: t.grad for k, t in model._tensors.items() if t.kind == 0}
+
+
+def test_config3_full_iteration_matches_oracle_fixture(dbm, gold):
+    """BASELINE config 3: batch 64, 12 RRDB, D-step + G-step exactly as bench.py runs them (device-resident batch,
+    prefetched G-step forward, cudnn_deterministic)."""
+    og, od = mgf.models_c3()
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=12, initialize=False), og.params)
+    d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+    a = mgf.arrays(64, 4200)
+    batch = dbm.device_batch(a)
+    with dbm.using_config("enable_backprop", False):
+        y = g.forward(batch["X"], batch["W1"], batch["W2"], batch["W3"]).array.get()
+    assert rel(y, gold["c3/g_forward"]) < TOL_FWD
+    d_opt = dbm.optimizers.Adam(alpha=mgf.ALPHA, eps=mgf.EPS).setup(d)
+    g_opt = dbm.optimizers.Adam(alpha=mgf.ALPHA, eps=mgf.EPS).setup(g)
+    got_d = dbm.train_eval_discriminator(batch, g, d, d_opt, prefetch_generator_forward=True)
+    ref_d = gold["c3/d_step"]
+    assert abs(got_d[0] - ref_d[0]) < 2e-4 * max(1.0, abs(ref_d[0])), (got_d, ref_d)
+    assert abs(got_d[1] - ref_d[1]) <= 2.0 / 128 + 1e-6, (got_d, ref_d)  # logits near 0 may flip a thresholded sample
+    worst = mgf.check_digest_dict(gold, "c3/gradD/", grads_of(d), 2 * TOL_GRAD, 2 * TOL_GRAD, floor=1e-4)
+    assert worst[0] < 1.0, worst
+    pers = {k: t.array for k, t in d._tensors.items() if t.kind == 1 and not k.endswith("/N")}
+    worst = mgf.check_digest_dict(gold, "c3/persD/", pers, 1e-4, 1e-4)
+    assert worst[0] < 1.0, worst
+    got_g = dbm.train_eval_generator(batch, g, d, g_opt)
+    ref_g = gold["c3/g_step"]
+    # the adversarial term sees D after its first Adam step (~alpha * sign(gradient)): rounding-noise gradients may flip
+    assert np.allclose(got_g, ref_g, rtol=5e-4, atol=1e-5), (got_g, ref_g)
+    worst = mgf.check_digest_dict(gold, "c3/gradG/", grads_of(g), TOL_GRAD, TOL_GRAD)
+    assert worst[0] < 1.0, worst
+
+
+def test_config3_sequential_path_gives_the_same_numbers(dbm, gold):
+    """The same iteration without the prefetch and through host arrays (the reference's calling pattern)."""
+    og, od = mgf.models_c3()
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=12, initialize=False), og.params)
+    d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+    a = mgf.arrays(64, 4200)
+    d_opt = dbm.optimizers.Adam(alpha=mgf.ALPHA, eps=mgf.EPS).setup(d)
+    g_opt = dbm.optimizers.Adam(alpha=mgf.ALPHA, eps=mgf.EPS).setup(g)
+    got_d = dbm.train_eval_discriminator(a, g, d, d_opt)
+    got_g = dbm.train_eval_generator(a, g, d, g_opt)
+    assert abs(got_d[0] - gold["c3/d_step"][0]) < 2e-4 * max(1.0, abs(gold["c3/d_step"][0]))
+    assert np.allclose(got_g, gold["c3/g_step"], rtol=5e-4, atol=1e-5), (got_g, gold["c3/g_step"])
+    worst = mgf.check_digest_dict(gold, "c3/gradG/", grads_of(g), TOL_GRAD, TOL_GRAD)
+    assert worst[0] < 1.0, worst
+
+
+def test_config2_generator_only_l1_matches_oracle_fixture(dbm, gold):
+    """BASELINE config 2: generator only, 16 RRDB, batch 32, pixel-L1 loss."""
+    og = mgf.models_c2()
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=16, initialize=False), og.params)
+    a = mgf.arrays(32, 3100)
+    t = mgf.target_c2()
+    ins = [dbm.to_device(a[k]) for k in ("X", "W1", "W2", "W3")]
+    y = g.forward(*ins).array.get()
+    assert rel(y, gold["c2/g_forward"]) < TOL_FWD
+    loss = float(np.abs(y - t).mean())
+    assert abs(loss - float(gold["c2/loss"])) < 1e-5
+    ref_y = gold["c2/g_forward"]
+    gy = (np.sign(ref_y - t) / np.float32(ref_y.size)).astype(np.float32)  # the oracle's gy: sign() must not flip on noise
+    g.cleargrads()
+    g.backward(gy)
+    worst = mgf.check_digest_dict(gold, "c2/gradG/", grads_of(g), TOL_GRAD, TOL_GRAD)
+    assert worst[0] < 1.0, worst
+
+
+def _c5_check(y, gold, tol):
+    assert tuple(y.shape) == tuple(gold["c5/shape"])
+    scale = float(gold["c5/stats"][1])
+    c = y.shape[2] // 2 - mgf.C5_BLOCK // 2
+    e_grid = np.abs(y[0, 0, ::mgf.C5_STRIDE, ::mgf.C5_STRIDE] - gold["c5/grid"]).max() / scale
+    e_centre = np.abs(y[0, 0, c:c + mgf.C5_BLOCK, c:c + mgf.C5_BLOCK] - gold["c5/centre"]).max() / scale
+    s, st = mgf.digest("c5/y", y)
+    e_sample = np.abs(s - gold["c5/samples"]).max() / scale
+    e_proj = np.abs(st[2:] - gold["c5/stats"][2:]).max() / gold["c5/stats"][0]
+    assert max(e_grid, e_centre, e_sample, e_proj) < tol, (e_grid, e_centre, e_sample, e_proj)
+    return max(e_grid, e_centre, e_sample)
+
+
+def test_config5_full_crop_fp32_and_bf16_match_oracle_fixture(dbm, gold):
+    """BASELINE config 5's unit of work: one interior 288 x 288 crop of the continent sweep -> 1144 x 1144
+    (deepbedmap.py:706-728), fp32 against the oracle at 1e-4 and the bf16 sweep mode at 3e-2."""
+    og = mgf.models_c5()
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=12, initialize=False), og.params)
+    a = mgf.arrays(1, 5100, h=288, w=288)
+    ins = [dbm.to_device(a[k]) for k in ("X", "W1", "W2", "W3")]
+    with dbm.using_config("enable_backprop", False):
+        y32 = g.forward(*ins).array.get()
+        with dbm.using_config("dtype", "bfloat16"):
+            y16 = g.forward(*ins).array.get()
+    _c5_check(y32, gold, TOL_FWD)
+    e16 = _c5_check(y16, gold, TOL_BF16)
+    assert e16 > 1e-5  # really the bf16 arithmetic
+
+
+def test_config5_sweep_slice_two_ranks_bf16(dbm, gold):
+    """Config 5's loop on a slice of the continent that holds full-size tiles: 2 x 2 output tiles of 1000 x 1000 with the
+    reference's 18-pixel halo (interior crops are 288 x 288; deepbedmap.py:689-741), grids resident in HBM, tiles dealt
+    round-robin over two ranks with no collective, bf16 arithmetic; the fp32 resident sweep of the same area is the
+    yardstick (3e-2) and the two-rank canvas must equal the one-rank canvas bitwise."""
+    og = mgf.models_c5()
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=12, initialize=False), og.params)
+    H, W = 500, 500
+    r = np.random.RandomState(9)
+    X = r.rand(1, 1, H, W).astype(np.float32)
+    W1 = r.rand(1, 1, 10 * H, 10 * W).astype(np.float32)
+    W2 = r.rand(1, 2, 2 * H, 2 * W).astype(np.float32)
+    W3 = r.rand(1, 1, H, W).astype(np.float32)
+    S = dbm.Shape
+    final = S(y=4 * H, x=4 * W)
+    grids = [dbm.to_device(v) for v in (X, W1, W2, W3)]
+    kw = dict(final_shape=final, ary_shape=S(y=1000, x=1000), stride=S(y=1000, x=1000), xtrapad=S(y=18, x=18))
+    shapes = {(y1 - y0, x1 - x0) for y0, y1, x0, x1 in
+              (dbm.crop_bounds(s, final, kw["ary_shape"], kw["xtrapad"]) for s in dbm.tile_steps(final, kw["stride"]))}
+    assert shapes == {(269, 269)}  # edge tiles of a 2 x 2 area (interior tiles of the continent: 288 x 288)
+    y32 = dbm.predict_tiled_resident(g, *grids, **kw)
+    y16 = dbm.predict_tiled_resident(g, *grids, dtype="bfloat16", **kw)
+    parts = [dbm.predict_tiled_resident(g, *grids, dtype="bfloat16", rank=k, world=2, **kw) for k in range(2)]
+    m = ~np.isnan(y32)
+    frame = (18 + 1) * 4
+    assert m[:, frame:-frame, frame:-frame].all() and not m[:, :frame].any()
+    assert np.array_equal(np.isnan(y16), ~m)
+    err = np.abs(y16[m] - y32[m]).max() / np.abs(y32[m]).max()
+    assert 1e-5 < err < TOL_BF16, err
+    assert np.array_equal(np.nan_to_num(dbm.merge_ranks(parts), nan=-1.0), np.nan_to_num(y16, nan=-1.0))

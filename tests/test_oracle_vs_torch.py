@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import model, ops, train
-import torch_ref as tr
+from oracle import torch_ref as tr
 
 torch.set_num_threads(4)
 
