@@ -154,14 +154,52 @@ def spawn_ranks(n_gpus):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # a rank that dies leaves the others waiting in a collective or the rendezvous: end them (these exact children only)
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.1)
+    out, _ = procs[0].communicate()  # (rank 0 writes one JSON line: far below the pipe's capacity)
+    codes = [p.wait() for p in procs]
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
         return 1
+    return 0
+
+
+def launcher_selftest(args):
+    """What a rank does under --selftest-launcher: the rendezvous, barrier and max-over-ranks plumbing of the real run on
+    the CPU (gloo), then ONE JSON line from rank 0."""
+    import torch
+
+    from deepbedmap_amd.parallel import DataParallel
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("DBM_SELFTEST_FAIL_RANK") == str(rank):
+        return 3  # a rank that dies must turn into a non-zero exit code of the launcher
+    comm = DataParallel(backend="gloo", device="cpu")
+    seen = torch.zeros(world, dtype=torch.int64)
+    seen[rank] = 1
+    if world > 1:
+        comm.dist.all_reduce(seen)
+    slowest = comm.max_over_ranks(float(rank))
+    comm.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": seen.tolist(), "max_over_ranks": slowest,
+                          "local_rank_env": os.environ.get("LOCAL_RANK"), "master": os.environ.get("MASTER_ADDR")}), flush=True)
+    if world > 1:
+        comm.dist.destroy_process_group()
     return 0
 
 
@@ -184,10 +222,15 @@ def main():
     ap.add_argument("--dist-backend", default=None, choices=["rccl", "nccl", "gloo"],
                     help="N > 1: rccl (default) = libdbm's native communicator, gradient buckets overlapped with the backward "
                          "passes; nccl = torch.distributed's RCCL, one all-reduce after each backward (round-1 form)")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="no GPU work: the ranks only rendezvous over gloo on the CPU and rank 0 prints a JSON line "
+                         "(tests/test_parallel_gloo.py drives the self-spawn path with it)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    if args.selftest_launcher:
+        sys.exit(launcher_selftest(args))
 
     # Contract: rank 0 prints ONE JSON line on stdout.  Libraries write banners to file descriptor 1 from C (RCCL prints its
     # version block when the first communicator is created): everything that is not the result goes to stderr.

@@ -48,6 +48,7 @@ SIGNATURES = {
     "dbm_profile_end": [C.c_void_p, C.POINTER(C.c_double)],
     "dbm_profile_end_ex": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
     "dbm_set_sync_batch_stats": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    "dbm_debug_inject_timeout": [C.c_void_p],
     "dbm_timer": [C.c_void_p, C.c_int, C.POINTER(C.c_double)],
     "dbm_phase_marks": [C.c_void_p, C.c_int, C.c_char_p, C.c_int],
     "dbm_malloc": [C.c_void_p, C.c_size_t, c_void_pp],
@@ -95,7 +96,7 @@ _lib = None
 
 
 class DbmError(RuntimeError):
-    pass
+    code = None  # libdbm status (7: a persistent kernel timed out, the optimizer steps were skipped: repeat the iteration)
 
 
 def build(verbose=False):
@@ -133,7 +134,9 @@ def lib():
 def check(rc, ctx=None):
     if rc != 0:
         msg = lib().dbm_last_error(ctx)
-        raise DbmError(f"libdbm error {rc}: {msg.decode() if msg else '?'}")
+        err = DbmError(f"libdbm error {rc}: {msg.decode() if msg else '?'}")
+        err.code = rc
+        raise err
 
 
 _default_ctx = None

@@ -7,10 +7,28 @@ static thread_local std::string g_last_error;
 #define DBM_API_BEGIN(ctxptr) \
   dbm_ctx* _ectx = (ctxptr);  \
   try {
+// A persistent trunk kernel that gives up waiting for a neighbouring workgroup (another process starving the GPU, a
+// partitioned device) raises the context's error word.  The optimizer kernels have skipped their updates since (device
+// flag), so no parameter or moment was touched by the invalid pass: the flags are cleared, the persistent kernels are
+// switched off for the rest of the process (the layer-by-layer trunk path takes over) and the call that observes the
+// word returns status 7: the caller repeats the iteration.
+static void dbm_handle_persistent_timeout(dbm_ctx* c) {
+  (void)hipDeviceSynchronize();
+  *(volatile int*)c->dev_err = 0;
+  if (c->dev_err_flag) (void)hipMemset(c->dev_err_flag, 0, sizeof(int));
+  (void)hipDeviceSynchronize();
+  if (!g_trunk_fused_off) {
+    g_trunk_fused_off = true;
+    fprintf(stderr, "libdbm: a persistent trunk kernel gave up waiting for a neighbouring workgroup; the optimizer step was "
+                    "skipped and the layer-by-layer trunk path is used from now on (repeat the iteration)\n");
+  }
+}
+
 #define DBM_API_END                                   \
   if (_ectx && _ectx->dev_err && *(volatile int*)_ectx->dev_err) {                                    \
-    *(volatile int*)_ectx->dev_err = 0;                                                               \
-    throw DbmError(5, "a persistent kernel gave up waiting for a neighbouring workgroup (results of the last calls are invalid)"); \
+    dbm_handle_persistent_timeout(_ectx);                                                             \
+    throw DbmError(7, "a persistent kernel gave up waiting for a neighbouring workgroup: the last iteration is invalid, " \
+                      "its optimizer steps were skipped; repeat it (the layer-by-layer trunk path is active now)");        \
   }                                                   \
   return 0;                                           \
   }                                                   \
@@ -88,6 +106,10 @@ int dbm_init(int hip_device, dbm_ctx** out) {
     throw DbmError(4, std::string("dbm_init: libdbm is built for gfx950 only, device is ") + prop.gcnArchName);
   dbm_ctx* c = new dbm_ctx();
   c->device = hip_device;
+  {  // persistent trunk kernels: three workgroups per image, every workgroup of a launch resident at once (one per CU)
+    int imgs = (prop.multiProcessorCount / 3) & ~7;
+    c->trunk_imgs = imgs > 64 ? 64 : (imgs < 8 ? 8 : imgs);
+  }
   DBM_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   {  // the side stream only carries filler work (weight gradients): lowest priority, so that the latency-bound
@@ -102,6 +124,8 @@ int dbm_init(int hip_device, dbm_ctx** out) {
   DBM_HIP(hipHostMalloc((void**)&c->dev_err, sizeof(int), hipHostMallocMapped));
   *c->dev_err = 0;
   DBM_HIP(hipHostGetDevicePointer((void**)&c->dev_err_d, c->dev_err, 0));
+  DBM_HIP(hipMalloc((void**)&c->dev_err_flag, 256));
+  DBM_HIP(hipMemset(c->dev_err_flag, 0, 256));
   DBM_HIP(hipMalloc((void**)&c->zeros, 256));
   DBM_HIP(hipMemset(c->zeros, 0, 256));
   float w[9];
@@ -123,6 +147,7 @@ int dbm_shutdown(dbm_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipFree(ctx->zeros);
   if (ctx->dev_err) (void)hipHostFree(ctx->dev_err);
+  (void)hipFree(ctx->dev_err_flag);
   (void)hipFree(ctx->ssim_win[0]);
   (void)hipFree(ctx->ssim_win[1]);
   ctx->comm_destroy();
@@ -255,6 +280,7 @@ int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam) {
 int dbm_memcpy2d_d2d(dbm_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
                      size_t height) {
   DBM_API_BEGIN(ctx)
+  ctx->data_epoch++;  // caller-visible device memory changes: retained generator forwards keyed on it go stale
   if (width_bytes && height)
     DBM_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, hipMemcpyDeviceToDevice, ctx->stream));
   DBM_API_END
@@ -262,6 +288,7 @@ int dbm_memcpy2d_d2d(dbm_ctx* ctx, void* dst, size_t dpitch, const void* src, si
 
 int dbm_gather_rows(dbm_ctx* ctx, void* dst, const void* src, const int* idx_host, int n, size_t row_bytes) {
   DBM_API_BEGIN(ctx)
+  ctx->data_epoch++;  // caller-visible device memory changes: retained generator forwards keyed on it go stale
   DBM_CHECK(n >= 0 && row_bytes % 4 == 0, "dbm_gather_rows: rows must be whole float32 elements");
   if (n && row_bytes) {
     DBM_CHECK(idx_host != nullptr, "dbm_gather_rows: idx is NULL");
@@ -274,7 +301,18 @@ int dbm_gather_rows(dbm_ctx* ctx, void* dst, const void* src, const int* idx_hos
 
 int dbm_fill_f32(dbm_ctx* ctx, float* dst, size_t n, float value) {
   DBM_API_BEGIN(ctx)
+  ctx->data_epoch++;  // caller-visible device memory changes: retained generator forwards keyed on it go stale
   if (n) launch_fill(dst, (long)n, value, ctx->stream);
+  DBM_API_END
+}
+
+int dbm_debug_inject_timeout(dbm_ctx* ctx) {
+  DBM_API_BEGIN(nullptr)  // (not observed by this call itself)
+  DBM_CHECK(ctx != nullptr, "dbm_debug_inject_timeout: ctx is NULL");
+  DBM_HIP(hipStreamSynchronize(ctx->stream));
+  const int one = 1;
+  DBM_HIP(hipMemcpy(ctx->dev_err_flag, &one, sizeof(int), hipMemcpyHostToDevice));
+  *(volatile int*)ctx->dev_err = 1;
   DBM_API_END
 }
 
@@ -317,6 +355,7 @@ int dbm_phase_marks(dbm_ctx* ctx, int enable, char* out, int cap) {
 
 int dbm_malloc(dbm_ctx* ctx, size_t bytes, void** dptr) {
   DBM_API_BEGIN(ctx)
+  ctx->data_epoch++;  // caller-visible device memory changes: retained generator forwards keyed on it go stale
   // 128-byte guards on both sides (see DevBuf): kernels may read one word outside a tensor
   char* base = nullptr;
   DBM_HIP(hipMalloc((void**)&base, bytes + 256));
@@ -327,12 +366,14 @@ int dbm_malloc(dbm_ctx* ctx, size_t bytes, void** dptr) {
 }
 int dbm_free(dbm_ctx* ctx, void* dptr) {
   DBM_API_BEGIN(ctx)
+  ctx->data_epoch++;  // caller-visible device memory changes: retained generator forwards keyed on it go stale
   DBM_HIP(hipStreamSynchronize(ctx->stream));
   DBM_HIP(hipFree(dptr ? (char*)dptr - 128 : nullptr));
   DBM_API_END
 }
 int dbm_memcpy_h2d(dbm_ctx* ctx, void* dst, const void* src, size_t bytes) {
   DBM_API_BEGIN(ctx)
+  ctx->data_epoch++;  // caller-visible device memory changes: retained generator forwards keyed on it go stale
   DBM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   DBM_HIP(hipStreamSynchronize(ctx->stream));
   DBM_API_END
@@ -660,7 +701,7 @@ int dbm_adam_update(dbm_model* m, double grad_scale) {
   const double alpha_t = m->alpha * std::sqrt(fix2) / fix1;  // AdamRule.alpha_t
   DBM_MARK(m->ctx->stream, m->type == 0 ? "G:optimizer_begin" : "D:optimizer_begin");
   launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (long)m->nparam, (float)alpha_t, (float)(1.0 - m->beta1),
-              (float)(1.0 - m->beta2), (float)m->eps, (float)grad_scale, m->ctx->stream);
+              (float)(1.0 - m->beta2), (float)m->eps, (float)grad_scale, m->ctx->stream, m->ctx->dev_err_flag);
   DBM_MARK(m->ctx->stream, m->type == 0 ? "G:optimizer" : "D:optimizer");
   m->packed_dirty = true;
   m->param_version++;
@@ -694,6 +735,9 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     ~CommScope() { c->comm_in_step = false; }
   } comm_scope(c, (train & 1) && !(train & 16) && c->comm_active());
   train &= 1;
+  // whatever an earlier call retained for a following G-step is void now (n_critic > 1 loops, refilled arrays)
+  g->graph_version = -1;
+  if (g->twin) g->twin->graph_version = -1;
   g->ensure_ws(N, H, W, share && train);
   d->g_out.ensure(4 * (size_t)N);
   float* lr = d->g_out.p;
@@ -722,6 +766,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   // fake images under enable_backprop=False (:1131-1137)
   g->forward(N, H, W, X, W1, W2, W3, g->yout.p, share && train);
   g->graph_version = g->param_version;
+  g->graph_epoch = c->data_epoch;
   g->graph_in[0] = X; g->graph_in[1] = W1; g->graph_in[2] = W2; g->graph_in[3] = W3;
   DBM_MARK(s, "D:generator_forward");
   if (prefetch && train) {
@@ -742,6 +787,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     t->max_split = 2;
     c->stream = s;
     t->graph_version = g->param_version;
+    t->graph_epoch = c->data_epoch;
     t->graph_in[0] = X; t->graph_in[1] = W1; t->graph_in[2] = W2; t->graph_in[3] = W3;
   }
   c->join_side();
@@ -809,6 +855,10 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
   hipStream_t s = c->stream;
   const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
   const bool share = (train & 2) != 0;
+  // bit 2 (4): the caller asserts that the five arrays are the ones, unchanged, the preceding dbm_discriminator_step saw:
+  // only then may the forward that step prefetched be consumed.  (Pointers, shapes, the parameter version and the
+  // library's own record of writes to device memory are checked on top; writes by anybody else are invisible here.)
+  const bool use_prefetched = (train & 4) != 0;
   struct CommScope {
     dbm_ctx* c;
     CommScope(dbm_ctx* ctx, bool on) : c(ctx) { c->comm_in_step = on; }
@@ -818,11 +868,12 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
   // Opt-in: the generator and its inputs are unchanged since the D-step of this iteration, so that step's forward
   // (bitwise the same numbers) is reused instead of recomputed.  Off by default: the reference runs it twice.
   const bool reuse = share && train && g->have_graph && g->wsTrain && g->graph_version == g->param_version &&
-                     g->wsN == N && g->wsH == H && g->wsW == W && g->graph_in[0] == X && g->graph_in[1] == W1 &&
+                     g->graph_epoch == c->data_epoch && g->wsN == N && g->wsH == H && g->wsW == W && g->graph_in[0] == X && g->graph_in[1] == W1 &&
                      g->graph_in[2] == W2 && g->graph_in[3] == W3;
   DBM_MARK(s, "G:begin");
   Generator* t = g->twin;
-  const bool prefetched = train && t && t->have_graph && t->wsTrain && t->graph_version == g->param_version && t->wsN == N &&
+  const bool prefetched = train && use_prefetched && t && t->have_graph && t->wsTrain && t->graph_version == g->param_version &&
+                          t->graph_epoch == c->data_epoch && t->wsN == N &&
                           t->wsH == H && t->wsW == W && t->graph_in[0] == X && t->graph_in[1] == W1 && t->graph_in[2] == W2 &&
                           t->graph_in[3] == W3;
   Generator* gg = prefetched ? t : g;  // the workspace that holds this step's graph

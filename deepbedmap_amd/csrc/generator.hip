@@ -71,9 +71,10 @@ Generator::~Generator() {
 }
 
 // ---- fused 9x9 trunk forward (trunk_fused.hip) ----
+bool g_trunk_fused_off = false;
 static bool trunk_fused_enabled() {
   static const bool on = !(getenv("DBM_TRUNK_FUSED") && atoi(getenv("DBM_TRUNK_FUSED")) == 0);
-  return on;
+  return on && !g_trunk_fused_off;
 }
 
 bool Generator::trunk_fused_ok(int h, int w) const {
@@ -248,10 +249,10 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   if (fused) {
     const Generator* src = owner ? owner : this;
     DBM_CHECK(src->tf_wstream != nullptr, "fused trunk: weight streams not packed");
-    const int IMGS = 64;  // 192 workgroups: resident at once on 256 CUs
+    const int IMGS = ctx->trunk_imgs;  // three workgroups per image, all resident at once: 64 images = 192 of 256 CUs
     if (!tf_inbox) {
-      DBM_HIP(hipMalloc((void**)&tf_inbox, trunk_fused_inbox_bytes(IMGS)));
-      DBM_HIP(hipMemsetAsync(tf_inbox, 0, trunk_fused_inbox_bytes(IMGS), s));
+      DBM_HIP(hipMalloc((void**)&tf_inbox, trunk_fused_inbox_bytes(64)));
+      DBM_HIP(hipMemsetAsync(tf_inbox, 0, trunk_fused_inbox_bytes(64), s));
     }
     std::vector<float*> ptrs(nrdb + 1);
     for (int i = 0; i <= nrdb && keep; ++i) ptrs[i] = cat[i].p;
@@ -259,7 +260,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       TrunkFusedLaunch L;
       L.wstream = src->tf_wstream; L.bstream = src->tf_bstream; L.in = cat[0].p;
       L.cat = keep ? ptrs.data() : nullptr; L.out = cat[slot(nrdb)].p;
-      L.inbox = tf_inbox; L.err = ctx->dev_err_d;
+      L.inbox = tf_inbox; L.err = ctx->dev_err_d; L.err_dev = ctx->dev_err_flag;
       L.nrdb = nrdb; L.nimg = std::min(IMGS, N - i0); L.img0 = i0; L.epoch = ++tf_epoch;
       L.rs = rs; L.slope = SLOPE;
       launch_trunk_fused(L, s);
@@ -441,10 +442,10 @@ void Generator::backward(const float* gy) {
   if (fused) {  // one persistent launch per group (trunk_fused_bwd.hip); the group's weight gradients follow on the side stream
     const Generator* src = owner ? owner : this;
     DBM_CHECK(src->tf_bwd_wstream != nullptr, "fused trunk: weight streams not packed");
-    const int IMGS = 64;
+    const int IMGS = ctx->trunk_imgs;
     if (!tf_inbox) {
-      DBM_HIP(hipMalloc((void**)&tf_inbox, trunk_fused_inbox_bytes(IMGS)));
-      DBM_HIP(hipMemsetAsync(tf_inbox, 0, trunk_fused_inbox_bytes(IMGS), s));
+      DBM_HIP(hipMalloc((void**)&tf_inbox, trunk_fused_inbox_bytes(64)));
+      DBM_HIP(hipMemsetAsync(tf_inbox, 0, trunk_fused_inbox_bytes(64), s));
     }
     std::vector<float*> dAp(nrdb);
     std::vector<const float*> catp(nrdb);
@@ -465,7 +466,7 @@ void Generator::backward(const float* gy) {
           L.wstream = src->tf_bwd_wstream;
           L.gin = dA[j + 1].p; L.gin_sn = (j + 1 == nrdb) ? 64 * hw : 192 * hw;
           L.dA = dAp.data(); L.cat = catp.data(); L.g_a3 = g_a3.p;
-          L.inbox = tf_inbox; L.err = ctx->dev_err_d;
+          L.inbox = tf_inbox; L.err = ctx->dev_err_d; L.err_dev = ctx->dev_err_flag;
           L.nrdb = nrdb; L.j0 = jlo; L.j1 = j + 1; L.nimg = std::min(IMGS, N - i0); L.img0 = i0; L.epoch = ++tf_epoch;
           L.rs = rs; L.slope = SLOPE;
           launch_trunk_fused_bwd(L, s);

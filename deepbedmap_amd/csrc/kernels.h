@@ -58,8 +58,10 @@ void launch_gen_loss(const float* y, const float* t, const float* X, int N, int 
                      const float* win1d, float* sums, float* gy, hipStream_t s);
 
 // Adam (Chainer form, srgan_train.py:1043-1048): one fused pass over the flat arenas.
+// skip (may be null): device word; while it is non-zero the update is a no-op (a persistent kernel gave up: the
+// gradients of this iteration are invalid, parameters and moments must not be touched)
 void launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha_t, float one_minus_beta1,
-                 float one_minus_beta2, float eps, float gscale, hipStream_t s);
+                 float one_minus_beta2, float eps, float gscale, hipStream_t s, const int* skip = nullptr);
 void launch_fill(float* p, long n, float v, hipStream_t s);
 void launch_gather_rows(const void* src, void* dst, const int* d_idx, int n, size_t row_bytes, hipStream_t s);
 int sqdiff_blocks(long n);  // partial sums launch_sqdiff writes to out[0..blocks)
@@ -74,7 +76,8 @@ struct TrunkFusedLaunch {
   float* const* cat;     // HOST table of nrdb + 1 concat buffers (training: every layer output is kept), or null
   float* out;            // cat == null: concat buffer receiving the trunk output in channels 0..63
   unsigned long long* inbox;  // trunk_fused_inbox_bytes(images per launch)
-  int* err;              // device word raised when a neighbour never answered (bounded spins)
+  int* err;              // host-mapped word raised when a neighbour never answered (bounded spins)
+  int* err_dev;          // the same flag in device memory: the optimizer kernels skip their update while it is set
   int nrdb, nimg, img0, epoch;
   float rs, slope;
 };
@@ -94,6 +97,7 @@ struct TrunkFusedBwdLaunch {
   const float* g_a3;         // (N, 64, 81): added to the trunk input gradient at j == 0
   unsigned long long* inbox;
   int* err;
+  int* err_dev;
   int nrdb, j0, j1;          // dense blocks j1 - 1 ... j0 (both multiples of 3)
   int nimg, img0, epoch;
   float rs, slope;

@@ -51,8 +51,11 @@ struct dbm_ctx {
   void comm_bucket(float* const* p, const size_t* n, int nranges, hipStream_t producer);
   void comm_bucket(float* p, size_t n, hipStream_t producer) { comm_bucket(&p, &n, 1, producer); }
   void comm_join(hipStream_t consumer);
+  int trunk_imgs = 64;        // images per launch of the persistent trunk kernels: min(64, CUs / 3) (one workgroup per CU)
+  long data_epoch = 0;        // bumped by every entry point that writes / frees caller-visible device memory
   int* dev_err = nullptr;     // host-mapped word a persistent kernel raises when a bounded spin runs out (checked by every API call)
   int* dev_err_d = nullptr;   // its device address
+  int* dev_err_flag = nullptr;  // the same flag in device memory (read by the optimizer kernels: no update while it is set)
   float* zeros = nullptr;     // 256 B of zeros (igemm out-of-image taps)
   float* ssim_win[2] = {nullptr, nullptr};  // 9-tap 1-D windows: gaussian(1.5), uniform
   DevBuf loss_tmp;            // scratch for the loss entry points
@@ -60,6 +63,7 @@ struct dbm_ctx {
 };
 
 void dbm_comm_unique_id_impl(void* out128);  // comm.hip: ncclGetUniqueId
+extern bool g_trunk_fused_off;  // set when a persistent trunk kernel timed out: the layer-by-layer path from then on
 
 struct Tensor {
   std::string key;
@@ -145,6 +149,7 @@ struct Generator : dbm_model {
   bool have_graph = false;
   // what the retained graph was computed from (opt-in reuse of the D-step's generator forward by the G-step)
   long graph_version = -1;
+  long graph_epoch = -1;   // dbm_ctx::data_epoch at the time of that forward
   const float* graph_in[4] = {nullptr, nullptr, nullptr, nullptr};
   const float* bw_in[4] = {nullptr, nullptr, nullptr, nullptr};  // forward inputs, needed by the input-block wgrad
   static const int NWB = 7;

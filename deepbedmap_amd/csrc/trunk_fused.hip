@@ -47,6 +47,7 @@ struct Args {
   float* out;             // inference: concat buffer receiving the trunk output in channels 0..63
   unsigned long long* inbox;  // [3 * images][2][2][64][9] granules {value, tag}
   int* err;
+  int* err_dev;
   int nrdb, nimg, img0, epoch;
   float rs, slope;
 };
@@ -200,7 +201,7 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
             while ((unsigned)(gv[q][r] >> 32) != tag_in) {
               __builtin_amdgcn_s_sleep(1);
               gv[q][r] = granule_load(gp[q][r]);
-              if (++spins > SPIN_LIMIT) { *a.err = 1; break; }
+              if (++spins > SPIN_LIMIT) { *a.err = 1; *a.err_dev = 1; break; }
             }
           }
         }
@@ -389,7 +390,7 @@ void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
   a.store_all = L.cat != nullptr;
   for (int i = 0; i < TRUNK_FUSED_MAXCAT; ++i) a.cat[i] = (L.cat && i <= L.nrdb) ? L.cat[i] : nullptr;
   DBM_CHECK(L.nrdb + 1 <= TRUNK_FUSED_MAXCAT, "fused trunk: too many dense blocks");
-  a.inbox = L.inbox; a.err = L.err;
+  a.inbox = L.inbox; a.err = L.err; a.err_dev = L.err_dev;
   a.nrdb = L.nrdb; a.nimg = L.nimg; a.img0 = L.img0; a.epoch = L.epoch & 0xFFFFF; a.rs = L.rs; a.slope = L.slope;
   const int grid = ((L.nimg + 7) / 8) * 24;
   const double flop = 2.0 * 19408896.0 * L.nrdb * L.nimg;  // 19 408 896 MAC per dense block and tile

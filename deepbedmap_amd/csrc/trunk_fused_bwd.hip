@@ -57,6 +57,7 @@ struct Args {
   const float* g_a3;       // (N, 64, 81), added at j == 0
   unsigned long long* inbox;
   int* err;
+  int* err_dev;
   int nrdb, j0, j1, nimg, img0, epoch;
   float rs, slope;
   int abl;  // measurement aid (DBM_TFB_ABL): 1 = no halo exchange, 2 = no epilogue (results are then wrong)
@@ -156,7 +157,7 @@ template <int NCH> DI void halo_finish(const Args& a, const Wave& W, int plane0,
       while ((unsigned)(v >> 32) != tag) {
         __builtin_amdgcn_s_sleep(1);
         v = granule_load(p);
-        if (++spins > SPIN_LIMIT) { *a.err = 1; break; }
+        if (++spins > SPIN_LIMIT) { *a.err = 1; *a.err_dev = 1; break; }
       }
       lds[dst] = __uint_as_float((unsigned)v);
     }
@@ -418,7 +419,7 @@ void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s) {
   DBM_CHECK(L.nrdb + 1 <= TRUNK_FUSED_MAXCAT, "fused trunk: too many dense blocks");
   DBM_CHECK(L.j0 % 3 == 0 && L.j1 % 3 == 0 && L.j0 < L.j1 && L.j1 <= L.nrdb, "fused trunk backward: launches cover whole RRDBs");
   Args a;
-  a.wstream = L.wstream; a.gin = L.gin; a.gin_sn = L.gin_sn; a.g_a3 = L.g_a3; a.inbox = L.inbox; a.err = L.err;
+  a.wstream = L.wstream; a.gin = L.gin; a.gin_sn = L.gin_sn; a.g_a3 = L.g_a3; a.inbox = L.inbox; a.err = L.err; a.err_dev = L.err_dev;
   for (int i = 0; i < TRUNK_FUSED_MAXCAT; ++i) {
     a.dA[i] = i < L.nrdb ? L.dA[i] : nullptr;
     a.cat[i] = i < L.nrdb ? L.cat[i] : nullptr;

@@ -76,6 +76,7 @@ class DeviceArray:
         self._own = ptr is None
         self.ptr = self.ctx.malloc(4 * max(self.size, 1)) if ptr is None else int(ptr)
         self._owner = owner
+        self._gen = 0  # content version: bumped by every write through this object
 
     @property
     def nbytes(self):
@@ -90,6 +91,7 @@ class DeviceArray:
     def set(self, host):
         host = np.ascontiguousarray(host, dtype=np.float32)
         assert host.size == self.size, (host.shape, self.shape)
+        self._gen += 1
         _lib.check(_lib.lib().dbm_memcpy_h2d(self.ctx.handle, C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p),
                                              self.nbytes), self.ctx.handle)
         return self
@@ -202,6 +204,9 @@ class Parameter:
 
     @array.setter
     def array(self, value):
+        value = np.asarray(value)
+        if tuple(value.shape) != self.shape and not (value.size == 1 and self.size == 1):
+            raise ValueError(f"shape mismatch for {self.name}: {tuple(value.shape)} vs {self.shape}")
         v = _f32(value).reshape(-1)
         _lib.check(_lib.lib().dbm_model_set_tensor(self._model._h, self.name.encode(), _hp(v), v.size),
                    self._model.ctx.handle)
@@ -323,6 +328,11 @@ class GeneratorModel(_Link):
                  num_residual_blocks: int = 12, residual_scaling: float = 0.1, out_channels: int = 1, ctx=None,
                  initialize=True):
         super().__init__(ctx)
+        # the two block classes are compiled into the HIP kernels: anything but the reference's own is refused loudly
+        if inblock_class is not DeepbedmapInputBlock:
+            raise ValueError("GeneratorModel: only inblock_class=DeepbedmapInputBlock is implemented (srgan_train.py:201-266)")
+        if resblock_class is not ResInResDenseBlock:
+            raise ValueError("GeneratorModel: only resblock_class=ResInResDenseBlock is implemented (srgan_train.py:364-404)")
         self.num_residual_blocks = num_residual_blocks
         self.residual_scaling = residual_scaling
         _lib.check(_lib.lib().dbm_gen_create(self.ctx.handle, int(num_residual_blocks), float(residual_scaling),
@@ -473,8 +483,10 @@ def load_npz(file, obj, strict=True):
                     raise KeyError(f"{name} is not in the npz file")
                 continue
             a = f[name]
-            if a.size != p.size:
-                raise ValueError(f"shape mismatch for {name}: {a.shape} vs {p.shape}")
+            # chainer's deserializer copies into the existing array and raises on a shape mismatch; only the scalar
+            # persistent `N` of BatchNormalization is stored 0-d
+            if tuple(a.shape) != tuple(p.shape) and not (a.ndim == 0 and p.size == 1):
+                raise ValueError(f"shape mismatch for {name}: file {tuple(a.shape)} vs model {tuple(p.shape)}")
             p.array = a
     return obj
 

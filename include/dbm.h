@@ -5,7 +5,10 @@
  * (file:line under the reference checkout) it stands in for; INTEGRATION.md shows the ctypes
  * binding a reference maintainer would add.  Conventions:
  *   - every function returns 0 on success, non-zero on error; dbm_last_error() gives the text;
- *     nothing throws across the boundary;
+ *     nothing throws across the boundary.  Status 7 is recoverable: a persistent kernel gave up waiting for a
+ *     neighbouring workgroup (the GPU is shared or partitioned), the optimizer updates of that iteration were skipped
+ *     (parameters and Adam moments untouched) and the layer-by-layer kernels serve the trunk from now on -- repeat
+ *     the iteration;
  *   - tensors are NCHW float32, C-contiguous; weights OIHW, exactly the arrays stored by
  *     chainer.serializers.save_npz (key layout: SURVEY.md Appendix B);
  *   - pointers are HOST pointers unless flags contains DBM_DEVICE_PTRS, in which case they are
@@ -43,7 +46,8 @@ int dbm_set_stream(dbm_ctx* ctx, void* hip_stream); /* run on a caller-owned hip
 int dbm_synchronize(dbm_ctx* ctx);
 /* chainer.global_config.cudnn_deterministic (srgan_train.py:69, deepbedmap.py:689).  on = 1: every gradient is folded in a
  * fixed order (no fp32 atomics over a K split: partial sums + an ordered fold kernel, sorted sampling lists, a separate
- * offset-gradient kernel), so a training run is bitwise reproducible; costs a few per cent.  Default 0.  Process-wide. */
+ * offset-gradient kernel), so a training run is bitwise reproducible; costs a few per cent.  Default 1, the reference's
+ * setting.  Process-wide. */
 int dbm_set_deterministic(dbm_ctx* ctx, int on);
 /* sync_batch_stats (data-parallel training that must equal ONE process at the global batch): with world > 1 the
  * discriminator's training-mode BatchNorm layers (srgan_train.py:636-644, 663-689) use the statistics of the global batch in
@@ -85,6 +89,10 @@ int dbm_profile_end(dbm_ctx* ctx, double out[8]);
 /* the same for nfam <= 4 kernel families, three values each: igemm_conv_kernel, the weight-gradient kernels,
  * trunk_fused_kernel (RRDB trunk forward, srgan_train.py:546), trunk_fused_bwd_kernel (its data-gradient chain) */
 int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam);
+/* testing aid: raises the condition a persistent trunk kernel raises when it gives up waiting for a neighbouring
+ * workgroup.  From then on the optimizer kernels skip their updates; the next API call that completes returns status 7
+ * ("repeat the iteration"), clears the condition and switches the process to the layer-by-layer trunk path. */
+int dbm_debug_inject_timeout(dbm_ctx* ctx);
 /* measurement aid: HIP-event stopwatch on the context's stream.  op 0 = record the start event, 1 = record the stop
  * event (both asynchronous), 2 = wait for the stop event and write the elapsed milliseconds to *ms. */
 int dbm_timer(dbm_ctx* ctx, int op, double* ms);
@@ -193,7 +201,14 @@ int dbm_allreduce_grads(dbm_model* m, double* grad_scale);
 int dbm_discriminator_step(dbm_model* g, dbm_model* d, int N, int H, int W, const float* X, const float* W1,
                            const float* W2, const float* W3, const float* Y, int train, float* metrics_dev);
 /* train_eval_generator: srgan_train.py:1170-1263 up to and including g_loss.backward().
- * metrics_dev receives [., ., g_loss, psnr, ssim]. */
+ * metrics_dev receives [., ., g_loss, psnr, ssim].
+ * train: bit 0 = training mode; bit 1 (2) = reuse the generator forward the preceding dbm_discriminator_step kept
+ * (its bit 1); bit 2 (4) = consume the forward that step prefetched (its bit 2): the caller asserts that the five
+ * arrays are the same, UNCHANGED, device arrays.  The library additionally checks pointers, shapes, the parameter
+ * version and its own record of writes to device memory (dbm_memcpy_h2d, dbm_gather_rows, dbm_fill_f32,
+ * dbm_memcpy2d_d2d, dbm_malloc, dbm_free); writes by anybody else (another library filling the same buffer in
+ * place) are invisible to it, hence the explicit bit.  Without it the prefetched pass is discarded and the forward is
+ * recomputed.  bit 4 (16) = see dbm_discriminator_step. */
 int dbm_generator_step(dbm_model* g, dbm_model* d, int N, int H, int W, const float* X, const float* W1,
                        const float* W2, const float* W3, const float* Y, const float weights[4], int ssim_window,
                        int train, float* metrics_dev);

@@ -19,6 +19,17 @@ Large tensors are stored as a digest: a seeded sample of entries, the l2 norm, t
 +-1 projections in float64 (a projection error relative to the l2 norm IS the relative rms error of the tensor, and
 any misplaced / missing block of contributions shows up in it).  Weights and inputs are NOT stored: they are seeded
 (`models_c3` ..., `arrays`) and rebuilt by the test through the same functions.
+
+Conditioning.  At batch 64 a training iteration is NOT reproducible to 1e-4 by ANY two float32 implementations: with
+~10^7 activations per layer a handful sit within one rounding error of zero, their LeakyReLU slope flips between 1 and
+0.2 from one summation order to the next, and BatchNorm's backward pass (which removes the batch-constant part of the
+gradient) amplifies what is left.  The float32 oracle itself moves by up to 1e-2 (max-norm of a weight gradient) when
+its arithmetic is switched to float64.  c3 therefore stores the FLOAT64 oracle as the reference and, per tensor, how
+far the float32 oracle is from it (`.../dev`): the GPU test requires the HIP path to be as close to the float64
+numbers as the float32 CPU restatement is (a small multiple of `dev`, never below the plain tolerance).  The
+generator's weights are HeNormal x 8 there, so that the fakes carry texture (std 0.47 around a mean of 0.19); with
+the reference's own 0.1 scale the fakes are constant to 1e-3, BatchNorm on the fake batch divides by that, and even
+the two oracles disagree by 50 %.
 """
 import os
 import sys
@@ -49,14 +60,26 @@ def arrays(n, seed, h=11, w=11):
             "Y": r[4].rand(n, 1, 4 * (h - 2), 4 * (w - 2)).astype(f)}
 
 
-def oracle_generator(n_blocks, seed, bias_noise=0.1):
-    """The reference's initialisation (HeNormal(0.1), srgan_train.py:220) plus non-zero biases."""
+def oracle_generator(n_blocks, seed, bias_noise=0.1, scale=1.0):
+    """The reference's initialisation (HeNormal(0.1), srgan_train.py:220), optionally scaled, plus non-zero biases."""
     g = omodel.GeneratorModel(num_residual_blocks=n_blocks, seed=seed)
     r = np.random.RandomState(seed + 1)
     for k in sorted(g.params):
-        if not k.endswith("/W"):
+        if k.endswith("/W"):
+            g.params[k] *= np.float32(scale)
+        else:
             g.params[k] += r.normal(0, bias_noise, g.params[k].shape).astype(np.float32)
     return g
+
+
+def to_float64(model):
+    """The same model (bitwise the same float32 parameter values) computing in float64."""
+    model.dtype = np.float64
+    for k in model.params:
+        model.params[k] = model.params[k].astype(np.float64)
+    for k in getattr(model, "persistent", {}):
+        model.persistent[k] = np.asarray(model.persistent[k], np.float64 if not k.endswith("/N") else np.int64)
+    return model
 
 
 def oracle_discriminator(seed):
@@ -73,7 +96,7 @@ def oracle_discriminator(seed):
 
 
 def models_c3():
-    return oracle_generator(12, 101), oracle_discriminator(202)
+    return oracle_generator(12, 101, scale=8.0), oracle_discriminator(202)
 
 
 def models_c2():
@@ -119,41 +142,81 @@ def digest_dict(prefix, tensors):
             prefix + "offsets": np.array(offs, np.int64)}
 
 
-def check_digest_dict(gold, prefix, tensors, tol_sample, tol_proj, floor=1e-6):
-    """Compares a dict of arrays with a stored digest_dict.  Returns the worst (error / tolerance, name, what).
-    A tensor's errors are relative to its own largest magnitude, but never finer than `floor` x the largest magnitude
-    of the whole dict (gradients that are exactly zero in theory only carry rounding noise)."""
+def digest_errors(gold, prefix, tensors, floor=1e-6):
+    """name -> (sample error, projection error) of a dict of arrays against a stored digest_dict: the sample error is
+    max-norm relative to the tensor's largest magnitude, the projection error (incl. the l2 norm itself) relative to
+    its l2 norm = the relative rms error.  Neither scale is finer than `floor` x the largest magnitude of the whole
+    dict (gradients that are exactly zero in theory only carry rounding noise)."""
     names = sorted(tensors)
     stats, offs, samples = gold[prefix + "stats"], gold[prefix + "offsets"], gold[prefix + "samples"]
     assert len(names) == len(stats), (len(names), len(stats))
     gmax = float(stats[:, 1].max())
-    worst = (0.0, "", "")
+    out = {}
     for i, k in enumerate(names):
         s, st = digest(prefix + k, tensors[k])
         ref_s = samples[offs[i]:offs[i + 1]]
         assert s.shape == ref_s.shape, k
         scale = max(float(stats[i, 1]), floor * gmax)
-        e_s = float(np.abs(s.astype(np.float64) - ref_s).max()) / scale / tol_sample
-        # a projection of n entries with independent errors of relative size e has an error of e * l2
+        e_s = float(np.abs(s.astype(np.float64) - ref_s).max()) / scale
         l2 = max(float(stats[i, 0]), floor * gmax * np.sqrt(np.asarray(tensors[k]).size))
-        e_p = float(np.abs(st[2:] - stats[i, 2:]).max()) / l2 / tol_proj
-        e_n = abs(st[0] - stats[i, 0]) / l2 / tol_proj
-        for e, what in ((e_s, "sample"), (e_p, "projection"), (e_n, "l2")):
+        e_p = max(float(np.abs(st[2:] - stats[i, 2:]).max()), abs(st[0] - stats[i, 0])) / l2
+        out[k] = (e_s, e_p)
+    return out
+
+
+def check_digest_dict(gold, prefix, tensors, tol_sample, tol_proj, floor=1e-6, dev_factor=0.0):
+    """Compares a dict of arrays with a stored digest_dict.  Returns the worst (error / tolerance, name, what).
+    dev_factor > 0: a tensor's tolerance is max(tol, dev_factor x the float32 oracle's own deviation from this float64
+    reference), stored as `prefix + "dev"` (see the module docstring, Conditioning)."""
+    errs = digest_errors(gold, prefix, tensors, floor)
+    dev = gold[prefix + "dev"] if dev_factor > 0 else None
+    worst = (0.0, "", "")
+    for i, k in enumerate(sorted(tensors)):
+        ts = max(tol_sample, dev_factor * dev[i, 0]) if dev is not None else tol_sample
+        tp = max(tol_proj, dev_factor * dev[i, 1]) if dev is not None else tol_proj
+        for e, what in ((errs[k][0] / ts, "sample"), (errs[k][1] / tp, "projection")):
             if e > worst[0]:
                 worst = (e, k, what)
     return worst
 
 
+def with_dev(gold_part, prefix, tensors32, floor):
+    """Adds `prefix + "dev"` (n_tensors, 2): the float32 oracle's deviation from the float64 digests in gold_part."""
+    errs = digest_errors(gold_part, prefix, tensors32, floor)
+    gold_part[prefix + "dev"] = np.array([errs[k] for k in sorted(tensors32)], np.float64)
+    return gold_part
+
+
 # ---- the three configurations ----
-def compute_c3():
+D_FLOOR, G_FLOOR = 1e-4, 1e-6
+
+
+def _iteration_c3(f64):
     a = arrays(64, 4200)
     g, d = models_c3()
-    out = {"c3/g_forward": g.forward(a["X"], a["W1"], a["W2"], a["W3"])}
-    out["c3/d_step"] = np.array(otrain.train_eval_discriminator(a, g, d, otrain.Adam(d.params, alpha=ALPHA, eps=EPS)), np.float64)
-    out.update(digest_dict("c3/gradD/", d.grads))
-    out.update(digest_dict("c3/persD/", {k: v for k, v in d.persistent.items() if not k.endswith("/N")}))
-    out["c3/g_step"] = np.array(otrain.train_eval_generator(a, g, d, otrain.Adam(g.params, alpha=ALPHA, eps=EPS)), np.float64)
-    out.update(digest_dict("c3/gradG/", g.grads))
+    if f64:
+        to_float64(g), to_float64(d)
+        a = {k: v.astype(np.float64) for k, v in a.items()}
+    out = {"g_forward": g.forward(a["X"], a["W1"], a["W2"], a["W3"])}
+    out["d_step"] = np.array(otrain.train_eval_discriminator(a, g, d, otrain.Adam(d.params, alpha=ALPHA, eps=EPS)), np.float64)
+    out["gradD"] = {k: v.copy() for k, v in d.grads.items()}
+    out["persD"] = {k: np.asarray(v, np.float64) for k, v in d.persistent.items() if not k.endswith("/N")}
+    out["g_step"] = np.array(otrain.train_eval_generator(a, g, d, otrain.Adam(g.params, alpha=ALPHA, eps=EPS)), np.float64)
+    out["gradG"] = {k: v.copy() for k, v in g.grads.items()}
+    return out
+
+
+def compute_c3():
+    """Reference = the float64 oracle; `dev` = how far the float32 oracle is from it (see Conditioning above)."""
+    r64, r32 = _iteration_c3(True), _iteration_c3(False)
+    y64 = r64["g_forward"]
+    out = {"c3/g_forward": y64.astype(np.float32),
+           "c3/g_forward_dev": np.array(np.abs(r32["g_forward"] - y64).max() / np.abs(y64).max()),
+           "c3/d_step": r64["d_step"], "c3/d_step_f32": r32["d_step"],
+           "c3/g_step": r64["g_step"], "c3/g_step_f32": r32["g_step"]}
+    for name, floor in (("gradD", D_FLOOR), ("persD", G_FLOOR), ("gradG", G_FLOOR)):
+        part = digest_dict(f"c3/{name}/", r64[name])
+        out.update(with_dev(part, f"c3/{name}/", r32[name], floor))
     return out
 
 

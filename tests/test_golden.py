@@ -24,6 +24,31 @@ def test_oracle_reproduces_golden_vectors():
         assert rel(out[k], v) < 1e-5, k  # BLAS summation order may differ between hosts
 
 
+def test_full_size_fixture_belongs_to_this_oracle():
+    """tests/golden/esrgan_full.npz (batch 64 / 16 RRDB / 288 x 288: minutes of oracle time, made by make_golden_full.py)
+    is pinned to the current oracle code on the CPU through what is cheap: the generator has no cross-sample coupling, so
+    the first two images of the stored forward outputs must be the oracle's outputs for the first two tiles; and every
+    array of the three configurations is present with a consistent layout."""
+    import make_golden_full as mgf
+
+    gold = dict(np.load(mgf.PATH))
+    a = mgf.arrays(64, 4200)
+    g, _ = mgf.models_c3()
+    y = g.forward(*(a[k][:2] for k in ("X", "W1", "W2", "W3")))
+    assert rel(y, gold["c3/g_forward"][:2]) < max(1e-5, 3 * float(gold["c3/g_forward_dev"]))
+    a = mgf.arrays(32, 3100)
+    y = mgf.models_c2().forward(*(a[k][:2] for k in ("X", "W1", "W2", "W3")))
+    assert rel(y, gold["c2/g_forward"][:2]) < 1e-5
+    for prefix, shapes in (("c3/gradG/", mgf.omodel.generator_param_shapes(12)), ("c2/gradG/", mgf.omodel.generator_param_shapes(16)),
+                           ("c3/gradD/", mgf.omodel.discriminator_param_shapes())):
+        stats, offs = gold[prefix + "stats"], gold[prefix + "offsets"]
+        sizes = [min(int(np.prod(shapes[k])), mgf.NSAMPLE) for k in sorted(shapes)]
+        assert stats.shape == (len(shapes), 2 + mgf.NPROJ) and list(np.diff(offs)) == sizes and offs[-1] == gold[prefix + "samples"].size
+        assert np.isfinite(stats).all() and (stats[:, 0] >= 0).all()
+    assert gold["c3/gradD/dev"].shape == (len(mgf.omodel.discriminator_param_shapes()), 2)
+    assert tuple(gold["c5/shape"]) == (1, 1, 1144, 1144) and gold["c5/grid"].shape == (143, 143)
+
+
 @pytest.mark.gpu
 def test_hip_reproduces_golden_vectors():
     import deepbedmap_amd as dbm

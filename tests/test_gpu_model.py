@@ -682,3 +682,122 @@ def test_device_resident_dataset_gather_and_epoch(dbm):
     for c in cols:
         assert len(results[0][c]) > 0 and np.isfinite(results[0][c]).all()
         np.testing.assert_array_equal(results[0][c], results[1][c])
+
+
+# ---- robustness of the scheduling shortcuts and the persistent kernels ----
+def test_prefetched_forward_is_not_reused_for_refilled_arrays(dbm):
+    """A prefetched G-step forward must never be consumed for other DATA: the same DeviceArray objects refilled in place
+    between the two calls (same pointers, same shapes) give the G-step of the new data, bitwise."""
+    def models():
+        og = scaled_oracle_generator(1, 3.0)
+        od = omodel.DiscriminatorModel(seed=5)
+        g = copy_params(dbm.GeneratorModel(num_residual_blocks=1, initialize=False), og.params)
+        d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+        return (g, d, dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(g), dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(d))
+
+    a1, a2 = fixture_arrays(n=4), {k: np.ascontiguousarray(v[::-1] * 0.5 + 0.1) for k, v in fixture_arrays(n=4).items()}
+    # reference: D-step on a1, then a G-step on a2 without any prefetch
+    g, d, g_opt, d_opt = models()
+    dbm.train_eval_discriminator(dbm.device_batch(a1), g, d, d_opt)
+    ref = dbm.train_eval_generator(dbm.device_batch(a2), g, d, g_opt)
+    # same, but the D-step prefetches for a1 and the SAME device arrays are then refilled with a2
+    g, d, g_opt, d_opt = models()
+    batch = dbm.device_batch(a1)
+    ptrs = {k: v.ptr for k, v in batch.items()}
+    dbm.train_eval_discriminator(batch, g, d, d_opt, prefetch_generator_forward=True)
+    for k in batch:
+        batch[k].set(a2[k])
+    assert {k: v.ptr for k, v in batch.items()} == ptrs
+    got = dbm.train_eval_generator(batch, g, d, g_opt)
+    assert got == ref
+    # and the unchanged-arrays case still consumes the prefetched pass with identical numbers (covered bitwise by
+    # test_shared_generator_forward_is_equivalent); a second D-step voids what the first one prefetched
+    g, d, g_opt, d_opt = models()
+    batch = dbm.device_batch(a1)
+    dbm.train_eval_discriminator(batch, g, d, d_opt, prefetch_generator_forward=True)
+    dbm.train_eval_discriminator(dbm.device_batch(a2), g, d, d_opt)
+    g2, d2, g_opt2, d_opt2 = models()
+    dbm.train_eval_discriminator(dbm.device_batch(a1), g2, d2, d_opt2)
+    dbm.train_eval_discriminator(dbm.device_batch(a2), g2, d2, d_opt2)
+    assert dbm.train_eval_generator(batch, g, d, g_opt) == dbm.train_eval_generator(dbm.device_batch(a1), g2, d2, g_opt2)
+
+
+_TIMEOUT_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import deepbedmap_amd as d
+from deepbedmap_amd import _lib
+np.random.seed(4)
+g, g_opt, dm, d_opt = d.compile_srgan_model(num_residual_blocks=1, residual_scaling=0.3, learning_rate=1e-3)
+rs = np.random.RandomState(5)
+batch = d.device_batch({"X": rs.rand(4, 1, 11, 11), "W1": rs.rand(4, 1, 110, 110), "W2": rs.rand(4, 2, 22, 22),
+                        "W3": rs.rand(4, 1, 11, 11), "Y": rs.rand(4, 1, 36, 36)})
+before = {k: np.array(v) for k, v in g.serialize_dict().items()}
+inject = sys.argv[3] == "1"
+if inject:
+    _lib.check(_lib.lib().dbm_debug_inject_timeout(g.ctx.handle), g.ctx.handle)
+    # while the condition is up the optimizer is a no-op: parameters must not move
+    g_opt.update()
+    try:
+        g.ctx.synchronize()
+        raise SystemExit("status 7 expected")
+    except _lib.DbmError as e:
+        assert e.code == 7, e
+    assert all(np.array_equal(before[k], v) for k, v in g.serialize_dict().items())
+    g_opt.t -= 1
+    _lib.check(_lib.lib().dbm_debug_inject_timeout(g.ctx.handle), g.ctx.handle)
+m = list(d.train_eval_discriminator(batch, g, dm, d_opt, prefetch_generator_forward=True))   # observes, recovers, repeats
+m += list(d.train_eval_generator(batch, g, dm, g_opt))
+np.savez(sys.argv[2], m=np.array(m), **{"g/" + k: v for k, v in g.serialize_dict().items()})
+"""
+
+
+def test_persistent_kernel_timeout_is_recovered(dbm, tmp_path):
+    """A persistent trunk kernel that gives up (injected: dbm_debug_inject_timeout) must not corrupt anything: the
+    optimizer kernels skip their update while the condition is up, the observing call returns status 7, the Python
+    mirror repeats the step on the layer-by-layer trunk path, and training ends where an undisturbed run with
+    DBM_TRUNK_FUSED=0 ends."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "timeout.py"
+    script.write_text(_TIMEOUT_SCRIPT)
+    outs = []
+    for inject, fused in (("1", "1"), ("0", "0")):
+        out = str(tmp_path / f"t{inject}.npz")
+        res = subprocess.run([sys.executable, str(script), root, out, inject], env=dict(os.environ, DBM_TRUNK_FUSED=fused),
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        if inject == "1":
+            assert "layer-by-layer trunk path" in res.stderr
+        outs.append(dict(np.load(out)))
+    assert np.allclose(outs[0]["m"], outs[1]["m"], rtol=2e-4, atol=1e-6)
+    for k in outs[0]:
+        if k != "m":
+            assert np.abs(outs[0][k] - outs[1][k]).max() <= 2.1e-3, k  # at most one Adam step (1e-3) apart per update
+
+
+def test_api_refuses_what_it_does_not_implement(dbm, tmp_path):
+    class OtherBlock:
+        pass
+
+    with pytest.raises(ValueError):
+        dbm.GeneratorModel(inblock_class=OtherBlock)
+    with pytest.raises(ValueError):
+        dbm.GeneratorModel(resblock_class=OtherBlock)
+    # chainer.serializers.load_npz raises on a shape mismatch: a transposed tensor of the right SIZE must not load
+    g = dbm.GeneratorModel(num_residual_blocks=1)
+    path = str(tmp_path / "g.npz")
+    dbm.serializers.save_npz(path, g)
+    with np.load(path) as f:
+        tensors = {k: f[k] for k in f.files}
+    key = "residual_network/0/residual_dense_block1/conv_layer2/W"
+    assert tensors[key].shape == (32, 96, 3, 3)
+    tensors[key] = np.ascontiguousarray(tensors[key].transpose(1, 0, 2, 3))
+    bad = str(tmp_path / "bad.npz")
+    np.savez_compressed(bad, **tensors)
+    with pytest.raises(ValueError):
+        dbm.serializers.load_npz(bad, dbm.GeneratorModel(num_residual_blocks=1))
+    with pytest.raises(ValueError):
+        g._tensors[key].array = tensors[key]

@@ -138,3 +138,93 @@ def test_sync_batch_stats_equals_one_process_at_the_global_batch(tmp_path):
         worst_ctl = max(worst_ctl, float(np.abs(ctl[k] - v).max()) / 1e-3)
     assert worst < 0.08, (worst, worst_key, worst_ctl)  # measured 0.035 (one near-zero gradient of conv_layer1/W); control 1.68
     assert worst_ctl > 10 * worst, (worst, worst_ctl)  # per-rank statistics are a visibly different training run
+
+
+# ---- native RCCL communicator (dbm_comm_*: the product path of an N-GPU run) ----
+def test_native_rccl_communicator_on_one_gpu():
+    """World 1 through libdbm's own communicator: librccl is opened at run time, ncclCommInitRank runs, every exchange is
+    a no-op, the fused steps still work and report scale 1; dbm_comm_allreduce / dbm_comm_broadcast leave data alone."""
+    import ctypes as C
+    import subprocess
+
+    script = r"""
+import os, sys, ctypes as C, numpy as np
+sys.path.insert(0, sys.argv[1])
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2])
+import deepbedmap_amd as dbm
+from deepbedmap_amd import _lib
+comm = dbm.DataParallel(backend="rccl")
+assert comm.native and comm.world == 1
+ctx = dbm.Context(0); _lib._default_ctx = ctx
+comm.attach(ctx)
+assert comm.exchanges_in_step(ctx) and comm.step_flags(ctx) == 0
+np.random.seed(3)
+g, g_opt, d, d_opt = dbm.compile_srgan_model(num_residual_blocks=1, residual_scaling=0.3, learning_rate=5e-4)
+comm.broadcast_params(g)
+r = np.random.RandomState(7)
+batch = dbm.device_batch({"X": r.rand(3, 1, 11, 11), "W1": r.rand(3, 1, 110, 110), "W2": r.rand(3, 2, 22, 22),
+                          "W3": r.rand(3, 1, 11, 11), "Y": r.rand(3, 1, 36, 36)}, ctx)
+m = list(dbm.train_eval_discriminator(batch, g, d, d_opt, comm=comm, prefetch_generator_forward=True))
+m += list(dbm.train_eval_generator(batch, g, d, g_opt, comm=comm))
+assert np.isfinite(m).all() and comm.allreduce_grads(g) == 1.0
+a = dbm.to_device(np.arange(8, dtype=np.float32), ctx)
+_lib.check(_lib.lib().dbm_comm_allreduce(ctx.handle, C.c_void_p(a.ptr), 8), ctx.handle)
+_lib.check(_lib.lib().dbm_comm_broadcast(ctx.handle, C.c_void_p(a.ptr), 8, 0), ctx.handle)
+assert np.array_equal(a.get(), np.arange(8, dtype=np.float32))
+comm.detach(ctx)
+print("native-ok")
+"""
+    res = subprocess.run([sys.executable, "-c", script, ROOT, str(_free_port())], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "native-ok" in res.stdout, res.stderr[-3000:]
+
+
+def _native_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import deepbedmap_amd as dbm
+
+    comm = dbm.DataParallel(backend="rccl")
+    ctx = dbm.Context(rank)
+    dbm._lib._default_ctx = ctx
+    comm.attach(ctx)
+    np.random.seed(100 + rank)
+    g, g_opt, d, d_opt = dbm.compile_srgan_model(num_residual_blocks=2, residual_scaling=0.3, learning_rate=5e-4)
+    comm.broadcast_params(g)
+    comm.broadcast_params(d)
+    r = np.random.RandomState(7)
+    full = {"X": r.rand(8, 1, 11, 11), "W1": r.rand(8, 1, 110, 110), "W2": r.rand(8, 2, 22, 22), "W3": r.rand(8, 1, 11, 11),
+            "Y": r.rand(8, 1, 36, 36)}
+    batch = dbm.device_batch({k: v.astype(np.float32) for k, v in dbm.shard_batch(full, rank, world).items()}, ctx)
+    for _ in range(2):
+        dbm.train_eval_discriminator(batch, g, d, d_opt, comm=comm, prefetch_generator_forward=True)
+        dbm.train_eval_generator(batch, g, d, g_opt, comm=comm)
+    np.savez(os.path.join(out_dir, f"native{rank}.npz"), **{"g/" + k: v for k, v in g.serialize_dict().items()},
+             **{"d/" + k: v for k, v in d.serialize_dict().items()})
+    comm.barrier()
+    comm.detach(ctx)
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL wants one device per rank)")
+def test_native_rccl_two_gpus_stay_identical(tmp_path):
+    """Two ranks on two devices over RCCL / xGMI, gradient buckets exchanged inside the fused steps."""
+    mp.spawn(_native_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = dict(np.load(tmp_path / "native0.npz")), dict(np.load(tmp_path / "native1.npz"))
+    for k in r0:
+        if k.endswith("avg_mean") or k.endswith("avg_var") or k.endswith("/N"):
+            continue
+        assert np.array_equal(r0[k], r1[k]), k
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_bench_two_gpus_self_spawned():
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["gradient_exchange"]["world"] == 2 and out["value"] > 0

@@ -134,3 +134,45 @@ def test_shard_slices_cover_the_batch():
             assert np.array_equal(idx, np.arange(n))
             sizes = [len(np.arange(n)[shard_slice(n, r, world)]) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _run_bench(args, env=None):
+    import json
+    import subprocess
+
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)  # `python bench.py --gpus N` as the driver starts it: no launcher environment
+    e.update(env or {})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e,
+                         timeout=300)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res.returncode, [json.loads(ln) for ln in lines], res.stderr
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run: bench.py starts one child per rank itself (fresh
+    processes, nothing exec'ed), they rendezvous on 127.0.0.1 over gloo, rank 0's single JSON line is forwarded."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--selftest-launcher"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, lines
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == [1, 1] and out["max_over_ranks"] == 1.0
+    assert out["local_rank_env"] == "0" and out["master"] == "127.0.0.1"
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    rc, lines, err = _run_bench(["--gpus", "2", "--selftest-launcher"], env={"DBM_SELFTEST_FAIL_RANK": "1"})
+    assert rc != 0
+
+
+def test_bench_under_an_external_launcher_keeps_its_world():
+    """Started by torch.distributed.run (the driver's N > 1 form) the environment is already there: no second spawn."""
+    import subprocess
+
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--selftest-launcher"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and '"n_gpus": 2' in lines[0]

@@ -4,11 +4,12 @@
 # usage: tools/pmc_traffic.sh <tag>
 set -e
 TAG=${1:-pmc}
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+cd /tmp && export TMPDIR=/tmp && cd "${ROOT:?repository root not found}"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -f csv -d "$OUT" -o $C -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/$C.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $C -f csv -d "$OUT" -o $C -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/$C.log" 2>&1 || { echo "rocprofv3 failed; last lines of "$OUT/$C.log":" >&2; tail -n 30 "$OUT/$C.log" >&2; exit 1; }
 done
 python3 - "$OUT" <<'PY'
 import csv, json, sys, collections
