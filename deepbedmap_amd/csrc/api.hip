@@ -16,6 +16,13 @@ static void dbm_handle_persistent_timeout(dbm_ctx* c) {
   (void)hipDeviceSynchronize();
   *(volatile int*)c->dev_err = 0;
   if (c->dev_err_flag) (void)hipMemset(c->dev_err_flag, 0, sizeof(int));
+  for (dbm_model* m : c->models) {  // optimizer launches that found the condition up did nothing: take their step counts back
+    int n = 0;
+    if (m->d_adam_skipped && hipMemcpy(&n, m->d_adam_skipped, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && n > 0) {
+      m->adam_t -= n;
+      (void)hipMemset(m->d_adam_skipped, 0, sizeof(int));
+    }
+  }
   (void)hipDeviceSynchronize();
   if (!g_trunk_fused_off) {
     g_trunk_fused_off = true;
@@ -701,7 +708,8 @@ int dbm_adam_update(dbm_model* m, double grad_scale) {
   const double alpha_t = m->alpha * std::sqrt(fix2) / fix1;  // AdamRule.alpha_t
   DBM_MARK(m->ctx->stream, m->type == 0 ? "G:optimizer_begin" : "D:optimizer_begin");
   launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (long)m->nparam, (float)alpha_t, (float)(1.0 - m->beta1),
-              (float)(1.0 - m->beta2), (float)m->eps, (float)grad_scale, m->ctx->stream, m->ctx->dev_err_flag);
+              (float)(1.0 - m->beta2), (float)m->eps, (float)grad_scale, m->ctx->stream, m->ctx->dev_err_flag,
+              m->d_adam_skipped);
   DBM_MARK(m->ctx->stream, m->type == 0 ? "G:optimizer" : "D:optimizer");
   m->packed_dirty = true;
   m->param_version++;

@@ -117,6 +117,8 @@ Generator* Generator::get_twin() {
       if (L.wb[i]) (void)hipFree(L.wb[i]);
   }
   (void)hipFree(t->params); (void)hipFree(t->grads); (void)hipFree(t->adam_m); (void)hipFree(t->adam_v); (void)hipFree(t->pers);
+  (void)hipFree(t->d_adam_skipped);
+  t->d_adam_skipped = nullptr;
   t->layers = layers;
   t->params = params; t->grads = grads; t->adam_m = adam_m; t->adam_v = adam_v; t->pers = pers;
   t->is_view = true;

@@ -61,7 +61,8 @@ void launch_gen_loss(const float* y, const float* t, const float* X, int N, int 
 // skip (may be null): device word; while it is non-zero the update is a no-op (a persistent kernel gave up: the
 // gradients of this iteration are invalid, parameters and moments must not be touched)
 void launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha_t, float one_minus_beta1,
-                 float one_minus_beta2, float eps, float gscale, hipStream_t s, const int* skip = nullptr);
+                 float one_minus_beta2, float eps, float gscale, hipStream_t s, const int* skip = nullptr,
+                 int* skipped = nullptr);  // *skipped counts the no-op launches
 void launch_fill(float* p, long n, float v, hipStream_t s);
 void launch_gather_rows(const void* src, void* dst, const int* d_idx, int n, size_t row_bytes, hipStream_t s);
 int sqdiff_blocks(long n);  // partial sums launch_sqdiff writes to out[0..blocks)

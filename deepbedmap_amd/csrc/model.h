@@ -52,6 +52,7 @@ struct dbm_ctx {
   void comm_bucket(float* p, size_t n, hipStream_t producer) { comm_bucket(&p, &n, 1, producer); }
   void comm_join(hipStream_t consumer);
   int trunk_imgs = 64;        // images per launch of the persistent trunk kernels: min(64, CUs / 3) (one workgroup per CU)
+  std::vector<struct dbm_model*> models;  // every model of this context (optimizer bookkeeping after a kernel timeout)
   long data_epoch = 0;        // bumped by every entry point that writes / frees caller-visible device memory
   int* dev_err = nullptr;     // host-mapped word a persistent kernel raises when a bounded spin runs out (checked by every API call)
   int* dev_err_d = nullptr;   // its device address
@@ -100,6 +101,7 @@ struct dbm_model {
   size_t npers = 0;
   double alpha = 1.6e-4, beta1 = 0.9, beta2 = 0.999, eps = 1e-8;
   long adam_t = 0;
+  int* d_adam_skipped = nullptr;  // device counter of optimizer launches that were no-ops (dbm_ctx::dev_err_flag was set)
   bool adam_ready = false;
   bool packed_dirty = true;
   long param_version = 0;  // bumped by every write to the parameter arena

@@ -42,7 +42,11 @@ void DevBuf::release() {
 }
 
 dbm_model::~dbm_model() {
+  if (ctx)
+    for (size_t i = 0; i < ctx->models.size(); ++i)
+      if (ctx->models[i] == this) { ctx->models.erase(ctx->models.begin() + i); break; }
   if (is_view) return;  // nothing here is owned
+  if (d_adam_skipped) (void)hipFree(d_adam_skipped);
   for (auto& L : layers) {
     if (L.wf) (void)hipFree(L.wf);
     if (L.wf16) (void)hipFree(L.wf16);
@@ -86,6 +90,9 @@ void dbm_model::alloc_arenas() {
   DBM_HIP(hipMemset(adam_m, 0, np * sizeof(float)));
   DBM_HIP(hipMemset(adam_v, 0, np * sizeof(float)));
   DBM_HIP(hipMemset(pers, 0, ns * sizeof(float)));
+  DBM_HIP(hipMalloc((void**)&d_adam_skipped, 256));
+  DBM_HIP(hipMemset(d_adam_skipped, 0, 256));
+  if (ctx) ctx->models.push_back(this);
   DBM_HIP(hipDeviceSynchronize());  // NULL-stream memsets vs. the context's non-blocking stream
 }
 

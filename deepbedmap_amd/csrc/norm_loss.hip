@@ -611,8 +611,12 @@ void launch_gen_loss(const float* y, const float* t, const float* X, int N, int 
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float alpha_t,
-                                                   float omb1, float omb2, float eps, float gscale, const int* skip) {
-  if (skip && *skip) return;  // (wave-uniform scalar load, L2-resident)
+                                                   float omb1, float omb2, float eps, float gscale, const int* skip,
+                                                   int* skipped) {
+  if (skip && *skip) {  // (wave-uniform scalar load, L2-resident)
+    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) *skipped += 1;  // the host takes the step count back (adam_t)
+    return;
+  }
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
     const float gr = g[e] * gscale;
     float mm = m[e], vv = v[e];
@@ -625,11 +629,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 void launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha_t, float one_minus_beta1,
-                 float one_minus_beta2, float eps, float gscale, hipStream_t s, const int* skip) {
+                 float one_minus_beta2, float eps, float gscale, hipStream_t s, const int* skip, int* skipped) {
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, alpha_t, one_minus_beta1,
-                     one_minus_beta2, eps, gscale, skip);
+                     one_minus_beta2, eps, gscale, skip, skipped);
   DBM_HIP(hipGetLastError());
 }
 

@@ -732,19 +732,23 @@ g, g_opt, dm, d_opt = d.compile_srgan_model(num_residual_blocks=1, residual_scal
 rs = np.random.RandomState(5)
 batch = d.device_batch({"X": rs.rand(4, 1, 11, 11), "W1": rs.rand(4, 1, 110, 110), "W2": rs.rand(4, 2, 22, 22),
                         "W3": rs.rand(4, 1, 11, 11), "Y": rs.rand(4, 1, 36, 36)})
-before = {k: np.array(v) for k, v in g.serialize_dict().items()}
 inject = sys.argv[3] == "1"
 if inject:
+    # a retained generator gradient that is NOT zero, then the condition: the optimizer launch must be a no-op
+    with d.using_config("enable_backprop", True):
+        y = g.forward(batch["X"], batch["W1"], batch["W2"], batch["W3"])
+    g.cleargrads()
+    g.backward(rs.normal(size=y.shape).astype(np.float32))
+    assert max(float(np.abs(p.grad).max()) for p in g.params()) > 0
+    before = {k: np.array(v) for k, v in g.serialize_dict().items()}
     _lib.check(_lib.lib().dbm_debug_inject_timeout(g.ctx.handle), g.ctx.handle)
-    # while the condition is up the optimizer is a no-op: parameters must not move
-    g_opt.update()
     try:
-        g.ctx.synchronize()
+        g_opt.update()
         raise SystemExit("status 7 expected")
     except _lib.DbmError as e:
         assert e.code == 7, e
     assert all(np.array_equal(before[k], v) for k, v in g.serialize_dict().items())
-    g_opt.t -= 1
+    g.cleargrads()
     _lib.check(_lib.lib().dbm_debug_inject_timeout(g.ctx.handle), g.ctx.handle)
 m = list(d.train_eval_discriminator(batch, g, dm, d_opt, prefetch_generator_forward=True))   # observes, recovers, repeats
 m += list(d.train_eval_generator(batch, g, dm, g_opt))
@@ -775,7 +779,10 @@ def test_persistent_kernel_timeout_is_recovered(dbm, tmp_path):
     assert np.allclose(outs[0]["m"], outs[1]["m"], rtol=2e-4, atol=1e-6)
     for k in outs[0]:
         if k != "m":
-            assert np.abs(outs[0][k] - outs[1][k]).max() <= 2.1e-3, k  # at most one Adam step (1e-3) apart per update
+            # the skipped optimizer launch gave its step count back: the same Adam step as the undisturbed run, except
+            # where a gradient is rounding noise (its first step is alpha * sign(g))
+            assert np.abs(outs[0][k] - outs[1][k]).max() <= 2.1e-3, k
+            assert np.mean(np.abs(outs[0][k] - outs[1][k]) < 2e-5) > 0.97, k
 
 
 def test_api_refuses_what_it_does_not_implement(dbm, tmp_path):
