@@ -59,7 +59,8 @@ def grads_of(model):
     return {k: t.grad for k, t in model._tensors.items() if t.kind == 0}
 
 
-DEV = 3.0  # the HIP path may be this many times further from the float64 oracle than the float32 oracle is
+DEV = 3.0    # the HIP path may be this many times further from the float64 oracle than the float32 oracle is
+DEV_G = 5.0  # ... and for the generator's gradients of c3, than the float32 oracle's WORST tensor is (coherent flip noise)
 
 
 def _close(got, ref64, ref32, rtol, atol=1e-6):
@@ -91,7 +92,9 @@ def _c3_check_d(d, got_d, gold):
 def _c3_check_g(g, got_g, gold):
     # (the adversarial term sees D after its first Adam step, ~alpha * sign(gradient): rounding-noise gradients may flip)
     assert _close(got_g, gold["c3/g_step"], gold["c3/g_step_f32"], 5e-4, 1e-5), (got_g, gold["c3/g_step"])
-    worst = mgf.check_digest_dict(gold, "c3/gradG/", grads_of(g), TOL_GRAD, TOL_GRAD, floor=mgf.G_FLOOR, dev_factor=DEV)
+    dev = gold["c3/gradG/dev"]
+    worst = mgf.check_digest_dict(gold, "c3/gradG/", grads_of(g), max(TOL_GRAD, DEV_G * float(dev[:, 0].max())),
+                                  max(TOL_GRAD, DEV_G * float(dev[:, 1].max())), floor=mgf.G_FLOOR)
     assert worst[0] < 1.0, worst
 
 
@@ -121,6 +124,21 @@ def test_config3_sequential_path_gives_the_same_numbers(dbm, gold):
             _c3_check_d(d, got_d, gold)
             got_g = dbm.train_eval_generator(a, g, d, g_opt)
             _c3_check_g(g, got_g, gold)
+
+
+def test_config3_generator_step_reference_init_tight(dbm, gold):
+    """The G-step of config 3 with the reference's initialisation (c3lin: no slope hangs on a rounding error): loss, PSNR,
+    SSIM and EVERY generator gradient at 5e-4 against the float32 oracle -- the persistent forward and backward trunk
+    kernels at 192 workgroups, the tail, the deformable layers, the batched weight gradients with their ordered folds."""
+    og, od = mgf.models_c3lin()
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=12, initialize=False), og.params)
+    d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+    g_opt = dbm.optimizers.Adam(alpha=mgf.ALPHA, eps=mgf.EPS).setup(g)
+    batch = dbm.device_batch(mgf.arrays(64, 6200))
+    got = dbm.train_eval_generator(batch, g, d, g_opt)
+    assert np.allclose(got, gold["c3lin/g_step"], rtol=2e-4, atol=1e-6), (got, gold["c3lin/g_step"])
+    worst = mgf.check_digest_dict(gold, "c3lin/gradG/", grads_of(g), TOL_GRAD, TOL_GRAD)
+    assert worst[0] < 1.0, worst
 
 
 def test_config2_generator_only_l1_matches_oracle_fixture(dbm, gold):
