@@ -267,10 +267,9 @@ def main():
     dbm.global_config.cudnn_deterministic = not args.no_deterministic
     prefetch = not (args.share_generator_forward or args.no_prefetch)
 
-    def step():  # one minibatch of deepbedmap_amd.trainer (srgan_train.py:1286-1309)
-        dbm.train_eval_discriminator(batch, g, d, d_opt, comm=comm, share_generator_forward=args.share_generator_forward,
-                                     prefetch_generator_forward=prefetch)
-        dbm.train_eval_generator(batch, g, d, g_opt, comm=comm, share_generator_forward=args.share_generator_forward)
+    def step():  # one minibatch of deepbedmap_amd.trainer (srgan_train.py:1286-1309), its five metrics fetched to the host
+        return dbm.train_minibatch(batch, g, g_opt, d, d_opt, comm=comm, share_generator_forward=args.share_generator_forward,
+                                   prefetch_generator_forward=prefetch)
 
     lib = dbm._lib.lib()
     for _ in range(args.warmup):

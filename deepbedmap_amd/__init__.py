@@ -12,7 +12,7 @@ from .srgan import (  # noqa: F401
 )
 from .training import (  # noqa: F401
     SerialIterator, compile_srgan_model, concat_examples, dataset_to_device, device_batch, get_train_dev_iterators,
-    save_model_weights_and_architecture, split_dataset_random, train_eval_discriminator, train_eval_generator, trainer,
+    save_model_weights_and_architecture, split_dataset_random, train_eval_discriminator, train_eval_generator, train_minibatch, trainer,
 )
 from .parallel import DataParallel, shard_batch, shard_slice  # noqa: F401
 from .inference import (Shape, clip_inputs, crop_bounds, merge_ranks, predict_tiled, predict_tiled_resident,  # noqa: F401

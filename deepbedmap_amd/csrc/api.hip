@@ -713,6 +713,11 @@ int dbm_adam_update(dbm_model* m, double grad_scale) {
   DBM_MARK(m->ctx->stream, m->type == 0 ? "G:optimizer" : "D:optimizer");
   m->packed_dirty = true;
   m->param_version++;
+  // The generator's packed weight images and trunk weight streams are rebuilt right behind its update: the caller is
+  // about to fetch this iteration's metrics (a host round trip during which the GPU would idle), and the next forward
+  // finds them ready instead of starting with 0.13 ms of repacking.  (The discriminator's repack already hides under
+  // the generator passes that precede its next use.)
+  if (m->type == 0) m->ensure_packed();
   DBM_API_END
 }
 
@@ -826,9 +831,24 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     d->merge_slots = true;  // one weight-gradient launch per layer group for both graphs
     d->comm_sent_lo = d->comm_sent_hi = 0;
     try {
-      d->backward(1, gf, false);
-      c->stream = s;
-      d->backward(0, gr, false);
+      // The pass on the MAIN stream (real batch) is enqueued first: the main stream is the one the step's tail waits
+      // for (measured: D-step 5.72 -> 5.39 ms against enqueueing the fake batch's pass first); whichever pass is enqueued
+      // second launches the merged weight-gradient groups behind both passes' events.
+      static const bool fake_first = getenv("DBM_DBWD_ORDER") && atoi(getenv("DBM_DBWD_ORDER")) == 0;
+      hipStream_t other = c->stream;  // chain[0] when two streams are used, else the main stream
+      if (fake_first) {
+        d->merge_launcher = 0;
+        d->backward(1, gf, false);
+        c->stream = s;
+        d->backward(0, gr, false);
+      } else {
+        d->merge_launcher = 1;
+        c->stream = s;
+        d->backward(0, gr, false);
+        c->stream = other;
+        d->backward(1, gf, false);
+        c->stream = s;
+      }
     } catch (...) {
       c->stream = s;
       d->merge_slots = false;

@@ -110,8 +110,8 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
 }
 
 // Weight gradients of one layer group go to the side stream once their inputs are final.  Merged mode (the fused
-// D-step): the fake batch's pass (slot 1, enqueued first, on its own stream) only records an event; the real batch's
-// pass (slot 0) launches the group for both graphs behind both events.
+// D-step): the pass that is enqueued first only records an event per group; the pass enqueued second
+// (`merge_launcher`) launches the group for both graphs behind both events.
 void Discriminator::launch_group(int slot, int g) {
   if (!merge_slots) {
     ctx->fork_to_side(2 + slot);
@@ -120,9 +120,9 @@ void Discriminator::launch_group(int slot, int g) {
   }
   if (!ev_grp[slot][g]) DBM_HIP(hipEventCreateWithFlags(&ev_grp[slot][g], hipEventDisableTiming));
   DBM_HIP(hipEventRecord(ev_grp[slot][g], ctx->stream));
-  if (slot == 0) {
-    DBM_HIP(hipStreamWaitEvent(ctx->side, ev_grp[0][g], 0));
-    if (ev_grp[1][g]) DBM_HIP(hipStreamWaitEvent(ctx->side, ev_grp[1][g], 0));
+  if (slot == merge_launcher) {  // the pass that is enqueued second: both events of this step exist now
+    DBM_HIP(hipStreamWaitEvent(ctx->side, ev_grp[slot][g], 0));
+    if (ev_grp[1 - slot][g]) DBM_HIP(hipStreamWaitEvent(ctx->side, ev_grp[1 - slot][g], 0));
     wbm[g].launch(ctx->side);
     // Data-parallel run: group 0 = conv_layer6..9 is 89 % of the discriminator's parameters, one contiguous range of the
     // gradient arena, and final as soon as this launch is: its all-reduce runs underneath the rest of the backward pass.

@@ -204,6 +204,7 @@ struct Discriminator : dbm_model {
   WgradBatch wbm[NWG];     // the same for BOTH graphs in one launch per group (the fused D-step: twice the work per launch)
   hipEvent_t ev_grp[2][NWG] = {};
   size_t comm_sent_lo = 0, comm_sent_hi = 0;  // gradient range already handed to the exchange by launch_group (this step)
+  int merge_launcher = 0;    // merged mode: the slot whose backward pass is enqueued SECOND (it launches the groups)
   bool merge_slots = false;  // set by dbm_discriminator_step around its two backward calls (fake first, then real)
   void launch_group(int slot, int g);
   WgradBatch wb[2][NWG];  // batched weight gradients per retained graph (real / fake batch): layers 9..6, 5..4, 3..2, 1

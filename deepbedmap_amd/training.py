@@ -237,17 +237,32 @@ def get_train_dev_iterators(dataset, first_size: int, batch_size: int = 128, see
     return train_iter, n_train, dev_iter, n_dev
 
 
+def train_minibatch(train_arrays, g_model, g_optimizer, d_model, d_optimizer, comm=None, share_generator_forward=False,
+                    prefetch_generator_forward=True):
+    """The body of `trainer`'s training loop (srgan_train.py:1286-1309) for one minibatch of device arrays:
+    train_eval_discriminator, then train_eval_generator, metrics fetched once.  Returns (d_loss, d_accu, g_loss,
+    g_psnr, g_ssim) as floats."""
+    prefetch = prefetch_generator_forward and not share_generator_forward
+    train_eval_discriminator(train_arrays, g_model, d_model, d_optimizer, comm=comm, sync=False,
+                             share_generator_forward=share_generator_forward, prefetch_generator_forward=prefetch)
+    m = train_eval_generator(train_arrays, g_model, d_model, g_optimizer, comm=comm, sync=False,
+                             share_generator_forward=share_generator_forward)
+    out = m.get()
+    return float(out[0]), float(out[1]), float(out[2]), float(out[3]), float(out[4])
+
+
 def trainer(i: int, columns: list, train_iter, dev_iter, g_model, g_optimizer, d_model, d_optimizer, comm=None):
     """srgan_train.py:1267-1329: one epoch of D-step/G-step minibatches, then the dev-set evaluation."""
     metrics_dict = {mn: [] for mn in columns}
     while i == train_iter.epoch:
         train_arrays = device_batch(concat_examples(train_iter.dataset, train_iter.next()), g_model.ctx)
-        d_train_loss, d_train_accu = train_eval_discriminator(train_arrays, g_model, d_model, d_optimizer, comm=comm,
-                                                              prefetch_generator_forward=True)
+        # Both steps are enqueued back to back and the five metrics of the minibatch come back with ONE device-to-host
+        # copy (the reference's `float(...)` after each step is a host round trip during which the GPU idles); the
+        # numbers are the ones the two calls would have returned one by one.
+        d_train_loss, d_train_accu, g_train_loss, g_train_psnr, g_train_ssim = train_minibatch(
+            train_arrays, g_model, g_optimizer, d_model, d_optimizer, comm=comm)
         metrics_dict["discriminator_loss"].append(d_train_loss)
         metrics_dict["discriminator_accu"].append(d_train_accu)
-        g_train_loss, g_train_psnr, g_train_ssim = train_eval_generator(train_arrays, g_model, d_model, g_optimizer,
-                                                                        comm=comm)
         metrics_dict["generator_loss"].append(g_train_loss)
         metrics_dict["generator_psnr"].append(g_train_psnr)
         metrics_dict["generator_ssim"].append(g_train_ssim)
