@@ -146,7 +146,8 @@ struct WgradPlan {
   int fast;
   unsigned planeM, winM;  // ceil(2^32 / (Hin*Win)), ceil(2^32 / Win): exact quotients for the sizes staged here
   unsigned oplaneM;       // ceil(2^32 / (OH*OW))
-  int wave_task;          // 0: wgrad_kernel (workgroup form), 2: wgrad_wave_dma_kernel, 3: wgrad_band_dma_kernel
+  int wave_task;          // 0: wgrad_kernel (workgroup form), 2: wgrad_wave_dma_kernel, 3: wgrad_band_dma_kernel,
+                          // 4: wgrad_direct_kernel (Wst = segments per output row, nbands = segments, S = K slices)
   const float* zeros;     // >= 4 bytes of device zeros (out-of-image rows of the row-band DMA form)
   // deterministic folding (no fp32 atomics): partial[slice][cout tile][group][wave][tap][16][64] in accumulator order,
   // partial_b[slice][cout tile][32]; summed in slice order by wgrad_fold_kernel.  null = atomics.
@@ -177,7 +178,7 @@ struct WgradBatch {
   // training step: cleargrads, then one backward pass).  Two K slices may then fold with atomics even in deterministic
   // mode: (0 + a) + b == (0 + b) + a bit for bit -- no partial tiles, no fold kernel for those layers.
   bool cleared_target = false, built_cleared = false;
-  static const int NCAT = 6;  // see WgradBatch::build
+  static const int NCAT = 9;  // see WgradBatch::build
   WgradPlan* d_plans[NCAT] = {};
   int* d_starts[NCAT] = {};
   int nplans[NCAT] = {}, total_wg[NCAT] = {};

@@ -761,6 +761,191 @@ __global__ __launch_bounds__(128, 2) void wgrad_band_dma_kernel(const WgradPlan*
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Direct form: 3x3 / stride 1 (plain or on a nearest-x2 input) and 4x4 / stride 2 layers on planes of >= 16 columns
+// (generator tail, discriminator stem).  No LDS staging at all: the position axis is the MFMA K axis, and ANY
+// assignment of positions to (instruction, k) is valid as long as both operands use it -- so lane (j, kh) takes four
+// CONSECUTIVE positions of one output row segment (b0 = 8 q + 4 kh .. + 3) and reads them with one 16-byte load from
+// ITS OWN row of dy (out channel j) and, per kernel row, one run of 6 / 4 / 10 floats from ITS OWN plane of x (in
+// channel j): four instructions per tap consume them, k = 0 from the lanes kh = 0, k = 1 from the lanes kh = 1.
+// Per segment of 8 positions a wavefront issues 36 (32) MFMAs against 1 + 6 (5) loads; the loads of the next segment are
+// in flight meanwhile.  Borders are selects on the loaded values (masks depend on indices only), out-of-range addresses
+// are clamped (every tensor carries a 128-byte guard).  A workgroup = four wavefronts = four consecutive K sub-slices of
+// one (layer, out tile, in tile, tap half); they are summed through LDS and leave as ONE contribution per K slice.
+// ---------------------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) f32x4u { float v[4]; };
+struct __attribute__((packed, aligned(4))) f32x2u { float v[2]; };
+
+template <int MODE>  // 0: 3x3 s1 p1;  1: 3x3 s1 p1 on a nearest-x2 input;  2: 4x4 s2 p1 (one tap half per workgroup)
+__global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ starts,
+                                                              int nplans) {
+  constexpr int T = MODE == 2 ? 16 : 9;
+  constexpr int TPW = MODE == 2 ? 8 : 9;
+  constexpr int TG = T / TPW;
+  constexpr int KWc = MODE == 2 ? 4 : 3;
+  constexpr int NR = MODE == 2 ? 2 : 3;                       // kernel rows per wavefront
+  constexpr int NB = MODE == 0 ? 6 : (MODE == 1 ? 4 : 10);     // floats per kernel row and lane
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  int lo = 0, hi = nplans - 1;
+  const int wg = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= wg) lo = mid; else hi = mid - 1;
+  }
+  const WgradPlan& p = plans[lo];
+  const WgradDesc& d = p.d;
+  int local = wg - starts[lo];
+  const int bx = local % p.groups; local /= p.groups;
+  const int by = local % p.coutTiles; local /= p.coutTiles;
+  const int tg = local % TG;
+  const int bz = local / TG;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  const int cout0 = by * 32, cin_w = bx * 32;
+  const int SPR = p.Wst;                 // segments of 8 positions per output row
+  const int nseg = p.nbands;             // N * OH * SPR
+  const int per = (nseg + p.S - 1) / p.S;
+  const int g0 = bz * per, g1 = min(nseg, g0 + per);
+  const int perw = (max(g1 - g0, 0) + 3) >> 2;
+  const int s0 = g0 + wave * perw, s1 = min(g1, s0 + perw);
+  const int Hl = d.Hin << d.ups, Wl = d.Win << d.ups;
+  const int oc = min(cout0 + j, d.Cout - 1), ic = min(cin_w + j, d.Cin - 1);
+  const float* dyl = d.dy + (long)oc * d.dysc;
+  const float* xl = d.x + (long)ic * d.xsc;
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+  const bool want_bias = d.gb && bx == 0 && tg == 0;
+
+  struct Seg {
+    float a[4];
+    float b[NR][NB];
+    unsigned am;        // valid positions (4 bits)
+    unsigned rm;        // valid kernel rows (NR bits)
+    unsigned cm;        // valid columns (NB bits)
+  };
+  auto load = [&](int g, Seg& sg) {
+    const int row = g / SPR, q = g - row * SPR;
+    const int n = row / d.OH, a = row - n * d.OH;
+    const int b0 = 8 * q + 4 * kh;
+    const f32x4u av = *reinterpret_cast<const f32x4u*>(dyl + (long)n * d.dysn + a * d.OW + b0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) sg.a[m] = av.v[m];
+    sg.am = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) sg.am |= (b0 + m < d.OW) ? (1u << m) : 0u;
+    const float* xn = xl + (long)n * d.xsn;
+    sg.rm = 0;
+    sg.cm = 0;
+    int c0;   // first physical column of the run
+    if (MODE == 0) c0 = b0 - 1;
+    else if (MODE == 1) c0 = (b0 >> 1) - 1;
+    else c0 = 2 * b0 - 1;
+#pragma unroll
+    for (int e = 0; e < (MODE == 1 ? 6 : NB); ++e) {
+      // logical column of element e (MODE 1: six logical columns share four physical ones)
+      const int ix = (MODE == 2 ? 2 * b0 : b0) - 1 + e;
+      if ((unsigned)ix < (unsigned)Wl) sg.cm |= 1u << e;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int il = (MODE == 2) ? 2 * a + 2 * tg + r - 1 : a + r - 1;   // logical input row
+      const bool ok = (unsigned)il < (unsigned)Hl;
+      if (ok) sg.rm |= 1u << r;
+      const int iy = (ok ? il : 0) >> d.ups;
+      const float* src = xn + iy * d.Win + c0;
+      const f32x4u v0 = *reinterpret_cast<const f32x4u*>(src);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sg.b[r][e] = v0.v[e];
+      if (MODE == 0) {
+        const f32x2u v1 = *reinterpret_cast<const f32x2u*>(src + 4);
+        sg.b[r][4] = v1.v[0]; sg.b[r][5] = v1.v[1];
+      } else if (MODE == 2) {
+        const f32x4u v1 = *reinterpret_cast<const f32x4u*>(src + 4);
+        const f32x2u v2 = *reinterpret_cast<const f32x2u*>(src + 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sg.b[r][4 + e] = v1.v[e];
+        sg.b[r][8] = v2.v[0]; sg.b[r][9] = v2.v[1];
+      }
+    }
+  };
+  auto compute = [&](const Seg& sg) {
+    float a[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = ((sg.am >> m) & 1u) ? sg.a[m] : 0.f;
+    if (want_bias) bsum += (a[0] + a[1]) + (a[2] + a[3]);
+    // logical-column view of the runs, borders zeroed
+    constexpr int NL = MODE == 1 ? 6 : NB;
+    float bl[NR][NL];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int e = 0; e < NL; ++e) {
+        const int pe = MODE == 1 ? (((e - 1) >> 1) + 1) : e;   // physical element of logical column e
+        const bool ok = ((sg.rm >> r) & 1u) && ((sg.cm >> e) & 1u);
+        bl[r][e] = ok ? sg.b[r][pe] : 0.f;
+      }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const int r = t / KWc, kx = t % KWc;
+        const int e = (MODE == 2 ? 2 * m : m) + kx;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bl[r][e], acc[t], 0, 0, 0);
+      }
+  };
+
+  if (s0 < s1) {
+    Seg cur, nxt;
+    load(s0, cur);
+    for (int g = s0; g < s1; ++g) {
+      load(g + 1 < s1 ? g + 1 : g, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+  }
+
+  // ---- four K sub-slices -> one contribution: 8 output rows at a time through LDS, atomics over consecutive addresses ----
+  float *gWt, *gbt;
+  pair_targets(p, bz, gWt, gbt);
+  constexpr int ROWF = 32 * T;
+  float* tw = lds + wave * (8 * ROWF);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) tw[(rr + 4 * kh) * ROWF + j * T + tg * TPW + t] = acc[t][4 * q + rr];
+    __syncthreads();
+    for (int e = tid; e < 8 * ROWF; e += 256) {
+      const int rl = e / ROWF;
+      const int rem = e - rl * ROWF;
+      const int c = rem / T, t = rem - c * T;
+      if (TG > 1 && (t / TPW) != tg) continue;
+      const int o = cout0 + 8 * q + rl;
+      if (o < d.Cout && cin_w + c < d.Cin) {
+        const float v = ((lds[e] + lds[8 * ROWF + e]) + lds[2 * 8 * ROWF + e]) + lds[3 * 8 * ROWF + e];
+        atomicAdd(gWt + ((long)o * d.Cin + cin_w) * T + rem, d.scale * v);
+      }
+    }
+    __syncthreads();
+  }
+  if (want_bias) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (kh == 0) lds[wave * 32 + j] = bsum;
+    __syncthreads();
+    if (tid < 32 && cout0 + tid < d.Cout)
+      atomicAdd(gbt + cout0 + tid, d.scale * (((lds[tid] + lds[32 + tid]) + lds[64 + tid]) + lds[96 + tid]));
+  }
+}
+
 // Sums the K-slice partials of a weight-gradient launch in slice order and adds them to gW (OIHW) / gb: one workgroup per
 // 256 elements of one wavefront slot's tile.  No fp32 atomics on the K split (the one atomic per element below only
 // serialises the real- and the fake-batch graph of the discriminator: two contributions onto a cleared gradient, and
@@ -874,6 +1059,40 @@ static size_t band_plan(const WgradDesc& d, WgradPlan& p, int S_fixed) {
   return std::max(stage, sizeof(float) * 2 * 8 * 32 * (size_t)9);
 }
 
+// direct form (wgrad_direct_kernel): mode 0 / 1 / 2 or -1 if the layer is not eligible
+static int direct_mode(const WgradDesc& d) {
+  const int T = d.KH * d.KW;
+  const int Hl = d.Hin << d.ups, Wl = d.Win << d.ups;
+  if (d.KH != d.KW || d.pad != 1 || d.OW < 16 || d.xsc != d.Hin * d.Win || d.dysc != d.OH * d.OW) return -1;
+  if (T == 9 && d.stride == 1 && d.OH == Hl && d.OW == Wl) return d.ups ? 1 : 0;
+  if (T == 16 && d.stride == 2 && d.ups == 0 && 2 * d.OH == Hl && 2 * d.OW == Wl) return 2;
+  return -1;
+}
+
+// segs_per_wg: K segments (8 positions each) one workgroup (four wavefronts) works through
+static size_t direct_plan(const WgradDesc& d, WgradPlan& p, long segs_per_wg) {
+  const int mode = direct_mode(d);
+  DBM_CHECK(mode >= 0, "wgrad: layer not eligible for the direct form");
+  const int T = d.KH * d.KW;
+  p.d = d;
+  p.wave_task = 4;
+  p.zeros = nullptr;
+  p.groups = (d.Cin + 31) / 32;
+  p.G = 1;
+  p.coutTiles = (d.Cout + 31) / 32;
+  p.Wst = (d.OW + 7) / 8;
+  const long nseg = (long)d.N * d.OH * p.Wst;
+  DBM_CHECK(nseg < (1L << 30), "wgrad: too many positions");
+  p.nbands = (int)nseg;
+  long S = (nseg + segs_per_wg - 1) / segs_per_wg;
+  if (S < 1) S = 1;
+  p.S = (int)S;
+  p.wg_count = p.groups * p.coutTiles * (mode == 2 ? 2 : 1) * p.S;
+  p.IB = 1; p.R = 1; p.nbr = d.OH; p.BP = p.BPp = 8; p.YS = p.XS = 0; p.Rin = 0; p.ImgS = 0;
+  p.fast = 0; p.planeM = p.winM = p.oplaneM = 0;
+  return sizeof(float) * 4 * 8 * 32 * (size_t)T;  // four transpose areas of 8 output rows
+}
+
 size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level, int wave_task, int S_fixed) {
   const int T = d.KH * d.KW;
   DBM_CHECK(T == 1 || T == 9 || T == 16, "wgrad: supported kernels are 1x1, 3x3, 4x4");
@@ -982,6 +1201,15 @@ void WgradBatch::reset() {
   }
 }
 
+static int direct_form_enabled() {  // DBM_WGRAD_DIRECT: 1 (default) = wgrad_direct_kernel for the large-plane 3x3 / 4x4 layers
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DBM_WGRAD_DIRECT");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 static int dma_forms_enabled() {  // DBM_WGRAD_WAVE: 0 = workgroup form only, 1 = + trunk LDS-DMA tasks, 2 (default) = + row-band LDS-DMA
   static int v = -1;
   if (v < 0) {
@@ -1003,17 +1231,20 @@ static const float* device_zeros() {
 
 void WgradBatch::build() {
   // categories: 0 = 1x1, 1 = 3x3 workgroup form, 2 = 4x4 workgroup form, 3 = 3x3 trunk LDS-DMA tasks (whole-image bands
-  // of small planes), 4 = 3x3 row-band LDS-DMA, 5 = 4x4 row-band LDS-DMA
-  static const int TT[NCAT] = {1, 9, 16, 9, 9, 16};
-  static const int MODE[NCAT] = {0, 0, 0, 2, 3, 3};
+  // of small planes), 4 = 3x3 row-band LDS-DMA, 5 = 4x4 row-band LDS-DMA, 6 / 7 / 8 = direct form (3x3, 3x3 on a
+  // nearest-x2 input, 4x4 stride 2)
+  static const int TT[NCAT] = {1, 9, 16, 9, 9, 16, 9, 9, 16};
+  static const int MODE[NCAT] = {0, 0, 0, 2, 3, 3, 4, 4, 4};
+  const bool direct = direct_form_enabled() != 0;
   std::vector<int> cat(descs.size());
   const int forms = dma_forms_enabled();
   for (size_t i = 0; i < descs.size(); ++i) {
     const int T = descs[i].KH * descs[i].KW;
     WgradPlan p;
+    const int dm = direct ? direct_mode(descs[i]) : -1;
     if (T == 1) cat[i] = 0;
-    else if (T == 9) cat[i] = (forms >= 1 && wgrad_plan(descs[i], p, 0, 2) != 0) ? 3 : (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 4 : 1;
-    else cat[i] = (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 5 : 2;
+    else if (T == 9) cat[i] = (forms >= 1 && wgrad_plan(descs[i], p, 0, 2) != 0) ? 3 : dm >= 0 ? 6 + dm : (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 4 : 1;
+    else cat[i] = dm >= 0 ? 6 + dm : (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 5 : 2;
   }
   for (int g = 0; g < NCAT; ++g) {
     std::vector<WgradPlan> plans;
@@ -1024,7 +1255,19 @@ void WgradBatch::build() {
     // LDS-DMA forms: the K split is chosen so that the launch is ONE round of equally long two-wavefront groups
     // (four per CU for the trunk form; two or four per CU for row bands, by their LDS footprint)
     int S_fixed = 0;
-    if (g >= 3) {
+    long segs_per_wg = 0;
+    if (g >= 6) {
+      // direct form: equally long workgroups, about two per CU over the whole launch (a workgroup's K range should stay
+      // long enough that its closing atomics are a small fraction: >= 64 segments = 512 positions)
+      long work = 0;
+      for (size_t i = 0; i < descs.size(); ++i) {
+        if (cat[i] != g) continue;
+        const WgradDesc& d = descs[i];
+        work += (long)((d.Cin + 31) / 32) * ((d.Cout + 31) / 32) * (g == 8 ? 2 : 1) * d.N * d.OH * ((d.OW + 7) / 8);
+      }
+      static const int slots_env = getenv("DBM_WGRAD_DIRECT_WGS") ? atoi(getenv("DBM_WGRAD_DIRECT_WGS")) : 512;
+      segs_per_wg = std::max(64L, (work + slots_env - 1) / slots_env);
+    } else if (g >= 3) {
       long units = 0;
       size_t need = 0;
       for (size_t i = 0; i < descs.size(); ++i) {
@@ -1045,7 +1288,7 @@ void WgradBatch::build() {
         if (cat[i] != g) continue;
         const WgradDesc& d = descs[i];
         WgradPlan p;
-        maxlds = std::max(maxlds, wgrad_plan(d, p, g >= 3 ? 0 : level, MODE[g], S_fixed));
+        maxlds = std::max(maxlds, g >= 6 ? direct_plan(d, p, segs_per_wg) : wgrad_plan(d, p, g >= 3 ? 0 : level, MODE[g], S_fixed));
         p.zeros = device_zeros();
         p.partial = nullptr; p.partial_b = nullptr; p.fold_start = 0;
         p.pairW = nullptr; p.pair_n = 0; p.pair_direct = 0; p.pair_stride = 0;
@@ -1061,9 +1304,9 @@ void WgradBatch::build() {
     std::vector<int> fstarts;
     fold_wgs[g] = 0;
     if (g_wgrad_deterministic && !plans.empty()) {
-      static const int SLOTS[NCAT] = {4, 4, 8, 2, 2, 2}, CTS[NCAT] = {4, 4, 4, 2, 2, 1}, TPWS[NCAT] = {1, 9, 8, 9, 9, 8};
+      static const int SLOTS[NCAT] = {4, 4, 8, 2, 2, 2, 0, 0, 0}, CTS[NCAT] = {4, 4, 4, 2, 2, 1, 0, 0, 0}, TPWS[NCAT] = {1, 9, 8, 9, 9, 8, 0, 0, 0};
       static const int pairs_env = getenv("DBM_WGRAD_PAIRS") ? atoi(getenv("DBM_WGRAD_PAIRS")) : 1;
-      pair_mode[g] = pairs_env != 0;
+      pair_mode[g] = pairs_env != 0 || g >= 6;  // (the direct form folds through pair buffers only)
       size_t floats = 0, bfloats = 0;
       int fw = 0;
       if (pair_mode[g]) {
@@ -1137,15 +1380,19 @@ void WgradBatch::build() {
 }
 
 template <typename K>
-static void launch_dma(K kernel, const WgradPlan* plans, const int* starts, int nplans, int total_wg, size_t lds, hipStream_t s) {
+static void launch_dma(K kernel, const WgradPlan* plans, const int* starts, int nplans, int total_wg, size_t lds, hipStream_t s,
+                       int threads = 128) {
   static bool attr_set = false;
   if (!attr_set) {  // (one flag for the three kernels: they share this instantiation's signature)
     DBM_HIP(hipFuncSetAttribute((const void*)wgrad_wave_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     DBM_HIP(hipFuncSetAttribute((const void*)wgrad_band_dma_kernel<9, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     DBM_HIP(hipFuncSetAttribute((const void*)wgrad_band_dma_kernel<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_direct_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_direct_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kernel, dim3(total_wg), dim3(128), lds, s, plans, starts, nplans);
+  hipLaunchKernelGGL(kernel, dim3(total_wg), dim3(threads), lds, s, plans, starts, nplans);
   DBM_HIP(hipGetLastError());
 }
 
@@ -1167,7 +1414,10 @@ void WgradBatch::launch(hipStream_t s) {
     else if (g == 2) launch_T<16, 8>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else if (g == 3) launch_dma(wgrad_wave_dma_kernel, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else if (g == 4) launch_dma(wgrad_band_dma_kernel<9, 9>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
-    else launch_dma(wgrad_band_dma_kernel<16, 8>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else if (g == 5) launch_dma(wgrad_band_dma_kernel<16, 8>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
+    else if (g == 6) launch_dma(wgrad_direct_kernel<0>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
+    else if (g == 7) launch_dma(wgrad_direct_kernel<1>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
+    else launch_dma(wgrad_direct_kernel<2>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
     if (fold_wgs[g]) {
       if (pair_mode[g])
         hipLaunchKernelGGL(wgrad_pair_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);

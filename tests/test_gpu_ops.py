@@ -59,6 +59,13 @@ CONV_CASES = [
     (37, 512, 2, 2, 512, 3, 1, 1, 0, 0),   # D conv_layer8
     (9, 64, 18, 18, 128, 3, 1, 1, 0, 0),   # D conv_layer2: whole-image bands do not fit a wavefront's LDS share
     (5, 64, 11, 13, 32, 3, 1, 1, 0, 0),    # odd, non-square plane (contiguous runs not a multiple of 16 bytes)
+    # direct form (no LDS staging; rows of >= 16 positions): many K slices through the pair buffers, ragged segments
+    # (36 = 4.5 segments, 18 = 2.25, 21 odd), the folded nearest x2 resize, the two tap halves of a 4x4 stride-2 layer
+    (24, 64, 36, 36, 64, 3, 1, 1, 0, 0),   # post_upsample_2-sized plain layer, 4 tiles
+    (20, 64, 18, 18, 64, 3, 1, 1, 1, 0),   # post_upsample_2: 36 x 36 output from an 18 x 18 input
+    (12, 96, 36, 36, 32, 4, 2, 1, 0, 0),   # 4x4 stride 2, 36 -> 18, three input tiles
+    (3, 64, 23, 21, 32, 3, 1, 1, 0, 0),    # odd widths: misaligned rows, ragged last segment
+    (2, 32, 21, 19, 64, 4, 2, 1, 0, 0),    # odd input of a stride-2 layer: NOT the direct form (2 * OW != W)
 ]
 
 
