@@ -946,6 +946,130 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(const WgradPlan* _
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 layers on large contiguous planes (the deformable convolution's 576 -> 64 GEMM over the sampled columns,
+// srgan_train.py:506-523): gW[o][c] = sum over positions of dy[o][pos] * x[c][pos], K = N * plane positions.  Both
+// operands are K-contiguous in memory, so they are staged through LDS in full 128-byte rows (16-byte loads and stores),
+// double buffered: the loads of band k + 1 are in flight while band k feeds the matrix pipe.  A workgroup owns
+// 64 (out) x 128 (in) of the gradient: wavefront w the 32 input channels 32 w .. 32 w + 31 against BOTH output tiles
+// (two accumulators, three ds_read_b128 per eight MFMAs); a lane's 16-byte read covers four consecutive positions of its
+// row -- any position-to-(instruction, k) assignment is valid as long as both operands use it.  Row stride 36 floats:
+// 16-byte aligned and conflict-free for the 16-lane groups of ds_read_b128.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad_1x1_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ starts,
+                                                           int nplans) {
+  constexpr int BP = 32, BS = 36;             // positions per band, LDS row stride
+  constexpr int ROWS = 64 + 128;              // dy rows, then x rows
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x ROWS x BS
+  int lo = 0, hi = nplans - 1;
+  const int wg = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (starts[mid] <= wg) lo = mid; else hi = mid - 1;
+  }
+  const WgradPlan& p = plans[lo];
+  const WgradDesc& d = p.d;
+  int local = wg - starts[lo];
+  const int bx = local % p.groups; local /= p.groups;     // 128 input channels
+  const int by = local % p.coutTiles;                     // 64 output channels
+  const int bz = local / p.coutTiles;                     // K slice
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  const int cout0 = by * 64, cin0 = bx * 128;
+  const int plane = d.OH * d.OW;
+  const int bpi = p.nbr;                                  // bands per image
+  const int per = (p.nbands + p.S - 1) / p.S;
+  const int k0 = bz * per, k1 = min(p.nbands, k0 + per);
+  // staging: thread `tid` moves rows r0 + 32 i (i < 6), positions 4 * (tid & 7) .. + 3
+  const int sp = 4 * (tid & 7), r0 = tid >> 3;
+  const float* src[6];
+  bool rok[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int r = r0 + 32 * i;
+    if (r < 64) {
+      rok[i] = cout0 + r < d.Cout;
+      src[i] = d.dy + (long)(rok[i] ? cout0 + r : 0) * d.dysc;
+    } else {
+      rok[i] = cin0 + r - 64 < d.Cin;
+      src[i] = d.x + (long)(rok[i] ? cin0 + r - 64 : 0) * d.xsc;
+    }
+  }
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 stage[6];
+  auto issue = [&](int k) {
+    const int n = k / bpi, pos = (k - n * bpi) * BP + sp;
+    const bool pok = pos < plane;   // (planes are multiples of 4 positions: a 16-byte run is all in or all out)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const long img = (long)n * (i < 2 ? d.dysn : d.xsn);
+      stage[i] = *reinterpret_cast<const f4*>(src[i] + img + (pok ? pos : 0));
+      if (!(pok && rok[i])) stage[i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto commit = [&](int buf) {
+    float* base = lds + buf * (ROWS * BS);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f4*>(base + (r0 + 32 * i) * BS + sp) = stage[i];
+  };
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  float bs0 = 0.f, bs1 = 0.f;
+  const bool want_bias = d.gb && bx == 0 && wave == 0;
+  if (k0 < k1) {
+    issue(k0);
+    commit(0);
+    __syncthreads();
+    for (int k = k0; k < k1; ++k) {
+      const int buf = (k - k0) & 1;
+      if (k + 1 < k1) issue(k + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const float* A = lds + buf * (ROWS * BS) + j * BS + 4 * kh;
+      const float* B = lds + buf * (ROWS * BS) + (64 + 32 * wave + j) * BS + 4 * kh;
+#pragma unroll
+      for (int u = 0; u < BP / 8; ++u) {
+        const f4 a0 = *reinterpret_cast<const f4*>(A + 8 * u);
+        const f4 a1 = *reinterpret_cast<const f4*>(A + 32 * BS + 8 * u);
+        const f4 b = *reinterpret_cast<const f4*>(B + 8 * u);
+        if (want_bias) { bs0 += (a0.x + a0.y) + (a0.z + a0.w); bs1 += (a1.x + a1.y) + (a1.z + a1.w); }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b.w, acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + 1 < k1) commit(buf ^ 1);
+      __syncthreads();  // band k + 1 is in place; every wavefront is done with band k's buffer
+    }
+  }
+  // ---- fold: gW[o][c] rows are contiguous along c, the accumulators' lane axis: coalesced atomics, no transpose ----
+  float *gWt, *gbt;
+  pair_targets(p, bz, gWt, gbt);
+  const int c = cin0 + 32 * wave + j;
+  if (c < d.Cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = cout0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (o < d.Cout) atomicAdd(gWt + (long)o * d.Cin + c, d.scale * acc0[r]);
+      if (o + 32 < d.Cout) atomicAdd(gWt + (long)(o + 32) * d.Cin + c, d.scale * acc1[r]);
+    }
+  }
+  if (want_bias) {
+    bs0 += __shfl_xor(bs0, 32, 64);
+    bs1 += __shfl_xor(bs1, 32, 64);
+    if (kh == 0) {
+      if (cout0 + j < d.Cout) atomicAdd(gbt + cout0 + j, d.scale * bs0);
+      if (cout0 + 32 + j < d.Cout) atomicAdd(gbt + cout0 + 32 + j, d.scale * bs1);
+    }
+  }
+}
+
 // Sums the K-slice partials of a weight-gradient launch in slice order and adds them to gW (OIHW) / gb: one workgroup per
 // 256 elements of one wavefront slot's tile.  No fp32 atomics on the K split (the one atomic per element below only
 // serialises the real- and the fake-batch graph of the discriminator: two contributions onto a cleared gradient, and
@@ -1093,6 +1217,33 @@ static size_t direct_plan(const WgradDesc& d, WgradPlan& p, long segs_per_wg) {
   return sizeof(float) * 4 * 8 * 32 * (size_t)T;  // four transpose areas of 8 output rows
 }
 
+// 1x1 layers on large contiguous planes (wgrad_1x1_kernel)
+static bool gemm1x1_eligible(const WgradDesc& d) {
+  const int plane = d.OH * d.OW;
+  return d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && d.ups == 0 && d.Hin == d.OH && d.Win == d.OW && plane >= 256 &&
+         plane % 4 == 0 && d.xsc == plane && d.dysc == plane && d.xsn % 4 == 0 && d.dysn % 4 == 0 &&
+         ((uintptr_t)d.x % 16) == 0 && ((uintptr_t)d.dy % 16) == 0;
+}
+
+static size_t gemm1x1_plan(const WgradDesc& d, WgradPlan& p, long bands_per_wg) {
+  p.d = d;
+  p.wave_task = 5;
+  p.zeros = nullptr;
+  p.groups = (d.Cin + 127) / 128;
+  p.G = 4;
+  p.coutTiles = (d.Cout + 63) / 64;
+  const int plane = d.OH * d.OW;
+  p.nbr = (plane + 31) / 32;
+  p.nbands = d.N * p.nbr;
+  long S = (p.nbands + bands_per_wg - 1) / bands_per_wg;
+  if (S < 1) S = 1;
+  p.S = (int)S;
+  p.wg_count = p.groups * p.coutTiles * p.S;
+  p.IB = 1; p.R = 1; p.BP = p.BPp = 32; p.YS = p.XS = 36; p.Rin = 0; p.ImgS = 0; p.Wst = 0;
+  p.fast = 0; p.planeM = p.winM = p.oplaneM = 0;
+  return sizeof(float) * 2 * (64 + 128) * 36;
+}
+
 size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level, int wave_task, int S_fixed) {
   const int T = d.KH * d.KW;
   DBM_CHECK(T == 1 || T == 9 || T == 16, "wgrad: supported kernels are 1x1, 3x3, 4x4");
@@ -1233,8 +1384,9 @@ void WgradBatch::build() {
   // categories: 0 = 1x1, 1 = 3x3 workgroup form, 2 = 4x4 workgroup form, 3 = 3x3 trunk LDS-DMA tasks (whole-image bands
   // of small planes), 4 = 3x3 row-band LDS-DMA, 5 = 4x4 row-band LDS-DMA, 6 / 7 / 8 = direct form (3x3, 3x3 on a
   // nearest-x2 input, 4x4 stride 2)
-  static const int TT[NCAT] = {1, 9, 16, 9, 9, 16, 9, 9, 16};
-  static const int MODE[NCAT] = {0, 0, 0, 2, 3, 3, 4, 4, 4};
+  // 9 = 1x1 on large contiguous planes (LDS-staged GEMM, wgrad_1x1_kernel)
+  static const int TT[NCAT] = {1, 9, 16, 9, 9, 16, 9, 9, 16, 1};
+  static const int MODE[NCAT] = {0, 0, 0, 2, 3, 3, 4, 4, 4, 5};
   const bool direct = direct_form_enabled() != 0;
   std::vector<int> cat(descs.size());
   const int forms = dma_forms_enabled();
@@ -1242,7 +1394,7 @@ void WgradBatch::build() {
     const int T = descs[i].KH * descs[i].KW;
     WgradPlan p;
     const int dm = direct ? direct_mode(descs[i]) : -1;
-    if (T == 1) cat[i] = 0;
+    if (T == 1) cat[i] = (direct && gemm1x1_eligible(descs[i])) ? 9 : 0;
     else if (T == 9) cat[i] = (forms >= 1 && wgrad_plan(descs[i], p, 0, 2) != 0) ? 3 : dm >= 0 ? 6 + dm : (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 4 : 1;
     else cat[i] = dm >= 0 ? 6 + dm : (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 5 : 2;
   }
@@ -1256,7 +1408,16 @@ void WgradBatch::build() {
     // (four per CU for the trunk form; two or four per CU for row bands, by their LDS footprint)
     int S_fixed = 0;
     long segs_per_wg = 0;
-    if (g >= 6) {
+    if (g == 9) {
+      long work = 0;
+      for (size_t i = 0; i < descs.size(); ++i) {
+        if (cat[i] != g) continue;
+        const WgradDesc& d = descs[i];
+        work += (long)((d.Cin + 127) / 128) * ((d.Cout + 63) / 64) * d.N * ((d.OH * d.OW + 31) / 32);
+      }
+      static const int slots_env = getenv("DBM_WGRAD_1X1_WGS") ? atoi(getenv("DBM_WGRAD_1X1_WGS")) : 512;
+      segs_per_wg = std::max(8L, (work + slots_env - 1) / slots_env);   // bands of 32 positions per workgroup
+    } else if (g >= 6) {
       // direct form: equally long workgroups, about two per CU over the whole launch (a workgroup's K range should stay
       // long enough that its closing atomics are a small fraction: >= 64 segments = 512 positions)
       long work = 0;
@@ -1288,7 +1449,8 @@ void WgradBatch::build() {
         if (cat[i] != g) continue;
         const WgradDesc& d = descs[i];
         WgradPlan p;
-        maxlds = std::max(maxlds, g >= 6 ? direct_plan(d, p, segs_per_wg) : wgrad_plan(d, p, g >= 3 ? 0 : level, MODE[g], S_fixed));
+        maxlds = std::max(maxlds, g == 9 ? gemm1x1_plan(d, p, segs_per_wg) : g >= 6 ? direct_plan(d, p, segs_per_wg)
+                                                                                    : wgrad_plan(d, p, g >= 3 ? 0 : level, MODE[g], S_fixed));
         p.zeros = device_zeros();
         p.partial = nullptr; p.partial_b = nullptr; p.fold_start = 0;
         p.pairW = nullptr; p.pair_n = 0; p.pair_direct = 0; p.pair_stride = 0;
@@ -1304,7 +1466,8 @@ void WgradBatch::build() {
     std::vector<int> fstarts;
     fold_wgs[g] = 0;
     if (g_wgrad_deterministic && !plans.empty()) {
-      static const int SLOTS[NCAT] = {4, 4, 8, 2, 2, 2, 0, 0, 0}, CTS[NCAT] = {4, 4, 4, 2, 2, 1, 0, 0, 0}, TPWS[NCAT] = {1, 9, 8, 9, 9, 8, 0, 0, 0};
+      static const int SLOTS[NCAT] = {4, 4, 8, 2, 2, 2, 0, 0, 0, 0}, CTS[NCAT] = {4, 4, 4, 2, 2, 1, 0, 0, 0, 0},
+                       TPWS[NCAT] = {1, 9, 8, 9, 9, 8, 0, 0, 0, 0};
       static const int pairs_env = getenv("DBM_WGRAD_PAIRS") ? atoi(getenv("DBM_WGRAD_PAIRS")) : 1;
       pair_mode[g] = pairs_env != 0 || g >= 6;  // (the direct form folds through pair buffers only)
       size_t floats = 0, bfloats = 0;
@@ -1390,6 +1553,7 @@ static void launch_dma(K kernel, const WgradPlan* plans, const int* starts, int 
     DBM_HIP(hipFuncSetAttribute((const void*)wgrad_direct_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     DBM_HIP(hipFuncSetAttribute((const void*)wgrad_direct_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     DBM_HIP(hipFuncSetAttribute((const void*)wgrad_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL(kernel, dim3(total_wg), dim3(threads), lds, s, plans, starts, nplans);
@@ -1417,7 +1581,8 @@ void WgradBatch::launch(hipStream_t s) {
     else if (g == 5) launch_dma(wgrad_band_dma_kernel<16, 8>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else if (g == 6) launch_dma(wgrad_direct_kernel<0>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
     else if (g == 7) launch_dma(wgrad_direct_kernel<1>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
-    else launch_dma(wgrad_direct_kernel<2>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
+    else if (g == 8) launch_dma(wgrad_direct_kernel<2>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
+    else launch_dma(wgrad_1x1_kernel, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
     if (fold_wgs[g]) {
       if (pair_mode[g])
         hipLaunchKernelGGL(wgrad_pair_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);

@@ -66,6 +66,10 @@ CONV_CASES = [
     (12, 96, 36, 36, 32, 4, 2, 1, 0, 0),   # 4x4 stride 2, 36 -> 18, three input tiles
     (3, 64, 23, 21, 32, 3, 1, 1, 0, 0),    # odd widths: misaligned rows, ragged last segment
     (2, 32, 21, 19, 64, 4, 2, 1, 0, 0),    # odd input of a stride-2 layer: NOT the direct form (2 * OW != W)
+    # 1x1 on large planes (LDS-staged double-buffered GEMM): the deformable conv's 576 -> 64 at 36 x 36, ragged last band
+    # (1296 = 40.5 bands of 32), ragged channel group (576 = 4.5 x 128), many K slices
+    (9, 576, 36, 36, 64, 1, 1, 0, 0, 0),
+    (3, 160, 20, 20, 96, 1, 1, 0, 0, 0),   # two output groups (96 = 64 + 32), 400 positions = 12.5 bands
 ]
 
 
