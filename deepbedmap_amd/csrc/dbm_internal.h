@@ -178,7 +178,7 @@ struct WgradBatch {
   // training step: cleargrads, then one backward pass).  Two K slices may then fold with atomics even in deterministic
   // mode: (0 + a) + b == (0 + b) + a bit for bit -- no partial tiles, no fold kernel for those layers.
   bool cleared_target = false, built_cleared = false;
-  static const int NCAT = 11;  // see WgradBatch::build
+  static const int NCAT = 10;  // see WgradBatch::build
   WgradPlan* d_plans[NCAT] = {};
   int* d_starts[NCAT] = {};
   int nplans[NCAT] = {}, total_wg[NCAT] = {};

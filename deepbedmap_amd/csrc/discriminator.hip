@@ -175,9 +175,12 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
     if (i == 1) {  // through conv_layer0's LeakyReLU
       d.mask = c.h[0].p; d.masksn = 64L * c.H * c.W; d.mask_c0 = 0;
     }
+    // this layer closes its group: the group's weight gradients only need the g_z slabs written so far -- they go out
+    // BEFORE this layer's data gradient (conv_layer1's, the largest of the chain, used to stand between the last slab and
+    // the last group's launch: that much shorter is the wait for the side stream at the end of the step)
+    if (i == 1 || wgroup(i - 1) != wgroup(i)) launch_group(slot, wgroup(i));
     run_dgrad(L, d, hin, win);
     float* t = gh; gh = gh_next; gh_next = t;
-    if (i > 1 && wgroup(i - 1) != wgroup(i)) launch_group(slot, wgroup(i));  // underneath the rest of the chain
   }
   {  // conv_layer0 weight / bias gradient
     SmallConvDesc q;
@@ -187,8 +190,6 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
     c0_scratch[slot].ensure(smallcin_wgrad_scratch_floats(64));
     launch_smallcin_conv_wgrad(q, gh, 64L * c.H * c.W, G(T_c0W), G(T_c0b), s, c0_scratch[slot].p);
   }
-  // conv_layer1..9 weight gradients: one launch per kernel size and half of the stack, on the side stream (they
-  // overlap the data-gradient chain and the other batch's backward pass); each slot has its own slabs g_z[slot][*]
-  launch_group(slot, NWG - 1);
+  // (conv_layer1..9 weight gradients: one launch per kernel form and layer group, on the side stream -- see the loop)
   if (join) ctx->join_side();
 }

@@ -1071,135 +1071,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_1x1_kernel(const WgradPlan* __re
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Small-plane form: 4x4 / stride 2 layers whose output plane is at most 8 x 8 (discriminator conv_layer5 / 7 / 9:
-// 9x9 -> 4x4, 4x4 -> 2x2, 2x2 -> 1x1).  These are GEMMs with a SHORT K (64 .. 1024 positions per graph) and a large
-// output (up to 4.2 M weights): what counts is the number of independent (out tile, in tile, tap half) tasks, not the
-// depth of one.  One wavefront = one task: operands straight from L2 (one dword per lane and MFMA for dy, one per live
-// tap for x), no LDS staging, no workgroup-level synchronisation; taps that lie outside the image for EVERY output
-// position (12 of 16 on a 2x2 plane) cost nothing.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void wgrad_small_kernel(const WgradPlan* __restrict__ plans, const int* __restrict__ starts,
-                                                             int nplans) {
-  constexpr int T = 16, TPW = 8;
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // per wavefront: 8 output rows x 32 channels x 16 taps
-  int lo = 0, hi = nplans - 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int task = blockIdx.x * 4 + wave;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (starts[mid] <= task) lo = mid; else hi = mid - 1;
-  }
-  const WgradPlan& p = plans[lo];
-  const WgradDesc& d = p.d;
-  int local = task - starts[lo];
-  const bool active = local < p.wg_count;   // (the last workgroup of a launch may carry idle wavefronts)
-  if (!active) return;                      // no workgroup barrier below: wavefronts are independent
-  const int bx = local % p.groups; local /= p.groups;
-  const int by = local % p.coutTiles; local /= p.coutTiles;
-  const int tg = local & 1;
-  const int bz = local >> 1;
-  const int j = lane & 31, kh = lane >> 5;
-  const int cout0 = by * 32, cin_w = bx * 32;
-  const int plane = d.OH * d.OW;
-  const int K = d.N * plane;
-  const int per = (((K + p.S - 1) / p.S) + 1) & ~1;   // even: a step consumes two positions
-  const int k0 = bz * per, k1 = min(K, k0 + per);
-  const int oc = min(cout0 + j, d.Cout - 1), ic = min(cin_w + j, d.Cin - 1);
-  const float* dyl = d.dy + (long)oc * d.dysc;
-  const float* xl = d.x + (long)ic * d.xsc;
-  // taps of this half that are inside the image for at least one output position
-  unsigned live = 0;
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int ky = 2 * tg + t / 4, kx = t % 4;
-    bool any = false;
-    for (int a = 0; a < d.OH; ++a) any = any || (unsigned)(2 * a + ky - 1) < (unsigned)d.Hin;
-    bool anyx = false;
-    for (int b = 0; b < d.OW; ++b) anyx = anyx || (unsigned)(2 * b + kx - 1) < (unsigned)d.Win;
-    if (any && anyx) live |= 1u << t;
-  }
-  f32x16 acc[TPW];
-#pragma unroll
-  for (int t = 0; t < TPW; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  float bsum = 0.f;
-  const bool want_bias = d.gb && bx == 0 && tg == 0;
-  float av, bv[TPW];
-  unsigned bm;
-  auto load = [&](int k, float& a_out, float (&b_out)[TPW], unsigned& mask) {
-    const int pk = k + kh;
-    const bool pv = pk < k1;
-    const int pc = pv ? pk : k0;
-    const int n = pc / plane, pos = pc - n * plane;
-    const int a = pos / d.OW, b = pos - a * d.OW;
-    a_out = dyl[(long)n * d.dysn + pos];
-    if (!pv) a_out = 0.f;
-    const float* xn = xl + (long)n * d.xsn;
-    mask = 0;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      b_out[t] = 0.f;
-      if (live & (1u << t)) {
-        const int iy = 2 * a + 2 * tg + t / 4 - 1, ix = 2 * b + t % 4 - 1;
-        const bool ok = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
-        b_out[t] = xn[ok ? iy * d.Win + ix : 0];
-        if (ok) mask |= 1u << t;
-      }
-    }
-  };
-  if (k0 < k1 && live) {
-    load(k0, av, bv, bm);
-    for (int k = k0; k < k1; k += 2) {
-      float an, bn[TPW];
-      unsigned mn;
-      load(k + 2 < k1 ? k + 2 : k, an, bn, mn);
-      __builtin_amdgcn_sched_barrier(0);
-      if (want_bias) bsum += av;
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        if (live & (1u << t)) {
-          const float bq = ((bm >> t) & 1u) ? bv[t] : 0.f;
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq, acc[t], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      av = an; bm = mn;
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) bv[t] = bn[t];
-    }
-  }
-  float *gWt, *gbt;
-  pair_targets(p, bz, gWt, gbt);
-  if (live) {
-    constexpr int ROWF = 32 * T;
-    float* tw = lds + wave * (8 * ROWF);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) tw[(rr + 4 * kh) * ROWF + j * T + tg * TPW + t] = d.scale * acc[t][4 * q + rr];
-      __builtin_amdgcn_wave_barrier();
-      for (int e = lane; e < 8 * ROWF; e += 64) {
-        const int rl = e / ROWF;
-        const int rem = e - rl * ROWF;
-        const int t = rem & 15;
-        if ((t >> 3) != tg || !((live >> (t & 7)) & 1u)) continue;
-        const int o = cout0 + 8 * q + rl;
-        const int c = cin_w + (rem >> 4);
-        if (o < d.Cout && c < d.Cin) atomicAdd(gWt + ((long)o * d.Cin + cin_w) * T + rem, tw[e]);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-  if (want_bias) {
-    bsum += __shfl_xor(bsum, 32, 64);
-    if (kh == 0 && cout0 + j < d.Cout) atomicAdd(gbt + cout0 + j, d.scale * bsum);
-  }
-}
-
 // Sums the K-slice partials of a weight-gradient launch in slice order and adds them to gW (OIHW) / gb: one workgroup per
 // 256 elements of one wavefront slot's tile.  No fp32 atomics on the K split (the one atomic per element below only
 // serialises the real- and the fake-batch graph of the discriminator: two contributions onto a cleared gradient, and
@@ -1345,30 +1216,6 @@ static size_t direct_plan(const WgradDesc& d, WgradPlan& p, long segs_per_wg) {
   p.IB = 1; p.R = 1; p.nbr = d.OH; p.BP = p.BPp = 8; p.YS = p.XS = 0; p.Rin = 0; p.ImgS = 0;
   p.fast = 0; p.planeM = p.winM = p.oplaneM = 0;
   return sizeof(float) * 4 * 8 * 32 * (size_t)T;  // four transpose areas of 8 output rows
-}
-
-// 4x4 / stride 2 / pad 1 layers on tiny planes (wgrad_small_kernel): one wavefront per (in tile, out tile, tap half, K slice)
-static bool small_eligible(const WgradDesc& d) {
-  return d.KH == 4 && d.KW == 4 && d.stride == 2 && d.pad == 1 && d.ups == 0 && d.OW <= 8 && d.OH <= 8 &&
-         d.xsc == d.Hin * d.Win && d.dysc == d.OH * d.OW;
-}
-
-static size_t small_plan(const WgradDesc& d, WgradPlan& p, long pos_per_task) {
-  p.d = d;
-  p.wave_task = 6;
-  p.zeros = nullptr;
-  p.groups = (d.Cin + 31) / 32;
-  p.G = 1;
-  p.coutTiles = (d.Cout + 31) / 32;
-  const long K = (long)d.N * d.OH * d.OW;
-  long S = (K + pos_per_task - 1) / pos_per_task;
-  if (S < 1) S = 1;
-  p.S = (int)S;
-  p.nbands = (int)K;
-  p.wg_count = p.groups * p.coutTiles * 2 * p.S;   // TASKS (wavefronts), four per workgroup
-  p.IB = 1; p.R = 1; p.nbr = 1; p.BP = p.BPp = 2; p.YS = p.XS = 0; p.Rin = 0; p.ImgS = 0; p.Wst = 0;
-  p.fast = 0; p.planeM = p.winM = p.oplaneM = 0;
-  return sizeof(float) * 4 * 8 * 32 * 16;
 }
 
 // 1x1 layers on large contiguous planes (wgrad_1x1_kernel)
@@ -1539,9 +1386,8 @@ void WgradBatch::build() {
   // of small planes), 4 = 3x3 row-band LDS-DMA, 5 = 4x4 row-band LDS-DMA, 6 / 7 / 8 = direct form (3x3, 3x3 on a
   // nearest-x2 input, 4x4 stride 2)
   // 9 = 1x1 on large contiguous planes (LDS-staged GEMM, wgrad_1x1_kernel)
-  // 10 = 4x4 stride 2 on tiny planes (one wavefront per task, wgrad_small_kernel)
-  static const int TT[NCAT] = {1, 9, 16, 9, 9, 16, 9, 9, 16, 1, 16};
-  static const int MODE[NCAT] = {0, 0, 0, 2, 3, 3, 4, 4, 4, 5, 6};
+  static const int TT[NCAT] = {1, 9, 16, 9, 9, 16, 9, 9, 16, 1};
+  static const int MODE[NCAT] = {0, 0, 0, 2, 3, 3, 4, 4, 4, 5};
   const bool direct = direct_form_enabled() != 0;
   std::vector<int> cat(descs.size());
   const int forms = dma_forms_enabled();
@@ -1551,7 +1397,7 @@ void WgradBatch::build() {
     const int dm = direct ? direct_mode(descs[i]) : -1;
     if (T == 1) cat[i] = (direct && gemm1x1_eligible(descs[i])) ? 9 : 0;
     else if (T == 9) cat[i] = (forms >= 1 && wgrad_plan(descs[i], p, 0, 2) != 0) ? 3 : dm >= 0 ? 6 + dm : (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 4 : 1;
-    else cat[i] = dm >= 0 ? 6 + dm : (direct && small_eligible(descs[i])) ? 10 : (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 5 : 2;
+    else cat[i] = dm >= 0 ? 6 + dm : (forms >= 2 && wgrad_plan(descs[i], p, 0, 3) != 0) ? 5 : 2;
   }
   for (int g = 0; g < NCAT; ++g) {
     std::vector<WgradPlan> plans;
@@ -1563,8 +1409,7 @@ void WgradBatch::build() {
     // (four per CU for the trunk form; two or four per CU for row bands, by their LDS footprint)
     int S_fixed = 0;
     long segs_per_wg = 0;
-    if (g == 10) {
-    } else if (g == 9) {
+    if (g == 9) {
       long work = 0;
       for (size_t i = 0; i < descs.size(); ++i) {
         if (cat[i] != g) continue;
@@ -1605,7 +1450,7 @@ void WgradBatch::build() {
         if (cat[i] != g) continue;
         const WgradDesc& d = descs[i];
         WgradPlan p;
-        maxlds = std::max(maxlds, g == 10 ? small_plan(d, p, 128) : g == 9 ? gemm1x1_plan(d, p, segs_per_wg) : g >= 6 ? direct_plan(d, p, segs_per_wg)
+        maxlds = std::max(maxlds, g == 9 ? gemm1x1_plan(d, p, segs_per_wg) : g >= 6 ? direct_plan(d, p, segs_per_wg)
                                                                                     : wgrad_plan(d, p, g >= 3 ? 0 : level, MODE[g], S_fixed));
         p.zeros = device_zeros();
         p.partial = nullptr; p.partial_b = nullptr; p.fold_start = 0;
@@ -1616,14 +1461,16 @@ void WgradBatch::build() {
         plans.push_back(p);
         fl += 2.0 * (double)d.N * d.OH * d.OW * d.Cout * d.Cin * TT[g];
       }
-      // (deterministic mode: no finer K split than necessary -- every extra slice is a partial tile to write and fold)
-      if (total >= 448 || plans.empty() || g >= 3 || g_wgrad_deterministic) break;
+      // (deterministic mode: no finer K split than necessary -- every extra slice is a pair buffer to write and fold --
+      // but a launch of a few dozen workgroups, e.g. the 4x4 layers of the deep discriminator, is split as well)
+      static const int det_min = getenv("DBM_WGRAD_DET_MINWG") ? atoi(getenv("DBM_WGRAD_DET_MINWG")) : 128;
+      if (total >= 448 || plans.empty() || g >= 3 || (g_wgrad_deterministic && total >= det_min)) break;
     }
     std::vector<int> fstarts;
     fold_wgs[g] = 0;
     if (g_wgrad_deterministic && !plans.empty()) {
-      static const int SLOTS[NCAT] = {4, 4, 8, 2, 2, 2, 0, 0, 0, 0, 0}, CTS[NCAT] = {4, 4, 4, 2, 2, 1, 0, 0, 0, 0, 0},
-                       TPWS[NCAT] = {1, 9, 8, 9, 9, 8, 0, 0, 0, 0, 0};
+      static const int SLOTS[NCAT] = {4, 4, 8, 2, 2, 2, 0, 0, 0, 0}, CTS[NCAT] = {4, 4, 4, 2, 2, 1, 0, 0, 0, 0},
+                       TPWS[NCAT] = {1, 9, 8, 9, 9, 8, 0, 0, 0, 0};
       static const int pairs_env = getenv("DBM_WGRAD_PAIRS") ? atoi(getenv("DBM_WGRAD_PAIRS")) : 1;
       pair_mode[g] = pairs_env != 0 || g >= 6;  // (the direct form folds through pair buffers only)
       size_t floats = 0, bfloats = 0;
@@ -1710,7 +1557,6 @@ static void launch_dma(K kernel, const WgradPlan* plans, const int* starts, int 
     DBM_HIP(hipFuncSetAttribute((const void*)wgrad_direct_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     DBM_HIP(hipFuncSetAttribute((const void*)wgrad_direct_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     DBM_HIP(hipFuncSetAttribute((const void*)wgrad_1x1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-    DBM_HIP(hipFuncSetAttribute((const void*)wgrad_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL(kernel, dim3(total_wg), dim3(threads), lds, s, plans, starts, nplans);
@@ -1739,8 +1585,7 @@ void WgradBatch::launch(hipStream_t s) {
     else if (g == 6) launch_dma(wgrad_direct_kernel<0>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
     else if (g == 7) launch_dma(wgrad_direct_kernel<1>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
     else if (g == 8) launch_dma(wgrad_direct_kernel<2>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
-    else if (g == 9) launch_dma(wgrad_1x1_kernel, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
-    else launch_dma(wgrad_small_kernel, d_plans[g], d_starts[g], nplans[g], (total_wg[g] + 3) / 4, lds[g], s, 256);  // (tasks -> workgroups)
+    else launch_dma(wgrad_1x1_kernel, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
     if (fold_wgs[g]) {
       if (pair_mode[g])
         hipLaunchKernelGGL(wgrad_pair_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);

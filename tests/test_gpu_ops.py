@@ -70,7 +70,7 @@ CONV_CASES = [
     # (1296 = 40.5 bands of 32), ragged channel group (576 = 4.5 x 128), many K slices
     (9, 576, 36, 36, 64, 1, 1, 0, 0, 0),
     (3, 160, 20, 20, 96, 1, 1, 0, 0, 0),   # two output groups (96 = 64 + 32), 400 positions = 12.5 bands
-    # small-plane form of the 4x4 stride-2 layers (one wavefront per task): K slices, dead taps, odd channel tiles
+    # 4x4 stride-2 layers on tiny planes (workgroup form, several K slices through the pair buffers), odd channel tiles
     (64, 128, 9, 9, 256, 4, 2, 1, 0, 0),   # D conv_layer5 at the full batch: 1024 positions -> 8 K slices (pair buffers)
     (37, 256, 4, 4, 512, 4, 2, 1, 0, 0),   # D conv_layer7
     (64, 96, 2, 2, 160, 4, 2, 1, 0, 0),    # conv_layer9-shaped: 12 of 16 taps never inside the image; 3 x 5 tiles
