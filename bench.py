@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--dist-backend", default=None, choices=["rccl", "nccl", "gloo"],
                     help="N > 1: rccl (default) = libdbm's native communicator, gradient buckets overlapped with the backward "
                          "passes; nccl = torch.distributed's RCCL, one all-reduce after each backward (round-1 form)")
+    ap.add_argument("--sync-metrics", action="store_true",
+                    help="fetch the five metrics to the host after every minibatch (the reference's float(...) pattern) instead "
+                         "of once at the end of the run")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="no GPU work: the ranks only rendezvous over gloo on the CPU and rank 0 prints a JSON line "
                          "(tests/test_parallel_gloo.py drives the self-spawn path with it)")
@@ -267,9 +270,14 @@ def main():
     dbm.global_config.cudnn_deterministic = not args.no_deterministic
     prefetch = not (args.share_generator_forward or args.no_prefetch)
 
-    def step():  # one minibatch of deepbedmap_amd.trainer (srgan_train.py:1286-1309), its five metrics fetched to the host
+    # One step = one minibatch of deepbedmap_amd.trainer's training loop (srgan_train.py:1286-1309): D-step + G-step, the
+    # five metrics written to a device-resident log that the host reads once at the end (trainer: once per epoch, where
+    # their only consumer, the per-epoch mean, runs); --sync-metrics fetches them after every minibatch instead.
+    log = None if args.sync_metrics else dbm.MetricsLog(ctx, rows=args.steps + args.warmup + 4)
+
+    def step():
         return dbm.train_minibatch(batch, g, g_opt, d, d_opt, comm=comm, share_generator_forward=args.share_generator_forward,
-                                   prefetch_generator_forward=prefetch)
+                                   prefetch_generator_forward=prefetch, log=log)
 
     lib = dbm._lib.lib()
     for _ in range(args.warmup):
@@ -282,6 +290,7 @@ def main():
     for _ in range(args.steps):
         step()
     dbm._lib.check(lib.dbm_timer(ctx.handle, 1, None), ctx.handle)
+    metrics_rows = log.fetch() if log is not None else None  # (inside the timed region: the epoch's single read-back)
     torch.cuda.synchronize()
     if comm is not None:
         comm.barrier()
@@ -299,6 +308,7 @@ def main():
 
     # ---- roofline leg (outside the timed region): hipEvent-bracketed launches of the dominant kernel ----
     prof = (C.c_double * 12)()
+    assert metrics_rows is None or (len(metrics_rows) == args.steps + args.warmup and np.isfinite(metrics_rows[:, :5]).all())
     dbm._lib.check(lib.dbm_profile_begin(ctx.handle), ctx.handle)
     step()
     dbm._lib.check(lib.dbm_profile_end_ex(ctx.handle, prof, 4), ctx.handle)
@@ -339,6 +349,7 @@ def main():
                        "generator_forwards_per_iteration": 1 if args.share_generator_forward else 2,
                        "g_step_forward_prefetched_under_d_step": bool(prefetch),
                        "cudnn_deterministic": bool(dbm.global_config.cudnn_deterministic),
+                       "metrics_read_back": "every minibatch" if args.sync_metrics else "once per run (device-resident log)",
                        "sync_batch_stats": bool(args.sync_batch_stats and world > 1)},
             "roofline": {
                 "bound": "mfma", "kernel": dom["kernel"],

@@ -11,7 +11,7 @@ from .srgan import (  # noqa: F401
     load_npz, optimizers, psnr, save_npz, serializers, ssim_loss_func, to_device, using_config,
 )
 from .training import (  # noqa: F401
-    SerialIterator, compile_srgan_model, concat_examples, dataset_to_device, device_batch, get_train_dev_iterators,
+    MetricsLog, SerialIterator, compile_srgan_model, concat_examples, dataset_to_device, device_batch, get_train_dev_iterators,
     save_model_weights_and_architecture, split_dataset_random, train_eval_discriminator, train_eval_generator, train_minibatch, trainer,
 )
 from .parallel import DataParallel, shard_batch, shard_slice  # noqa: F401

@@ -84,7 +84,7 @@ def _repeat_after_timeout(fn):
 @_repeat_after_timeout
 def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, train: bool = True, comm=None,
                              sync: bool = True, share_generator_forward: bool = False,
-                             prefetch_generator_forward: bool = False):
+                             prefetch_generator_forward: bool = False, metrics=None):
     """srgan_train.py:1084-1166.  Returns (d_loss, d_accu) as floats (like the reference's float(...) D2H syncs);
     sync=False returns the device metrics buffer instead and keeps the stream running.
     share_generator_forward=True (opt-in, not the reference's behaviour) retains this call's generator forward so
@@ -101,7 +101,7 @@ def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, t
         assert d_optimizer is not None  # Optimizer required for neural network training
     dev = device_batch(input_arrays, g_model.ctx)
     n, h, w = _check_batch(dev)
-    m = _metrics_buffer(g_model.ctx)
+    m = metrics if metrics is not None else _metrics_buffer(g_model.ctx)  # >= 8 floats on the device
     _apply_config(g_model.ctx)
     _lib.check(_lib.lib().dbm_discriminator_step(g_model._h, d_model._h, n, h, w, *[_dev_ptr(dev[k]) for k in _KEYS],
                                                  int(bool(train)) | (2 if share_generator_forward else 0) |
@@ -122,14 +122,14 @@ def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, t
 
 @_repeat_after_timeout
 def train_eval_generator(input_arrays, g_model, d_model, g_optimizer=None, train: bool = True, comm=None,
-                         sync: bool = True, share_generator_forward: bool = False):
+                         sync: bool = True, share_generator_forward: bool = False, metrics=None):
     """srgan_train.py:1170-1263.  Returns (g_loss, g_psnr, g_ssim)."""
     global_config.train = train  # srgan_train.py:1216
     if train is True:
         assert g_optimizer is not None  # Optimizer required for neural network training
     dev = device_batch(input_arrays, g_model.ctx)
     n, h, w = _check_batch(dev)
-    m = _metrics_buffer(g_model.ctx)
+    m = metrics if metrics is not None else _metrics_buffer(g_model.ctx)
     wts = (C.c_float * 4)(*LOSS_WEIGHTS)
     win = {"gaussian": 0, "uniform": 1}[global_config.ssim_window]
     _apply_config(g_model.ctx)
@@ -237,16 +237,48 @@ def get_train_dev_iterators(dataset, first_size: int, batch_size: int = 128, see
     return train_iter, n_train, dev_iter, n_dev
 
 
+class MetricsLog:
+    """Device-resident log of per-minibatch metrics: row r = [d_loss, d_accu, g_loss, g_psnr, g_ssim, -, -, -] of the
+    r-th minibatch.  The fused steps write their metrics straight into a row; nothing is copied to the host until
+    `fetch()` -- `trainer` only needs the numbers at the end of the epoch (np.mean per column, srgan_train.py:1617-1619),
+    so the GPU never waits for a host round trip between minibatches."""
+
+    def __init__(self, ctx, rows=1024):
+        self.ctx, self.rows, self.n = ctx, rows, 0
+        self.buf = DeviceArray((rows, 8), ctx)
+
+    def next_row(self):
+        if self.n == self.rows:  # grow: keep what is there
+            old = self.fetch()
+            self.rows *= 2
+            self.buf = DeviceArray((self.rows, 8), self.ctx)
+            pad = np.zeros((self.rows, 8), np.float32)
+            pad[:self.n] = old
+            self.buf.set(pad)
+        row = DeviceArray((8,), self.ctx, ptr=self.buf.ptr + 32 * self.n, owner=self.buf)
+        self.n += 1
+        return row
+
+    def fetch(self):
+        """(n, 8) float32 array of the rows written so far (synchronises the stream)."""
+        return self.buf.get()[:self.n].copy()
+
+
 def train_minibatch(train_arrays, g_model, g_optimizer, d_model, d_optimizer, comm=None, share_generator_forward=False,
-                    prefetch_generator_forward=True):
+                    prefetch_generator_forward=True, log=None):
     """The body of `trainer`'s training loop (srgan_train.py:1286-1309) for one minibatch of device arrays:
-    train_eval_discriminator, then train_eval_generator, metrics fetched once.  Returns (d_loss, d_accu, g_loss,
-    g_psnr, g_ssim) as floats."""
+    train_eval_discriminator, then train_eval_generator.  With `log` (a MetricsLog) the five metrics stay on the device
+    (one row of the log) and None is returned; without, they are fetched with ONE device-to-host copy and returned as
+    (d_loss, d_accu, g_loss, g_psnr, g_ssim) floats."""
     prefetch = prefetch_generator_forward and not share_generator_forward
+    row = log.next_row() if log is not None else None
     train_eval_discriminator(train_arrays, g_model, d_model, d_optimizer, comm=comm, sync=False,
-                             share_generator_forward=share_generator_forward, prefetch_generator_forward=prefetch)
+                             share_generator_forward=share_generator_forward, prefetch_generator_forward=prefetch,
+                             metrics=row)
     m = train_eval_generator(train_arrays, g_model, d_model, g_optimizer, comm=comm, sync=False,
-                             share_generator_forward=share_generator_forward)
+                             share_generator_forward=share_generator_forward, metrics=row)
+    if log is not None:
+        return None
     out = m.get()
     return float(out[0]), float(out[1]), float(out[2]), float(out[3]), float(out[4])
 
@@ -254,18 +286,16 @@ def train_minibatch(train_arrays, g_model, g_optimizer, d_model, d_optimizer, co
 def trainer(i: int, columns: list, train_iter, dev_iter, g_model, g_optimizer, d_model, d_optimizer, comm=None):
     """srgan_train.py:1267-1329: one epoch of D-step/G-step minibatches, then the dev-set evaluation."""
     metrics_dict = {mn: [] for mn in columns}
+    log = MetricsLog(g_model.ctx)
     while i == train_iter.epoch:
         train_arrays = device_batch(concat_examples(train_iter.dataset, train_iter.next()), g_model.ctx)
-        # Both steps are enqueued back to back and the five metrics of the minibatch come back with ONE device-to-host
-        # copy (the reference's `float(...)` after each step is a host round trip during which the GPU idles); the
-        # numbers are the ones the two calls would have returned one by one.
-        d_train_loss, d_train_accu, g_train_loss, g_train_psnr, g_train_ssim = train_minibatch(
-            train_arrays, g_model, g_optimizer, d_model, d_optimizer, comm=comm)
-        metrics_dict["discriminator_loss"].append(d_train_loss)
-        metrics_dict["discriminator_accu"].append(d_train_accu)
-        metrics_dict["generator_loss"].append(g_train_loss)
-        metrics_dict["generator_psnr"].append(g_train_psnr)
-        metrics_dict["generator_ssim"].append(g_train_ssim)
+        # both steps of every minibatch are enqueued back to back; the metrics stay on the device until the epoch ends
+        # (the reference's `float(...)` after each step is a host round trip during which the GPU idles; its only
+        # consumer is the per-epoch mean)
+        train_minibatch(train_arrays, g_model, g_optimizer, d_model, d_optimizer, comm=comm, log=log)
+    rows = log.fetch()
+    for col, name in enumerate(("discriminator_loss", "discriminator_accu", "generator_loss", "generator_psnr", "generator_ssim")):
+        metrics_dict[name].extend(float(v) for v in rows[:, col])
     while i == dev_iter.epoch:
         dev_arrays = concat_examples(dev_iter.dataset, dev_iter.next())
         d_dev_loss, d_dev_accu = train_eval_discriminator(dev_arrays, g_model, d_model, train=False)
