@@ -48,6 +48,9 @@ SIGNATURES = {
     "dbm_profile_end": [C.c_void_p, C.POINTER(C.c_double)],
     "dbm_profile_end_ex": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
     "dbm_set_sync_batch_stats": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    "dbm_f32_to_i16": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
+    "dbm_lzw_encode_tiles": [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int],
+    "dbm_lzw_decode": [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)],
     "dbm_debug_inject_timeout": [C.c_void_p],
     "dbm_timer": [C.c_void_p, C.c_int, C.POINTER(C.c_double)],
     "dbm_phase_marks": [C.c_void_p, C.c_int, C.c_char_p, C.c_int],

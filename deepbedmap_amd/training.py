@@ -308,6 +308,48 @@ def trainer(i: int, columns: list, train_iter, dev_iter, g_model, g_optimizer, d
     return metrics_dict
 
 
+class TrialPruned(RuntimeError):
+    """The stand-in for optuna.structs.TrialPruned (srgan_train.py:1698-1706): diverged run."""
+
+
+METRIC_NAMES = ("discriminator_loss", "discriminator_accu", "generator_loss", "generator_psnr", "generator_ssim")
+
+
+def train_epochs(epochs: int, train_iter, dev_iter, g_model, g_optimizer, d_model, d_optimizer, score_fn=None,
+                 save_path: str = "model/weights", best_score: float = 250.0, comm=None, progress=None):
+    """The epoch loop of the reference's `objective` (srgan_train.py:1592-1706) without its SaaS parts (Comet, Optuna,
+    GMT plots): per epoch one `trainer` call, the MEAN of every metric column over the epoch's minibatches
+    (`dataframe.loc[i] = [np.mean(metrics_dict[metric]) ...]`, :1617-1619), the keep-best checkpoint
+    (`if rmse_test < best_rmse_test: ... save_model_weights_and_architecture(...)`, :1655-1666; `best_rmse_test` starts
+    at 250) and the divergence guard (:1698-1706: PSNR < 0 or NaN losses -> TrialPruned).
+
+    score_fn(g_model) -> float is the reference's `get_deepbedmap_test_result` (RMSE on the test area; lower is better);
+    None uses the epoch's mean validation generator loss.  progress(i, epoch_metrics) is called once per epoch.
+    Returns (table, best_score, saved_paths): table = {column: np.ndarray[epochs]} of epoch means."""
+    columns = list(METRIC_NAMES) + [f"val_{m}" for m in METRIC_NAMES]
+    table = {c: np.full(epochs, np.nan, dtype=np.float64) for c in columns}
+    train_iter.reset()
+    dev_iter.reset()
+    saved = None
+    for i in range(epochs):
+        metrics_dict = trainer(i=i, columns=columns, train_iter=train_iter, dev_iter=dev_iter, g_model=g_model,
+                               g_optimizer=g_optimizer, d_model=d_model, d_optimizer=d_optimizer, comm=comm)
+        for c in columns:
+            table[c][i] = np.mean(metrics_dict[c]) if len(metrics_dict[c]) else np.nan
+        epoch_metrics = {c: float(table[c][i]) for c in columns}
+        if progress is not None:
+            progress(i, epoch_metrics)
+        score = float(score_fn(g_model)) if score_fn is not None else epoch_metrics["val_generator_loss"]
+        if score < best_score:  # save generator and discriminator weights, and the generator's architecture (:1655-1666)
+            best_score = score
+            saved = save_model_weights_and_architecture(generator_model=g_model, discriminator_model=d_model, save_path=save_path)
+        if (epoch_metrics["generator_psnr"] < 0 or np.isnan(epoch_metrics["generator_loss"])
+                or np.isnan(epoch_metrics["discriminator_loss"])):
+            raise TrialPruned(f"epoch {i}: generator_psnr {epoch_metrics['generator_psnr']}, losses "
+                              f"{epoch_metrics['generator_loss']} / {epoch_metrics['discriminator_loss']}")
+    return table, best_score, saved
+
+
 def save_model_weights_and_architecture(generator_model, discriminator_model, save_path: str = "model/weights"):
     """srgan_train.py:1333-1383: two Chainer-layout .npz files (+ a plain layer listing as .dot)."""
     os.makedirs(name=save_path, exist_ok=True)

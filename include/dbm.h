@@ -213,6 +213,20 @@ int dbm_generator_step(dbm_model* g, dbm_model* d, int N, int H, int W, const fl
                        const float* W2, const float* W3, const float* Y, const float weights[4], int ssim_window,
                        int train, float* metrics_dev);
 
+/* ---- output format of the DEM (deepbedmap.py:749-756: `save_array_to_grid(array=Y_hat.astype(np.int16), dtype=np.int16,
+ * tiled=True, compression=lzw)` -> data_prep.py:779-834, a tiled LZW GeoTIFF written by rasterio / GDAL) ----
+ * dbm_f32_to_i16: `Y_hat.astype(np.int16)` on the device canvas (NumPy's cast: truncation, NaN / inf / out of range -> 0),
+ * asynchronous on the context's stream; dst_dev holds n int16 values.
+ * dbm_lzw_encode_tiles: TIFF 6.0 LZW of `ntiles` tiles of `tile_bytes` bytes each (host memory, tile t at
+ * tiles + t * tile_bytes) into out + t * out_stride (out_stride >= tile_bytes * 3 / 2 + 64 is always enough),
+ * encoded sizes in out_sizes[t]; tiles are spread over `nthreads` host threads.  dbm_lzw_decode: one stream back
+ * (round-trip check).  Host functions: no GPU, no context.  The TIFF container is written by the host shim
+ * (deepbedmap_amd/geotiff.py). */
+int dbm_f32_to_i16(dbm_ctx* ctx, const float* src_dev, void* dst_dev, size_t n);
+int dbm_lzw_encode_tiles(const void* tiles, size_t tile_bytes, int ntiles, void* out, size_t out_stride, size_t* out_sizes,
+                         int nthreads);
+int dbm_lzw_decode(const void* src, size_t nbytes, void* dst, size_t cap, size_t* out_bytes);
+
 /* ---- op-level entry points (used by the parity tests; same kernels the models run) ---- */
 /* L.Convolution2D forward on the MFMA implicit-GEMM kernel. x (N,C,H,W) w (O,C,k,k) b (O) or NULL -> y; all DEVICE. */
 int dbm_op_conv2d(dbm_ctx* ctx, const float* x, const float* w, const float* b, float* y, int N, int C, int H, int W,

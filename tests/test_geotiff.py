@@ -1,0 +1,89 @@
+"""The DEM's output format (deepbedmap.py:749-756 -> data_prep.py:779-834: int16, tiled, LZW GeoTIFF): host codec and
+container.  CPU tests: libdbm's host functions need no GPU.  Byte work: bit-exact round trips; the streams are also decoded
+by an independent implementation (Pillow / libtiff) when it is installed."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deepbedmap_amd import geotiff  # noqa: E402
+
+
+def _dem(h, w, seed=0):
+    r = np.random.RandomState(seed)
+    z = np.cumsum(np.cumsum(r.normal(size=(h, w)), axis=0), axis=1) * 3.0 + 500.0  # smooth "terrain", metres
+    z[:7] = np.nan   # the frame no tile covers stays NaN on the canvas (deepbedmap.py:686)
+    z[:, -5:] = np.nan
+    return z.astype(np.float32)[None]
+
+
+@pytest.mark.parametrize("data", ["empty", "one", "zeros", "noise", "ramp", "period7", "all-codes"])
+def test_lzw_round_trip_edge_cases(data):
+    r = np.random.RandomState(3)
+    raw = {"empty": np.zeros(0, np.uint8), "one": np.array([255], np.uint8), "zeros": np.zeros(131072, np.uint8),
+           "noise": r.randint(0, 256, 131072).astype(np.uint8),            # incompressible: the stream grows by 3/8
+           "ramp": (np.arange(200000) % 251).astype(np.uint8),
+           "period7": np.tile(np.arange(7, dtype=np.uint8), 30000),       # KwKwK strings
+           "all-codes": r.randint(0, 3, 600000).astype(np.uint8)}[data]   # fills the 4094-entry table several times
+    (stream,) = geotiff.lzw_encode_tiles(raw[None, :] if raw.size else np.zeros((1, 0), np.uint8))
+    assert np.array_equal(geotiff.lzw_decode(stream, raw.size), raw)
+    if data == "zeros":
+        assert len(stream) < 1000
+    if data == "empty":
+        assert stream == bytes([0x80, 0x40, 0x40])  # ClearCode, EndOfInformation in 9-bit codes, MSB first
+
+
+def test_int16_cast_matches_numpy():
+    z = np.array([np.nan, -1.7, 1.7, 40000.0, -40000.0, 3e9, -3e9, np.inf, -np.inf, -2000.4, 32767.9], np.float32)
+    with np.errstate(invalid="ignore"):
+        ref = z.astype(np.int16)
+    assert np.array_equal(geotiff.canvas_to_int16(z), ref)
+    assert ref[0] == 0 and ref[1] == -1 and ref[3] == -25536  # what the reference's astype does on x86-64
+
+
+@pytest.mark.parametrize("tiled,compression,bigtiff", [(True, "lzw", True), (True, "lzw", False), (False, "none", False), (False, "lzw", True)])
+def test_geotiff_round_trip(tmp_path, tiled, compression, bigtiff):
+    dem = _dem(300, 517)
+    bound = (-2700000.0, -2200000.0, 2800000.0, 2300000.0)  # window_bound_big of the reference, metres
+    path = geotiff.save_array_to_grid(str(tmp_path / "deepbedmap_dem"), bound, dem, dtype=np.int16, tiled=tiled,
+                                      compression=compression, bigtiff=bigtiff)
+    assert path.endswith("deepbedmap_dem.tif")
+    got, info = geotiff.read_geotiff(path)
+    with np.errstate(invalid="ignore"):
+        ref = dem.astype(np.int16)
+    assert got.dtype == np.int16 and np.array_equal(got, ref)
+    assert info["bigtiff"] == bigtiff and info["compression"] == (5 if compression == "lzw" else 1) and info["nodata"] == "-2000"
+    assert info["tile"] == ((256, 256) if tiled else (256, 517))
+    assert np.allclose(info["pixel_scale"], [5500000.0 / 517, 4500000.0 / 300, 0.0])
+    assert info["tiepoint"] == [0.0, 0.0, 0.0, -2700000.0, 2300000.0, 0.0]
+    assert info["geokeys"][-4:] == [3072, 0, 1, 3031]
+    if compression == "lzw":
+        assert os.path.getsize(path) < ref.nbytes  # (edge tiles are padded to 256 x 256 before compression)
+
+
+def test_geotiff_is_readable_by_libtiff(tmp_path):
+    """An independent decoder (Pillow's libtiff) reads the classic-TIFF variant: header, tags, tile layout and LZW streams."""
+    PIL = pytest.importorskip("PIL.Image")
+    dem = _dem(300, 517, seed=4)
+    path = geotiff.save_array_to_grid(str(tmp_path / "dem"), (0.0, 0.0, 517.0, 300.0), dem, dtype=np.int16, tiled=True,
+                                      compression="lzw", bigtiff=False)
+    with PIL.open(path) as im:
+        assert im.size == (517, 300)
+        got = np.array(im)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(got.astype(np.int16), dem[0].astype(np.int16))
+
+
+def test_float32_grid_and_errors(tmp_path):
+    z = _dem(40, 33)
+    z = np.nan_to_num(z, nan=-2000.0)
+    path = geotiff.save_array_to_grid(str(tmp_path / "f"), (0, 0, 33, 40), z, tiled=True, compression="lzw")
+    got, _ = geotiff.read_geotiff(path)
+    assert got.dtype == np.float32 and np.array_equal(got, z)
+    with pytest.raises(ValueError):
+        geotiff.save_array_to_grid(str(tmp_path / "g"), (0, 0, 1, 1), z, compression="zstd")
+    with pytest.raises(AssertionError):
+        geotiff.save_array_to_grid(str(tmp_path / "g"), (0, 0, 1, 1), z[0])

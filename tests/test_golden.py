@@ -79,3 +79,49 @@ def test_hip_reproduces_golden_vectors():
     with dbm.using_config("enable_backprop", False):
         y2 = g.forward(arrays["X"], arrays["W1"], arrays["W2"], arrays["W3"]).array
     assert rel(y2, GOLD["g_forward_after_step"]) < 5e-3  # after one Adam step (sign-like first update)
+
+
+def test_chainer_layout_files_match_the_parameter_tables():
+    """tests/golden/chainer_layout_*.npz are written by hand from the layout listing; the oracle's
+    parameter tables (built from srgan_train.py's constructor calls) must name exactly the same arrays with the same
+    shapes, and `N` must be the 0-d integer Chainer stores."""
+    from oracle import model as omodel
+
+    with np.load(os.path.join(HERE, "golden", "chainer_layout_generator.npz")) as f:
+        shapes = omodel.generator_param_shapes(2)
+        assert set(f.files) == set(shapes)
+        for k in f.files:
+            assert f[k].shape == tuple(shapes[k]) and f[k].dtype == np.float32, k
+    with np.load(os.path.join(HERE, "golden", "chainer_layout_discriminator.npz")) as f:
+        shapes = dict(omodel.discriminator_param_shapes())
+        shapes.update(omodel.discriminator_persistent_shapes())
+        assert set(f.files) == set(shapes)
+        for k in f.files:
+            assert f[k].shape == tuple(shapes[k]), k
+        assert f["batch_norm4/N"].ndim == 0 and f["batch_norm4/N"].dtype.kind == "i" and int(f["batch_norm4/N"]) == 12
+
+
+@pytest.mark.gpu
+def test_chainer_layout_files_load_strictly():
+    """deepbedmap.py:402-408: `chainer.serializers.load_npz(file=..., obj=model)` on weight files in Chainer's layout."""
+    import deepbedmap_amd as dbm
+
+    g = dbm.GeneratorModel(num_residual_blocks=2, initialize=False)
+    d = dbm.DiscriminatorModel(initialize=False)
+    gpath = os.path.join(HERE, "golden", "chainer_layout_generator.npz")
+    dpath = os.path.join(HERE, "golden", "chainer_layout_discriminator.npz")
+    dbm.serializers.load_npz(gpath, g, strict=True)
+    dbm.serializers.load_npz(dpath, d, strict=True)
+    with np.load(gpath) as f:
+        for k in ("input_block/conv_on_W1/W", "residual_network/1/residual_dense_block3/conv_layer5/W", "final_conv_layer2/deform_conv/b"):
+            assert np.array_equal(g._tensors[k].array, f[k]), k
+    with np.load(dpath) as f:
+        for k in ("conv_layer9/W", "batch_norm7/avg_var", "linear_1/W"):
+            assert np.array_equal(d._tensors[k].array, f[k]), k
+        assert int(d.serialize_dict()["batch_norm4/N"]) == int(f["batch_norm4/N"])
+    with pytest.raises(KeyError):  # a 3-RRDB model is not in a 2-RRDB file
+        dbm.serializers.load_npz(gpath, dbm.GeneratorModel(num_residual_blocks=3, initialize=False), strict=True)
+    x = np.random.RandomState(0).rand(1, 1, 11, 11).astype(np.float32)
+    with dbm.using_config("enable_backprop", False):
+        y = g.forward(x, np.zeros((1, 1, 110, 110), np.float32), np.zeros((1, 2, 22, 22), np.float32), x).array
+    assert y.shape == (1, 1, 36, 36) and np.isfinite(y).all()

@@ -808,3 +808,37 @@ def test_api_refuses_what_it_does_not_implement(dbm, tmp_path):
         dbm.serializers.load_npz(bad, dbm.GeneratorModel(num_residual_blocks=1))
     with pytest.raises(ValueError):
         g._tensors[key].array = tensors[key]
+
+
+def test_train_epochs_means_best_checkpoint_and_pruning(dbm, tmp_path):
+    """The epoch loop of the reference's `objective` (srgan_train.py:1592-1706): per-epoch MEANS of every metric column,
+    a checkpoint whenever the score improves (starting from 250), TrialPruned on a diverged run."""
+    np.random.seed(5)
+    r = np.random.RandomState(1)
+    n = 12
+    ds = {"X": r.rand(n, 1, 11, 11), "W1": r.rand(n, 1, 110, 110), "W2": r.rand(n, 2, 22, 22), "W3": r.rand(n, 1, 11, 11),
+          "Y": r.rand(n, 1, 36, 36)}
+    ds = dbm.dataset_to_device({k: v.astype(np.float32) for k, v in ds.items()})
+    train_iter, n_train, dev_iter, n_dev = dbm.get_train_dev_iterators(ds, first_size=8, batch_size=4, seed=42)
+    g, g_opt, d, d_opt = dbm.compile_srgan_model(num_residual_blocks=1, residual_scaling=0.3, learning_rate=5e-4)
+    scores = iter([300.0, 200.0, 220.0])  # RMSE on the "test area": only the second epoch beats 250
+    seen = []
+    table, best, saved = dbm.train_epochs(3, train_iter, dev_iter, g, g_opt, d, d_opt, score_fn=lambda m: next(scores),
+                                          save_path=str(tmp_path / "w"), progress=lambda i, m: seen.append((i, dict(m))))
+    assert best == 200.0 and saved is not None and os.path.exists(saved[0]) and os.path.exists(saved[1])
+    assert set(table) == set(dbm.METRIC_NAMES) | {"val_" + m for m in dbm.METRIC_NAMES}
+    assert all(v.shape == (3,) and np.isfinite(v).all() for v in table.values())
+    assert [i for i, _ in seen] == [0, 1, 2] and seen[1][1]["generator_psnr"] == table["generator_psnr"][1]
+    # the checkpoint holds the weights after epoch 2 (index 1), not the final ones
+    g2 = dbm.GeneratorModel(num_residual_blocks=1, initialize=False)
+    dbm.serializers.load_npz(saved[0], g2)
+    assert any(not np.array_equal(g2._tensors[k].array, p.array) for k, p in g._tensors.items())
+    # epoch means: one trainer call gives the per-minibatch lists the means are taken of
+    train_iter.reset(); dev_iter.reset()
+    cols = list(dbm.METRIC_NAMES) + ["val_" + m for m in dbm.METRIC_NAMES]
+    md = dbm.trainer(0, cols, train_iter, dev_iter, g, g_opt, d, d_opt)
+    assert len(md["generator_loss"]) == 2 and len(md["val_generator_loss"]) == 1
+    # divergence guard
+    with pytest.raises(dbm.TrialPruned):
+        dbm.train_epochs(1, train_iter, dev_iter, g, dbm.optimizers.Adam(alpha=float("nan")).setup(g), d, d_opt,
+                         save_path=str(tmp_path / "w2"))
