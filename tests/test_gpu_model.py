@@ -842,3 +842,20 @@ def test_train_epochs_means_best_checkpoint_and_pruning(dbm, tmp_path):
     with pytest.raises(dbm.TrialPruned):
         dbm.train_epochs(1, train_iter, dev_iter, g, dbm.optimizers.Adam(alpha=float("nan")).setup(g), d, d_opt,
                          save_path=str(tmp_path / "w2"))
+
+
+def test_device_canvas_to_int16_geotiff(dbm, tmp_path):
+    """deepbedmap.py:749-756 on the device-resident canvas of predict_tiled_resident: the int16 cast runs on the GPU with
+    NumPy's semantics (the NaN frame becomes 0), the tiled LZW GeoTIFF decodes back bit for bit."""
+    r = np.random.RandomState(2)
+    canvas = (r.rand(1, 300, 420).astype(np.float32) - 0.3) * 5000.0
+    canvas[:, :76] = np.nan
+    canvas[0, 100, 100:104] = [np.inf, -np.inf, 3e9, 70000.0]
+    dev = dbm.to_device(canvas)
+    with np.errstate(invalid="ignore"):
+        ref = canvas.astype(np.int16)
+    assert np.array_equal(dbm.canvas_to_int16(dev), ref)
+    path = dbm.save_array_to_grid(str(tmp_path / "deepbedmap_dem"), (-2700000.0, -2200000.0, 2800000.0, 2300000.0), dev,
+                                  dtype=np.int16, tiled=True, compression="lzw")
+    got, info = dbm.read_geotiff(path)
+    assert np.array_equal(got, ref) and info["nodata"] == "-2000" and info["bigtiff"]
