@@ -24,6 +24,7 @@
 // latency: the loop is unrolled over the T taps of one channel pair and the 2T loads of the NEXT
 // pair are issued before the T MFMAs of the current one.
 #include "dbm_internal.h"
+#include <algorithm>
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -38,6 +39,68 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // gathers saturate first.  The word before / after a row may belong to the neighbouring row, channel or image (or to
 // the 128-byte guard every activation buffer carries); such taps are zeroed by the validity mask as before.
 struct __attribute__((packed, aligned(4))) f32x3 { float x, y, z; };
+
+// Split-K reduction over the WAVES wavefronts through LDS + epilogue (bias, residual axpy's, LeakyReLU, gradient mask,
+// accumulate), shared by the kernel forms below.
+template <int WAVES>
+__device__ __forceinline__ void igemm_epilogue(const ConvDesc& d, float* red, const f32x16& acc, int tid, int wave, int j, int kh, bool pv,
+                                               int n, int a, int b, int cout0, int ks) {
+  const long pix = (long)(a * d.so + d.oy0) * d.OWp + (b * d.so + d.ox0);
+  constexpr int ROWS_PER_PASS = 2 * WAVES;        // threads / 32
+  constexpr int PASSES = 32 / ROWS_PER_PASS;      // 4, 2, 1 for WAVES = 4, 8, 16
+  const int irow = tid >> 5;
+  // Two phases: first every global read of the epilogue (residuals, accumulate target, mask) for ALL of this thread's
+  // outputs is issued -- before the cross-wavefront reduction, whose LDS traffic and barrier hide their latency --
+  // then the arithmetic and the stores.  (One pass at a time, the compiler cannot hoist the next
+  // pass's loads above the previous pass's store -- y, r1, r2 and mask may alias -- and a short-K layer then spends
+  // more time in PASSES serialised memory round trips than in its MFMAs.)
+  float e_r1[PASSES], e_r2[PASSES], e_y[PASSES], e_m[PASSES], e_b[PASSES];
+#pragma unroll
+  for (int q = 0; q < PASSES; ++q) {
+    const int i = irow + ROWS_PER_PASS * q;
+    const int c = cout0 + i;
+    e_r1[q] = e_r2[q] = e_y[q] = e_b[q] = 0.f;
+    e_m[q] = 1.f;
+    if (!pv || c >= d.Cout || ks > 1) continue;
+    const long co = (long)c * d.ysc + pix;
+    if (d.bias) e_b[q] = d.bias[c];
+    if (d.r1 && c < d.r1_nch) e_r1[q] = d.r1[(long)n * d.r1sn + co];
+    if (d.r2) e_r2[q] = d.r2[(long)n * d.r2sn + co];
+    if (d.accumulate) e_y[q] = d.y[(long)n * d.ysn + co];
+    if (d.mask && c >= d.mask_c0) e_m[q] = d.mask[(long)n * d.masksn + co];
+  }
+  // split-K reduction through LDS
+  float* mine = red + wave * 1024;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * kh;
+    mine[i * 32 + j] = acc[r];
+  }
+  __syncthreads();
+  if (!pv) return;
+#pragma unroll
+  for (int q = 0; q < PASSES; ++q) {
+    const int i = irow + ROWS_PER_PASS * q;
+    const int c = cout0 + i;
+    if (c >= d.Cout) continue;
+    const int e = i * 32 + j;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += red[w * 1024 + e];
+    const long co = (long)c * d.ysc + pix;
+    float* yp = d.y + (long)n * d.ysn + co;
+    if (ks > 1) {  // plain layer, output pre-zeroed by the launcher
+      atomicAdd(yp, v);
+      continue;
+    }
+    v = (v + e_b[q]) * d.s1 + d.r1s * e_r1[q];
+    if (d.r2) v = d.s2 * v + e_r2[q];
+    v += e_y[q];
+    if (d.act) v = v >= 0.f ? v : d.slope * v;
+    v = e_m[q] >= 0.f ? v : d.slope * v;
+    *yp = v;
+  }
+}
 
 template <int T, int WAVES, int NPB, bool ROW>
 __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d) {
@@ -252,62 +315,9 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     }
   }
 
-  const long pix = (long)(a * d.so + d.oy0) * d.OWp + (b * d.so + d.ox0);
-  constexpr int ROWS_PER_PASS = 2 * WAVES;        // threads / 32
-  constexpr int PASSES = 32 / ROWS_PER_PASS;      // 4, 2, 1 for WAVES = 4, 8, 16
-  const int irow = tid >> 5;
-  // Two phases: first every global read of the epilogue (residuals, accumulate target, mask) for ALL of this thread's
-  // outputs is issued -- before the cross-wavefront reduction, whose LDS traffic and barrier hide their latency --
-  // then the arithmetic and the stores.  (One pass at a time, the compiler cannot hoist the next
-  // pass's loads above the previous pass's store -- y, r1, r2 and mask may alias -- and a short-K layer then spends
-  // more time in PASSES serialised memory round trips than in its MFMAs.)
-  float e_r1[PASSES], e_r2[PASSES], e_y[PASSES], e_m[PASSES], e_b[PASSES];
-#pragma unroll
-  for (int q = 0; q < PASSES; ++q) {
-    const int i = irow + ROWS_PER_PASS * q;
-    const int c = cout0 + i;
-    e_r1[q] = e_r2[q] = e_y[q] = e_b[q] = 0.f;
-    e_m[q] = 1.f;
-    if (!pv || c >= d.Cout || ks > 1) continue;
-    const long co = (long)c * d.ysc + pix;
-    if (d.bias) e_b[q] = d.bias[c];
-    if (d.r1 && c < d.r1_nch) e_r1[q] = d.r1[(long)n * d.r1sn + co];
-    if (d.r2) e_r2[q] = d.r2[(long)n * d.r2sn + co];
-    if (d.accumulate) e_y[q] = d.y[(long)n * d.ysn + co];
-    if (d.mask && c >= d.mask_c0) e_m[q] = d.mask[(long)n * d.masksn + co];
-  }
-  // split-K reduction through LDS
-  float* mine = red + wave * 1024;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = (r & 3) + 8 * (r >> 2) + 4 * kh;
-    mine[i * 32 + j] = acc[r];
-  }
-  __syncthreads();
-  if (!pv) return;
-#pragma unroll
-  for (int q = 0; q < PASSES; ++q) {
-    const int i = irow + ROWS_PER_PASS * q;
-    const int c = cout0 + i;
-    if (c >= d.Cout) continue;
-    const int e = i * 32 + j;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) v += red[w * 1024 + e];
-    const long co = (long)c * d.ysc + pix;
-    float* yp = d.y + (long)n * d.ysn + co;
-    if (ks > 1) {  // plain layer, output pre-zeroed by the launcher
-      atomicAdd(yp, v);
-      continue;
-    }
-    v = (v + e_b[q]) * d.s1 + d.r1s * e_r1[q];
-    if (d.r2) v = d.s2 * v + e_r2[q];
-    v += e_y[q];
-    if (d.act) v = v >= 0.f ? v : d.slope * v;
-    v = e_m[q] >= 0.f ? v : d.slope * v;
-    *yp = v;
-  }
+  igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks);
 }
+
 
 KernelProfiler g_profiler;
 
