@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--dist-backend", default=None, choices=["rccl", "nccl", "gloo"],
                     help="N > 1: rccl (default) = libdbm's native communicator, gradient buckets overlapped with the backward "
                          "passes; nccl = torch.distributed's RCCL, one all-reduce after each backward (round-1 form)")
+    ap.add_argument("--no-fused-iteration", action="store_true",
+                    help="the two step calls + two optimizer calls per minibatch instead of dbm_train_iteration (N = 1 only uses "
+                         "the fused call; data-parallel runs always use the step calls)")
     ap.add_argument("--sync-metrics", action="store_true",
                     help="fetch the five metrics to the host after every minibatch (the reference's float(...) pattern) instead "
                          "of once at the end of the run")
@@ -277,7 +280,7 @@ def main():
 
     def step():
         return dbm.train_minibatch(batch, g, g_opt, d, d_opt, comm=comm, share_generator_forward=args.share_generator_forward,
-                                   prefetch_generator_forward=prefetch, log=log)
+                                   prefetch_generator_forward=prefetch, log=log, fused=not args.no_fused_iteration)
 
     lib = dbm._lib.lib()
     for _ in range(args.warmup):
@@ -349,6 +352,7 @@ def main():
                        "generator_forwards_per_iteration": 1 if args.share_generator_forward else 2,
                        "g_step_forward_prefetched_under_d_step": bool(prefetch),
                        "cudnn_deterministic": bool(dbm.global_config.cudnn_deterministic),
+                       "fused_iteration_call": bool(not args.no_fused_iteration and comm is None and prefetch),
                        "metrics_read_back": "every minibatch" if args.sync_metrics else "once per run (device-resident log)",
                        "sync_batch_stats": bool(args.sync_batch_stats and world > 1)},
             "roofline": {

@@ -12,7 +12,7 @@ from .srgan import (  # noqa: F401
 )
 from .training import (  # noqa: F401
     METRIC_NAMES, MetricsLog, SerialIterator, TrialPruned, compile_srgan_model, concat_examples, dataset_to_device, device_batch, get_train_dev_iterators,
-    save_model_weights_and_architecture, split_dataset_random, train_epochs, train_eval_discriminator, train_eval_generator, train_minibatch, trainer,
+    save_model_weights_and_architecture, split_dataset_random, train_epochs, train_eval_discriminator, train_eval_generator, train_iteration, train_minibatch, trainer,
 )
 from .parallel import DataParallel, shard_batch, shard_slice  # noqa: F401
 from .geotiff import canvas_to_int16, read_geotiff, save_array_to_grid  # noqa: F401

@@ -89,6 +89,8 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "dbm_generator_step": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_void_p],
+    "dbm_train_iteration": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_void_p],
     "dbm_op_conv2d": [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int] * 10,
     "dbm_op_conv2d_backward": [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int] * 9,
     "dbm_op_deform_conv2d": [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int] * 5,

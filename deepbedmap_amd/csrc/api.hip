@@ -160,6 +160,8 @@ int dbm_shutdown(dbm_ctx* ctx) {
   ctx->comm_destroy();
   for (auto& e : ctx->ev_timer)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->ev_iter)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->ev_comm) (void)hipEventDestroy(ctx->ev_comm);
   if (ctx->ev_comm_done) (void)hipEventDestroy(ctx->ev_comm_done);
   ctx->loss_tmp.release();
@@ -699,8 +701,7 @@ int dbm_adam_setup(dbm_model* m, double alpha, double beta1, double beta2, doubl
   DBM_API_END
 }
 
-int dbm_adam_update(dbm_model* m, double grad_scale) {
-  DBM_API_BEGIN(m->ctx)
+static void adam_update_impl(dbm_model* m, double grad_scale) {
   DBM_CHECK(m->adam_ready, "dbm_adam_update before dbm_adam_setup");
   m->adam_t += 1;
   const double fix1 = 1.0 - std::pow(m->beta1, (double)m->adam_t);
@@ -718,6 +719,11 @@ int dbm_adam_update(dbm_model* m, double grad_scale) {
   // finds them ready instead of starting with 0.13 ms of repacking.  (The discriminator's repack already hides under
   // the generator passes that precede its next use.)
   if (m->type == 0) m->ensure_packed();
+}
+
+int dbm_adam_update(dbm_model* m, double grad_scale) {
+  DBM_API_BEGIN(m->ctx)
+  adam_update_impl(m, grad_scale);
   DBM_API_END
 }
 
@@ -960,6 +966,113 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
       DBM_MARK(s, "G:generator_backward_joined");
     }
   }
+  DBM_API_END
+}
+
+// One training iteration (srgan_train.py:1286-1309: train_eval_discriminator, then train_eval_generator, both optimizer
+// updates included) as ONE call, scheduled as a whole.  Nothing is skipped or reordered numerically: the discriminator
+// is updated from its own gradients first, the generator's gradients come from its own retained forward, the adversarial
+// term of g_loss is evaluated with the UPDATED discriminator -- but the generator's backward pass does not depend on
+// anything the D-step computes (the adversarial term is detached, :1228-1229), so it is enqueued behind the prefetched
+// forward on chain[1] and runs underneath the discriminator's backward passes and weight gradients, whose chains of
+// small kernels leave most of the chip idle.  Bitwise the same result as the two step calls + two dbm_adam_update calls.
+int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const float* X, const float* W1, const float* W2,
+                        const float* W3, const float* Y, const float weights[4], int ssim_window, int flags, float* metrics) {
+  DBM_API_BEGIN(gm->ctx)
+  DBM_CHECK(gm->type == 0 && dm->type == 1, "dbm_train_iteration: (generator, discriminator) expected");
+  Generator* g = static_cast<Generator*>(gm);
+  Discriminator* d = static_cast<Discriminator*>(dm);
+  dbm_ctx* c = g->ctx;
+  DBM_CHECK(g->adam_ready && d->adam_ready, "dbm_train_iteration: both optimizers must be set up (dbm_adam_setup)");
+  DBM_CHECK(!c->comm_active() && !c->sync_stats(), "dbm_train_iteration: data-parallel runs use the two step calls");
+  DBM_CHECK(ssim_window == 0 || ssim_window == 1, "ssim_window must be 0 (gaussian) or 1 (uniform)");
+  (void)flags;
+  hipStream_t s = c->stream;
+  hipStream_t pf = c->chain[1];
+  const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
+  g->graph_version = -1;
+  if (g->twin) g->twin->graph_version = -1;
+  g->ensure_ws(N, H, W, false);
+  d->g_out.ensure(5 * (size_t)N);
+  float* lr = d->g_out.p;
+  float* lf = lr + N;
+  float* gr = lf + N;
+  float* gf = gr + N;
+  float* lf_eval = gf + N;  // logits of the G-step's eval-mode pass (lf / gf are still being read by the backward passes)
+  if (!c->ev_iter[0]) for (auto& e : c->ev_iter) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  struct StreamScope {  // every helper below enqueues on ctx->stream: restore it whatever happens
+    dbm_ctx* c; hipStream_t s;
+    ~StreamScope() { c->stream = s; }
+  } scope{c, s};
+  DBM_MARK(s, "D:begin");
+  // ---- D(real) forward on the side stream, underneath the generator forward (:1145) ----
+  c->fork_to_side(0);
+  c->stream = c->side;
+  d->forward(N, H4, W4, Y, lr, true, true, 0);
+  c->stream = s;
+  // ---- fakes under enable_backprop=False (:1131-1137) ----
+  g->forward(N, H, W, X, W1, W2, W3, g->yout.p, false);
+  DBM_MARK(s, "D:generator_forward");
+  // ---- the G-step's own forward (:1222-1227), retained graph, second workspace, on chain[1] ----
+  Generator* t = g->get_twin();
+  t->ensure_ws(N, H, W, true);
+  t->max_split = 1;
+  c->fork(s, pf, 6);
+  c->stream = pf;
+  t->forward(N, H, W, X, W1, W2, W3, t->yout.p, true);
+  c->stream = s;
+  t->max_split = 2;
+  // ---- D(fake) forward, RaGAN loss, cleargrads (:1146-1162) ----
+  c->join_side();
+  d->forward(N, H4, W4, g->yout.p, lf, true, true, 1);
+  launch_ragan_loss(lr, lf, N, 1, 0, metrics, gr, gf, s);
+  DBM_MARK(s, "D:disc_forward_fake+loss");
+  DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));
+  // ---- d_loss.backward() (:1163): real batch on the main stream, fake batch on chain[0], weight gradients on side ----
+  c->fork(s, c->chain[0], 7);
+  d->merge_slots = true;
+  d->merge_launcher = 1;
+  d->comm_sent_lo = d->comm_sent_hi = 0;
+  try {
+    d->backward(0, gr, false);
+    c->stream = c->chain[0];
+    d->backward(1, gf, false);
+    c->stream = s;
+  } catch (...) {
+    d->merge_slots = false;
+    throw;
+  }
+  d->merge_slots = false;
+  c->fork(c->chain[0], s, 7);
+  c->join_side();  // (the discriminator's weight gradients: everything on the side stream so far)
+  DBM_MARK(s, "D:weight_gradients_joined");
+  // ---- the generator's loss terms and backward pass (:1248-1256) on chain[1], behind its forward ----
+  c->stream = pf;
+  gen_loss_terms(c, t->yout.p, Y, X, N, H4, W4, weights, ssim_window, t->g_y.p);
+  DBM_HIP(hipEventRecord(c->ev_iter[0], pf));
+  DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), pf));  // cleargrads (:1255)
+  t->grads_cleared = true;
+  t->use_aux = false;  // (chain[0] carries the discriminator's fake-batch pass)
+  try {
+    t->backward(t->g_y.p);
+  } catch (...) {
+    t->grads_cleared = false; t->use_aux = true;
+    throw;
+  }
+  t->grads_cleared = false;
+  t->use_aux = true;
+  t->graph_version = -1;
+  DBM_HIP(hipEventRecord(c->ev_iter[1], pf));
+  c->stream = s;
+  // ---- discriminator update (:1164), then the G-step's detached eval-mode discriminator pass (:1228-1237) ----
+  adam_update_impl(d, 1.0);
+  d->forward(N, H4, W4, t->yout.p, lf_eval, false, false, 1);
+  DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[0], 0));  // the loss scratch was cleared on chain[1]
+  gen_loss_adv(c, nullptr, lf_eval, N, 0, 1);
+  DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[1], 0));  // generator backward (and its weight gradients) done
+  gen_loss_finish(c, N, H4, W4, weights, metrics + 2);
+  DBM_MARK(s, "G:generator_backward_joined");
+  adam_update_impl(g, 1.0);  // (:1257)
   DBM_API_END
 }
 

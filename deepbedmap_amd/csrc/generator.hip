@@ -345,7 +345,7 @@ void Generator::backward(const float* gy) {
   ctx->fork_to_side(5);
   launch_gemv_cols_wgrad(col2.p, gy, G(T_def2W), G(T_def2b), N, 576, (int)P4, ctx->side);
   launch_deform_backward(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, goff2.p, N, 64, H4, W4, 32 * P4, s,
-                         ctx->chain[chain_base], &ctx->ev_fork[2]);
+                         use_aux ? ctx->chain[chain_base] : nullptr, use_aux ? &ctx->ev_fork[2] : nullptr);
   {
     const IgLayer& L = layers[L_off2];
     run_wgrad(L, a51.p, 64 * P4, H4, W4, 0, goff2.p, 32 * P4, H4, W4, N, 1.f, &wbs[0]);
@@ -366,7 +366,7 @@ void Generator::backward(const float* gy) {
     d.y = gcol.p; d.ysn = 576 * P4; d.s1 = 1.f; d.s2 = 1.f;
     run_dgrad(L, d, H4, W4);
     launch_deform_backward(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, goff1.p, N, 64, H4, W4, 32 * P4, s,
-                           ctx->chain[chain_base], &ctx->ev_fork[2]);
+                           use_aux ? ctx->chain[chain_base] : nullptr, use_aux ? &ctx->ev_fork[2] : nullptr);
   }
   {
     const IgLayer& L = layers[L_off1];

@@ -41,6 +41,7 @@ struct dbm_ctx {
   bool comm_in_step = false;  // set by the fused steps: the backward passes hand finished buckets to comm_bucket
   hipEvent_t ev_comm = nullptr, ev_comm_done = nullptr;
   hipEvent_t ev_timer[2] = {nullptr, nullptr};  // dbm_timer
+  hipEvent_t ev_iter[2] = {nullptr, nullptr};   // dbm_train_iteration: loss scratch cleared / generator backward done
   size_t comm_bytes = 0, comm_calls = 0;  // statistics (dbm_comm_stats)
   bool comm_active() const { return comm_world > 1 && (nccl_comm != nullptr || comm_hook != nullptr); }
   void comm_init(int rank, int world, const void* id128);
@@ -169,6 +170,7 @@ struct Generator : dbm_model {
   Generator* twin = nullptr;
   Generator* owner = nullptr;  // twin only: the model whose arenas and weight images it aliases
   int chain_base = 0;
+  bool use_aux = true;  // backward(): the deformable layers' offset-gradient kernel may run on chain[chain_base]
   int max_split = 2;  // image ranges the 9x9 stage may be cut into (1: everything on the caller's stream)
   hipEvent_t ev_prefetch = nullptr;
   // fused 9x9 trunk forward (trunk_fused.hip): per-wavefront weight streams (owner only), per-workspace hand-off granules

@@ -35,6 +35,9 @@ class _Config:
     # gradients (ordered folds instead of fp32 atomics).  False buys about 2 % of the step time.  Applied by the
     # training / backward entry points.
     cudnn_deterministic = True
+    # train_minibatch / trainer: one library call per minibatch (dbm_train_iteration: the generator's backward pass is
+    # scheduled underneath the discriminator's) instead of the two step calls; same numbers bit for bit
+    fused_iteration = True
 
 
 global_config = _Config()

@@ -264,19 +264,47 @@ class MetricsLog:
         return self.buf.get()[:self.n].copy()
 
 
+@_repeat_after_timeout
+def train_iteration(train_arrays, g_model, g_optimizer, d_model, d_optimizer, metrics=None):
+    """dbm_train_iteration: D-step, discriminator update, G-step, generator update of one minibatch of DEVICE arrays as one
+    library call.  Returns the device metrics buffer [d_loss, d_accu, g_loss, g_psnr, g_ssim, ...] (no host
+    synchronisation)."""
+    global_config.train = True
+    assert d_optimizer is not None and g_optimizer is not None  # Optimizer required for neural network training
+    n, h, w = _check_batch(train_arrays)
+    m = metrics if metrics is not None else _metrics_buffer(g_model.ctx)
+    wts = (C.c_float * 4)(*LOSS_WEIGHTS)
+    win = {"gaussian": 0, "uniform": 1}[global_config.ssim_window]
+    _apply_config(g_model.ctx)
+    _prefetch_tokens.pop(id(g_model), None)
+    _lib.check(_lib.lib().dbm_train_iteration(g_model._h, d_model._h, n, h, w, *[_dev_ptr(train_arrays[k]) for k in _KEYS], wts,
+                                              win, 0, m.ptr), g_model.ctx.handle)
+    d_optimizer.t += 1
+    g_optimizer.t += 1
+    return m
+
+
 def train_minibatch(train_arrays, g_model, g_optimizer, d_model, d_optimizer, comm=None, share_generator_forward=False,
-                    prefetch_generator_forward=True, log=None):
+                    prefetch_generator_forward=True, log=None, fused=None):
     """The body of `trainer`'s training loop (srgan_train.py:1286-1309) for one minibatch of device arrays:
     train_eval_discriminator, then train_eval_generator.  With `log` (a MetricsLog) the five metrics stay on the device
     (one row of the log) and None is returned; without, they are fetched with ONE device-to-host copy and returned as
     (d_loss, d_accu, g_loss, g_psnr, g_ssim) floats."""
     prefetch = prefetch_generator_forward and not share_generator_forward
     row = log.next_row() if log is not None else None
-    train_eval_discriminator(train_arrays, g_model, d_model, d_optimizer, comm=comm, sync=False,
-                             share_generator_forward=share_generator_forward, prefetch_generator_forward=prefetch,
-                             metrics=row)
-    m = train_eval_generator(train_arrays, g_model, d_model, g_optimizer, comm=comm, sync=False,
-                             share_generator_forward=share_generator_forward, metrics=row)
+    if fused is None:
+        fused = bool(global_config.fused_iteration)
+    if (fused and prefetch and comm is None and g_optimizer is not None and d_optimizer is not None
+            and all(_is_device(train_arrays[k]) for k in _KEYS)):
+        # ONE library call for the whole minibatch (dbm_train_iteration): the same numbers as the two calls below, bit for
+        # bit, with the generator's backward pass scheduled underneath the discriminator's
+        m = train_iteration(train_arrays, g_model, g_optimizer, d_model, d_optimizer, metrics=row)
+    else:
+        train_eval_discriminator(train_arrays, g_model, d_model, d_optimizer, comm=comm, sync=False,
+                                 share_generator_forward=share_generator_forward, prefetch_generator_forward=prefetch,
+                                 metrics=row)
+        m = train_eval_generator(train_arrays, g_model, d_model, g_optimizer, comm=comm, sync=False,
+                                 share_generator_forward=share_generator_forward, metrics=row)
     if log is not None:
         return None
     out = m.get()

@@ -227,6 +227,17 @@ int dbm_lzw_encode_tiles(const void* tiles, size_t tile_bytes, int ntiles, void*
                          int nthreads);
 int dbm_lzw_decode(const void* src, size_t nbytes, void* dst, size_t cap, size_t* out_bytes);
 
+/* One minibatch of `trainer` (srgan_train.py:1286-1309) as ONE call: train_eval_discriminator (:1084-1166) with its
+ * optimizer update, then train_eval_generator (:1170-1263) with its update; both optimizers must have been set up
+ * (dbm_adam_setup).  Numerically the two step calls + two dbm_adam_update calls, bit for bit; scheduled as a whole: the
+ * generator's backward pass -- independent of everything the D-step computes, since the adversarial term is detached
+ * (:1228-1229) -- runs on a library stream underneath the discriminator's backward passes.  metrics_dev (device, >= 8
+ * floats) receives [d_loss, d_accu, g_loss, psnr, ssim].  Single-GPU form: with a communicator or sync_batch_stats on the
+ * context the call is refused (use the two step calls). */
+int dbm_train_iteration(dbm_model* g, dbm_model* d, int N, int H, int W, const float* X, const float* W1, const float* W2,
+                        const float* W3, const float* Y, const float weights[4], int ssim_window, int flags,
+                        float* metrics_dev);
+
 /* ---- op-level entry points (used by the parity tests; same kernels the models run) ---- */
 /* L.Convolution2D forward on the MFMA implicit-GEMM kernel. x (N,C,H,W) w (O,C,k,k) b (O) or NULL -> y; all DEVICE. */
 int dbm_op_conv2d(dbm_ctx* ctx, const float* x, const float* w, const float* b, float* y, int N, int C, int H, int W,

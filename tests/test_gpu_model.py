@@ -859,3 +859,25 @@ def test_device_canvas_to_int16_geotiff(dbm, tmp_path):
                                   dtype=np.int16, tiled=True, compression="lzw")
     got, info = dbm.read_geotiff(path)
     assert np.array_equal(got, ref) and info["nodata"] == "-2000" and info["bigtiff"]
+
+
+def test_fused_iteration_equals_the_two_step_calls(dbm):
+    """dbm_train_iteration (what trainer / train_minibatch use on one GPU) schedules the generator's backward pass
+    underneath the discriminator's; nothing changes numerically: metrics, parameters, Adam state (through a third
+    iteration) and BatchNorm running statistics are bitwise those of train_eval_discriminator + train_eval_generator."""
+    arrays = dbm.device_batch(fixture_arrays(n=6))
+    runs = []
+    for fused in (False, True):
+        og = scaled_oracle_generator(2, 3.0)
+        od = omodel.DiscriminatorModel(seed=5)
+        g = copy_params(dbm.GeneratorModel(num_residual_blocks=2, initialize=False), og.params)
+        d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+        g_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(g)
+        d_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(d)
+        out = [dbm.train_minibatch(arrays, g, g_opt, d, d_opt, fused=fused) for _ in range(3)]
+        runs.append((out, g.serialize_dict(), d.serialize_dict()))
+    assert runs[0][0] == runs[1][0]
+    for k, v in runs[0][1].items():
+        assert np.array_equal(v, runs[1][1][k]), k
+    for k, v in runs[0][2].items():
+        assert np.array_equal(v, runs[1][2][k]), k
