@@ -77,12 +77,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDesc& d, float* red, co
     mine[i * 32 + j] = acc[r];
   }
   __syncthreads();
-  if (!pv) return;
 #pragma unroll
   for (int q = 0; q < PASSES; ++q) {
     const int i = irow + ROWS_PER_PASS * q;
     const int c = cout0 + i;
-    if (c >= d.Cout) continue;
+    if (!pv || c >= d.Cout) continue;
     const int e = i * 32 + j;
     float v = 0.f;
 #pragma unroll
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     a = (int)qa;
     b = (int)rb;
   }
-  const int cout0 = blockIdx.y * 32;
+  const int cout0 = blockIdx.y * (NPB == -4 ? 64 : 32);
   const int ks = d.ksplit > 1 ? d.ksplit : 1;
   const int cpw = d.Cin / ks / WAVES;                                // input channels per wavefront (even)
   const int c0 = (int)blockIdx.z * (d.Cin / ks) + wave * cpw + kh;   // first input channel of this lane
@@ -173,9 +172,9 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     }
   };
 
-  f32x16 acc;
+  f32x16 acc, acc2;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
 
   if constexpr (NPB > 0) {
     float bq[NPB][T];
@@ -253,6 +252,36 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
       }
     }
+  } else if constexpr (NPB == -4) {
+    // TWO output-channel tiles per wavefront (layers with >= 64 output channels on large grids): the gathered B operand --
+    // what the texture addresser and the vector L1 saturate on first -- is loaded once and feeds two MFMA chains; only
+    // the (coalesced, L2-hot) weight loads double.  blockIdx.y counts 64-channel groups; the second tile's accumulator
+    // is `acc2` and goes through the same epilogue after the first.
+    float av[T], aw[T], bv[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) { av[t] = wlane[t * wtap]; aw[t] = wlane[t * wtap + 32]; }
+    load_b(xn, bv);
+    for (int p = 0; p < npairs; ++p) {
+      const int pn = (p + 1 < npairs) ? p + 1 : p;
+      const float* xc = xn + pn * xstep;
+      const float* wc = wlane + pn * wstep;
+      float an[T], awn[T], bn[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) { an[t] = wc[t * wtap]; awn[t] = wc[t * wtap + 32]; }
+      load_b(xc, bn);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float bm = ((okmask >> t) & 1u) ? bv[t] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bm, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], bm, acc2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        av[t] = an[t];
+        aw[t] = awn[t];
+        bv[t] = bn[t];
+      }
+    }
   } else if constexpr (NPB < 0) {
     // (NPB = -1) 4x4 stride-2 layers on tiny planes (2x2 -> 1x1: 12 of the 16 taps fall outside the image for EVERY position of
     // the tile): taps that no lane of the wavefront needs are skipped, loads and MFMA alike
@@ -316,6 +345,10 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
   }
 
   igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks);
+  if constexpr (NPB == -4) {
+    __syncthreads();  // the first tile's partial sums have been read
+    igemm_epilogue<WAVES>(d, red, acc2, tid, wave, j, kh, pv, n, a, b, cout0 + 32, ks);
+  }
 }
 
 
@@ -392,6 +425,15 @@ static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s) {
   if constexpr (T == 16 && !ROW) {
     if (d.Hin * d.Win <= 16) {  // most taps of a 4x4 window fall outside such planes: the tap-skipping variant
       hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -1, ROW>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+      return;
+    }
+  }
+  if constexpr (WAVES == 4) {
+    // large grids with >= 64 output channels: two output tiles per wavefront (half the gathers per MFMA)
+    static const int mt2 = getenv("DBM_IGEMM_MT2") ? atoi(getenv("DBM_IGEMM_MT2")) : 1;
+    if (mt2 && d.ksplit <= 1 && d.CoutP % 64 == 0 && grid.y % 2 == 0 && (long)grid.x * (grid.y / 2) >= 1024) {
+      dim3 g2(grid.x, grid.y / 2, grid.z);
+      hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -4, ROW>), g2, dim3(64 * WAVES), WAVES * 4096, s, d);
       return;
     }
   }

@@ -1,6 +1,7 @@
 """Where a training step goes: hipEvents at the phase boundaries of the main stream (dbm_phase_marks), unprofiled.
 
-    python tools/phases.py [prefetch|narrow|share|atomics]   (atomics: prefetch with cudnn_deterministic=False)
+    python tools/phases.py [prefetch|narrow|share|atomics|fused]   (atomics: prefetch with cudnn_deterministic=False;
+                                                                    fused: dbm_train_iteration, marks of several streams)
 """
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -18,7 +19,10 @@ class FakeComm:
     def allreduce_grads(self, model):
         return 1.0
 comm = FakeComm() if len(sys.argv) > 1 and sys.argv[1] == "narrow" else None
+fused = len(sys.argv) > 1 and sys.argv[1] == "fused"
 def step():
+    if fused:
+        dbm.train_minibatch(batch, g, go, d, do, fused=True); return
     dbm.train_eval_discriminator(batch, g, d, do, share_generator_forward=share, prefetch_generator_forward=prefetch, comm=comm); dbm.train_eval_generator(batch, g, d, go, share_generator_forward=share)
 for _ in range(4): step()
 lib = dbm._lib.lib()
