@@ -77,8 +77,19 @@ struct ConvDesc {
   const float* zeros;  // >= 4 bytes of device zeros
   unsigned planeM, owM; // set by the launcher: floor(2^32 / (OHl*OWl)), floor(2^32 / OWl) (division-free position decode)
   const void* wp16;    // bf16 forward image [T][Cin/16][2][CoutP][8] (null: fp32 MFMA path)
-  int ksplit;          // set by the launcher: > 1 = blockIdx.z owns Cin / ksplit input channels and the plain result is
-                       // folded into a pre-zeroed y with atomics (few-tile, long-K layers: the deep discriminator convs)
+  int ksplit;          // set by the launcher: > 1 = blockIdx.z % ksplit owns Cin / ksplit input channels (few-tile, long-K
+                       // layers: the deep discriminator convs).  Deterministic: every workgroup writes its partial tile to
+                       // ks_part, the LAST one to arrive at the tile's counter sums the slices in index order and runs the
+                       // epilogue.  (DBM_IGEMM_KSPLIT=2: the older form, fp32 atomics onto a pre-zeroed y, plain layers only.)
+  float* ks_part;      // set by the launcher: [tile][ksplit][32 x 32] partial tiles (workspace of the launch stream)
+  unsigned* ks_cnt;    // set by the launcher: one arrival counter per tile, zero between launches
+  // Merged phases of a stride-2 data gradient (T == 4): blockIdx.z / ksplit = phase ph = 2 py + px, whose four taps are
+  // dy/dx[4 ph ..], whose weight image is phwp[ph], output offset (py, px) and logical plane phOH[ph] x phOW[ph]
+  // (the planes differ by one row / column when the gradient's dims are odd).  nphase <= 1: a single-phase launch.
+  int nphase;
+  const float* phwp[4];
+  short phOH[4], phOW[4];
+  unsigned phPlaneM[4], phOwM[4];
 };
 
 void launch_igemm_conv(const ConvDesc& d, hipStream_t s);

@@ -41,11 +41,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct __attribute__((packed, aligned(4))) f32x3 { float x, y, z; };
 
 // Split-K reduction over the WAVES wavefronts through LDS + epilogue (bias, residual axpy's, LeakyReLU, gradient mask,
-// accumulate), shared by the kernel forms below.
+// accumulate), shared by the kernel forms below.  ks > 1 (cross-workgroup split-K): the workgroup's partial tile goes to
+// d.ks_part with agent-scope write-through stores; the workgroup that arrives LAST at the tile's counter adds the ks slices
+// in index order -- the result does not depend on who is last -- and runs the epilogue.
 template <int WAVES>
 __device__ __forceinline__ void igemm_epilogue(const ConvDesc& d, float* red, const f32x16& acc, int tid, int wave, int j, int kh, bool pv,
-                                               int n, int a, int b, int cout0, int ks) {
-  const long pix = (long)(a * d.so + d.oy0) * d.OWp + (b * d.so + d.ox0);
+                                               int n, int a, int b, int cout0, int ks, int kz, unsigned tile, int oy0, int ox0) {
+  const long pix = (long)(a * d.so + oy0) * d.OWp + (b * d.so + ox0);
   constexpr int ROWS_PER_PASS = 2 * WAVES;        // threads / 32
   constexpr int PASSES = 32 / ROWS_PER_PASS;      // 4, 2, 1 for WAVES = 4, 8, 16
   const int irow = tid >> 5;
@@ -55,20 +57,23 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDesc& d, float* red, co
   // pass's loads above the previous pass's store -- y, r1, r2 and mask may alias -- and a short-K layer then spends
   // more time in PASSES serialised memory round trips than in its MFMAs.)
   float e_r1[PASSES], e_r2[PASSES], e_y[PASSES], e_m[PASSES], e_b[PASSES];
+  auto load_operands = [&]() {
 #pragma unroll
-  for (int q = 0; q < PASSES; ++q) {
-    const int i = irow + ROWS_PER_PASS * q;
-    const int c = cout0 + i;
-    e_r1[q] = e_r2[q] = e_y[q] = e_b[q] = 0.f;
-    e_m[q] = 1.f;
-    if (!pv || c >= d.Cout || ks > 1) continue;
-    const long co = (long)c * d.ysc + pix;
-    if (d.bias) e_b[q] = d.bias[c];
-    if (d.r1 && c < d.r1_nch) e_r1[q] = d.r1[(long)n * d.r1sn + co];
-    if (d.r2) e_r2[q] = d.r2[(long)n * d.r2sn + co];
-    if (d.accumulate) e_y[q] = d.y[(long)n * d.ysn + co];
-    if (d.mask && c >= d.mask_c0) e_m[q] = d.mask[(long)n * d.masksn + co];
-  }
+    for (int q = 0; q < PASSES; ++q) {
+      const int i = irow + ROWS_PER_PASS * q;
+      const int c = cout0 + i;
+      e_r1[q] = e_r2[q] = e_y[q] = e_b[q] = 0.f;
+      e_m[q] = 1.f;
+      if (!pv || c >= d.Cout) continue;
+      const long co = (long)c * d.ysc + pix;
+      if (d.bias) e_b[q] = d.bias[c];
+      if (d.r1 && c < d.r1_nch) e_r1[q] = d.r1[(long)n * d.r1sn + co];
+      if (d.r2) e_r2[q] = d.r2[(long)n * d.r2sn + co];
+      if (d.accumulate) e_y[q] = d.y[(long)n * d.ysn + co];
+      if (d.mask && c >= d.mask_c0) e_m[q] = d.mask[(long)n * d.masksn + co];
+    }
+  };
+  if (ks <= 1) load_operands();
   // split-K reduction through LDS
   float* mine = red + wave * 1024;
 #pragma unroll
@@ -77,22 +82,44 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDesc& d, float* red, co
     mine[i * 32 + j] = acc[r];
   }
   __syncthreads();
+  float vs[PASSES];
+#pragma unroll
+  for (int q = 0; q < PASSES; ++q) {
+    const int e = (irow + ROWS_PER_PASS * q) * 32 + j;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) v += red[w * 1024 + e];
+    vs[q] = v;
+  }
+  if (ks > 1) {
+    float* part = d.ks_part + ((size_t)tile * ks) * 1024;
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q)
+      __hip_atomic_store(part + (size_t)kz * 1024 + (irow + ROWS_PER_PASS * q) * 32 + j, vs[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wavefront's write-through stores have been acknowledged
+    __syncthreads();                      // ... and so have the other wavefronts' (the LDS words below are free again, too)
+    unsigned* flag = reinterpret_cast<unsigned*>(red);
+    if (tid == 0) flag[0] = __hip_atomic_fetch_add(d.ks_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flag[0] != (unsigned)(ks - 1)) return;
+    if (tid == 0) __hip_atomic_store(d.ks_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    load_operands();
+#pragma unroll
+    for (int q = 0; q < PASSES; ++q) {
+      const int e = (irow + ROWS_PER_PASS * q) * 32 + j;
+      float v = 0.f;
+      for (int z = 0; z < ks; ++z) v += __hip_atomic_load(part + (size_t)z * 1024 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vs[q] = v;
+    }
+  }
 #pragma unroll
   for (int q = 0; q < PASSES; ++q) {
     const int i = irow + ROWS_PER_PASS * q;
     const int c = cout0 + i;
     if (!pv || c >= d.Cout) continue;
-    const int e = i * 32 + j;
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) v += red[w * 1024 + e];
     const long co = (long)c * d.ysc + pix;
     float* yp = d.y + (long)n * d.ysn + co;
-    if (ks > 1) {  // plain layer, output pre-zeroed by the launcher
-      atomicAdd(yp, v);
-      continue;
-    }
-    v = (v + e_b[q]) * d.s1 + d.r1s * e_r1[q];
+    float v = (vs[q] + e_b[q]) * d.s1 + d.r1s * e_r1[q];
     if (d.r2) v = d.s2 * v + e_r2[q];
     v += e_y[q];
     if (d.act) v = v >= 0.f ? v : d.slope * v;
@@ -109,28 +136,42 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
   const int wave = tid >> 6;
   const int j = lane & 31;
   const int kh = lane >> 5;
-  const int plane = d.OHl * d.OWl;
+  const int ks = d.ksplit > 1 ? d.ksplit : 1;
+  // merged phases of a stride-2 data gradient (T == 4): blockIdx.z = phase * ks + K slice
+  int OHl = d.OHl, OWl = d.OWl, oy0 = d.oy0, ox0 = d.ox0, tb = 0, kz = (int)blockIdx.z, ph = 0;
+  unsigned planeM = d.planeM, owM = d.owM;
+  const float* wp = d.wp;
+  if constexpr (T == 4) {
+    if (d.nphase > 1) {
+      ph = (int)blockIdx.z / ks;
+      kz = (int)blockIdx.z - ph * ks;
+      OHl = d.phOH[ph]; OWl = d.phOW[ph]; planeM = d.phPlaneM[ph]; owM = d.phOwM[ph];
+      wp = d.phwp[ph]; oy0 = ph >> 1; ox0 = ph & 1; tb = 4 * ph;
+    }
+  }
+  const int plane = OHl * OWl;
+  if ((long)blockIdx.x * 32 >= (long)d.N * plane) return;  // a phase with fewer positions than the launch's widest one
   const long P = (long)blockIdx.x * 32 + j;
   const bool pv = P < (long)d.N * plane;
   int n = 0, a = 0, b = 0;
   if (pv) {  // P < 2^31 (checked by the launcher): multiply-high estimates are at most one short
-    unsigned q = __umulhi((unsigned)P, d.planeM);
+    unsigned q = __umulhi((unsigned)P, planeM);
     unsigned r = (unsigned)P - q * (unsigned)plane;
     if (r >= (unsigned)plane) { ++q; r -= (unsigned)plane; }
     n = (int)q;
-    unsigned qa = __umulhi(r, d.owM);
-    unsigned rb = r - qa * (unsigned)d.OWl;
-    if (rb >= (unsigned)d.OWl) { ++qa; rb -= (unsigned)d.OWl; }
+    unsigned qa = __umulhi(r, owM);
+    unsigned rb = r - qa * (unsigned)OWl;
+    if (rb >= (unsigned)OWl) { ++qa; rb -= (unsigned)OWl; }
     a = (int)qa;
     b = (int)rb;
   }
   const int cout0 = blockIdx.y * (NPB == -4 ? 64 : 32);
-  const int ks = d.ksplit > 1 ? d.ksplit : 1;
+  const unsigned tile = ((unsigned)ph * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;  // split-K: partial-tile slot
   const int cpw = d.Cin / ks / WAVES;                                // input channels per wavefront (even)
-  const int c0 = (int)blockIdx.z * (d.Cin / ks) + wave * cpw + kh;   // first input channel of this lane
+  const int c0 = kz * (d.Cin / ks) + wave * cpw + kh;                // first input channel of this lane
   const int Hl = d.Hin << d.ups, Wl = d.Win << d.ups;
   const float* xn = d.x + (long)n * d.xsn + (long)c0 * d.xsc;
-  const float* wlane = d.wp + (long)c0 * d.CoutP + cout0 + j;
+  const float* wlane = wp + (long)c0 * d.CoutP + cout0 + j;
   const long wtap = (long)d.Cin * d.CoutP;
   const long wstep = 2L * d.CoutP;
   const long xstep = 2L * d.xsc;
@@ -141,8 +182,8 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
   unsigned okmask = 0;
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    const int iy = a * d.sin + d.dy[t];
-    const int ix = b * d.sin + d.dx[t];
+    const int iy = a * d.sin + d.dy[tb + t];
+    const int ix = b * d.sin + d.dx[tb + t];
     const bool ok = pv && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
     xoff[t] = ok ? (iy >> d.ups) * d.Win + (ix >> d.ups) : 0;
     okmask |= ok ? (1u << t) : 0u;
@@ -344,10 +385,10 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     }
   }
 
-  igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks);
-  if constexpr (NPB == -4) {
+  igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, tile, oy0, ox0);
+  if constexpr (NPB == -4) {  // (never combined with split-K)
     __syncthreads();  // the first tile's partial sums have been read
-    igemm_epilogue<WAVES>(d, red, acc2, tid, wave, j, kh, pv, n, a, b, cout0 + 32, ks);
+    igemm_epilogue<WAVES>(d, red, acc2, tid, wave, j, kh, pv, n, a, b, cout0 + 32, 1, 0, 0u, oy0, ox0);
   }
 }
 
@@ -422,8 +463,9 @@ static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s) {
       return;
     }
   }
-  if constexpr (T == 16 && !ROW) {
-    if (d.Hin * d.Win <= 16) {  // most taps of a 4x4 window fall outside such planes: the tap-skipping variant
+  if constexpr ((T == 16 || T == 4) && !ROW) {
+    // most taps of a 4x4 window (of a 2x2 phase window of its data gradient) fall outside such planes: the tap-skipping variant
+    if (d.Hin * d.Win <= (T == 16 ? 16 : 4)) {
       hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -1, ROW>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
       return;
     }
@@ -431,7 +473,7 @@ static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s) {
   if constexpr (WAVES == 4) {
     // large grids with >= 64 output channels: two output tiles per wavefront (half the gathers per MFMA)
     static const int mt2 = getenv("DBM_IGEMM_MT2") ? atoi(getenv("DBM_IGEMM_MT2")) : 1;
-    if (mt2 && d.ksplit <= 1 && d.CoutP % 64 == 0 && grid.y % 2 == 0 && (long)grid.x * (grid.y / 2) >= 1024) {
+    if (mt2 && d.ksplit <= 1 && d.nphase <= 1 && d.CoutP % 64 == 0 && grid.y % 2 == 0 && (long)grid.x * (grid.y / 2) >= 1024) {
       dim3 g2(grid.x, grid.y / 2, grid.z);
       hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -4, ROW>), g2, dim3(64 * WAVES), WAVES * 4096, s, d);
       return;
@@ -462,22 +504,54 @@ static void launch_t(const ConvDesc& d, dim3 grid, int waves, hipStream_t s) {
   else launch_tw<T, 4>(d, grid, s);
 }
 
+// Workspace of the cross-workgroup split-K (partial tiles + arrival counters), one per launch stream: launches on one
+// stream never overlap, launches on different streams (the real- and the fake-batch passes of the discriminator) do.
+struct KsWorkspace { float* part = nullptr; unsigned* cnt = nullptr; };
+static const size_t KS_PART_FLOATS = 4u << 20;  // 16 MB: 4096 partial tiles
+static const size_t KS_COUNTERS = 4096;
+static KsWorkspace& ks_workspace(hipStream_t s) {
+  static std::map<hipStream_t, KsWorkspace> table;
+  KsWorkspace& w = table[s];
+  if (!w.part) {
+    DBM_HIP(hipMalloc((void**)&w.part, KS_PART_FLOATS * sizeof(float)));
+    DBM_HIP(hipMalloc((void**)&w.cnt, KS_COUNTERS * sizeof(unsigned)));
+    DBM_HIP(hipMemset(w.cnt, 0, KS_COUNTERS * sizeof(unsigned)));
+    DBM_HIP(hipDeviceSynchronize());  // the NULL-stream memset vs. non-blocking streams
+  }
+  return w;
+}
+
+static unsigned igemm_magic(unsigned long long dv) {  // floor(2^32 / dv), saturated (dv == 1: the kernel's one-step correction still lands)
+  const unsigned long long m = 0x100000000ULL / dv;
+  return (unsigned)(m > 0xffffffffULL ? 0xffffffffULL : m);
+}
+
 void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   ConvDesc d = d_in;
   d.ksplit = 1;
-  DBM_CHECK((long)d.N * d.OHl * d.OWl < (1L << 31), "igemm: more than 2^31 output positions");
-  auto magic = [](unsigned long long dv) {  // floor(2^32 / dv), saturated (dv == 1: the kernel's one-step correction still lands)
-    const unsigned long long m = 0x100000000ULL / dv;
-    return (unsigned)(m > 0xffffffffULL ? 0xffffffffULL : m);
-  };
-  d.planeM = magic((unsigned long long)d.OHl * d.OWl);
-  d.owM = magic((unsigned long long)d.OWl);
+  const int nph = d.nphase > 1 ? d.nphase : 1;
+  long total = (long)d.N * d.OHl * d.OWl;   // positions of the (widest) phase
+  double flop_positions = (double)total;    // ... of all phases
+  if (nph > 1) {
+    DBM_CHECK(d.T == 4 && nph == 4, "igemm: merged phases are the four 2x2-tap phases of a k4 s2 data gradient");
+    total = 0; flop_positions = 0;
+    for (int ph = 0; ph < 4; ++ph) {
+      const long tp = (long)d.N * d.phOH[ph] * d.phOW[ph];
+      DBM_CHECK(tp > 0, "igemm: empty phase");
+      total = std::max(total, tp);
+      flop_positions += (double)tp;
+      d.phPlaneM[ph] = igemm_magic((unsigned long long)d.phOH[ph] * d.phOW[ph]);
+      d.phOwM[ph] = igemm_magic((unsigned long long)d.phOW[ph]);
+    }
+  }
+  DBM_CHECK(total < (1L << 31), "igemm: more than 2^31 output positions");
+  d.planeM = igemm_magic((unsigned long long)d.OHl * d.OWl);
+  d.owM = igemm_magic((unsigned long long)d.OWl);
   DBM_CHECK(d.Cin % 32 == 0, "igemm: Cin must be a multiple of 32");
   DBM_CHECK(d.CoutP % 32 == 0 && d.Cout <= d.CoutP, "igemm: bad CoutP");
   DBM_CHECK(d.T == 1 || d.T == 4 || d.T == 9 || d.T == 16, "igemm: tap count must be 1, 4, 9 or 16");
-  const long total = (long)d.N * d.OHl * d.OWl;
-  dim3 grid((unsigned)((total + 31) / 32), (unsigned)((d.Cout + 31) / 32));
-  const long tiles = (long)grid.x * grid.y;
+  dim3 grid((unsigned)((total + 31) / 32), (unsigned)((d.Cout + 31) / 32), (unsigned)nph);
+  const long tiles = (long)grid.x * grid.y * nph;
   // few tiles -> more wavefronts per tile (Cin % 32 == 0 keeps Cin / WAVES even for every choice)
   int waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
   // ... but a wavefront should own a few channel pairs: with a short K (the 32-channel data gradients of the dense
@@ -485,22 +559,24 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   static const int min_pairs = getenv("DBM_IGEMM_MINPAIRS") ? atoi(getenv("DBM_IGEMM_MINPAIRS")) : 6;
   static const int min_tiles = getenv("DBM_IGEMM_MINTILES") ? atoi(getenv("DBM_IGEMM_MINTILES")) : 96;
   while (tiles > min_tiles && waves > 4 && d.Cin / (2 * waves) < min_pairs) waves >>= 1;
-  // Few tiles and a long K (the deep discriminator layers: 8..128 tiles, K = 2304..8192): the input channels are
-  // also split across workgroups; only for plain layers (no bias / residual / activation / mask / accumulate) whose
-  // output is one dense [N][Cout][OH*OW] block, which is zeroed first and folded with atomics.
-  static const int ks_enable = getenv("DBM_IGEMM_KSPLIT") ? atoi(getenv("DBM_IGEMM_KSPLIT")) : 0;  // opt-in: costs the forward its run-to-run bitwise reproducibility for ~0.1 ms per step
-  if (ks_enable && tiles <= 128 && (long)d.Cin * d.T >= 2048 && !d.bias && !d.r1 && !d.r2 && !d.act && !d.mask && !d.accumulate &&
-      d.s1 == 1.f && d.so == 1 && d.oy0 == 0 && d.ox0 == 0 && d.OWp == d.OWl && d.ysc == d.OHl * d.OWl &&
-      d.ysn == (long)d.Cout * d.ysc) {
+  // Few tiles and a long K (the deep discriminator layers: 32..512 tiles, K = 2048..8192): the input channels are also split
+  // across workgroups of four wavefronts, about 1024 workgroups per launch; partial tiles are folded deterministically by
+  // the last workgroup of each tile (igemm_epilogue).  The bf16 inference images keep the one-workgroup form.
+  static const int ks_enable = getenv("DBM_IGEMM_KSPLIT") ? atoi(getenv("DBM_IGEMM_KSPLIT")) : 1;
+  static const int ks_target = getenv("DBM_IGEMM_KSTARGET") ? atoi(getenv("DBM_IGEMM_KSTARGET")) : 1024;
+  if (ks_enable && tiles <= 512 && (long)d.Cin * d.T >= 1024 && !d.wp16) {
     int ks = 1;
-    while (ks < 16 && tiles * ks * 2 <= 512 && (d.Cin / (ks * 2)) % (2 * waves) == 0 && d.Cin / (ks * 2) / waves >= 4) ks *= 2;
-    if (ks > 1) {
+    while (ks < 32 && tiles * ks * 2 <= ks_target && (d.Cin / (ks * 2)) % 8 == 0 && d.Cin / (ks * 2) >= 32) ks *= 2;
+    if (ks > 1 && (size_t)tiles * ks * 1024 <= KS_PART_FLOATS && (size_t)tiles <= KS_COUNTERS) {
+      KsWorkspace& w = ks_workspace(s);
       d.ksplit = ks;
-      grid.z = ks;
-      DBM_HIP(hipMemsetAsync(d.y, 0, sizeof(float) * (size_t)d.N * d.ysn, s));
+      d.ks_part = w.part;
+      d.ks_cnt = w.cnt;
+      grid.z = (unsigned)(nph * ks);
+      waves = 4;
     }
   }
-  if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)total * d.Cout * d.Cin * d.T);
+  if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * flop_positions * d.Cout * d.Cin * d.T);
   switch (d.T) {
     case 1: launch_t<1>(d, grid, waves, s); break;
     case 4: launch_t<4>(d, grid, waves, s); break;

@@ -286,12 +286,27 @@ void dbm_model::run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_
     base.wp = L.wb[0];
     launch_igemm_conv(base, s);
   } else {
+    // the four phases (py, px) of the stride-2 gradient -- output positions (2a + py, 2b + px), 2x2 taps each -- as ONE launch
+    // (blockIdx.z = phase); planes that lack a phase (a single row or column) fall back to one launch per phase
+    static const int merge = getenv("DBM_IGEMM_MERGE_PHASES") ? atoi(getenv("DBM_IGEMM_MERGE_PHASES")) : 1;
+    base.so = 2; base.T = 4;
+    if (merge && Hin_fwd >= 2 && Win_fwd >= 2) {
+      base.nphase = 4;
+      for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        base.phOH[ph] = (short)((Hin_fwd - py + 1) / 2); base.phOW[ph] = (short)((Win_fwd - px + 1) / 2);
+        for (int t = 0; t < 4; ++t) { base.dy[4 * ph + t] = L.bdy[ph][t]; base.dx[4 * ph + t] = L.bdx[ph][t]; }
+        base.phwp[ph] = L.wb[ph];
+      }
+      base.OHl = base.phOH[0]; base.OWl = base.phOW[0]; base.oy0 = 0; base.ox0 = 0; base.wp = L.wb[0];
+      launch_igemm_conv(base, s);
+      return;
+    }
     for (int ph = 0; ph < 4; ++ph) {
       const int py = ph >> 1, px = ph & 1;
       base.OHl = (Hin_fwd - py + 1) / 2; base.OWl = (Win_fwd - px + 1) / 2;
       if (base.OHl <= 0 || base.OWl <= 0) continue;
-      base.so = 2; base.oy0 = py; base.ox0 = px;
-      base.T = 4;
+      base.oy0 = py; base.ox0 = px;
       for (int t = 0; t < 4; ++t) { base.dy[t] = L.bdy[ph][t]; base.dx[t] = L.bdx[ph][t]; }
       base.wp = L.wb[ph];
       launch_igemm_conv(base, s);
