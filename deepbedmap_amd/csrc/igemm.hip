@@ -45,7 +45,7 @@ struct __attribute__((packed, aligned(4))) f32x3 { float x, y, z; };
 // d.ks_part with agent-scope write-through stores; the workgroup that arrives LAST at the tile's counter adds the ks slices
 // in index order -- the result does not depend on who is last -- and runs the epilogue.
 template <int WAVES>
-__device__ __forceinline__ void igemm_epilogue(const ConvDesc& d, float* red, const f32x16& acc, int tid, int wave, int j, int kh, bool pv,
+__device__ __forceinline__ bool igemm_epilogue(const ConvDesc& d, float* red, const f32x16& acc, int tid, int wave, int j, int kh, bool pv,
                                                int n, int a, int b, int cout0, int ks, int kz, unsigned tile, int oy0, int ox0) {
   const long pix = (long)(a * d.so + oy0) * d.OWp + (b * d.so + ox0);
   constexpr int ROWS_PER_PASS = 2 * WAVES;        // threads / 32
@@ -101,15 +101,27 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDesc& d, float* red, co
     unsigned* flag = reinterpret_cast<unsigned*>(red);
     if (tid == 0) flag[0] = __hip_atomic_fetch_add(d.ks_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (flag[0] != (unsigned)(ks - 1)) return;
+    if (flag[0] != (unsigned)(ks - 1)) return false;
     if (tid == 0) __hip_atomic_store(d.ks_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     load_operands();
+    // (the loads bypass the caches: a microsecond each -- eight slices of all passes are in flight together; slices past
+    // the last one re-read it and add nothing)
 #pragma unroll
-    for (int q = 0; q < PASSES; ++q) {
-      const int e = (irow + ROWS_PER_PASS * q) * 32 + j;
-      float v = 0.f;
-      for (int z = 0; z < ks; ++z) v += __hip_atomic_load(part + (size_t)z * 1024 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      vs[q] = v;
+    for (int q = 0; q < PASSES; ++q) vs[q] = 0.f;
+    for (int z0 = 0; z0 < ks; z0 += 8) {
+      float t[PASSES][8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int z = z0 + u < ks ? z0 + u : ks - 1;
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q)
+          t[q][u] = __hip_atomic_load(part + (size_t)z * 1024 + (irow + ROWS_PER_PASS * q) * 32 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+#pragma unroll
+        for (int q = 0; q < PASSES; ++q) vs[q] += z0 + u < ks ? t[q][u] : 0.f;
+      }
     }
   }
 #pragma unroll
@@ -126,6 +138,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvDesc& d, float* red, co
     v = e_m[q] >= 0.f ? v : d.slope * v;
     *yp = v;
   }
+  return true;
 }
 
 template <int T, int WAVES, int NPB, bool ROW>
@@ -294,33 +307,39 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
       }
     }
   } else if constexpr (NPB == -4) {
-    // TWO output-channel tiles per wavefront (layers with >= 64 output channels on large grids): the gathered B operand --
-    // what the texture addresser and the vector L1 saturate on first -- is loaded once and feeds two MFMA chains; only
-    // the (coalesced, L2-hot) weight loads double.  blockIdx.y counts 64-channel groups; the second tile's accumulator
-    // is `acc2` and goes through the same epilogue after the first.
-    float av[T], aw[T], bv[T];
+    // TWO output-channel tiles per wavefront (layers with >= 64 output channels): the gathered B operand -- what the
+    // texture addresser and the vector L1 saturate on first -- is loaded once and feeds two MFMA chains; only the
+    // (coalesced, L2-hot) weight loads double.  blockIdx.y counts 64-channel groups; the second tile's accumulator is
+    // `acc2` and goes through the same epilogue after the first.
+    // Software pipeline: two register sets in ping-pong.  (A single set refilled by copies `cur = next` makes hipcc
+    // interleave the copies with the MFMAs, and each copy waits for a load that has only just been issued: one exposed
+    // memory latency per channel pair.  The sched_barriers keep the requests in front of the MFMA block they overlap.)
+    float a0[T], w0[T], b0[T], a1[T], w1[T], b1[T];
+    auto load_set = [&](int p, float (&a)[T], float (&w)[T], float (&b)[T]) {
+      const float* wc = wlane + p * wstep;
 #pragma unroll
-    for (int t = 0; t < T; ++t) { av[t] = wlane[t * wtap]; aw[t] = wlane[t * wtap + 32]; }
-    load_b(xn, bv);
-    for (int p = 0; p < npairs; ++p) {
-      const int pn = (p + 1 < npairs) ? p + 1 : p;
-      const float* xc = xn + pn * xstep;
-      const float* wc = wlane + pn * wstep;
-      float an[T], awn[T], bn[T];
-#pragma unroll
-      for (int t = 0; t < T; ++t) { an[t] = wc[t * wtap]; awn[t] = wc[t * wtap + 32]; }
-      load_b(xc, bn);
+      for (int t = 0; t < T; ++t) { a[t] = wc[t * wtap]; w[t] = wc[t * wtap + 32]; }
+      load_b(xn + p * xstep, b);
+    };
+    auto mfma_set = [&](const float (&a)[T], const float (&w)[T], const float (&b)[T]) {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const float bm = ((okmask >> t) & 1u) ? bv[t] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bm, acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[t], bm, acc2, 0, 0, 0);
+        const float bm = ((okmask >> t) & 1u) ? b[t] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bm, acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], bm, acc2, 0, 0, 0);
       }
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        av[t] = an[t];
-        aw[t] = awn[t];
-        bv[t] = bn[t];
+    };
+    load_set(0, a0, w0, b0);
+    for (int p = 0; p < npairs; p += 2) {
+      load_set(p + 1 < npairs ? p + 1 : p, a1, w1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_set(a0, w0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p + 1 < npairs) {
+        load_set(p + 2 < npairs ? p + 2 : p + 1, a0, w0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(a1, w1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   } else if constexpr (NPB < 0) {
@@ -359,36 +378,42 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
       }
     }
   } else {
-    float av[T], bv[T];
+    // streaming loop, two register sets in ping-pong (see the two-tile form above)
+    float a0[T], b0[T], a1[T], b1[T];
+    auto load_set = [&](int p, float (&a)[T], float (&b)[T]) {
+      const float* wc = wlane + p * wstep;
 #pragma unroll
-    for (int t = 0; t < T; ++t) av[t] = wlane[t * wtap];
-    load_b(xn, bv);
-    for (int p = 0; p < npairs; ++p) {
-      // prefetch the next channel pair (the last iteration re-reads the current one: harmless, keeps the loop uniform)
-      const int pn = (p + 1 < npairs) ? p + 1 : p;
-      const float* xc = xn + pn * xstep;
-      const float* wc = wlane + pn * wstep;
-      float an[T], bn[T];
-#pragma unroll
-      for (int t = 0; t < T; ++t) an[t] = wc[t * wtap];
-      load_b(xc, bn);
+      for (int t = 0; t < T; ++t) a[t] = wc[t * wtap];
+      load_b(xn + p * xstep, b);
+    };
+    auto mfma_set = [&](const float (&a)[T], const float (&b)[T]) {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const float bm = ((okmask >> t) & 1u) ? bv[t] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bm, acc, 0, 0, 0);
+        const float bm = ((okmask >> t) & 1u) ? b[t] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bm, acc, 0, 0, 0);
       }
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        av[t] = an[t];
-        bv[t] = bn[t];
+    };
+    load_set(0, a0, b0);
+    for (int p = 0; p < npairs; p += 2) {
+      load_set(p + 1 < npairs ? p + 1 : p, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_set(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p + 1 < npairs) {
+        load_set(p + 2 < npairs ? p + 2 : p + 1, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
 
-  igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, tile, oy0, ox0);
-  if constexpr (NPB == -4) {  // (never combined with split-K)
-    __syncthreads();  // the first tile's partial sums have been read
-    igemm_epilogue<WAVES>(d, red, acc2, tid, wave, j, kh, pv, n, a, b, cout0 + 32, 1, 0, 0u, oy0, ox0);
+  if constexpr (NPB == -4) {  // two output tiles: partial-tile slots 2 tile, 2 tile + 1
+    igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, 2 * tile, oy0, ox0);
+    __syncthreads();  // the first tile's partial sums (and the arrival word) have been read
+    igemm_epilogue<WAVES>(d, red, acc2, tid, wave, j, kh, pv, n, a, b, cout0 + 32, ks, kz, 2 * tile + 1, oy0, ox0);
+  } else {
+    igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, tile, oy0, ox0);
   }
 }
 
@@ -446,13 +471,24 @@ std::string KernelProfiler::dump_marks() {
   return out;
 }
 
+static bool igemm_tap_skip(const ConvDesc& d) {
+  static const int skip_plane = getenv("DBM_IGEMM_SKIP_PLANE") ? atoi(getenv("DBM_IGEMM_SKIP_PLANE")) : 4;
+  return (d.T == 16 || d.T == 4) && d.Hin * d.Win <= skip_plane;
+}
+
 constexpr int IGEMM_NPB = 6;  // channel pairs a wavefront may hold entirely in registers (T = 9 -> 54 VGPRs)
 
 template <int T, int WAVES, bool ROW>
-static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s) {
+static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s, bool mt2) {
   if constexpr (!ROW) {
     if (d.wp16) {
       hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -2, false>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+      return;
+    }
+  }
+  if constexpr (WAVES == 4) {
+    if (mt2) {  // two output tiles per wavefront: grid.y counts 64-channel groups
+      hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -4, ROW>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
       return;
     }
   }
@@ -465,17 +501,8 @@ static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s) {
   }
   if constexpr ((T == 16 || T == 4) && !ROW) {
     // most taps of a 4x4 window (of a 2x2 phase window of its data gradient) fall outside such planes: the tap-skipping variant
-    if (d.Hin * d.Win <= (T == 16 ? 16 : 4)) {
+    if (igemm_tap_skip(d)) {
       hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -1, ROW>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
-      return;
-    }
-  }
-  if constexpr (WAVES == 4) {
-    // large grids with >= 64 output channels: two output tiles per wavefront (half the gathers per MFMA)
-    static const int mt2 = getenv("DBM_IGEMM_MT2") ? atoi(getenv("DBM_IGEMM_MT2")) : 1;
-    if (mt2 && d.ksplit <= 1 && d.nphase <= 1 && d.CoutP % 64 == 0 && grid.y % 2 == 0 && (long)grid.x * (grid.y / 2) >= 1024) {
-      dim3 g2(grid.x, grid.y / 2, grid.z);
-      hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -4, ROW>), g2, dim3(64 * WAVES), WAVES * 4096, s, d);
       return;
     }
   }
@@ -483,25 +510,25 @@ static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s) {
 }
 
 template <int T, int WAVES>
-static void launch_tw(const ConvDesc& d, dim3 grid, hipStream_t s) {
+static void launch_tw(const ConvDesc& d, dim3 grid, hipStream_t s, bool mt2) {
   if constexpr (T == 9) {
     // row-contiguous taps: 3x3, unit stride, no folded resize, taps ordered (dy, dx) with dx = -1,0,1 or 1,0,-1
     const bool row = d.sin == 1 && d.ups == 0 && d.dy[0] == d.dy[1] && d.dy[1] == d.dy[2] && d.dx[1] == 0 &&
                      d.dx[0] == -d.dx[2] && (d.dx[0] == 1 || d.dx[0] == -1) && d.dy[3] == d.dy[5] && d.dy[6] == d.dy[8] &&
                      d.dx[3] == d.dx[0] && d.dx[6] == d.dx[0] && d.dx[4] == 0 && d.dx[7] == 0;
     if (row && !d.wp16) {
-      launch_twr<T, WAVES, true>(d, grid, s);
+      launch_twr<T, WAVES, true>(d, grid, s, mt2);
       return;
     }
   }
-  launch_twr<T, WAVES, false>(d, grid, s);
+  launch_twr<T, WAVES, false>(d, grid, s, mt2);
 }
 
 template <int T>
-static void launch_t(const ConvDesc& d, dim3 grid, int waves, hipStream_t s) {
-  if (waves == 16) launch_tw<T, 16>(d, grid, s);
-  else if (waves == 8) launch_tw<T, 8>(d, grid, s);
-  else launch_tw<T, 4>(d, grid, s);
+static void launch_t(const ConvDesc& d, dim3 grid, int waves, hipStream_t s, bool mt2) {
+  if (waves == 16) launch_tw<T, 16>(d, grid, s, false);
+  else if (waves == 8) launch_tw<T, 8>(d, grid, s, false);
+  else launch_tw<T, 4>(d, grid, s, mt2);
 }
 
 // Workspace of the cross-workgroup split-K (partial tiles + arrival counters), one per launch stream: launches on one
@@ -551,9 +578,20 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   DBM_CHECK(d.CoutP % 32 == 0 && d.Cout <= d.CoutP, "igemm: bad CoutP");
   DBM_CHECK(d.T == 1 || d.T == 4 || d.T == 9 || d.T == 16, "igemm: tap count must be 1, 4, 9 or 16");
   dim3 grid((unsigned)((total + 31) / 32), (unsigned)((d.Cout + 31) / 32), (unsigned)nph);
-  const long tiles = (long)grid.x * grid.y * nph;
+  long tiles = (long)grid.x * grid.y * nph;
+  // Two output-channel tiles per wavefront (the gathered B operand feeds two MFMA chains): layers with >= 64 output
+  // channels on large grids -- or, with the cross-workgroup split-K below restoring the workgroup count, any layer
+  // with a long K (DBM_IGEMM_MT2: 0 never, 1 large grids only, 2 also with split-K).
+  static const int mt2_mode = getenv("DBM_IGEMM_MT2") ? atoi(getenv("DBM_IGEMM_MT2")) : 2;
+  static const int ks_enable = getenv("DBM_IGEMM_KSPLIT") ? atoi(getenv("DBM_IGEMM_KSPLIT")) : 1;
+  static const int ks_target = getenv("DBM_IGEMM_KSTARGET") ? atoi(getenv("DBM_IGEMM_KSTARGET")) : 1024;
+  static const int mt2_tiles = getenv("DBM_IGEMM_MT2_TILES") ? atoi(getenv("DBM_IGEMM_MT2_TILES")) : 1024;
+  const bool mt2_ok = mt2_mode && !d.wp16 && d.CoutP % 64 == 0 && grid.y % 2 == 0 && !igemm_tap_skip(d);
+  bool mt2 = mt2_ok && tiles / 2 >= mt2_tiles;
+  if (!mt2 && mt2_ok && mt2_mode >= 2 && ks_enable && (long)d.Cin * d.T >= 1024 && tiles / 2 <= 512 && tiles >= 64) mt2 = true;
+  if (mt2) { grid.y /= 2; tiles /= 2; }
   // few tiles -> more wavefronts per tile (Cin % 32 == 0 keeps Cin / WAVES even for every choice)
-  int waves = tiles >= 1024 ? 4 : (tiles >= 512 ? 8 : 16);
+  int waves = (tiles >= 1024 || mt2) ? 4 : (tiles >= 512 ? 8 : 16);
   // ... but a wavefront should own a few channel pairs: with a short K (the 32-channel data gradients of the dense
   // blocks) the cross-wavefront reduction and a 1024-thread workgroup cost more than the MFMAs they spread
   static const int min_pairs = getenv("DBM_IGEMM_MINPAIRS") ? atoi(getenv("DBM_IGEMM_MINPAIRS")) : 6;
@@ -562,12 +600,11 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   // Few tiles and a long K (the deep discriminator layers: 32..512 tiles, K = 2048..8192): the input channels are also split
   // across workgroups of four wavefronts, about 1024 workgroups per launch; partial tiles are folded deterministically by
   // the last workgroup of each tile (igemm_epilogue).  The bf16 inference images keep the one-workgroup form.
-  static const int ks_enable = getenv("DBM_IGEMM_KSPLIT") ? atoi(getenv("DBM_IGEMM_KSPLIT")) : 1;
-  static const int ks_target = getenv("DBM_IGEMM_KSTARGET") ? atoi(getenv("DBM_IGEMM_KSTARGET")) : 1024;
   if (ks_enable && tiles <= 512 && (long)d.Cin * d.T >= 1024 && !d.wp16) {
     int ks = 1;
     while (ks < 32 && tiles * ks * 2 <= ks_target && (d.Cin / (ks * 2)) % 8 == 0 && d.Cin / (ks * 2) >= 32) ks *= 2;
-    if (ks > 1 && (size_t)tiles * ks * 1024 <= KS_PART_FLOATS && (size_t)tiles <= KS_COUNTERS) {
+    const size_t slots = (size_t)tiles * (mt2 ? 2 : 1);
+    if (ks > 1 && slots * ks * 1024 <= KS_PART_FLOATS && slots <= KS_COUNTERS) {
       KsWorkspace& w = ks_workspace(s);
       d.ksplit = ks;
       d.ks_part = w.part;
@@ -576,12 +613,13 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
       waves = 4;
     }
   }
+  if (mt2 && waves != 4) { mt2 = false; grid.y *= 2; }
   if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * flop_positions * d.Cout * d.Cin * d.T);
   switch (d.T) {
-    case 1: launch_t<1>(d, grid, waves, s); break;
-    case 4: launch_t<4>(d, grid, waves, s); break;
-    case 9: launch_t<9>(d, grid, waves, s); break;
-    default: launch_t<16>(d, grid, waves, s); break;
+    case 1: launch_t<1>(d, grid, waves, s, mt2); break;
+    case 4: launch_t<4>(d, grid, waves, s, mt2); break;
+    case 9: launch_t<9>(d, grid, waves, s, mt2); break;
+    default: launch_t<16>(d, grid, waves, s, mt2); break;
   }
   if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
