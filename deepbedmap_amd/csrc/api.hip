@@ -1155,10 +1155,21 @@ int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const f
                          int N, int C, int H, int W, int O) {
   DBM_API_BEGIN(ctx)
   DBM_CHECK(C % 32 == 0, "deform conv op: C % 32 == 0");
+  static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  const bool fused = fused_env && deform_conv_fused_ok(C, O);
   DevBuf col;
-  col.ensure((size_t)N * C * 9 * H * W);
-  launch_deform_sample(x, off, col.p, N, C, H, W, 18L * H * W, ctx->stream);
-  if (O == 1) {
+  if (!fused) {
+    col.ensure((size_t)N * C * 9 * H * W);
+    launch_deform_sample(x, off, col.p, N, C, H, W, 18L * H * W, ctx->stream);
+  }
+  DevBuf xt;
+  if (fused) {
+    xt.ensure((size_t)N * C * H * W);
+    launch_nchw_to_nhwc64(x, xt.p, N, H * W, ctx->stream);
+  }
+  if (fused && O == 1) {
+    launch_deform_conv_fused(xt.p, off, w, b, y, nullptr, nullptr, N, C, H, W, 18L * H * W, 1, 0, 0.2f, ctx->stream);
+  } else if (O == 1) {
     launch_gemv_cols(col.p, w, b, y, N, C * 9, H * W, ctx->stream);
   } else {
     dbm_model holder;
@@ -1170,12 +1181,18 @@ int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const f
     if (b) DBM_HIP(hipMemcpyAsync(holder.params + (size_t)O * C * 9, b, sizeof(float) * O, hipMemcpyDeviceToDevice, ctx->stream));
     holder.add_iglayer("op", O, C, 3, 1, 0, true, true);
     holder.ensure_packed();
-    ConvDesc d = holder.fwd_desc(holder.layers[0], col.p, (long)C * 9 * H * W, H, W, 0, y, (long)O * H * W, N);
-    launch_igemm_conv(d, ctx->stream);
+    if (fused) {
+      launch_deform_conv_fused(xt.p, off, holder.layers[0].wf, b ? holder.P(holder.layers[0].bi) : nullptr, y, nullptr, nullptr, N, C, H, W,
+                               18L * H * W, O, 0, 0.2f, ctx->stream);
+    } else {
+      ConvDesc d = holder.fwd_desc(holder.layers[0], col.p, (long)C * 9 * H * W, H, W, 0, y, (long)O * H * W, N);
+      launch_igemm_conv(d, ctx->stream);
+    }
     DBM_HIP(hipStreamSynchronize(ctx->stream));
   }
   DBM_HIP(hipStreamSynchronize(ctx->stream));
   col.release();
+  xt.release();
   DBM_API_END
 }
 

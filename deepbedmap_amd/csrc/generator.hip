@@ -163,10 +163,12 @@ void Generator::ensure_ws(int N, int H, int W, bool train) {
   a42.ensure(n * 64 * 16 * hw);
   off1.ensure(n * 32 * 16 * hw);
   off2.ensure(n * 32 * 16 * hw);
-  col1.ensure(n * 576 * 16 * hw);
   a51.ensure(n * 64 * 16 * hw);
+  a42t.ensure(n * 64 * 16 * hw);
+  a51t.ensure(n * 64 * 16 * hw);
   yout.ensure(n * 16 * hw);
   if (tr) {
+    col1.ensure(n * 576 * 16 * hw);  // sample matrices of the deformable layers: retained passes only (forward())
     col2.ensure(n * 576 * 16 * hw);
     if ((int)dA.size() < nrdb + 1) dA.resize(nrdb + 1);
     for (int i = 0; i <= nrdb; ++i) dA[i].ensure(n * (i == nrdb ? 64 : 192) * hw);
@@ -313,21 +315,42 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   // ---- deformable conv 1 + LeakyReLU (:572-573): offset conv, sampler -> col, GEMM over 576 columns ----
   const int H4 = 4 * h, W4 = 4 * w;
   const long P4 = 16 * hw;
+  // The sampler is fused into the GEMM (deform_fused.hip), fed from a channels-last copy of the layer input; the
+  // (N, 576, H, W) sample matrices exist only in a retained pass, as a by-product for the two weight gradients.
+  static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  const bool dfused = fused_env && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch);
+  if (dfused) {
+    a42t.ensure((size_t)N * 64 * P4);
+    a51t.ensure((size_t)N * 64 * P4);
+  } else {
+    col1.ensure((size_t)N * 576 * P4);
+  }
   {
     ConvDesc d = fwd_desc(layers[L_off1], a42.p, 64 * P4, H4, W4, 0, off1.p, 32 * P4, N);
     launch_igemm_conv(d, s);
-    launch_deform_sample(a42.p, off1.p, col1.p, N, 64, H4, W4, 32 * P4, s);
-    ConvDesc g = fwd_desc(layers[L_def1], col1.p, 576 * P4, H4, W4, 0, a51.p, 64 * P4, N);
-    g.act = 1;
-    launch_igemm_conv(g, s);
+    if (dfused) {
+      launch_nchw_to_nhwc64(a42.p, a42t.p, N, (int)P4, s);
+      launch_deform_conv_fused(a42t.p, off1.p, layers[L_def1].wf, P(layers[L_def1].bi), a51.p, a51t.p, keep ? col1.p : nullptr, N, 64, H4,
+                               W4, 32 * P4, 64, 1, SLOPE, s);
+    } else {
+      launch_deform_sample(a42.p, off1.p, col1.p, N, 64, H4, W4, 32 * P4, s);
+      ConvDesc g = fwd_desc(layers[L_def1], col1.p, 576 * P4, H4, W4, 0, a51.p, 64 * P4, N);
+      g.act = 1;
+      launch_igemm_conv(g, s);
+    }
   }
   // ---- deformable conv 2 (:574) ----
   {
-    float* col = keep ? col2.p : col1.p;
     ConvDesc d = fwd_desc(layers[L_off2], a51.p, 64 * P4, H4, W4, 0, off2.p, 32 * P4, N);
     launch_igemm_conv(d, s);
-    launch_deform_sample(a51.p, off2.p, col, N, 64, H4, W4, 32 * P4, s);
-    launch_gemv_cols(col, P(T_def2W), P(T_def2b), y, N, 576, (int)P4, s);
+    if (dfused) {
+      launch_deform_conv_fused(a51t.p, off2.p, P(T_def2W), P(T_def2b), y, nullptr, nullptr, N, 64, H4, W4, 32 * P4, out_ch, 0, SLOPE, s);
+      if (keep) launch_deform_sample(a51.p, off2.p, col2.p, N, 64, H4, W4, 32 * P4, s);  // read by the layer's weight gradient
+    } else {
+      float* col = keep ? col2.p : col1.p;
+      launch_deform_sample(a51.p, off2.p, col, N, 64, H4, W4, 32 * P4, s);
+      launch_gemv_cols(col, P(T_def2W), P(T_def2b), y, N, 576, (int)P4, s);
+    }
   }
   bw_in[0] = x; bw_in[1] = w1; bw_in[2] = w2; bw_in[3] = w3;
   have_graph = keep;

@@ -22,6 +22,13 @@ void launch_im2col(const float* x, float* col, int N, int Cin, int Hin, int Win,
 void launch_deform_sample(const float* x, const float* off, float* col, int N, int C, int H, int W, long offsn, hipStream_t s);
 void launch_deform_backward(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy,
                             float* gx, float* goff, int N, int C, int H, int W, long offsn, hipStream_t s, hipStream_t aux = nullptr, hipEvent_t* ev = nullptr);
+// sampler fused into the GEMM (deform_fused.hip): no column matrix.  C == 64, O == 64 (w = packed [576][64] image) or 1 (w = OIHW).
+// xt = the layer input channels-last (N * H * W, 64); yt (optional, O == 64) = the output channels-last as well;
+// colout (optional, O == 64) = the sample matrix (N, 576, H, W) as a by-product (a retained pass: the weight gradient reads it)
+bool deform_conv_fused_ok(int C, int O);
+void launch_nchw_to_nhwc64(const float* x, float* xt, int N, int plane, hipStream_t s);
+void launch_deform_conv_fused(const float* xt, const float* off, const float* w, const float* bias, float* y, float* yt, float* colout,
+                              int N, int C, int H, int W, long offsn, int O, int act, float slope, hipStream_t s);
 void launch_gemv_cols(const float* col, const float* w, const float* bias, float* y, int N, int K, int plane, hipStream_t s);
 void launch_gemv_cols_wgrad(const float* col, const float* gy, float* gw, float* gb, int N, int K, int plane, hipStream_t s);
 void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int H, int W, float slope, hipStream_t s);

@@ -138,7 +138,9 @@ def test_generator_bf16_inference_mode(dbm):
         y32 = g.forward(*ins).array
     assert np.isfinite(y).all() and np.array_equal(y, y2)
     err = np.abs(y - ref).max() / np.abs(ref).max()
-    assert 1e-5 < err < 3e-2, err          # really a different arithmetic, and within bf16's reach
+    # really a different arithmetic, and within bf16's reach (the two deformable layers, whose sampler is fused into an
+    # fp32 MFMA GEMM, stay fp32 in this mode: with the reference's initialisation they used to carry most of the 1e-2)
+    assert err < 3e-2 and not np.array_equal(y, y32), err
     assert rel(y32, ref) < TOL               # the fp32 path is untouched by having built the bf16 images
     with pytest.raises(ValueError), dbm.using_config("dtype", "bfloat16"):
         g.forward(*ins)                      # enable_backprop is on
