@@ -1202,12 +1202,26 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
   DBM_CHECK(C % 32 == 0, "deform conv op: C % 32 == 0");
   hipStream_t s = ctx->stream;
   const long P = (long)H * W;
-  DevBuf col, gcol;
-  col.ensure((size_t)N * C * 9 * P);
-  launch_deform_sample(x, off, col.p, N, C, H, W, 18 * P, s);
+  static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  const bool fused = fused_env && deform_conv_fused_ok(C, O) && deform_input_grad_ok(C, H, W);
+  DevBuf col, gcol, xt, part;
+  if (fused) {
+    xt.ensure((size_t)N * C * P);
+    launch_nchw_to_nhwc64(x, xt.p, N, (int)P, s);
+  }
+  if (!(fused && O == 1)) {
+    col.ensure((size_t)N * C * 9 * P);
+    launch_deform_sample(x, off, col.p, N, C, H, W, 18 * P, s);
+  }
   if (O == 1) {
-    launch_deform_backward(x, off, nullptr, w, gy, gx, goff, N, C, H, W, 18 * P, s);
-    launch_gemv_cols_wgrad(col.p, gy, gw, gb, N, C * 9, (int)P, s);
+    if (fused) {
+      part.ensure(deform_bwd1_partial_floats(N, H, W));
+      launch_deform_bwd1_fused(xt.p, off, w, gy, goff, gw, gb, part.p, N, H, W, 18 * P, s);
+      launch_deform_input_grad(x, off, nullptr, w, gy, gx, N, C, H, W, 18 * P, s);
+    } else {
+      launch_deform_backward(x, off, nullptr, w, gy, gx, goff, N, C, H, W, 18 * P, s);
+      launch_gemv_cols_wgrad(col.p, gy, gw, gb, N, C * 9, (int)P, s);
+    }
   } else {
     DBM_CHECK(O % 32 == 0, "deform conv op backward: O == 1 or O % 32 == 0");
     dbm_model holder;
@@ -1220,11 +1234,16 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
     holder.ensure_packed();
     const IgLayer& L = holder.layers[0];
     gcol.ensure((size_t)N * C * 9 * P);
-    ConvDesc d;
-    memset(&d, 0, sizeof(d));
-    d.x = gy; d.xsn = O * P; d.N = N; d.y = gcol.p; d.ysn = C * 9 * P; d.s1 = 1.f; d.s2 = 1.f;
-    holder.run_dgrad(L, d, H, W);
-    launch_deform_backward(x, off, gcol.p, nullptr, nullptr, gx, goff, N, C, H, W, 18 * P, s);
+    if (fused) {
+      launch_deform_bwd64_fused(xt.p, off, L.wb[0], gy, gcol.p, goff, N, H, W, 18 * P, s);
+      launch_deform_input_grad(x, off, gcol.p, nullptr, nullptr, gx, N, C, H, W, 18 * P, s);
+    } else {
+      ConvDesc d;
+      memset(&d, 0, sizeof(d));
+      d.x = gy; d.xsn = O * P; d.N = N; d.y = gcol.p; d.ysn = C * 9 * P; d.s1 = 1.f; d.s2 = 1.f;
+      holder.run_dgrad(L, d, H, W);
+      launch_deform_backward(x, off, gcol.p, nullptr, nullptr, gx, goff, N, C, H, W, 18 * P, s);
+    }
     WgradDesc wd;
     memset(&wd, 0, sizeof(wd));
     wd.x = col.p; wd.xsn = C * 9 * P; wd.xsc = (int)P; wd.Cin = C * 9; wd.Hin = H; wd.Win = W;
@@ -1236,6 +1255,8 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
   DBM_HIP(hipStreamSynchronize(s));
   col.release();
   gcol.release();
+  xt.release();
+  part.release();
   DBM_API_END
 }
 

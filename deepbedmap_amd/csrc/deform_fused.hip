@@ -250,6 +250,273 @@ __global__ __launch_bounds__(256) void deform_conv1_fused_kernel(const float* __
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward: offset gradients (+ the pieces that share their gathers).  The corner table additionally keeps the four
+// one-dimensional weights, the corner validity and the coordinate-gradient masks.
+//   deform_bwd64_fused_kernel  64 -> 64 layer: dcol = W^T dy per tap on the MFMAs (M = 64 in channels, N = 64 positions,
+//                              K = 64 out channels) into an LDS tile, from there (a) to the column-gradient matrix the
+//                              CSR gather kernel reads and (b) into the offset gradients -- replaces a 1x1 implicit
+//                              GEMM writing 191 MB and deform_goff_kernel re-reading them
+//   deform_bwd1_fused_kernel   64 -> 1 layer: dcol = w (x) gy is rank one; offset gradients and, from the same
+//                              gathers, the layer's weight / bias gradient as per-workgroup partial sums
+//                              (deform_wgrad1_fold_kernel adds them in workgroup order) -- the sample matrix of this
+//                              layer is not needed at all
+// ---------------------------------------------------------------------------------------------------------------
+struct TileGeometryBwd {
+  int4 idx[9 * DF_POS];     // pixel index n * plane + offset of the four corners (0 where outside the image)
+  float4 wuv[9 * DF_POS];   // wu0, wu1, wv0, wv1
+  int flags[9 * DF_POS];    // bits 0..3: corner inside the image, bit 4: mu, bit 5: mv
+};
+
+__device__ __forceinline__ void build_geometry_bwd(TileGeometryBwd& g, const float* __restrict__ off, long offsn, long P0, long total,
+                                                   int plane, int H, int W, int tid) {
+  for (int e = tid; e < 9 * DF_POS; e += 256) {
+    const int t = e >> 6, pl = e & 63;
+    const long P = P0 + pl;
+    int4 id = make_int4(0, 0, 0, 0);
+    float4 wg = make_float4(0.f, 0.f, 0.f, 0.f);
+    int fl = 0;
+    if (P < total) {
+      const int n = (int)(P / plane);
+      const int p = (int)(P - (long)n * plane);
+      const int a = p / W, b = p - a * W;
+      const float* on = off + (long)n * offsn;
+      const DeformGeom q = deform_geom(on[(long)t * plane + p], on[(long)(9 + t) * plane + p], a, b, t / 3, t % 3, H, W, 1);
+      const int o1 = deform_corner(q.v0, q.u0, H, W, 1), o2 = deform_corner(q.v0, q.u0 + 1, H, W, 1);
+      const int o3 = deform_corner(q.v0 + 1, q.u0, H, W, 1), o4 = deform_corner(q.v0 + 1, q.u0 + 1, H, W, 1);
+      const int base = n * plane;
+      if (o1 >= 0) { id.x = base + o1; fl |= 1; }
+      if (o2 >= 0) { id.y = base + o2; fl |= 2; }
+      if (o3 >= 0) { id.z = base + o3; fl |= 4; }
+      if (o4 >= 0) { id.w = base + o4; fl |= 8; }
+      if (q.mu) fl |= 16;
+      if (q.mv) fl |= 32;
+      wg = make_float4(q.wu0, q.wu1, q.wv0, q.wv1);
+    }
+    g.idx[e] = id;
+    g.wuv[e] = wg;
+    g.flags[e] = fl;
+  }
+}
+
+__device__ __forceinline__ float4 mask4(const float4& v, bool ok) { return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// d sample / d u and d sample / d v of the four channels of a quad (deform_goff_kernel's expressions)
+__device__ __forceinline__ void coord_grads(const float4& wuv, const float4& x1, const float4& x2, const float4& x3, const float4& x4,
+                                            float4& du, float4& dv) {
+  const float wu0 = wuv.x, wu1 = wuv.y, wv0 = wuv.z, wv1 = wuv.w;
+  du.x = -wv1 * x1.x + wv1 * x2.x - wv0 * x3.x + wv0 * x4.x;
+  du.y = -wv1 * x1.y + wv1 * x2.y - wv0 * x3.y + wv0 * x4.y;
+  du.z = -wv1 * x1.z + wv1 * x2.z - wv0 * x3.z + wv0 * x4.z;
+  du.w = -wv1 * x1.w + wv1 * x2.w - wv0 * x3.w + wv0 * x4.w;
+  dv.x = -wu1 * x1.x - wu0 * x2.x + wu1 * x3.x + wu0 * x4.x;
+  dv.y = -wu1 * x1.y - wu0 * x2.y + wu1 * x3.y + wu0 * x4.y;
+  dv.z = -wu1 * x1.z - wu0 * x2.z + wu1 * x3.z + wu0 * x4.z;
+  dv.w = -wu1 * x1.w - wu0 * x2.w + wu1 * x3.w + wu0 * x4.w;
+}
+
+__device__ __forceinline__ float quad_sum16(float v) {  // over the sixteen channel quads of a position (lanes q = lane & 15)
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// gcol (N, 576, plane) = W^T gy (row c * 9 + t), goff (N, 18.., plane)[0:18] = offset gradients.  wb = the layer's
+// data-gradient image [o][c * 9 + t] (IgLayer::wb[0] of the layer viewed as a 1x1 convolution).
+__global__ __launch_bounds__(256) void deform_bwd64_fused_kernel(const float* __restrict__ xt, const float* __restrict__ off,
+                                                                 const float* __restrict__ wb, const float* __restrict__ gy,
+                                                                 float* __restrict__ gcol, float* __restrict__ goff, int N, int H, int W,
+                                                                 long offsn) {
+  __shared__ TileGeometryBwd geo;
+  __shared__ float dys[64 * DF_LD];  // [out channel][position]
+  __shared__ float dcl[64 * DF_LD];  // [in channel][position] of the current tap
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int plane = H * W;
+  const long total = (long)N * plane;
+  const long P0 = (long)blockIdx.x * DF_POS;
+  build_geometry_bwd(geo, off, offsn, P0, total, plane, H, W, tid);
+  {  // the tile of gy: wavefront w stages out channels 16 w .., 256-byte runs along the positions
+    const long P = P0 + lane;
+    const bool pv = P < total;
+    const long n = pv ? P / plane : 0;
+    const float* src = gy + n * 64 * plane + (pv ? P - n * plane : 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dys[(16 * wave + i) * DF_LD + lane] = pv ? src[(long)(16 * wave + i) * plane] : 0.f;
+  }
+  const int q = lane & 15, pi = lane >> 4;
+  const float* xq = xt + 4 * q;
+  const int ct = wave & 1, pt = wave >> 1, j = lane & 31, kh = lane >> 5;
+  const float* wl = wb + (long)kh * 576 + (long)(ct * 32 + j) * 9;  // + (2 op) * 576 + t
+  __syncthreads();
+  // B operands (gy) do not depend on the tap: kept in registers
+  float bv[32];
+#pragma unroll
+  for (int op = 0; op < 32; ++op) bv[op] = dys[(2 * op + kh) * DF_LD + pt * 32 + j];
+  const long Ps = P0 + lane;
+  const bool pvs = Ps < total;
+  const long nsp = pvs ? Ps / plane : 0;
+  float* gcl = gcol + nsp * 576 * plane + (pvs ? Ps - nsp * plane : 0);
+#pragma unroll 1
+  for (int t = 0; t < 9; ++t) {
+    float av[32];
+#pragma unroll
+    for (int op = 0; op < 32; ++op) av[op] = wl[(long)op * 2 * 576 + t];
+    __builtin_amdgcn_sched_barrier(0);
+    float4 c1[4], c2[4], c3[4], c4[4], cw[4];
+    int fl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // the corner gathers of this tap: in flight underneath the MFMAs
+      const int e = t * DF_POS + 16 * wave + 4 * i + pi;
+      const int4 id = geo.idx[e];
+      cw[i] = geo.wuv[e];
+      fl[i] = geo.flags[e];
+      c1[i] = *reinterpret_cast<const float4*>(xq + (long)id.x * 64);
+      c2[i] = *reinterpret_cast<const float4*>(xq + (long)id.y * 64);
+      c3[i] = *reinterpret_cast<const float4*>(xq + (long)id.z * 64);
+      c4[i] = *reinterpret_cast<const float4*>(xq + (long)id.w * 64);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int op = 0; op < 32; ++op) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[op], bv[op], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dcl[(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * DF_LD + pt * 32 + j] = acc[r];
+    __syncthreads();
+    // (a) the tap's column gradients to memory, 256-byte runs along the positions
+    if (pvs) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = 16 * wave + i;
+        gcl[((long)c * 9 + t) * plane] = dcl[c * DF_LD + lane];
+      }
+    }
+    // (b) offset gradients
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pl = 16 * wave + 4 * i + pi;
+      const float* dq = dcl + (4 * q) * DF_LD + pl;
+      const float4 g4 = make_float4(dq[0], dq[DF_LD], dq[2 * DF_LD], dq[3 * DF_LD]);
+      float4 du, dv;
+      coord_grads(cw[i], mask4(c1[i], fl[i] & 1), mask4(c2[i], fl[i] & 2), mask4(c3[i], fl[i] & 4), mask4(c4[i], fl[i] & 8), du, dv);
+      float gu = (g4.x * du.x + g4.y * du.y) + (g4.z * du.z + g4.w * du.w);
+      float gv = (g4.x * dv.x + g4.y * dv.y) + (g4.z * dv.z + g4.w * dv.w);
+      gu = quad_sum16(gu);
+      gv = quad_sum16(gv);
+      const long P = P0 + pl;
+      if (q == 0 && P < total) {
+        const long n = P / plane;
+        float* gn = goff + n * offsn + (P - n * plane);
+        gn[(long)t * plane] = (fl[i] & 16) ? gu : 0.f;
+        gn[(long)(9 + t) * plane] = (fl[i] & 32) ? gv : 0.f;
+      }
+    }
+    __syncthreads();  // the tile is rewritten by the next tap
+  }
+}
+
+// goff as above with gcol = w[c*9+t] * gy[n][p]; partial (gridDim.x, 580): this workgroup's sums of gy * sample per
+// (c * 9 + t), then of gy (the bias gradient) at [576].
+__global__ __launch_bounds__(256) void deform_bwd1_fused_kernel(const float* __restrict__ xt, const float* __restrict__ off,
+                                                                const float* __restrict__ w, const float* __restrict__ gy,
+                                                                float* __restrict__ goff, float* __restrict__ partial, int N, int H, int W,
+                                                                long offsn) {
+  __shared__ TileGeometryBwd geo;
+  __shared__ __attribute__((aligned(16))) float wsh[9 * 64];  // [tap][channel]
+  __shared__ __attribute__((aligned(16))) float red[4][9 * 64];  // per wavefront: [tap][channel] sums of gy * sample
+  __shared__ float gys[DF_POS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int plane = H * W;
+  const long total = (long)N * plane;
+  const long P0 = (long)blockIdx.x * DF_POS;
+  build_geometry_bwd(geo, off, offsn, P0, total, plane, H, W, tid);
+  for (int e = tid; e < 576; e += 256) wsh[(e % 9) * 64 + e / 9] = w[e];
+  if (tid < DF_POS) gys[tid] = (P0 + tid < total) ? gy[P0 + tid] : 0.f;  // (N, 1, plane) is flat in the position index
+  const int q = lane & 15, pi = lane >> 4;
+  const float* xq = xt + 4 * q;
+  __syncthreads();
+  float gyv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gyv[i] = gys[16 * wave + 4 * i + pi];
+#pragma unroll 1
+  for (int t = 0; t < 9; ++t) {
+    float4 c1[4], c2[4], c3[4], c4[4], cw[4];
+    int fl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t * DF_POS + 16 * wave + 4 * i + pi;
+      const int4 id = geo.idx[e];
+      cw[i] = geo.wuv[e];
+      fl[i] = geo.flags[e];
+      c1[i] = *reinterpret_cast<const float4*>(xq + (long)id.x * 64);
+      c2[i] = *reinterpret_cast<const float4*>(xq + (long)id.y * 64);
+      c3[i] = *reinterpret_cast<const float4*>(xq + (long)id.z * 64);
+      c4[i] = *reinterpret_cast<const float4*>(xq + (long)id.w * 64);
+    }
+    const float4 wr = *reinterpret_cast<const float4*>(wsh + t * 64 + 4 * q);
+    float4 ws = make_float4(0.f, 0.f, 0.f, 0.f);  // this lane's gy * sample of its four channels, over its four positions
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 x1 = mask4(c1[i], fl[i] & 1), x2 = mask4(c2[i], fl[i] & 2), x3 = mask4(c3[i], fl[i] & 4), x4 = mask4(c4[i], fl[i] & 8);
+      float4 du, dv;
+      coord_grads(cw[i], x1, x2, x3, x4, du, dv);
+      const float g = gyv[i];
+      float gu = g * ((wr.x * du.x + wr.y * du.y) + (wr.z * du.z + wr.w * du.w));
+      float gv = g * ((wr.x * dv.x + wr.y * dv.y) + (wr.z * dv.z + wr.w * dv.w));
+      gu = quad_sum16(gu);
+      gv = quad_sum16(gv);
+      const long P = P0 + 16 * wave + 4 * i + pi;
+      if (q == 0 && P < total) {
+        const long n = P / plane;
+        float* gn = goff + n * offsn + (P - n * plane);
+        gn[(long)t * plane] = (fl[i] & 16) ? gu : 0.f;
+        gn[(long)(9 + t) * plane] = (fl[i] & 32) ? gv : 0.f;
+      }
+      const float4 sw = make_float4(cw[i].y * cw[i].w, cw[i].x * cw[i].w, cw[i].y * cw[i].z, cw[i].x * cw[i].z);  // w1..w4
+      const float4 sm = blend4(sw, x1, x2, x3, x4);
+      ws.x = fmaf(g, sm.x, ws.x); ws.y = fmaf(g, sm.y, ws.y); ws.z = fmaf(g, sm.z, ws.z); ws.w = fmaf(g, sm.w, ws.w);
+    }
+    // the four position groups of the wavefront (lanes q, q + 16, q + 32, q + 48)
+    ws.x += __shfl_xor(ws.x, 16, 64); ws.y += __shfl_xor(ws.y, 16, 64); ws.z += __shfl_xor(ws.z, 16, 64); ws.w += __shfl_xor(ws.w, 16, 64);
+    ws.x += __shfl_xor(ws.x, 32, 64); ws.y += __shfl_xor(ws.y, 32, 64); ws.z += __shfl_xor(ws.z, 32, 64); ws.w += __shfl_xor(ws.w, 32, 64);
+    if (pi == 0) *reinterpret_cast<float4*>(&red[wave][t * 64 + 4 * q]) = ws;
+  }
+  __syncthreads();
+  float* po = partial + (long)blockIdx.x * 580;
+  for (int e = tid; e < 576; e += 256) {
+    const int t = e >> 6, c = e & 63;
+    po[c * 9 + t] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  }
+  if (tid < 64) {
+    float v = gys[tid];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (tid == 0) po[576] = v;
+  }
+}
+
+// gw[k] += sum over workgroups (in index order) of partial[wg][k], k < 576; gb[0] += ... [576]
+__global__ __launch_bounds__(64) void deform_wgrad1_fold_kernel(const float* __restrict__ partial, int nwg, float* gw, float* gb) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k > 576) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int g = 0;
+  for (; g + 3 < nwg; g += 4) {
+    a0 += partial[(long)g * 580 + k];
+    a1 += partial[(long)(g + 1) * 580 + k];
+    a2 += partial[(long)(g + 2) * 580 + k];
+    a3 += partial[(long)(g + 3) * 580 + k];
+  }
+  for (; g < nwg; ++g) a0 += partial[(long)g * 580 + k];
+  const float v = (a0 + a1) + (a2 + a3);
+  if (k < 576) gw[k] += v;
+  else if (gb) gb[0] += v;
+}
+
 }  // namespace
 
 bool deform_conv_fused_ok(int C, int O) { return C == 64 && (O == 64 || O == 1); }
@@ -275,5 +542,32 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
   else
     hipLaunchKernelGGL(deform_conv1_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, bias, y, N, H, W, offsn);
   if (g_profiler.enabled) g_profiler.end(s);
+  DBM_HIP(hipGetLastError());
+}
+
+// Backward of the 64 -> 64 layer: gcol (N, 576, H, W) and goff[:, 0:18] are overwritten (the input gradient is then
+// gathered from gcol by launch_deform_backward's CSR kernel).  wb = IgLayer::wb[0] of the layer's 1x1 view.
+void launch_deform_bwd64_fused(const float* xt, const float* off, const float* wb, const float* gy, float* gcol, float* goff, int N, int H,
+                               int W, long offsn, hipStream_t s) {
+  const long total = (long)N * H * W;
+  DBM_CHECK(total < (1L << 31), "fused deformable backward: more than 2^31 positions");
+  const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
+  if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)total * 64 * 576);
+  hipLaunchKernelGGL(deform_bwd64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, wb, gy, gcol, goff, N, H, W, offsn);
+  if (g_profiler.enabled) g_profiler.end(s);
+  DBM_HIP(hipGetLastError());
+}
+
+size_t deform_bwd1_partial_floats(int N, int H, int W) { return (size_t)(((long)N * H * W + DF_POS - 1) / DF_POS) * 580; }
+
+// Backward of the 64 -> 1 layer: goff[:, 0:18] overwritten, gw (576, OIHW of (1, 64, 3, 3)) and gb accumulated (+=) through
+// `partial` (deform_bwd1_partial_floats floats of scratch).
+void launch_deform_bwd1_fused(const float* xt, const float* off, const float* w, const float* gy, float* goff, float* gw, float* gb,
+                              float* partial, int N, int H, int W, long offsn, hipStream_t s) {
+  const long total = (long)N * H * W;
+  DBM_CHECK(total < (1L << 31), "fused deformable backward: more than 2^31 positions");
+  const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
+  hipLaunchKernelGGL(deform_bwd1_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, gy, goff, partial, N, H, W, offsn);
+  hipLaunchKernelGGL(deform_wgrad1_fold_kernel, dim3(10), dim3(64), 0, s, partial, (int)blocks, gw, gb);
   DBM_HIP(hipGetLastError());
 }

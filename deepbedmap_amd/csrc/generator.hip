@@ -141,6 +141,13 @@ static int trunk_split(int N, long hw) {
   return ns;
 }
 
+// The backward of the two deformable layers runs on the fused kernels (deform_fused.hip) when the forward did and the
+// planes fit the CSR input-gradient kernel.
+bool Generator::deform_bwd_fused(int H4, int W4) const {
+  static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  return fused_env && out_ch == 1 && deform_conv_fused_ok(64, 64) && deform_input_grad_ok(64, H4, W4);
+}
+
 void Generator::ensure_ws(int N, int H, int W, bool train) {
   const bool same = (N == wsN && H == wsH && W == wsW);
   if (same && (wsTrain || !train)) return;
@@ -168,8 +175,7 @@ void Generator::ensure_ws(int N, int H, int W, bool train) {
   a51t.ensure(n * 64 * 16 * hw);
   yout.ensure(n * 16 * hw);
   if (tr) {
-    col1.ensure(n * 576 * 16 * hw);  // sample matrices of the deformable layers: retained passes only (forward())
-    col2.ensure(n * 576 * 16 * hw);
+    col1.ensure(n * 576 * 16 * hw);  // sample matrix of the 64 -> 64 deformable layer: retained passes only (its weight gradient)
     if ((int)dA.size() < nrdb + 1) dA.resize(nrdb + 1);
     for (int i = 0; i <= nrdb; ++i) dA[i].ensure(n * (i == nrdb ? 64 : 192) * hw);
     g_a0.ensure(n * 128 * hw);
@@ -324,6 +330,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     a51t.ensure((size_t)N * 64 * P4);
   } else {
     col1.ensure((size_t)N * 576 * P4);
+    if (keep) col2.ensure((size_t)N * 576 * P4);
   }
   {
     ConvDesc d = fwd_desc(layers[L_off1], a42.p, 64 * P4, H4, W4, 0, off1.p, 32 * P4, N);
@@ -345,7 +352,11 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     launch_igemm_conv(d, s);
     if (dfused) {
       launch_deform_conv_fused(a51t.p, off2.p, P(T_def2W), P(T_def2b), y, nullptr, nullptr, N, 64, H4, W4, 32 * P4, out_ch, 0, SLOPE, s);
-      if (keep) launch_deform_sample(a51.p, off2.p, col2.p, N, 64, H4, W4, 32 * P4, s);  // read by the layer's weight gradient
+      // (unfused backward only: the 64 -> 1 layer's weight gradient then reads its sample matrix)
+      if (keep && !deform_bwd_fused(H4, W4)) {
+        col2.ensure((size_t)N * 576 * P4);
+        launch_deform_sample(a51.p, off2.p, col2.p, N, 64, H4, W4, 32 * P4, s);
+      }
     } else {
       float* col = keep ? col2.p : col1.p;
       launch_deform_sample(a51.p, off2.p, col, N, 64, H4, W4, 32 * P4, s);
@@ -364,11 +375,26 @@ void Generator::backward(const float* gy) {
   const int H4 = 4 * h, W4 = 4 * w, nrdb = 3 * n_rrdb;
   for (auto& b : wbs) b.cleared_target = grads_cleared;
   // ---- final_conv_layer2 (deformable, 64 -> 1) ----
-  // (its weight gradient only needs gy and the retained columns: side stream, underneath the sampler's backward)
-  ctx->fork_to_side(5);
-  launch_gemv_cols_wgrad(col2.p, gy, G(T_def2W), G(T_def2b), N, 576, (int)P4, ctx->side);
-  launch_deform_backward(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, goff2.p, N, 64, H4, W4, 32 * P4, s,
-                         use_aux ? ctx->chain[chain_base] : nullptr, use_aux ? &ctx->ev_fork[2] : nullptr);
+  const bool bfused = deform_bwd_fused(H4, W4);
+  if (bfused) {
+    // offset gradients + the layer's weight / bias gradient from one pass over the channels-last input (no sample matrix);
+    // on the aux stream next to the input-gradient gather when the caller has one
+    hipStream_t sg = s;
+    if (use_aux) {
+      ctx->fork(s, ctx->chain[chain_base], 2);
+      sg = ctx->chain[chain_base];
+    }
+    dw2_partial.ensure(deform_bwd1_partial_floats(N, H4, W4));
+    launch_deform_bwd1_fused(a51t.p, off2.p, P(T_def2W), gy, goff2.p, G(T_def2W), G(T_def2b), dw2_partial.p, N, H4, W4, 32 * P4, sg);
+    launch_deform_input_grad(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, N, 64, H4, W4, 32 * P4, s);
+    if (sg != s) ctx->fork(sg, s, 3);
+  } else {
+    // (its weight gradient only needs gy and the retained columns: side stream, underneath the sampler's backward)
+    ctx->fork_to_side(5);
+    launch_gemv_cols_wgrad(col2.p, gy, G(T_def2W), G(T_def2b), N, 576, (int)P4, ctx->side);
+    launch_deform_backward(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, goff2.p, N, 64, H4, W4, 32 * P4, s,
+                           use_aux ? ctx->chain[chain_base] : nullptr, use_aux ? &ctx->ev_fork[2] : nullptr);
+  }
   {
     const IgLayer& L = layers[L_off2];
     run_wgrad(L, a51.p, 64 * P4, H4, W4, 0, goff2.p, 32 * P4, H4, W4, N, 1.f, &wbs[0]);
@@ -383,13 +409,19 @@ void Generator::backward(const float* gy) {
   {
     const IgLayer& L = layers[L_def1];
     run_wgrad(L, col1.p, 576 * P4, H4, W4, 0, g_a51.p, 64 * P4, H4, W4, N, 1.f, &wbs[0]);
-    ConvDesc d;
-    memset(&d, 0, sizeof(d));
-    d.x = g_a51.p; d.xsn = 64 * P4; d.N = N;
-    d.y = gcol.p; d.ysn = 576 * P4; d.s1 = 1.f; d.s2 = 1.f;
-    run_dgrad(L, d, H4, W4);
-    launch_deform_backward(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, goff1.p, N, 64, H4, W4, 32 * P4, s,
-                           use_aux ? ctx->chain[chain_base] : nullptr, use_aux ? &ctx->ev_fork[2] : nullptr);
+    if (bfused) {
+      // column gradients W^T gy on the MFMAs, offset gradients from the same LDS tile; then the input-gradient gather
+      launch_deform_bwd64_fused(a42t.p, off1.p, L.wb[0], g_a51.p, gcol.p, goff1.p, N, H4, W4, 32 * P4, s);
+      launch_deform_input_grad(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, N, 64, H4, W4, 32 * P4, s);
+    } else {
+      ConvDesc d;
+      memset(&d, 0, sizeof(d));
+      d.x = g_a51.p; d.xsn = 64 * P4; d.N = N;
+      d.y = gcol.p; d.ysn = 576 * P4; d.s1 = 1.f; d.s2 = 1.f;
+      run_dgrad(L, d, H4, W4);
+      launch_deform_backward(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, goff1.p, N, 64, H4, W4, 32 * P4, s,
+                             use_aux ? ctx->chain[chain_base] : nullptr, use_aux ? &ctx->ev_fork[2] : nullptr);
+    }
   }
   {
     const IgLayer& L = layers[L_off1];

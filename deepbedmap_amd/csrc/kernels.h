@@ -29,6 +29,14 @@ bool deform_conv_fused_ok(int C, int O);
 void launch_nchw_to_nhwc64(const float* x, float* xt, int N, int plane, hipStream_t s);
 void launch_deform_conv_fused(const float* xt, const float* off, const float* w, const float* bias, float* y, float* yt, float* colout,
                               int N, int C, int H, int W, long offsn, int O, int act, float slope, hipStream_t s);
+void launch_deform_bwd64_fused(const float* xt, const float* off, const float* wb, const float* gy, float* gcol, float* goff, int N, int H,
+                               int W, long offsn, hipStream_t s);
+size_t deform_bwd1_partial_floats(int N, int H, int W);
+void launch_deform_bwd1_fused(const float* xt, const float* off, const float* w, const float* gy, float* goff, float* gw, float* gb,
+                              float* partial, int N, int H, int W, long offsn, hipStream_t s);
+bool deform_input_grad_ok(int C, int H, int W);
+void launch_deform_input_grad(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy, float* gx, int N,
+                              int C, int H, int W, long offsn, hipStream_t s);
 void launch_gemv_cols(const float* col, const float* w, const float* bias, float* y, int N, int K, int plane, hipStream_t s);
 void launch_gemv_cols_wgrad(const float* col, const float* gy, float* gw, float* gb, int N, int K, int plane, hipStream_t s);
 void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int H, int W, float slope, hipStream_t s);

@@ -526,6 +526,38 @@ void launch_deform_backward(const float* x, const float* off, const float* gcol,
   DBM_HIP(hipGetLastError());
 }
 
+// Input gradient only: the atomic-free CSR gather above without the offset gradients (which the fused kernels of
+// deform_fused.hip produce).  Returns false when a plane does not fit the kernel's LDS lists (the caller then takes
+// launch_deform_backward).
+bool deform_input_grad_ok(int C, int H, int W) {
+  const long plane = (long)H * W;
+  return C % 8 == 0 && sizeof(float) * ((size_t)8 * plane + 10 * plane + 1) <= 150 * 1024;
+}
+
+void launch_deform_input_grad(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy, float* gx, int N,
+                              int C, int H, int W, long offsn, hipStream_t s) {
+  DBM_CHECK(deform_input_grad_ok(C, H, W), "deformable input gradient: plane too large for the CSR kernel");
+  const long plane = (long)H * W;
+  constexpr int CH = 8, CHD = 16;
+  const bool wide = C % CHD == 0 && sizeof(float) * ((size_t)CHD * plane + 10 * plane + 1) <= 150 * 1024;
+  const size_t lds = sizeof(float) * ((size_t)(wide ? CHD : CH) * plane + 10 * plane + 1);
+  static bool attr_set = false;
+  if (!attr_set) {
+    DBM_HIP(hipFuncSetAttribute((const void*)deform_backward_csr_kernel<CH, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                152 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)deform_backward_csr_kernel<CHD, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                152 * 1024));
+    attr_set = true;
+  }
+  if (wide)
+    hipLaunchKernelGGL((deform_backward_csr_kernel<CHD, 1024, true>), dim3(N, C / CHD), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx,
+                       nullptr, N, C, H, W, offsn);
+  else
+    hipLaunchKernelGGL((deform_backward_csr_kernel<CH, 1024, true>), dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx,
+                       nullptr, N, C, H, W, offsn);
+  DBM_HIP(hipGetLastError());
+}
+
 // y[n][0][p] = b + sum_k w[k] * col[n][k][p]   (final_conv_layer2's 576 -> 1 GEMV, srgan_train.py:574)
 __global__ __launch_bounds__(256) void gemv_cols_kernel(const float* __restrict__ col, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int N,

@@ -161,6 +161,8 @@ struct Generator : dbm_model {
   WgradBatch wbs[NWB];  // batched weight gradients: tail, 5 trunk groups, pre-residual + input block (launched on the side stream)
   std::vector<DevBuf> cat, dA;
   DevBuf in_x, in_w1, in_w2, in_w3, a0, a3, a41, a42, off1, off2, col1, col2, a51, yout;
+  DevBuf dw2_partial;  // per-workgroup partial sums of final_conv_layer2's weight gradient (deform_bwd1_fused_kernel)
+  bool deform_bwd_fused(int H4, int W4) const;
   DevBuf a42t, a51t;  // channels-last copies of the deformable layers' inputs (what the fused sampler gathers from)
   DevBuf g_a0, g_a3, g_u1, g_z41, g_u2, g_a42, goff1, goff2, gcol, g_a51, g_y;
   // A second workspace on the same parameters: the G-step's generator forward can be enqueued while the D-step's
