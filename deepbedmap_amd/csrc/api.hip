@@ -1235,7 +1235,7 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
     const IgLayer& L = holder.layers[0];
     gcol.ensure((size_t)N * C * 9 * P);
     if (fused) {
-      launch_deform_bwd64_fused(xt.p, off, L.wb[0], gy, gcol.p, goff, N, H, W, 18 * P, s);
+      launch_deform_bwd64_fused(xt.p, off, L.wb[1], gy, gcol.p, goff, N, H, W, 18 * P, s);
       launch_deform_input_grad(x, off, gcol.p, nullptr, nullptr, gx, N, C, H, W, 18 * P, s);
     } else {
       ConvDesc d;

@@ -325,7 +325,7 @@ __device__ __forceinline__ float quad_sum16(float v) {  // over the sixteen chan
 }
 
 // gcol (N, 576, plane) = W^T gy (row c * 9 + t), goff (N, 18.., plane)[0:18] = offset gradients.  wb = the layer's
-// data-gradient image [o][c * 9 + t] (IgLayer::wb[0] of the layer viewed as a 1x1 convolution).
+// per-tap transposed image [t][o][c] (IgLayer::wb[1] of the layer viewed as a 1x1 convolution): coalesced A operands.
 __global__ __launch_bounds__(256) void deform_bwd64_fused_kernel(const float* __restrict__ xt, const float* __restrict__ off,
                                                                  const float* __restrict__ wb, const float* __restrict__ gy,
                                                                  float* __restrict__ gcol, float* __restrict__ goff, int N, int H, int W,
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void deform_bwd64_fused_kernel(const float* __
   const int q = lane & 15, pi = lane >> 4;
   const float* xq = xt + 4 * q;
   const int ct = wave & 1, pt = wave >> 1, j = lane & 31, kh = lane >> 5;
-  const float* wl = wb + (long)kh * 576 + (long)(ct * 32 + j) * 9;  // + (2 op) * 576 + t
+  const float* wl = wb + (long)kh * 64 + ct * 32 + j;  // + (t * 64 + 2 op) * 64
   __syncthreads();
   // B operands (gy) do not depend on the tap: kept in registers
   float bv[32];
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void deform_bwd64_fused_kernel(const float* __
   for (int t = 0; t < 9; ++t) {
     float av[32];
 #pragma unroll
-    for (int op = 0; op < 32; ++op) av[op] = wl[(long)op * 2 * 576 + t];
+    for (int op = 0; op < 32; ++op) av[op] = wl[(t * 64 + 2 * op) * 64];
     __builtin_amdgcn_sched_barrier(0);
     float4 c1[4], c2[4], c3[4], c4[4], cw[4];
     int fl[4];
@@ -499,22 +499,18 @@ __global__ __launch_bounds__(256) void deform_bwd1_fused_kernel(const float* __r
   }
 }
 
-// gw[k] += sum over workgroups (in index order) of partial[wg][k], k < 576; gb[0] += ... [576]
-__global__ __launch_bounds__(64) void deform_wgrad1_fold_kernel(const float* __restrict__ partial, int nwg, float* gw, float* gb) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
+// gw[k] += sum over workgroups of partial[wg][k], k < 576; gb[0] += ... [576].  One wavefront per output: lane l adds the
+// workgroups l, l + 64, ... in order, the lanes fold with a fixed xor tree (reproducible).
+__global__ __launch_bounds__(256) void deform_wgrad1_fold_kernel(const float* __restrict__ partial, int nwg, float* gw, float* gb) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (k > 576) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int g = 0;
-  for (; g + 3 < nwg; g += 4) {
-    a0 += partial[(long)g * 580 + k];
-    a1 += partial[(long)(g + 1) * 580 + k];
-    a2 += partial[(long)(g + 2) * 580 + k];
-    a3 += partial[(long)(g + 3) * 580 + k];
+  float a = 0.f;
+  for (int g = lane; g < nwg; g += 64) a += partial[(long)g * 580 + k];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0) {
+    if (k < 576) gw[k] += a;
+    else if (gb) gb[0] += a;
   }
-  for (; g < nwg; ++g) a0 += partial[(long)g * 580 + k];
-  const float v = (a0 + a1) + (a2 + a3);
-  if (k < 576) gw[k] += v;
-  else if (gb) gb[0] += v;
 }
 
 }  // namespace
@@ -546,7 +542,7 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
 }
 
 // Backward of the 64 -> 64 layer: gcol (N, 576, H, W) and goff[:, 0:18] are overwritten (the input gradient is then
-// gathered from gcol by launch_deform_backward's CSR kernel).  wb = IgLayer::wb[0] of the layer's 1x1 view.
+// gathered from gcol by launch_deform_input_grad).  wb = IgLayer::wb[1] of the layer's 1x1 view ([tap][o][c]).
 void launch_deform_bwd64_fused(const float* xt, const float* off, const float* wb, const float* gy, float* gcol, float* goff, int N, int H,
                                int W, long offsn, hipStream_t s) {
   const long total = (long)N * H * W;
@@ -568,6 +564,6 @@ void launch_deform_bwd1_fused(const float* xt, const float* off, const float* w,
   DBM_CHECK(total < (1L << 31), "fused deformable backward: more than 2^31 positions");
   const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
   hipLaunchKernelGGL(deform_bwd1_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, gy, goff, partial, N, H, W, offsn);
-  hipLaunchKernelGGL(deform_wgrad1_fold_kernel, dim3(10), dim3(64), 0, s, partial, (int)blocks, gw, gb);
+  hipLaunchKernelGGL(deform_wgrad1_fold_kernel, dim3(145), dim3(256), 0, s, partial, (int)blocks, gw, gb);
   DBM_HIP(hipGetLastError());
 }

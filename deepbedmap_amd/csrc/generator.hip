@@ -411,7 +411,7 @@ void Generator::backward(const float* gy) {
     run_wgrad(L, col1.p, 576 * P4, H4, W4, 0, g_a51.p, 64 * P4, H4, W4, N, 1.f, &wbs[0]);
     if (bfused) {
       // column gradients W^T gy on the MFMAs, offset gradients from the same LDS tile; then the input-gradient gather
-      launch_deform_bwd64_fused(a42t.p, off1.p, L.wb[0], g_a51.p, gcol.p, goff1.p, N, H4, W4, 32 * P4, s);
+      launch_deform_bwd64_fused(a42t.p, off1.p, L.wb[1], g_a51.p, gcol.p, goff1.p, N, H4, W4, 32 * P4, s);
       launch_deform_input_grad(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, N, 64, H4, W4, 32 * P4, s);
     } else {
       ConvDesc d;

@@ -127,6 +127,9 @@ int dbm_model::add_iglayer(const std::string& name, int O, int C, int K, int str
       L.bdy[0][t] = (signed char)(L.pad - ky); L.bdx[0][t] = (signed char)(L.pad - kx);
     }
     DBM_HIP(hipMalloc((void**)&L.wb[0], sizeof(float) * (size_t)T * L.OP * L.CP));
+    // a K x K layer viewed as 1x1 over (c, tap) columns (the deformable convolution's GEMM): also its per-tap transposed
+    // image [tap][o][c], the A operand of the fused column-gradient kernel (deform_bwd64_fused_kernel)
+    if (as_1x1 && K > 1 && K * K <= DBM_MAX_TAPS) DBM_HIP(hipMalloc((void**)&L.wb[1], sizeof(float) * (size_t)K * K * up32(O) * up32(C)));
   } else {
     DBM_CHECK(stride == 2 && L.Kview == 4 && pad == 1, "strided igemm layers must be k4 s2 p1");
     L.Tb = 4;
@@ -177,6 +180,20 @@ static void build_pack_table(const dbm_model& m, bool want_lazy, PackJob** d_job
     add(L, T, ky, kx, 0, L.CinP, L.CoutP, L.wf);
     const int nph = L.stride == 1 ? 1 : 4;
     for (int ph = 0; ph < nph; ++ph) add(L, L.Tb, L.bky[ph], L.bkx[ph], 1, L.OP, L.CP, L.wb[ph]);
+    if (L.stride == 1 && L.wb[1]) {  // per-tap transposed image of a 1x1-viewed K x K layer: dst[t][o][c] = W[o][c][ky][kx]
+      PackJob j;
+      memset(&j, 0, sizeof(j));
+      const int KK = L.K * L.K;
+      DBM_CHECK(KK <= DBM_MAX_TAPS, "pack: kernel too large");
+      j.w = m.P(L.wi); j.dst = L.wb[1]; j.O = L.O; j.C = L.C; j.KH = L.K; j.KW = L.K; j.T = KK;
+      j.transpose = 1; j.KP = up32(L.O); j.MP = up32(L.C);
+      for (int t = 0; t < KK; ++t) { j.ky[t] = (signed char)(t / L.K); j.kx[t] = (signed char)(t % L.K); }
+      const int TC = KK > 9 ? 16 : 32;
+      const int nb = (j.KP / 32) * (j.MP / TC);
+      j.block_start = blocks; j.block_count = nb;
+      blocks += nb;
+      jobs.push_back(j);
+    }
   }
   *njobs = (int)jobs.size();
   *nblocks = blocks;
