@@ -465,27 +465,39 @@ __global__ __launch_bounds__(128, 2) void wgrad_wave_dma_kernel(const WgradPlan*
       const float* xrow = ldsX - 1 + j * PS;
       // the odd padding position of a band has table entry 0: it re-reads position 0, so its A value is forced to 0
       const bool odd_tail = (p.BP & 1) != 0;
+      // Two operand sets in ping-pong (no `cur = next` copies, which hipcc places behind the MFMA block together with
+      // the wait for the reads they copy), and the LDS reads of step k+1 are dealt out BETWEEN the MFMAs of step k
+      // (sched_group_barrier: one MFMA, one DS read, ...): their issue slots disappear in the matrix pipe's shadow.
+      const int BPp = __builtin_amdgcn_readfirstlane(p.BPp);  // (uniform; read through a vector load: keep the loop scalar)
       int info = pinfo[kh];
-      float av = (odd_tail && kh == 1 && p.BPp == 2) ? 0.f : arow[info & 0xffff];
-      float bv[T];
+      float a0 = (odd_tail && kh == 1 && BPp == 2) ? 0.f : arow[info & 0xffff];
+      float b0[T], a1 = 0.f, b1[T];
 #pragma unroll
-      for (int t = 0; t < T; ++t) bv[t] = xrow[(info >> 16) + toff[t]];
-      info = pinfo[2 + kh];
+      for (int t = 0; t < T; ++t) { b0[t] = xrow[(info >> 16) + toff[t]]; b1[t] = 0.f; }
+      int i0 = pinfo[2 + kh], i1 = pinfo[4 + kh];  // table entries of steps 1 and 2: each is read two steps before its use
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the loop is entered with nothing pending
-      for (int kp = 0; kp < p.BPp; kp += 2) {
-        float av_n = arow[info & 0xffff];  // step k+1 (past the end: the guard entries)
-        float bv_n[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) bv_n[t] = xrow[(info >> 16) + toff[t]];
-        if (odd_tail && kh == 1 && kp + 4 >= p.BPp) av_n = 0.f;
-        info = pinfo[kp + 4 + kh];
+      auto half = [&](int kp, float& ac, float (&bc)[T], float& an, float (&bn)[T], int& ie) {
+        // consumes (ac, bc) = step kp; fetches (an, bn) = step kp + 2 (table entry ie) and the entry of step kp + 6
         __builtin_amdgcn_sched_barrier(0);
+        const int inf = ie;
+        ie = pinfo[kp + 6 + kh];
+        an = arow[inf & 0xffff];  // (past the end: the guard entries)
 #pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < T; ++t) bn[t] = xrow[(inf >> 16) + toff[t]];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, bc[t], acc[t], 0, 0, 0);
+        if (odd_tail && kh == 1 && kp + 4 >= BPp) an = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // the remaining reads
         __builtin_amdgcn_sched_barrier(0);
-        av = av_n;
-#pragma unroll
-        for (int t = 0; t < T; ++t) bv[t] = bv_n[t];
+      };
+      for (int kp = 0; kp < BPp; kp += 4) {
+        half(kp, a0, b0, a1, b1, i0);
+        if (kp + 2 < BPp) half(kp + 2, a1, b1, a0, b0, i1);
       }
     }
 #ifdef DBM_WG_TIMING
