@@ -695,26 +695,34 @@ __global__ __launch_bounds__(128, 2) void wgrad_band_dma_kernel(const WgradPlan*
       // K loop, software pipelined by one full step (see wgrad_wave_dma_kernel)
       const float* arow = ldsY + j * YS;
       const float* xrow = ldsX - d.pad + j * PSb;
+      const int BPp = __builtin_amdgcn_readfirstlane(p.BPp);
       int info = pinfo[kh];
-      float av = arow[info & 0xffff];
-      float bv[TPW];
+      float a0 = arow[info & 0xffff], a1 = 0.f;
+      float b0[TPW], b1[TPW];
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) bv[t] = xrow[(info >> 16) + toff[t]];
-      info = pinfo[2 + kh];
+      for (int t = 0; t < TPW; ++t) { b0[t] = xrow[(info >> 16) + toff[t]]; b1[t] = 0.f; }
+      int i0 = pinfo[2 + kh], i1 = pinfo[4 + kh];  // table entries of steps 1 and 2: read two steps before their use
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the loop is entered with nothing pending
-      for (int kp = 0; kp < p.BPp; kp += 2) {
-        const float av_n = arow[info & 0xffff];
-        float bv_n[TPW];
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) bv_n[t] = xrow[(info >> 16) + toff[t]];
-        info = pinfo[kp + 4 + kh];
+      auto half = [&](int kp, float& ac, float (&bc)[TPW], float& an, float (&bn)[TPW], int& ie) {
         __builtin_amdgcn_sched_barrier(0);
+        const int inf = ie;
+        ie = pinfo[kp + 6 + kh];
+        an = arow[inf & 0xffff];
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) bn[t] = xrow[(inf >> 16) + toff[t]];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, bc[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         __builtin_amdgcn_sched_barrier(0);
-        av = av_n;
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) bv[t] = bv_n[t];
+      };
+      for (int kp = 0; kp < BPp; kp += 4) {
+        half(kp, a0, b0, a1, b1, i0);
+        if (kp + 2 < BPp) half(kp + 2, a1, b1, a0, b0, i1);
       }
     }
 #ifdef DBM_WG_TIMING
@@ -913,14 +921,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(const WgradPlan* _
   };
 
   if (s0 < s1) {
-    Seg cur, nxt;
-    load(s0, cur);
-    for (int g = s0; g < s1; ++g) {
-      load(g + 1 < s1 ? g + 1 : g, nxt);
+    Seg sa, sb;  // ping-pong (a `cur = nxt` copy waits for the loads it copies: see igemm.hip)
+    load(s0, sa);
+    for (int g = s0; g < s1; g += 2) {
+      load(g + 1 < s1 ? g + 1 : g, sb);
       __builtin_amdgcn_sched_barrier(0);
-      compute(cur);
+      compute(sa);
       __builtin_amdgcn_sched_barrier(0);
-      cur = nxt;
+      if (g + 1 < s1) {
+        load(g + 2 < s1 ? g + 2 : g + 1, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(sb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
