@@ -478,10 +478,11 @@ void Generator::backward(const float* gy) {
   // ---- trunk, last dense block first ----
   const bool fused = trunk_fused_ok(h, w) && !(getenv("DBM_TRUNK_FUSED_BWD") && atoi(getenv("DBM_TRUNK_FUSED_BWD")) == 0);
   int final_hi = nrdb;  // dense blocks [0, final_hi): the trunk group whose weight gradients go out last, with the input block's
-  // fused chain: two equal groups measured best (1: 12.19, 2: 12.14, 3: 12.23, 4: 12.17 ms per step, shrinking groups 12.49)
-  // (data-parallel: four groups, so that the last, exposed, gradient bucket is a quarter of the trunk instead of half)
+  // fused chain: ONE launch, the whole trunk's weight gradients behind it (round 2, after the chain and the weight-gradient
+  // kernels got faster: 1: 8.85, 2: 9.04, 3: 9.00, 4: 9.05 ms per step; round 1: 12.19 / 12.14 / 12.23 / 12.17)
+  // (data-parallel: four groups, so that the last, exposed, gradient bucket is a quarter of the trunk instead of all of it)
   static const int ngroups_forced = getenv("DBM_BWD_GROUPS") ? atoi(getenv("DBM_BWD_GROUPS")) : -1;
-  const int ngroups_env = ngroups_forced >= 0 ? ngroups_forced : (ctx->comm_in_step ? 4 : 2);
+  const int ngroups_env = ngroups_forced >= 0 ? ngroups_forced : (ctx->comm_in_step ? 4 : 1);
   if (ngroups_env != wbs_groups) {
     for (int i = 1; i <= 5; ++i) wbs[i].reset();
     wbs_groups = ngroups_env;
