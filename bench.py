@@ -316,7 +316,7 @@ def main():
     step()
     dbm._lib.check(lib.dbm_profile_end_ex(ctx.handle, prof, 4), ctx.handle)
     FAMILIES = [
-        ("igemm_conv_kernel (per-layer conv forward + data gradient, v_mfma_f32_32x32x2_f32)", "igemm_conv_kernel"),
+        ("igemm_conv_kernel + the fused deformable-convolution GEMMs (per-layer conv forward + data gradient, v_mfma_f32_32x32x2_f32)", "igemm_conv_kernel"),
         ("weight gradients (wgrad_wave_dma_kernel, wgrad_band_dma_kernel, wgrad_kernel)", "wgrad_kernel"),
         ("trunk_fused_kernel (RRDB trunk forward, one persistent launch, v_mfma_f32_32x32x2_f32)", "trunk_fused_kernel"),
         ("trunk_fused_bwd_kernel (RRDB trunk data-gradient chain, persistent, v_mfma_f32_16x16x4_f32)", "trunk_fused_bwd_kernel"),
