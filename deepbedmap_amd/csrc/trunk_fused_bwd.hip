@@ -107,11 +107,17 @@ DI void mma_unit(const float (&A)[AU], int b, int b_next, float (&bq0)[9], f4v (
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) bq0[tap] = lds[b_next + (tap / 3) * 10 + tap % 3];
     }
-    __builtin_amdgcn_sched_barrier(0);
+    // (round 2) the nine reads above are dealt out BETWEEN the nine MFMAs below -- one MFMA, one DS read, ... -- instead
+    // of standing in front of them: their issue slots disappear in the matrix pipe's shadow
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
       acc[(q * 9 + tap) % NACC] =
           __builtin_amdgcn_mfma_f32_16x16x4f32(A[q * 9 + tap], bq[q & 1][tap], acc[(q * 9 + tap) % NACC], 0, 0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
