@@ -198,6 +198,11 @@ struct WgradBatch {
   int fold_wgs[NCAT] = {};
   bool pair_mode[NCAT] = {};     // deterministic folding through pair buffers (WgradPlan::pairW)
   double flops[NCAT] = {};
+  // 4x4 stride-2 layers on tiny planes (wgrad_s2tiny_kernel): their own plan table, outside the categories
+  void* d_tiny = nullptr;
+  int n_tiny = 0, tiny_wgs = 0;
+  double tiny_flops = 0.0;
+  std::vector<int> tiny_owner;
   void add(const WgradDesc& d) { if (!built) descs.push_back(d); }
   void build();
   void launch(hipStream_t s);

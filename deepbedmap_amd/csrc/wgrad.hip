@@ -1139,6 +1139,150 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradPlan* __rest
   if (o < d.Cout && c < d.Cin) atomicAdd(d.gW + ((long)o * d.Cin + c) * T + t, v);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 4x4 / stride 2 / pad 1 layers on tiny output planes (OW <= 4: the discriminator's conv_layer5 / 7 / 9, 9x9 -> 4x4,
+// 4x4 -> 2x2, 2x2 -> 1x1).  GEMM view per tap: M = out channels, N = in channels, K = (image, output position) -- a few
+// hundred at batch 64, against 16 taps x (Cout / 32) x (Cin / 32) output tiles: output-bound.  No LDS staging and no K
+// split: a workgroup owns one 16 (out) x 16 (in) tile (v_mfma_f32_16x16x4_f32: four times the workgroups of 32 x 32
+// tiles, which these layers need -- conv_layer5 has 64 of those) for ALL sixteen taps, wavefront w the kernel row ky = w
+// with one accumulator per kx.  Lane (j, k4) takes K entry 4 s + k4 of the row's valid (image, a, b) list; its A value is one
+// dword of dy (out channel j), its four B values -- the taps kx = 0..3 at input columns 2 b - 1 .. 2 b + 2 -- are ONE
+// 16-byte load from its own plane of x (in channel j; out-of-image columns are zeroed after the load, every tensor
+// carries a 128-byte guard).  Output rows whose input row 2 a + ky - 1 falls outside the image are not enumerated at
+// all.  Both graphs of the discriminator step (real and fake batch) are processed by the SAME workgroup, one after
+// the other, into the same accumulators: the gradient leaves with a plain read-modify-write of elements nobody else
+// touches -- no atomics, no partial buffers, bitwise reproducible.
+// ---------------------------------------------------------------------------------------------------------------
+struct TinyPlan {
+  const float* x[2];    // input activations of the (up to two) graphs; x[1] == null: one graph
+  const float* dy[2];
+  float* gW;
+  long xsn, dysn;
+  int N, Cin, Cout, Hin, Win, OH, OW;
+  float scale;
+  int wg_start, ctiles;  // workgroups of this layer: (Cout / 16) * ctiles, ctiles = Cin / 16
+};
+
+struct __attribute__((packed, aligned(4))) f32x4u4 { float v[4]; };
+constexpr int TINY_MAXK = 2048;  // K entries (images x valid output positions) a kernel row may have: 64 KB of LDS tables
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void wgrad_s2tiny_kernel(const TinyPlan* __restrict__ plans, int nplans) {
+  int lo = 0, hi = nplans - 1;
+  const int wg = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (plans[mid].wg_start <= wg) lo = mid; else hi = mid - 1;
+  }
+  const TinyPlan& p = plans[__builtin_amdgcn_readfirstlane(lo)];  // (uniform: the plan's fields become scalar loads)
+  const int local = wg - p.wg_start;
+  const int ot = local / p.ctiles, ctile = local - ot * p.ctiles;   // 16 x 16 tiles of (out, in) channels
+  const int lane = threadIdx.x & 63, ky = threadIdx.x >> 6;
+  const int j = lane & 15, k4 = lane >> 4;
+  const int OH = p.OH, OW = p.OW, Hin = p.Hin, Win = p.Win;
+  // output rows a whose input row 2 a + ky - 1 lies inside the image
+  const int a_lo = ky == 0 ? 1 : 0;
+  int a_hi = Hin - ky < 0 ? -1 : (Hin - ky) >> 1;  // 2 a + ky - 1 <= Hin - 1
+  if (a_hi > OH - 1) a_hi = OH - 1;
+  const int OHv = a_hi - a_lo + 1;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __shared__ int2 tbl[4][TINY_MAXK];  // per kernel row: K entry -> {x offset, dy offset | column mask << 27 | valid << 31}
+  if (OHv > 0) {
+    const int per_img = OHv * OW;
+    const int E = p.N * per_img;               // K entries of this kernel row
+    const int steps = (E + 3) >> 2;            // four per MFMA (v_mfma_f32_16x16x4_f32)
+    const int oplane = OH * OW, iplane = Hin * Win;
+    // The (image, a, b) decode of every K entry -- divisions, 64-bit products -- is done ONCE per wavefront into an LDS
+    // table (the first version decoded per fetch: 2000 VALU instructions per 64 MFMAs, five times the MFMA time);
+    // both graphs use it.  Entries past the end read offset 0 with an all-zero mask.
+    int2* tb = tbl[ky];
+    for (int e = lane; e < 4 * steps; e += 64) {
+      int2 v = make_int2(0, 0);
+      if (e < E) {
+        const int n = e / per_img;
+        const int rem = e - n * per_img;
+        const int ai = rem / OW, b = rem - ai * OW;
+        const int a = a_lo + ai;
+        const int row = 2 * a + ky - 1, col0 = 2 * b - 1;
+        unsigned cm = 0;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) cm |= ((unsigned)(col0 + kx) < (unsigned)Win) ? (1u << kx) : 0u;
+        v.x = (int)((long)n * p.xsn + row * Win + col0);
+        v.y = (int)((unsigned)((long)n * p.dysn + a * OW + b) | (cm << 27) | (1u << 31));
+      }
+      tb[e] = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wavefront wrote the table it reads (no other does)
+    __builtin_amdgcn_wave_barrier();
+    auto fetch = [&](const float* xl, const float* dyl, int s, float& av, f32x4u4& bv, unsigned& cm) {
+      const int2 t = tb[4 * s + k4];
+      cm = (unsigned)t.y >> 27;  // bit 4: valid entry
+      av = dyl[(unsigned)t.y & 0x7ffffffu];
+      bv = *reinterpret_cast<const f32x4u4*>(xl + t.x);
+    };
+    // Chunks of eight K steps in ping-pong: the sixteen loads of chunk q + 1 (scattered: every lane reads its own plane)
+    // are in flight underneath the 32 MFMAs of chunk q.
+    constexpr int CH = 8;
+    struct Chunk { float a[CH]; f32x4u4 b[CH]; unsigned m[CH]; };
+    auto fetch_chunk = [&](const float* xl, const float* dyl, int s0, Chunk& c) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) fetch(xl, dyl, s0 + u < steps ? s0 + u : steps - 1, c.a[u], c.b[u], c.m[u]);
+    };
+    auto mfma_chunk = [&](const Chunk& c, int s0) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        // (steps past the end re-read the last one, entries past the end read element 0: their A value is zeroed)
+        const float av = (s0 + u < steps && (c.m[u] & 16u)) ? c.a[u] : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx)
+          acc[kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ((c.m[u] >> kx) & 1u) ? c.b[u].v[kx] : 0.f, acc[kx], 0, 0, 0);
+      }
+    };
+    for (int g = 0; g < 2; ++g) {
+      if (!p.x[g]) break;
+      const float* xl = p.x[g] + (long)(ctile * 16 + j) * iplane;   // this lane's input plane / output-gradient plane
+      const float* dyl = p.dy[g] + (long)(ot * 16 + j) * oplane;
+      Chunk c0, c1;
+      fetch_chunk(xl, dyl, 0, c0);
+      for (int s = 0; s < steps; s += 2 * CH) {
+        fetch_chunk(xl, dyl, s + CH, c1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(c0, s);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + CH < steps) {
+          fetch_chunk(xl, dyl, s + 2 * CH, c0);
+          __builtin_amdgcn_sched_barrier(0);
+          mfma_chunk(c1, s + CH);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  // gW[o][c][ky][0..3] += scale * acc: 16 bytes per (o, c), this workgroup is their only writer.
+  // D layout of v_mfma_f32_16x16x4_f32: register r of lane (j, k4) is row 4 k4 + r (out channel), column j (in channel)
+  float* gbase = p.gW + ((long)(ot * 16) * p.Cin + ctile * 16 + j) * 16 + ky * 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int o = 4 * k4 + r;
+    f32x4u4* dst = reinterpret_cast<f32x4u4*>(gbase + (long)o * p.Cin * 16);  // (4-byte alignment is all the arena guarantees)
+    f32x4u4 v = *dst;
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) v.v[kx] += p.scale * acc[kx][r];
+    *dst = v;
+  }
+}
+
+static bool s2tiny_eligible(const WgradDesc& d) {
+  static const int on = getenv("DBM_WGRAD_TINY") ? atoi(getenv("DBM_WGRAD_TINY")) : 1;
+  return on && d.KH == 4 && d.KW == 4 && d.stride == 2 && d.pad == 1 && d.ups == 0 && d.OW <= 4 && d.OH <= 4 && d.gb == nullptr &&
+         d.Cin % 32 == 0 && d.Cout % 32 == 0 && d.xsc == d.Hin * d.Win && d.dysc == d.OH * d.OW && d.Win >= 2 &&
+         (long)d.N * d.OH * d.OW + 4 <= TINY_MAXK && (long)d.N * d.xsn < (1L << 31) && (long)d.N * d.dysn < (1L << 27);
+}
+
 static inline int odd_up(int v) { return v | 1; }
 
 // The other deterministic folding (pair buffers, see WgradPlan::pairW): gW += buffers in order, the buffers are cleared for
@@ -1364,6 +1508,11 @@ static void launch_T(const WgradPlan* plans, const int* starts, int nplans, int 
 void WgradBatch::reset() {
   descs.clear();
   built = false;
+  if (d_tiny) (void)hipFree(d_tiny);
+  d_tiny = nullptr;
+  n_tiny = tiny_wgs = 0;
+  tiny_flops = 0.0;
+  tiny_owner.clear();
   for (int g = 0; g < NCAT; ++g) {
     if (d_plans[g]) (void)hipFree(d_plans[g]);
     if (d_starts[g]) (void)hipFree(d_starts[g]);
@@ -1416,7 +1565,47 @@ void WgradBatch::build() {
   const bool direct = direct_form_enabled() != 0;
   std::vector<int> cat(descs.size());
   const int forms = dma_forms_enabled();
+  // ---- 4x4 stride-2 layers on tiny planes: their own kernel (wgrad_s2tiny_kernel), outside the category tables.  Two
+  // descriptors with the same gradient (the real- and the fake-batch graph of the discriminator) share a plan. ----
+  {
+    std::vector<TinyPlan> tp;
+    std::vector<int> owner(descs.size(), -1);
+    int wgs = 0;
+    double fl = 0.0;
+    for (size_t i = 0; i < descs.size(); ++i) {
+      if (owner[i] >= 0) continue;
+      const WgradDesc& d = descs[i];
+      // the descriptors that add to this gradient: all of them must qualify, at most two, same geometry
+      std::vector<size_t> grp;
+      bool ok = true;
+      for (size_t k = 0; k < descs.size(); ++k) {
+        if (descs[k].gW != d.gW) continue;
+        const WgradDesc& f = descs[k];
+        grp.push_back(k);
+        ok = ok && s2tiny_eligible(f) && f.N == d.N && f.Cin == d.Cin && f.Cout == d.Cout && f.Hin == d.Hin && f.Win == d.Win &&
+             f.OH == d.OH && f.OW == d.OW && f.xsn == d.xsn && f.dysn == d.dysn && f.scale == d.scale;
+      }
+      if (!ok || grp.size() > 2 || grp[0] != i) continue;
+      TinyPlan q;
+      memset(&q, 0, sizeof(q));
+      for (size_t u = 0; u < grp.size(); ++u) { q.x[u] = descs[grp[u]].x; q.dy[u] = descs[grp[u]].dy; owner[grp[u]] = (int)tp.size(); }
+      q.gW = d.gW; q.xsn = d.xsn; q.dysn = d.dysn;
+      q.N = d.N; q.Cin = d.Cin; q.Cout = d.Cout; q.Hin = d.Hin; q.Win = d.Win; q.OH = d.OH; q.OW = d.OW; q.scale = d.scale;
+      q.ctiles = d.Cin / 16; q.wg_start = wgs;
+      wgs += (d.Cout / 16) * q.ctiles;
+      tp.push_back(q);
+      fl += 2.0 * (double)grp.size() * d.N * d.OH * d.OW * d.Cout * d.Cin * 16;
+    }
+    n_tiny = (int)tp.size(); tiny_wgs = wgs; tiny_flops = fl;
+    tiny_owner = owner;
+    if (d_tiny) { (void)hipFree(d_tiny); d_tiny = nullptr; }
+    if (n_tiny) {
+      DBM_HIP(hipMalloc((void**)&d_tiny, tp.size() * sizeof(TinyPlan)));
+      DBM_HIP(hipMemcpy(d_tiny, tp.data(), tp.size() * sizeof(TinyPlan), hipMemcpyHostToDevice));
+    }
+  }
   for (size_t i = 0; i < descs.size(); ++i) {
+    if (tiny_owner[i] >= 0) { cat[i] = -1; continue; }
     const int T = descs[i].KH * descs[i].KW;
     WgradPlan p;
     const int dm = direct ? direct_mode(descs[i]) : -1;
@@ -1598,6 +1787,12 @@ void WgradBatch::launch(hipStream_t s) {
     descs = keep;
   }
   if (!built) build();
+  if (n_tiny) {
+    if (g_profiler.enabled) g_profiler.begin(s, 1, tiny_flops);
+    hipLaunchKernelGGL(wgrad_s2tiny_kernel, dim3(tiny_wgs), dim3(256), 0, s, (const TinyPlan*)d_tiny, n_tiny);
+    DBM_HIP(hipGetLastError());
+    if (g_profiler.enabled) g_profiler.end(s);
+  }
   for (int g = 0; g < NCAT; ++g) {
     if (nplans[g] == 0) continue;
     if (g_profiler.enabled) g_profiler.begin(s, 1, flops[g]);
