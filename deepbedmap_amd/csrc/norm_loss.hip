@@ -53,11 +53,38 @@ __global__ __launch_bounds__(NT) void bn_train_fwd_kernel(const float* __restric
       }
     }
   };
+  // wide form, <= 64 images of <= 512 positions (every training-step launch): a thread's <= 32 elements stay in registers
+  // across the three passes -- z is read once instead of three times, and the passes are no longer three dependent
+  // round trips to memory
+  constexpr int CI = 4, CP = 8;
+  const bool cached = WIDE && N <= (NT / 64) * CI && plane <= 64 * CP;
+  float zc[CI][CP];
+  unsigned vm = 0;
+  auto slot_idx = [&](int i, int jj) { return ((long)(wave + (NT / 64) * i) * C + c) * plane + lane + 64 * jj; };
+  if (cached) {
+#pragma unroll
+    for (int i = 0; i < CI; ++i)
+#pragma unroll
+      for (int jj = 0; jj < CP; ++jj) {
+        const bool ok = wave + (NT / 64) * i < N && lane + 64 * jj < plane;
+        zc[i][jj] = ok ? z[slot_idx(i, jj)] : 0.f;
+        vm |= ok ? (1u << (i * CP + jj)) : 0u;
+      }
+  }
+  auto for_cached = [&](auto&& f) {
+#pragma unroll
+    for (int i = 0; i < CI; ++i)
+#pragma unroll
+      for (int jj = 0; jj < CP; ++jj)
+        if ((vm >> (i * CP + jj)) & 1u) f(i, jj);
+  };
   float s = 0.f;
-  for_each([&](long idx) { s += z[idx]; });
+  if (cached) for_cached([&](int i, int jj) { s += zc[i][jj]; });
+  else for_each([&](long idx) { s += z[idx]; });
   const float mean = block_sum<NT>(s, sh) / (float)m;
   float q = 0.f;
-  for_each([&](long idx) { const float d = z[idx] - mean; q += d * d; });
+  if (cached) for_cached([&](int i, int jj) { const float d = zc[i][jj] - mean; q += d * d; });
+  else for_each([&](long idx) { const float d = z[idx] - mean; q += d * d; });
   const float var = block_sum<NT>(q, sh) / (float)m;
   const float istd = 1.f / sqrtf(var + eps);
   if (threadIdx.x == 0) {
@@ -68,10 +95,17 @@ __global__ __launch_bounds__(NT) void bn_train_fwd_kernel(const float* __restric
     avg_var[c] = avg_var[c] * decay + ((1.f - decay) * adjust) * var;
   }
   const float g = gamma[c], b = beta[c];
-  for_each([&](long idx) {
-    const float v = g * ((z[idx] - mean) * istd) + b;
-    y[idx] = v >= 0.f ? v : slope * v;
-  });
+  if (cached) {
+    for_cached([&](int i, int jj) {
+      const float v = g * ((zc[i][jj] - mean) * istd) + b;
+      y[slot_idx(i, jj)] = v >= 0.f ? v : slope * v;
+    });
+  } else {
+    for_each([&](long idx) {
+      const float v = g * ((z[idx] - mean) * istd) + b;
+      y[idx] = v >= 0.f ? v : slope * v;
+    });
+  }
 }
 
 void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* inv_std,
@@ -130,14 +164,41 @@ __global__ __launch_bounds__(NT) void bn_train_bwd_kernel(const float* __restric
       }
     }
   };
+  // (wide form: x-hat and the masked gradient of a thread's <= 32 elements stay in registers between the two passes)
+  constexpr int CI = 4, CP = 8;
+  const bool cached = WIDE && N <= (NT / 64) * CI && plane <= 64 * CP;
+  float xc[CI][CP], gc[CI][CP];
+  unsigned vm = 0;
+  auto slot_idx = [&](int i, int jj) { return ((long)(wave + (NT / 64) * i) * C + c) * plane + lane + 64 * jj; };
   float s1 = 0.f, s2 = 0.f;
-  for_each([&](long idx) {
-    const float xh = (z[idx] - mean) * istd;
-    const float yv = g * xh + b;
-    const float gt = yv >= 0.f ? gh[idx] : slope * gh[idx];
-    s1 += gt;
-    s2 += gt * xh;
-  });
+  if (cached) {
+#pragma unroll
+    for (int i = 0; i < CI; ++i)
+#pragma unroll
+      for (int jj = 0; jj < CP; ++jj) {
+        const bool ok = wave + (NT / 64) * i < N && lane + 64 * jj < plane;
+        float xh = 0.f, gt = 0.f;
+        if (ok) {
+          const long idx = slot_idx(i, jj);
+          xh = (z[idx] - mean) * istd;
+          const float yv = g * xh + b;
+          gt = yv >= 0.f ? gh[idx] : slope * gh[idx];
+          vm |= 1u << (i * CP + jj);
+          s1 += gt;
+          s2 += gt * xh;
+        }
+        xc[i][jj] = xh;
+        gc[i][jj] = gt;
+      }
+  } else {
+    for_each([&](long idx) {
+      const float xh = (z[idx] - mean) * istd;
+      const float yv = g * xh + b;
+      const float gt = yv >= 0.f ? gh[idx] : slope * gh[idx];
+      s1 += gt;
+      s2 += gt * xh;
+    });
+  }
   const float sg = block_sum<NT>(s1, sh);
   const float sgx = block_sum<NT>(s2, sh);
   if (threadIdx.x == 0) {
@@ -145,12 +206,20 @@ __global__ __launch_bounds__(NT) void bn_train_bwd_kernel(const float* __restric
     atomicAdd(gbeta + c, sg);
   }
   const float k = g * istd, im = 1.f / (float)m;
-  for_each([&](long idx) {
-    const float xh = (z[idx] - mean) * istd;
-    const float yv = g * xh + b;
-    const float gt = yv >= 0.f ? gh[idx] : slope * gh[idx];
-    gz[idx] = k * (gt - (sg + xh * sgx) * im);
-  });
+  if (cached) {
+#pragma unroll
+    for (int i = 0; i < CI; ++i)
+#pragma unroll
+      for (int jj = 0; jj < CP; ++jj)
+        if ((vm >> (i * CP + jj)) & 1u) gz[slot_idx(i, jj)] = k * (gc[i][jj] - (sg + xc[i][jj] * sgx) * im);
+  } else {
+    for_each([&](long idx) {
+      const float xh = (z[idx] - mean) * istd;
+      const float yv = g * xh + b;
+      const float gt = yv >= 0.f ? gh[idx] : slope * gh[idx];
+      gz[idx] = k * (gt - (sg + xh * sgx) * im);
+    });
+  }
 }
 
 void launch_bn_train_bwd(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
