@@ -45,6 +45,7 @@ SIGNATURES = {
     "dbm_fill_f32": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float],
     "dbm_gather_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_size_t],
     "dbm_profile_begin": [C.c_void_p],
+    "dbm_profile_begin_serial": [C.c_void_p],
     "dbm_profile_end": [C.c_void_p, C.POINTER(C.c_double)],
     "dbm_profile_end_ex": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
     "dbm_set_sync_batch_stats": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],

@@ -266,6 +266,16 @@ int dbm_profile_begin(dbm_ctx* ctx) {
   DBM_API_END
 }
 
+int dbm_profile_begin_serial(dbm_ctx* ctx) {
+  DBM_API_BEGIN(ctx)
+  DBM_HIP(hipDeviceSynchronize());
+  double junk[12];
+  g_profiler.collect(junk, 4);
+  g_profiler.enabled = true;
+  g_profiler.serial = true;
+  DBM_API_END
+}
+
 int dbm_profile_end(dbm_ctx* ctx, double out[8]) {
   DBM_API_BEGIN(ctx)
   g_profiler.enabled = false;
@@ -281,6 +291,7 @@ int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam) {
   DBM_API_BEGIN(ctx)
   DBM_CHECK(out != nullptr && nfam >= 1 && nfam <= 4, "dbm_profile_end_ex: nfam must be 1..4");
   g_profiler.enabled = false;
+  g_profiler.serial = false;
   DBM_HIP(hipStreamSynchronize(ctx->stream));
   g_profiler.collect(out, nfam);
   DBM_API_END
@@ -1204,8 +1215,9 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
   const long P = (long)H * W;
   static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
   const bool fused = fused_env && deform_conv_fused_ok(C, O) && deform_input_grad_ok(C, H, W);
-  DevBuf col, gcol, xt, part;
+  DevBuf col, gcol, xt, part, cws;
   if (fused) {
+    cws.ensure(deform_csr_workspace_floats(N, H, W));
     xt.ensure((size_t)N * C * P);
     launch_nchw_to_nhwc64(x, xt.p, N, (int)P, s);
   }
@@ -1217,7 +1229,7 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
     if (fused) {
       part.ensure(deform_bwd1_partial_floats(N, H, W));
       launch_deform_bwd1_fused(xt.p, off, w, gy, goff, gw, gb, part.p, N, H, W, 18 * P, s);
-      launch_deform_input_grad(x, off, nullptr, w, gy, gx, N, C, H, W, 18 * P, s);
+      launch_deform_input_grad(x, off, nullptr, w, gy, gx, N, C, H, W, 18 * P, s, cws.p);
     } else {
       launch_deform_backward(x, off, nullptr, w, gy, gx, goff, N, C, H, W, 18 * P, s);
       launch_gemv_cols_wgrad(col.p, gy, gw, gb, N, C * 9, (int)P, s);
@@ -1236,7 +1248,7 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
     gcol.ensure((size_t)N * C * 9 * P);
     if (fused) {
       launch_deform_bwd64_fused(xt.p, off, L.wb[1], gy, gcol.p, goff, N, H, W, 18 * P, s);
-      launch_deform_input_grad(x, off, gcol.p, nullptr, nullptr, gx, N, C, H, W, 18 * P, s);
+      launch_deform_input_grad(x, off, gcol.p, nullptr, nullptr, gx, N, C, H, W, 18 * P, s, cws.p);
     } else {
       ConvDesc d;
       memset(&d, 0, sizeof(d));
@@ -1257,6 +1269,7 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
   gcol.release();
   xt.release();
   part.release();
+  cws.release();
   DBM_API_END
 }
 

@@ -99,6 +99,7 @@ void launch_igemm_conv(const ConvDesc& d, hipStream_t s);
 // 3 = trunk_fused_bwd_kernel.
 struct KernelProfiler {
   bool enabled = false;
+  bool serial = false;   // dbm_profile_begin_serial: the host synchronises the device around every bracketed launch
   struct Rec { hipEvent_t a, b; double flops; int family; };
   std::vector<Rec> recs;
   void begin(hipStream_t s, int family, double flops);

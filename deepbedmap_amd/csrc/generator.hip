@@ -385,8 +385,9 @@ void Generator::backward(const float* gy) {
       sg = ctx->chain[chain_base];
     }
     dw2_partial.ensure(deform_bwd1_partial_floats(N, H4, W4));
+    csr_ws.ensure(deform_csr_workspace_floats(N, H4, W4));
     launch_deform_bwd1_fused(a51t.p, off2.p, P(T_def2W), gy, goff2.p, G(T_def2W), G(T_def2b), dw2_partial.p, N, H4, W4, 32 * P4, sg);
-    launch_deform_input_grad(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, N, 64, H4, W4, 32 * P4, s);
+    launch_deform_input_grad(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, N, 64, H4, W4, 32 * P4, s, csr_ws.p);
     if (sg != s) ctx->fork(sg, s, 3);
   } else {
     // (its weight gradient only needs gy and the retained columns: side stream, underneath the sampler's backward)
@@ -412,7 +413,7 @@ void Generator::backward(const float* gy) {
     if (bfused) {
       // column gradients W^T gy on the MFMAs, offset gradients from the same LDS tile; then the input-gradient gather
       launch_deform_bwd64_fused(a42t.p, off1.p, L.wb[1], g_a51.p, gcol.p, goff1.p, N, H4, W4, 32 * P4, s);
-      launch_deform_input_grad(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, N, 64, H4, W4, 32 * P4, s);
+      launch_deform_input_grad(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, N, 64, H4, W4, 32 * P4, s, csr_ws.p);
     } else {
       ConvDesc d;
       memset(&d, 0, sizeof(d));

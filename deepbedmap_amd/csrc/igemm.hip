@@ -421,6 +421,7 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
 KernelProfiler g_profiler;
 
 void KernelProfiler::begin(hipStream_t s, int family, double flops) {
+  if (serial) DBM_HIP(hipDeviceSynchronize());  // standalone durations: nothing else is running when the bracket opens
   Rec r;
   DBM_HIP(hipEventCreate(&r.a));
   DBM_HIP(hipEventCreate(&r.b));
@@ -430,7 +431,10 @@ void KernelProfiler::begin(hipStream_t s, int family, double flops) {
   recs.push_back(r);
 }
 
-void KernelProfiler::end(hipStream_t s) { DBM_HIP(hipEventRecord(recs.back().b, s)); }
+void KernelProfiler::end(hipStream_t s) {
+  DBM_HIP(hipEventRecord(recs.back().b, s));
+  if (serial) DBM_HIP(hipDeviceSynchronize());  // ... and nothing else starts before it closes
+}
 
 void KernelProfiler::collect(double* out, int nfam) {
   for (int i = 0; i < 3 * nfam; ++i) out[i] = 0.0;

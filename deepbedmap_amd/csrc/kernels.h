@@ -35,8 +35,11 @@ size_t deform_bwd1_partial_floats(int N, int H, int W);
 void launch_deform_bwd1_fused(const float* xt, const float* off, const float* w, const float* gy, float* goff, float* gw, float* gb,
                               float* partial, int N, int H, int W, long offsn, hipStream_t s);
 bool deform_input_grad_ok(int C, int H, int W);
+// ws (optional, deform_csr_workspace_floats floats): the sampling lists are built once per (image, tap) there and a
+// register-only kernel gathers (otherwise every channel-group workgroup rebuilds them in LDS)
+size_t deform_csr_workspace_floats(int N, int H, int W);
 void launch_deform_input_grad(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy, float* gx, int N,
-                              int C, int H, int W, long offsn, hipStream_t s);
+                              int C, int H, int W, long offsn, hipStream_t s, float* ws = nullptr);
 void launch_gemv_cols(const float* col, const float* w, const float* bias, float* y, int N, int K, int plane, hipStream_t s);
 void launch_gemv_cols_wgrad(const float* col, const float* gy, float* gw, float* gb, int N, int K, int plane, hipStream_t s);
 void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int H, int W, float slope, hipStream_t s);

@@ -5,6 +5,7 @@
 #include "dbm_internal.h"
 #include "deform_geom.h"
 #include "kernels.h"
+#include <cstdlib>
 
 // ----------------------------------------------------------------------------------------------
 // Convolution with 1 or 2 input channels (reference srgan_train.py:223-254 input block, :617-625
@@ -545,6 +546,140 @@ void launch_deform_backward(const float* x, const float* off, const float* gcol,
   DBM_HIP(hipGetLastError());
 }
 
+// ---- the same CSR gather in two kernels: the transposed sampling operator of an (image, tap) is built ONCE (the fused
+// form above rebuilds it in each of the C / 16 workgroups of an image), stored, and a register-only kernel gathers ----
+// lists of (image n, tap t): offs[(n * 9 + t) * (plane + 1) + q] .. [q + 1] delimit the entries of input pixel q in
+// ent[(n * 9 + t) * 4 * plane + ...] = {output position p, bilinear weight}, sorted by p (fixed summation order).
+template <int NT>
+__global__ __launch_bounds__(NT) void deform_csr_build_kernel(const float* __restrict__ off, int* __restrict__ g_offs,
+                                                              int2* __restrict__ g_ent, int H, int W, long offsn) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int wtot[NT / 64];
+  const int plane = H * W;
+  int* offs = (int*)sm;                        // plane + 1
+  int* cur = offs + plane + 1;                 // plane
+  int* ent_p = cur + plane;                    // 4 * plane
+  float* ent_w = (float*)(ent_p + 4 * plane);  // 4 * plane
+  const int n = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const float* on = off + (long)n * offsn;
+  const int per = (plane + NT - 1) / NT;
+  for (int e = tid; e <= plane; e += NT) offs[e] = 0;
+  __syncthreads();
+  for (int p = tid; p < plane; p += NT) {
+    const int a = p / W, b = p - a * W;
+    const DeformGeom g = deform_geom(on[(long)t * plane + p], on[(long)(9 + t) * plane + p], a, b, t / 3, t % 3, H, W, 1);
+    const int o1 = deform_corner(g.v0, g.u0, H, W, 1), o2 = deform_corner(g.v0, g.u0 + 1, H, W, 1);
+    const int o3 = deform_corner(g.v0 + 1, g.u0, H, W, 1), o4 = deform_corner(g.v0 + 1, g.u0 + 1, H, W, 1);
+    if (o1 >= 0) atomicAdd(offs + o1, 1);
+    if (o2 >= 0) atomicAdd(offs + o2, 1);
+    if (o3 >= 0) atomicAdd(offs + o3, 1);
+    if (o4 >= 0) atomicAdd(offs + o4, 1);
+  }
+  __syncthreads();
+  {
+    const int base = tid * per;
+    int loc = 0;
+    for (int i = 0; i < per; ++i)
+      if (base + i < plane) loc += offs[base + i];
+    int inc = loc;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int pre = inc - loc;
+    for (int w2 = 0; w2 < wave; ++w2) pre += wtot[w2];
+    for (int i = 0; i < per; ++i)
+      if (base + i < plane) {
+        const int cnt = offs[base + i];
+        offs[base + i] = pre;
+        cur[base + i] = pre;
+        pre += cnt;
+      }
+    if (tid == NT - 1) offs[plane] = pre;
+  }
+  __syncthreads();
+  for (int p = tid; p < plane; p += NT) {
+    const int a = p / W, b = p - a * W;
+    const DeformGeom g = deform_geom(on[(long)t * plane + p], on[(long)(9 + t) * plane + p], a, b, t / 3, t % 3, H, W, 1);
+    const int o1 = deform_corner(g.v0, g.u0, H, W, 1), o2 = deform_corner(g.v0, g.u0 + 1, H, W, 1);
+    const int o3 = deform_corner(g.v0 + 1, g.u0, H, W, 1), o4 = deform_corner(g.v0 + 1, g.u0 + 1, H, W, 1);
+    const float w1 = g.wu1 * g.wv1, w2 = g.wu0 * g.wv1, w3 = g.wu1 * g.wv0, w4 = g.wu0 * g.wv0;
+    if (o1 >= 0) { const int sl = atomicAdd(cur + o1, 1); ent_p[sl] = p; ent_w[sl] = w1; }
+    if (o2 >= 0) { const int sl = atomicAdd(cur + o2, 1); ent_p[sl] = p; ent_w[sl] = w2; }
+    if (o3 >= 0) { const int sl = atomicAdd(cur + o3, 1); ent_p[sl] = p; ent_w[sl] = w3; }
+    if (o4 >= 0) { const int sl = atomicAdd(cur + o4, 1); ent_p[sl] = p; ent_w[sl] = w4; }
+  }
+  __syncthreads();
+  int* go = g_offs + ((long)n * 9 + t) * (plane + 1);
+  int2* ge = g_ent + ((long)n * 9 + t) * 4 * plane;
+  for (int q = tid; q < plane; q += NT) {
+    const int s0 = offs[q], s1 = offs[q + 1];
+    for (int i = s0 + 1; i < s1; ++i) {  // the fill order varies from run to run: sort the few entries of a pixel by position
+      const int kp = ent_p[i];
+      const float kw = ent_w[i];
+      int jj = i - 1;
+      while (jj >= s0 && ent_p[jj] > kp) {
+        ent_p[jj + 1] = ent_p[jj];
+        ent_w[jj + 1] = ent_w[jj];
+        --jj;
+      }
+      ent_p[jj + 1] = kp;
+      ent_w[jj + 1] = kw;
+    }
+    go[q] = s0;
+    for (int sl = s0; sl < s1; ++sl) ge[sl] = make_int2(ent_p[sl], __float_as_int(ent_w[sl]));
+  }
+  if (tid == 0) go[plane] = offs[plane];
+}
+
+// gx[n][c0 .. c0 + CH)[q] = sum over taps and list entries of w * gcol[c][t][p]  (or w * gy[p] * w1o[c*9+t]): input pixel q
+// owned by one thread, its CH sums in registers over all nine taps, no LDS.
+template <int CH, int NT>
+__global__ __launch_bounds__(NT) void deform_csr_gather_kernel(const int* __restrict__ g_offs, const int2* __restrict__ g_ent,
+                                                               const float* __restrict__ gcol, const float* __restrict__ w1o,
+                                                               const float* __restrict__ gy, float* __restrict__ gx, int C, int plane) {
+  const int n = blockIdx.x, c0 = blockIdx.y * CH;
+  for (int q = threadIdx.x; q < plane; q += NT) {
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+    for (int t = 0; t < 9; ++t) {
+      const int* go = g_offs + ((long)n * 9 + t) * (plane + 1);
+      const int2* ge = g_ent + ((long)n * 9 + t) * 4 * plane;
+      const int s0 = go[q], s1 = go[q + 1];
+      const float* gc0 = gcol ? gcol + (((long)n * C + c0) * 9 + t) * plane : nullptr;
+      for (int sl = s0; sl < s1; ++sl) {
+        const int2 en = ge[sl];
+        const int p = en.x;
+        const float w = __int_as_float(en.y);
+        if (gc0) {
+          float gq[CH];
+#pragma unroll
+          for (int c = 0; c < CH; ++c) gq[c] = gc0[(long)c * 9 * plane + p];
+#pragma unroll
+          for (int c = 0; c < CH; ++c) acc[c] += w * gq[c];
+        } else {
+          const float gyv = w * gy[(long)n * plane + p];
+#pragma unroll
+          for (int c = 0; c < CH; ++c) acc[c] += gyv * w1o[(c0 + c) * 9 + t];
+        }
+      }
+    }
+    float* gxn = gx + ((long)n * C + c0) * plane + q;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) gxn[(long)c * plane] = acc[c];
+  }
+}
+
+size_t deform_csr_workspace_floats(int N, int H, int W) {  // offsets, then the 8-byte entries (8-byte aligned)
+  const size_t plane = (size_t)H * W;
+  const size_t no = ((size_t)N * 9 * (plane + 1) + 1) & ~(size_t)1;
+  return no + (size_t)N * 9 * 4 * plane * 2;
+}
+
 // Input gradient only: the atomic-free CSR gather above without the offset gradients (which the fused kernels of
 // deform_fused.hip produce).  Returns false when a plane does not fit the kernel's LDS lists (the caller then takes
 // launch_deform_backward).
@@ -554,9 +689,26 @@ bool deform_input_grad_ok(int C, int H, int W) {
 }
 
 void launch_deform_input_grad(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy, float* gx, int N,
-                              int C, int H, int W, long offsn, hipStream_t s) {
+                              int C, int H, int W, long offsn, hipStream_t s, float* ws) {
   DBM_CHECK(deform_input_grad_ok(C, H, W), "deformable input gradient: plane too large for the CSR kernel");
   const long plane = (long)H * W;
+  static const int split_env = getenv("DBM_DEFORM_CSR_SPLIT") ? atoi(getenv("DBM_DEFORM_CSR_SPLIT")) : 1;
+  if (ws && split_env && C % 16 == 0 && sizeof(float) * (10 * (size_t)plane + 1) <= 150 * 1024) {
+    // lists built once per (image, tap), then a register-only gather per (image, 16 channels)
+    int* g_offs = (int*)ws;
+    int2* g_ent = (int2*)(ws + (((size_t)N * 9 * (plane + 1) + 1) & ~(size_t)1));
+    static bool attr2 = false;
+    if (!attr2) {
+      DBM_HIP(hipFuncSetAttribute((const void*)deform_csr_build_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+      attr2 = true;
+    }
+    hipLaunchKernelGGL((deform_csr_build_kernel<1024>), dim3(N, 9), dim3(1024), sizeof(float) * (10 * (size_t)plane + 1), s, off, g_offs,
+                       g_ent, H, W, offsn);
+    hipLaunchKernelGGL((deform_csr_gather_kernel<16, 1024>), dim3(N, C / 16), dim3(1024), 0, s, g_offs, g_ent, gcol, w1o, gy, gx, C,
+                       (int)plane);
+    DBM_HIP(hipGetLastError());
+    return;
+  }
   constexpr int CH = 8, CHD = 16;
   const bool wide = C % CHD == 0 && sizeof(float) * ((size_t)CHD * plane + 10 * plane + 1) <= 150 * 1024;
   const size_t lds = sizeof(float) * ((size_t)(wide ? CHD : CH) * plane + 10 * plane + 1);

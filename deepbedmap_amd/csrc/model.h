@@ -161,6 +161,7 @@ struct Generator : dbm_model {
   WgradBatch wbs[NWB];  // batched weight gradients: tail, 5 trunk groups, pre-residual + input block (launched on the side stream)
   std::vector<DevBuf> cat, dA;
   DevBuf in_x, in_w1, in_w2, in_w3, a0, a3, a41, a42, off1, off2, col1, col2, a51, yout;
+  DevBuf csr_ws;       // sampling lists of the deformable layers' input-gradient gather (deform_csr_build_kernel)
   DevBuf dw2_partial;  // per-workgroup partial sums of final_conv_layer2's weight gradient (deform_bwd1_fused_kernel)
   bool deform_bwd_fused(int H4, int W4) const;
   DevBuf a42t, a51t;  // channels-last copies of the deformable layers' inputs (what the fused sampler gathers from)

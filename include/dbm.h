@@ -89,6 +89,10 @@ int dbm_profile_end(dbm_ctx* ctx, double out[8]);
 /* the same for nfam <= 4 kernel families, three values each: igemm_conv_kernel, the weight-gradient kernels,
  * trunk_fused_kernel (RRDB trunk forward, srgan_train.py:546), trunk_fused_bwd_kernel (its data-gradient chain) */
 int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam);
+/* the same brackets with the device synchronised before and after every bracketed launch: STANDALONE launch durations
+ * (inside a training step up to four streams share the chip and every bracket also contains the neighbours' work).
+ * Ended by dbm_profile_end_ex. */
+int dbm_profile_begin_serial(dbm_ctx* ctx);
 /* testing aid: raises the condition a persistent trunk kernel raises when it gives up waiting for a neighbouring
  * workgroup.  From then on the optimizer kernels skip their updates; the next API call that completes returns status 7
  * ("repeat the iteration"), clears the condition and switches the process to the layer-by-layer trunk path. */
