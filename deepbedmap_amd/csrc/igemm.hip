@@ -322,12 +322,14 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
       load_b(xn + p * xstep, b);
     };
     auto mfma_set = [&](const float (&a)[T], const float (&w)[T], const float (&b)[T]) {
+      __builtin_amdgcn_s_setprio(1);  // (a wavefront inside its MFMA block outranks the ones that are issuing loads)
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float bm = ((okmask >> t) & 1u) ? b[t] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bm, acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t], bm, acc2, 0, 0, 0);
       }
+      __builtin_amdgcn_s_setprio(0);
     };
     load_set(0, a0, w0, b0);
     for (int p = 0; p < npairs; p += 2) {
@@ -387,11 +389,13 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
       load_b(xn + p * xstep, b);
     };
     auto mfma_set = [&](const float (&a)[T], const float (&b)[T]) {
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float bm = ((okmask >> t) & 1u) ? b[t] : 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bm, acc, 0, 0, 0);
       }
+      __builtin_amdgcn_s_setprio(0);
     };
     load_set(0, a0, b0);
     for (int p = 0; p < npairs; p += 2) {
