@@ -64,6 +64,7 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
 Generator::~Generator() {
   if (twin) delete twin;
   if (ev_prefetch) (void)hipEventDestroy(ev_prefetch);
+  for (auto& e : ev_pack) if (e) (void)hipEventDestroy(e);
   if (!is_view) {
     (void)hipFree(tf_wstream); (void)hipFree(tf_bstream); (void)hipFree(tf_bwd_wstream); (void)hipFree((void*)tf_wsrc); (void)hipFree((void*)tf_bsrc);
   }
@@ -103,8 +104,21 @@ void Generator::pack_extra(hipStream_t s) {
     DBM_HIP(hipMemcpy((void*)tf_bsrc, bs.data(), bs.size() * sizeof(float*), hipMemcpyHostToDevice));
     DBM_HIP(hipDeviceSynchronize());
   }
-  launch_pack_trunk_fused(tf_wsrc, tf_bsrc, tf_wstream, tf_bstream, nrdb, s);
-  launch_pack_trunk_fused_bwd(tf_wsrc, tf_bwd_wstream, nrdb, s);
+  // The per-layer images (launched by the caller on `s` just before) are needed by the very next kernels, the input block's;
+  // the trunk's weight streams only by the persistent kernels behind it, the backward one not before the G-step: they are
+  // rebuilt on chain[0] (idle at this point of a step) and the persistent launches wait for their events (~90 us off the
+  // critical path of a training step).
+  static const int aside = getenv("DBM_PACK_ASIDE") ? atoi(getenv("DBM_PACK_ASIDE")) : 1;
+  hipStream_t ps = (aside && ctx->chain[0] && ctx->chain[0] != s) ? ctx->chain[0] : s;
+  if (!ev_pack[0]) for (auto& e : ev_pack) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (ps != s) {
+    DBM_HIP(hipEventRecord(ev_pack[0], s));
+    DBM_HIP(hipStreamWaitEvent(ps, ev_pack[0], 0));
+  }
+  launch_pack_trunk_fused(tf_wsrc, tf_bsrc, tf_wstream, tf_bstream, nrdb, ps);
+  DBM_HIP(hipEventRecord(ev_pack[1], ps));
+  launch_pack_trunk_fused_bwd(tf_wsrc, tf_bwd_wstream, nrdb, ps);
+  DBM_HIP(hipEventRecord(ev_pack[2], ps));
 }
 
 Generator* Generator::get_twin() {
@@ -273,6 +287,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       L.inbox = tf_inbox; L.err = ctx->dev_err_d; L.err_dev = ctx->dev_err_flag;
       L.nrdb = nrdb; L.nimg = std::min(IMGS, N - i0); L.img0 = i0; L.epoch = ++tf_epoch;
       L.rs = rs; L.slope = SLOPE;
+      if (src->ev_pack[1]) DBM_HIP(hipStreamWaitEvent(s, src->ev_pack[1], 0));  // the weight streams (pack_extra)
       launch_trunk_fused(L, s);
     }
   }
@@ -528,6 +543,7 @@ void Generator::backward(const float* gy) {
           L.inbox = tf_inbox; L.err = ctx->dev_err_d; L.err_dev = ctx->dev_err_flag;
           L.nrdb = nrdb; L.j0 = jlo; L.j1 = j + 1; L.nimg = std::min(IMGS, N - i0); L.img0 = i0; L.epoch = ++tf_epoch;
           L.rs = rs; L.slope = SLOPE;
+          if (src->ev_pack[2]) DBM_HIP(hipStreamWaitEvent(s, src->ev_pack[2], 0));
           launch_trunk_fused_bwd(L, s);
         }
         prev = grp;

@@ -177,6 +177,7 @@ struct Generator : dbm_model {
   bool use_aux = true;  // backward(): the deformable layers' offset-gradient kernel may run on chain[chain_base]
   int max_split = 2;  // image ranges the 9x9 stage may be cut into (1: everything on the caller's stream)
   hipEvent_t ev_prefetch = nullptr;
+  hipEvent_t ev_pack[3] = {nullptr, nullptr, nullptr};  // pack_extra: main stream reached the repack / forward streams built / backward streams built
   // fused 9x9 trunk forward (trunk_fused.hip): per-wavefront weight streams (owner only), per-workspace hand-off granules
   float* tf_wstream = nullptr;
   float* tf_bstream = nullptr;
