@@ -86,6 +86,8 @@ struct ConvDesc {
   // Merged phases of a stride-2 data gradient (T == 4): blockIdx.z / ksplit = phase ph = 2 py + px, whose four taps are
   // dy/dx[4 ph ..], whose weight image is phwp[ph], output offset (py, px) and logical plane phOH[ph] x phOW[ph]
   // (the planes differ by one row / column when the gradient's dims are odd).  nphase <= 1: a single-phase launch.
+  int nosplit;         // set by the launcher: every wavefront owns a position tile over the whole K (blockIdx.x counts groups
+                       // of WAVES tiles), no cross-wavefront reduction
   int nphase;
   const float* phwp[4];
   short phOH[4], phOW[4];

@@ -141,7 +141,43 @@ __device__ __forceinline__ bool igemm_epilogue(const ConvDesc& d, float* red, co
   return true;
 }
 
-template <int T, int WAVES, int NPB, bool ROW>
+// Epilogue of the no-split form (ConvDesc::nosplit): the wavefront owns its 32 x 32 tile over the whole K, so the
+// accumulators go out straight from the registers -- no LDS, no barrier; lanes j = consecutive positions (128-byte runs).
+__device__ __forceinline__ void igemm_epilogue_ns(const ConvDesc& d, const f32x16& acc, int kh, bool pv, int n, int a, int b, int cout0,
+                                                  int oy0, int ox0) {
+  if (!pv) return;
+  const long pix = (long)(a * d.so + oy0) * d.OWp + (b * d.so + ox0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // four channels at a time: their global reads first (they overlap), then arithmetic and stores
+    float e_r1[4], e_r2[4], e_y[4], e_m[4], e_b[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int c = cout0 + rr + 8 * q + 4 * kh;
+      e_r1[rr] = e_r2[rr] = e_y[rr] = e_b[rr] = 0.f;
+      e_m[rr] = 1.f;
+      if (c >= d.Cout) continue;
+      const long co = (long)c * d.ysc + pix;
+      if (d.bias) e_b[rr] = d.bias[c];
+      if (d.r1 && c < d.r1_nch) e_r1[rr] = d.r1[(long)n * d.r1sn + co];
+      if (d.r2) e_r2[rr] = d.r2[(long)n * d.r2sn + co];
+      if (d.accumulate) e_y[rr] = d.y[(long)n * d.ysn + co];
+      if (d.mask && c >= d.mask_c0) e_m[rr] = d.mask[(long)n * d.masksn + co];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int c = cout0 + rr + 8 * q + 4 * kh;
+      if (c >= d.Cout) continue;
+      float v = (acc[4 * q + rr] + e_b[rr]) * d.s1 + d.r1s * e_r1[rr];
+      if (d.r2) v = d.s2 * v + e_r2[rr];
+      v += e_y[rr];
+      if (d.act) v = v >= 0.f ? v : d.slope * v;
+      v = e_m[rr] >= 0.f ? v : d.slope * v;
+      d.y[(long)n * d.ysn + (long)c * d.ysc + pix] = v;
+    }
+  }
+}
+
+template <int T, int WAVES, int NPB, bool ROW, bool NS = false>
 __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // WAVES * 1024 floats
   const int tid = threadIdx.x;
@@ -163,8 +199,11 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     }
   }
   const int plane = OHl * OWl;
-  if ((long)blockIdx.x * 32 >= (long)d.N * plane) return;  // a phase with fewer positions than the launch's widest one
-  const long P = (long)blockIdx.x * 32 + j;
+  // no-split form (large grids): every wavefront owns a position tile of its own over the WHOLE K
+  constexpr bool ns = NS;  // (its own instantiation: the register-resident epilogue must not cost the split forms their occupancy)
+  const long ptile = ns ? (long)blockIdx.x * WAVES + wave : (long)blockIdx.x;
+  if (ptile * 32 >= (long)d.N * plane) return;  // a phase with fewer positions than the launch's widest one / ragged last workgroup
+  const long P = ptile * 32 + j;
   const bool pv = P < (long)d.N * plane;
   int n = 0, a = 0, b = 0;
   if (pv) {  // P < 2^31 (checked by the launcher): multiply-high estimates are at most one short
@@ -180,8 +219,8 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
   }
   const int cout0 = blockIdx.y * (NPB == -4 ? 64 : 32);
   const unsigned tile = ((unsigned)ph * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;  // split-K: partial-tile slot
-  const int cpw = d.Cin / ks / WAVES;                                // input channels per wavefront (even)
-  const int c0 = kz * (d.Cin / ks) + wave * cpw + kh;                // first input channel of this lane
+  const int cpw = ns ? d.Cin : d.Cin / ks / WAVES;                   // input channels per wavefront (even)
+  const int c0 = ns ? kh : kz * (d.Cin / ks) + wave * cpw + kh;      // first input channel of this lane
   const int Hl = d.Hin << d.ups, Wl = d.Win << d.ups;
   const float* xn = d.x + (long)n * d.xsn + (long)c0 * d.xsc;
   const float* wlane = wp + (long)c0 * d.CoutP + cout0 + j;
@@ -270,18 +309,51 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     const long wt = (long)groups * 2 * d.CoutP;   // bf16x8 units between taps
     const long wgs = 2L * d.CoutP;                // ... between channel groups
     const long xgs = 16L * d.xsc;
+    if constexpr (ROW) {
+      // 3x3 unit-stride layers (the trunk of an inference crop): a kernel row's three taps are ONE 12-byte load per
+      // channel, as in the fp32 row form -- 24 gathers + 9 weight loads per sixteen channels instead of 72 + 9 -- and a
+      // whole channel group's requests are in flight before its nine MFMAs (the gathers, not the 32-cycle bf16 MFMAs,
+      // bound this kernel: 63 -> ~30 us per trunk layer of a 288 x 288 crop).
+      for (int g = ns ? 0 : wave; g < groups; g += ns ? 1 : WAVES) {
+        const float* xc = xb + g * xgs;
+        f32x3 bx[3][8];
+        bf16x8 aw[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) bx[r][i] = *reinterpret_cast<const f32x3*>(xc + (long)i * d.xsc + roff[r]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) aw[t] = wb[g * wgs + t * wt];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int r = t / 3, k = t % 3;
+          const bool ok = (okmask >> t) & 1u;
+          bf16x8 bv;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const f32x3& v = bx[r][i];
+            const float e = k == 1 ? v.y : ((k == 0) != rev ? v.x : v.z);
+            bv[i] = (__bf16)(ok ? e : 0.f);
+          }
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[t], bv, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
     // out-of-image taps read element 0 of the plane (always valid memory) and are zeroed after the load: no
     // conditional loads in the loop; one (group, tap) step of software pipelining
     float br[8], bn[8];
     bf16x8 an;
-    int g = wave;
+    const int gstep = ns ? 1 : WAVES;
+    int g = ns ? 0 : wave;
     if (g < groups) {
       const float* xc = xb + g * xgs;
 #pragma unroll
       for (int i = 0; i < 8; ++i) bn[i] = xc[(long)i * d.xsc + xoff[0]];
       an = wb[g * wgs];
     }
-    for (; g < groups; g += WAVES) {
+    for (; g < groups; g += gstep) {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const bf16x8 av = an;
@@ -290,7 +362,7 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
         // request the next step: tap t + 1 of this group, or tap 0 of this wavefront's next group
         {
           const bool last = (t == T - 1);
-          const int gn = last ? g + WAVES : g;
+          const int gn = last ? g + gstep : g;
           const int tn = last ? 0 : t + 1;
           if (gn < groups) {
             const float* xq = xb + gn * xgs + xoff[tn];
@@ -305,6 +377,7 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
         for (int i = 0; i < 8; ++i) bv[i] = (__bf16)(ok ? br[i] : 0.f);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
       }
+    }
     }
   } else if constexpr (NPB == -4) {
     // TWO output-channel tiles per wavefront (layers with >= 64 output channels): the gathered B operand -- what the
@@ -412,7 +485,10 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     }
   }
 
-  if constexpr (NPB == -4) {  // two output tiles: partial-tile slots 2 tile, 2 tile + 1
+  if constexpr (NS) {
+    igemm_epilogue_ns(d, acc, kh, pv, n, a, b, cout0, oy0, ox0);
+    if constexpr (NPB == -4) igemm_epilogue_ns(d, acc2, kh, pv, n, a, b, cout0 + 32, oy0, ox0);
+  } else if constexpr (NPB == -4) {  // two output tiles: partial-tile slots 2 tile, 2 tile + 1
     igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, 2 * tile, oy0, ox0);
     __syncthreads();  // the first tile's partial sums (and the arrival word) have been read
     igemm_epilogue<WAVES>(d, red, acc2, tid, wave, j, kh, pv, n, a, b, cout0 + 32, ks, kz, 2 * tile + 1, oy0, ox0);
@@ -488,13 +564,24 @@ constexpr int IGEMM_NPB = 6;  // channel pairs a wavefront may hold entirely in 
 
 template <int T, int WAVES, bool ROW>
 static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s, bool mt2) {
-  if constexpr (!ROW) {
-    if (d.wp16) {
-      hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -2, false>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
+  if (d.wp16) {
+    if constexpr (!ROW || T == 9) {
+      if constexpr (WAVES == 4) {
+        if (d.nosplit) {
+          hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -2, ROW, true>), grid, dim3(64 * WAVES), 0, s, d);
+          return;
+        }
+      }
+      hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -2, ROW>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
       return;
     }
   }
   if constexpr (WAVES == 4) {
+    if (d.nosplit) {  // (decided by the launcher: large grids, no cross-workgroup split)
+      if (mt2) hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -4, ROW, true>), grid, dim3(64 * WAVES), 0, s, d);
+      else hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, 0, ROW, true>), grid, dim3(64 * WAVES), 0, s, d);
+      return;
+    }
     if (mt2) {  // two output tiles per wavefront: grid.y counts 64-channel groups
       hipLaunchKernelGGL((igemm_conv_kernel<T, WAVES, -4, ROW>), grid, dim3(64 * WAVES), WAVES * 4096, s, d);
       return;
@@ -524,7 +611,8 @@ static void launch_tw(const ConvDesc& d, dim3 grid, hipStream_t s, bool mt2) {
     const bool row = d.sin == 1 && d.ups == 0 && d.dy[0] == d.dy[1] && d.dy[1] == d.dy[2] && d.dx[1] == 0 &&
                      d.dx[0] == -d.dx[2] && (d.dx[0] == 1 || d.dx[0] == -1) && d.dy[3] == d.dy[5] && d.dy[6] == d.dy[8] &&
                      d.dx[3] == d.dx[0] && d.dx[6] == d.dx[0] && d.dx[4] == 0 && d.dx[7] == 0;
-    if (row && !d.wp16) {
+    static const int bf16_row = getenv("DBM_BF16_ROW") ? atoi(getenv("DBM_BF16_ROW")) : 1;
+    if (row && (!d.wp16 || bf16_row)) {
       launch_twr<T, WAVES, true>(d, grid, s, mt2);
       return;
     }
@@ -622,6 +710,18 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
     }
   }
   if (mt2 && waves != 4) { mt2 = false; grid.y *= 2; }
+  // bf16 inference on large grids (>= 2048 position tiles: the crops of the area sweep): no split-K at all -- each of a
+  // workgroup's four wavefronts owns a position tile of its own over the whole K; no LDS reduction, no barrier, the
+  // accumulators go out from the registers.  (With sixteen channels per 32-cycle MFMA a K slice is a handful of
+  // instructions and the cross-wavefront reduction costs more than it spreads: 14.2 -> 13.2 ms per 288 x 288 crop.  The
+  // fp32 layers keep the split: 88 vs 93-100 us on the 36 x 36 layers, 22.0 vs 25.4 ms per fp32 crop -- DBM_IGEMM_NOSPLIT_F32=1.)
+  static const int ns_tiles = getenv("DBM_IGEMM_NOSPLIT") ? atoi(getenv("DBM_IGEMM_NOSPLIT")) : 2048;
+  static const int ns_f32 = getenv("DBM_IGEMM_NOSPLIT_F32") ? atoi(getenv("DBM_IGEMM_NOSPLIT_F32")) : 0;
+  d.nosplit = 0;
+  if (ns_tiles > 0 && (d.wp16 || ns_f32) && d.ksplit <= 1 && waves == 4 && (long)grid.x >= ns_tiles) {
+    d.nosplit = 1;
+    grid.x = (grid.x + 3) / 4;
+  }
   if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * flop_positions * d.Cout * d.Cin * d.T);
   switch (d.T) {
     case 1: launch_t<1>(d, grid, waves, s, mt2); break;
