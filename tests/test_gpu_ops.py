@@ -127,12 +127,15 @@ def test_conv2d_backward(dbm, case):
         assert rel(gx.get(), gx_ref) < TOL
 
 
-@pytest.mark.parametrize("O,scale", [(64, 0.3), (1, 0.3), (64, 3.0), (1, 3.0)])
-def test_deform_conv_forward_backward(dbm, O, scale):
+@pytest.mark.parametrize("O,scale,shape", [(64, 0.3, (2, 12, 10)), (1, 0.3, (2, 12, 10)), (64, 3.0, (2, 12, 10)), (1, 3.0, (2, 12, 10)),
+                                           # the model's own plane: 3 x 1296 positions = 60.75 tiles of the fused kernels (ragged
+                                           # last workgroup, tiles straddling images), CSR lists of a full 36 x 36 plane
+                                           (64, 1.0, (3, 36, 36)), (1, 1.0, (3, 36, 36))])
+def test_deform_conv_forward_backward(dbm, O, scale, shape):
     """final_conv_layer1 (64->64) and final_conv_layer2 (64->1); scale 3.0 drives samples out of the image
     so that the border clipping and the coordinate-gradient masks are exercised."""
     d, _lib, ctx = dbm
-    N, Cc, H, W = 2, 64, 12, 10
+    (N, H, W), Cc = shape, 64
     rs = np.random.RandomState(int(scale * 10) + O)
     x = rs.normal(size=(N, Cc, H, W)).astype(np.float32)
     off = rs.normal(scale=scale, size=(N, 18, H, W)).astype(np.float32)
