@@ -883,3 +883,40 @@ def test_fused_iteration_equals_the_two_step_calls(dbm):
         assert np.array_equal(v, runs[1][1][k]), k
     for k, v in runs[0][2].items():
         assert np.array_equal(v, runs[1][2][k]), k
+
+
+def test_profiler_brackets_in_step_and_standalone(dbm):
+    """bench.py's roofline leg: hipEvent brackets around the launches of the MFMA kernel families, in the running step
+    (dbm_profile_begin) and with the device synchronised around every launch (dbm_profile_begin_serial: standalone
+    durations).  Both report the same launches and the same algorithmic FLOP; the instrumented steps compute what an
+    uninstrumented one computes."""
+    import ctypes as C
+    lib = dbm._lib.lib()
+    ctx = dbm._lib.default_context()
+    arrays = dbm.device_batch(fixture_arrays(n=4))
+    og = scaled_oracle_generator(1, 3.0)
+    od = omodel.DiscriminatorModel(seed=5)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=1, initialize=False), og.params)
+    d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+    g_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(g)
+    d_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(d)
+    ref = [dbm.train_minibatch(arrays, g, g_opt, d, d_opt) for _ in range(3)]
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=1, initialize=False), og.params)
+    d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+    g_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(g)
+    d_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(d)
+    got, prof = [], []
+    for begin in (None, lib.dbm_profile_begin, lib.dbm_profile_begin_serial):
+        out = (C.c_double * 12)()
+        if begin is not None:
+            dbm._lib.check(begin(ctx.handle), ctx.handle)
+        got.append(dbm.train_minibatch(arrays, g, g_opt, d, d_opt))
+        if begin is not None:
+            dbm._lib.check(lib.dbm_profile_end_ex(ctx.handle, out, 4), ctx.handle)
+            prof.append(list(out))
+    assert got == ref                       # bitwise: the brackets (and the host synchronisation) change nothing
+    step, alone = prof
+    for fam in range(2):                    # per-layer convolutions, weight gradients (the 1-RRDB trunk here is 9x9: fused too)
+        ms, flop, n = step[3 * fam:3 * fam + 3]
+        ms_s, flop_s, n_s = alone[3 * fam:3 * fam + 3]
+        assert n > 0 and n == n_s and flop == flop_s and ms > 0 and ms_s > 0
