@@ -911,7 +911,8 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
   } comm_scope(c, (train & 1) && !(train & 16) && c->comm_active());
   train &= 1;
   // Opt-in: the generator and its inputs are unchanged since the D-step of this iteration, so that step's forward
-  // (bitwise the same numbers) is reused instead of recomputed.  Off by default: the reference runs it twice.
+  // (the same numbers: it is the retained form of the pass) is reused instead of recomputed.  Off by default: the
+  // reference runs it twice.
   const bool reuse = share && train && g->have_graph && g->wsTrain && g->graph_version == g->param_version &&
                      g->graph_epoch == c->data_epoch && g->wsN == N && g->wsH == H && g->wsW == W && g->graph_in[0] == X && g->graph_in[1] == W1 &&
                      g->graph_in[2] == W2 && g->graph_in[3] == W3;

@@ -391,10 +391,16 @@ def test_config3_full_batch_permutation_invariance(dbm):
         out.append((m, gd, gg))
     (m0, gd0, gg0), (m1, gd1, gg1) = out
     assert np.allclose(m0, m1, rtol=2e-5, atol=1e-6), (m0, m1)
+    # A gradient tensor normally moves by < 1e-4 of its largest entry.  The discriminator at its initial weights is
+    # ill-conditioned, though: when one pre-activation lies within rounding of zero, the permuted BatchNorm sums flip
+    # its LeakyReLU slope and the early layers' bias / beta gradients move by some 1e-3 (measured over four weight
+    # seeds: 2e-5, 2e-6, 2e-5 and -- one flip -- 6.5e-3 in conv_layer0/b, batch_norm1/beta, batch_norm2/beta).
+    # So: every tensor within 2e-2, and at least 80 % of the tensors of each model within 1e-3.
     for a, b in ((gd0, gd1), (gg0, gg1)):
         gmax = max(float(np.abs(v).max()) for v in a.values())
-        for k in a:
-            assert np.abs(a[k] - b[k]).max() <= 1e-3 * max(float(np.abs(a[k]).max()), 1e-3 * gmax), k
+        dev = {k: float(np.abs(a[k] - b[k]).max()) / max(float(np.abs(a[k]).max()), 1e-3 * gmax) for k in a}
+        assert gmax > 0 and max(dev.values()) <= 2e-2, max(dev.items(), key=lambda kv: kv[1])
+        assert sum(v <= 1e-3 for v in dev.values()) >= 0.8 * len(dev), sorted(dev.items(), key=lambda kv: -kv[1])[:8]
 
 
 def test_cudnn_deterministic_training_is_bitwise_reproducible(dbm):
@@ -590,9 +596,14 @@ def test_shared_generator_forward_is_equivalent(dbm, mode):
             kw = {mode: share} if mode == "share_generator_forward" else {}
             out += list(dbm.train_eval_generator(arrays, g, d, g_opt, **kw))
         results.append(out)
-    # cudnn_deterministic = True (the default): the scheduling variants run the same arithmetic in the same order, so
-    # every loss, accuracy and metric of both iterations is bitwise the one of the plain sequential path
-    assert results[0] == results[1]
+    # cudnn_deterministic = True (the default): the prefetch variants run the same arithmetic in the same order, so
+    # every loss, accuracy and metric of both iterations is bitwise the one of the plain sequential path.  The shared
+    # forward is the RETAINED pass; the D-step's own pass keeps nothing and runs the trunk with a helper workgroup per
+    # image, whose conv_layer5 sums its input channels in another order: same numbers up to fp32 rounding.
+    if mode == "share_generator_forward":
+        assert np.allclose(results[0], results[1], rtol=2e-5, atol=1e-7), (results[0], results[1])
+    else:
+        assert results[0] == results[1]
 
 
 # ---- the persistent RRDB-trunk kernels (trunk_fused.hip / trunk_fused_bwd.hip: 9x9 planes only) ----
@@ -605,6 +616,9 @@ def test_fused_trunk_forward_backward_parity(dbm, n_blocks, n, rs):
     g = copy_params(dbm.GeneratorModel(num_residual_blocks=n_blocks, residual_scaling=rs, initialize=False), og.params)
     ins = tile_inputs(n, 11)
     ref = og.forward(*ins, keep=True)
+    with dbm.using_config("enable_backprop", False):  # nothing retained: the pass with a helper workgroup per image
+        y0 = g.forward(*ins)
+    assert rel(y0.array, ref) < TOL
     y = g.forward(*ins)
     assert rel(y.array, ref) < TOL
     gy = np.random.RandomState(3).normal(size=ref.shape).astype(np.float32)
@@ -638,21 +652,29 @@ np.savez(sys.argv[2], y0=np.asarray(y0), y=np.asarray(y.array), grads=grads)
 
 def test_fused_trunk_matches_layerwise_path(dbm, tmp_path):
     """The same forward / backward with DBM_TRUNK_FUSED=0 (one launch per layer) in a second process: the two paths
-    only differ in summation order.  70 tiles: more than one 64-image launch of the persistent kernels."""
+    only differ in summation order.  70 tiles: more than one 64-image launch of the persistent kernels.  Every form of the
+    forward kernel: the default (a helper workgroup per image in passes that keep nothing), helpers in retained passes
+    too, no helpers, and tiles of 32 consecutive positions across rows and images."""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "ab.py"
     script.write_text(_FUSED_AB_SCRIPT)
+    variants = {"layerwise": {"DBM_TRUNK_FUSED": "0"}, "default": {}, "helpers_everywhere": {"DBM_TRUNK_HELPER": "3"},
+                "no_helpers": {"DBM_TRUNK_HELPER": "0"}, "flat_tiles": {"DBM_TRUNK_TP": "32"}}
     outs = {}
-    for fused in ("1", "0"):
-        env = dict(os.environ, DBM_TRUNK_FUSED=fused)
-        out = str(tmp_path / f"o{fused}.npz")
+    for name, extra in variants.items():
+        env = {k: v for k, v in os.environ.items() if not k.startswith("DBM_TRUNK_")}
+        env.update(extra)
+        out = str(tmp_path / f"o_{name}.npz")
         subprocess.run([sys.executable, str(script), root, out, "70"], check=True, env=env, timeout=600)
-        outs[fused] = np.load(out)
-    for k in ("y0", "y", "grads"):
-        assert rel(outs["1"][k], outs["0"][k]) < 2e-5, k
+        outs[name] = np.load(out)
+    for name in variants:
+        if name == "layerwise":
+            continue
+        for k in ("y0", "y", "grads"):
+            assert rel(outs[name][k], outs["layerwise"][k]) < 2e-5, (name, k)
 
 
 def test_device_resident_dataset_gather_and_epoch(dbm):
