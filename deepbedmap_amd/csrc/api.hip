@@ -162,6 +162,7 @@ int dbm_shutdown(dbm_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->ev_iter)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->ev_persist) (void)hipEventDestroy(ctx->ev_persist);
   if (ctx->ev_comm) (void)hipEventDestroy(ctx->ev_comm);
   if (ctx->ev_comm_done) (void)hipEventDestroy(ctx->ev_comm_done);
   ctx->loss_tmp.release();

@@ -288,7 +288,9 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       L.nrdb = nrdb; L.nimg = std::min(IMGS, N - i0); L.img0 = i0; L.epoch = ++tf_epoch;
       L.rs = rs; L.slope = SLOPE;
       if (src->ev_pack[1]) DBM_HIP(hipStreamWaitEvent(s, src->ev_pack[1], 0));  // the weight streams (pack_extra)
+      ctx->persist_begin(s);
       launch_trunk_fused(L, s);
+      ctx->persist_end(s);
     }
   }
   if (!fused) (owner ? owner : this)->ensure_packed_lazy();
@@ -544,7 +546,9 @@ void Generator::backward(const float* gy) {
           L.nrdb = nrdb; L.j0 = jlo; L.j1 = j + 1; L.nimg = std::min(IMGS, N - i0); L.img0 = i0; L.epoch = ++tf_epoch;
           L.rs = rs; L.slope = SLOPE;
           if (src->ev_pack[2]) DBM_HIP(hipStreamWaitEvent(s, src->ev_pack[2], 0));
+          ctx->persist_begin(s);
           launch_trunk_fused_bwd(L, s);
+          ctx->persist_end(s);
         }
         prev = grp;
         prev_lo = jlo; prev_hi = j + 1;

@@ -42,6 +42,13 @@ struct dbm_ctx {
   hipEvent_t ev_comm = nullptr, ev_comm_done = nullptr;
   hipEvent_t ev_timer[2] = {nullptr, nullptr};  // dbm_timer
   hipEvent_t ev_iter[2] = {nullptr, nullptr};   // dbm_train_iteration: loss scratch cleared / generator backward done
+  // The persistent trunk kernels need every workgroup of a launch resident at once: two of them on different streams, each
+  // holding part of the chip, would wait for each other's compute units until their spin limits.  Every persistent launch
+  // therefore waits for the previous one (whatever its stream) and leaves its own completion here.
+  hipEvent_t ev_persist = nullptr;
+  bool persist_pending = false;
+  void persist_begin(hipStream_t s);
+  void persist_end(hipStream_t s);
   size_t comm_bytes = 0, comm_calls = 0;  // statistics (dbm_comm_stats)
   bool comm_active() const { return comm_world > 1 && (nccl_comm != nullptr || comm_hook != nullptr); }
   void comm_init(int rank, int world, const void* id128);

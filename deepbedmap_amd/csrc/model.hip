@@ -25,6 +25,15 @@ void dbm_ctx::fork_to_side(int k) {
   DBM_HIP(hipStreamWaitEvent(side, ev_fork[k & 7], 0));
 }
 
+void dbm_ctx::persist_begin(hipStream_t s) {
+  if (persist_pending) DBM_HIP(hipStreamWaitEvent(s, ev_persist, 0));
+}
+void dbm_ctx::persist_end(hipStream_t s) {
+  if (!ev_persist) DBM_HIP(hipEventCreateWithFlags(&ev_persist, hipEventDisableTiming));
+  DBM_HIP(hipEventRecord(ev_persist, s));
+  persist_pending = true;
+}
+
 void dbm_ctx::fork(hipStream_t from, hipStream_t to, int k) {
   DBM_HIP(hipEventRecord(ev_fork[k & 7], from));
   DBM_HIP(hipStreamWaitEvent(to, ev_fork[k & 7], 0));
