@@ -310,20 +310,23 @@ def main():
                       "collectives_per_step": cc.value / max(args.steps + args.warmup, 1)}
 
     # ---- roofline leg (outside the timed region): hipEvent-bracketed launches of the dominant kernel ----
-    prof = (C.c_double * 12)()
+    prof = (C.c_double * 15)()
     assert metrics_rows is None or (len(metrics_rows) == args.steps + args.warmup and np.isfinite(metrics_rows[:, :5]).all())
     dbm._lib.check(lib.dbm_profile_begin(ctx.handle), ctx.handle)
     step()
-    dbm._lib.check(lib.dbm_profile_end_ex(ctx.handle, prof, 4), ctx.handle)
-    prof_s = (C.c_double * 12)()   # the same brackets with the device synchronised around each launch: standalone durations
+    dbm._lib.check(lib.dbm_profile_end_ex(ctx.handle, prof, 5), ctx.handle)
+    prof_s = (C.c_double * 15)()   # the same brackets with the device synchronised around each launch: standalone durations
     dbm._lib.check(lib.dbm_profile_begin_serial(ctx.handle), ctx.handle)
     step()
-    dbm._lib.check(lib.dbm_profile_end_ex(ctx.handle, prof_s, 4), ctx.handle)
+    dbm._lib.check(lib.dbm_profile_end_ex(ctx.handle, prof_s, 5), ctx.handle)
     FAMILIES = [
         ("igemm_conv_kernel + the fused deformable-convolution GEMMs (per-layer conv forward + data gradient, v_mfma_f32_32x32x2_f32)", "igemm_conv_kernel"),
         ("weight gradients (wgrad_wave_dma_kernel, wgrad_band_dma_kernel, wgrad_kernel)", "wgrad_kernel"),
-        ("trunk_fused_kernel (RRDB trunk forward, one persistent launch, v_mfma_f32_32x32x2_f32)", "trunk_fused_kernel"),
+        ("trunk_fused_kernel (RRDB trunk forward of a retained pass, one persistent launch on 192 CUs, v_mfma_f32_32x32x2_f32)",
+         "trunk_fused_kernel"),
         ("trunk_fused_bwd_kernel (RRDB trunk data-gradient chain, persistent, v_mfma_f32_16x16x4_f32)", "trunk_fused_bwd_kernel"),
+        ("trunk_fused_kernel, helper form (RRDB trunk forward of a pass that keeps nothing -- the D-step's fakes, inference: a fourth "
+         "workgroup per image takes half of conv_layer5, 256 CUs)", "trunk_fused_kernel"),
     ]
     fam = []
     for i, (label, key) in enumerate(FAMILIES):
@@ -379,7 +382,13 @@ def main():
                 "algorithmic_gflop_per_launch": dom["algorithmic_gflop_per_launch"],
                 "other_kernels": [{k: f[k] for k in ("kernel", "achieved", "achieved_standalone", "ms_per_step", "standalone_ms_per_step",
                                                      "launches_per_step", "avg_launch_us")}
-                                  for f in fam if f is not dom],
+                                  for f in fam if f is not dom and f["launches_per_step"] > 0],
+                # SURVEY 8d's second figure: the RRDB trunk forward of one 64-tile batch against the fp32 MFMA roof (target
+                # >= 0.50 = 1.14 ms), standalone, in the form a forward-only pass runs
+                "rrdb_forward": (lambda f: {"ms_per_batch": f["standalone_ms_per_step"] / max(f["launches_per_step"], 1),
+                                            "achieved_standalone": f["achieved_standalone"],
+                                            "frac_standalone": f["achieved_standalone"] / PEAK_FP32_MFMA_TFLOPS,
+                                            "form": f["kernel"]})(fam[4] if fam[4]["launches_per_step"] > 0 else fam[2]),
             },
         }
         try:  # HBM bytes per launch of the dominant kernel: PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, from the committed pass

@@ -290,7 +290,7 @@ int dbm_profile_end(dbm_ctx* ctx, double out[8]) {
 
 int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam) {
   DBM_API_BEGIN(ctx)
-  DBM_CHECK(out != nullptr && nfam >= 1 && nfam <= 4, "dbm_profile_end_ex: nfam must be 1..4");
+  DBM_CHECK(out != nullptr && nfam >= 1 && nfam <= 5, "dbm_profile_end_ex: nfam must be 1..5");
   g_profiler.enabled = false;
   g_profiler.serial = false;
   DBM_HIP(hipStreamSynchronize(ctx->stream));

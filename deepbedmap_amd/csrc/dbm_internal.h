@@ -98,7 +98,7 @@ void launch_igemm_conv(const ConvDesc& d, hipStream_t s);
 
 // Per-kernel-family timing with HIP events on the launch stream (bench.py's roofline leg).
 // family 0 = igemm_conv_kernel (forward + data gradient), 1 = weight-gradient kernels, 2 = trunk_fused_kernel,
-// 3 = trunk_fused_bwd_kernel.
+// 3 = trunk_fused_bwd_kernel, 4 = trunk_fused_kernel with a helper workgroup per image (counted as 2 when four are asked for).
 struct KernelProfiler {
   bool enabled = false;
   bool serial = false;   // dbm_profile_begin_serial: the host synchronises the device around every bracketed launch

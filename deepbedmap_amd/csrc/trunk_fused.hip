@@ -715,7 +715,7 @@ void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
   a.off_hb = (unsigned)(3 * L.nimg * 2 * 2 * 64 * HS);
   a.off_bh = a.off_hb + (unsigned)(L.nimg * 2 * 5 * 32 * 81);
   const double flop = 2.0 * 19408896.0 * L.nrdb * L.nimg;  // 19 408 896 MAC per dense block and tile
-  if (g_profiler.enabled) g_profiler.begin(s, 2, flop);
+  if (g_profiler.enabled) g_profiler.begin(s, helper ? 4 : 2, flop);
   if (helper)
     hipLaunchKernelGGL((trunk_fused_kernel<27, true>), dim3(32 * ((L.nimg + 7) / 8)), dim3(NTHREADS), LDS_HELPER, s, a);
   else if (TP == 27)

@@ -86,8 +86,10 @@ int dbm_comm_stats(dbm_ctx* ctx, int* world, size_t* bytes, size_t* calls, int r
  * gradient), then the same three for wgrad_kernel. */
 int dbm_profile_begin(dbm_ctx* ctx);
 int dbm_profile_end(dbm_ctx* ctx, double out[8]);
-/* the same for nfam <= 4 kernel families, three values each: igemm_conv_kernel, the weight-gradient kernels,
- * trunk_fused_kernel (RRDB trunk forward, srgan_train.py:546), trunk_fused_bwd_kernel (its data-gradient chain) */
+/* the same for nfam <= 5 kernel families, three values each: igemm_conv_kernel, the weight-gradient kernels,
+ * trunk_fused_kernel (RRDB trunk forward, srgan_train.py:546), trunk_fused_bwd_kernel (its data-gradient chain),
+ * trunk_fused_kernel in the form with a helper workgroup per image (passes that keep nothing; nfam <= 4: counted with the
+ * third family) */
 int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam);
 /* the same brackets with the device synchronised before and after every bracketed launch: STANDALONE launch durations
  * (inside a training step up to four streams share the chip and every bracket also contains the neighbours' work).
