@@ -215,6 +215,15 @@ static void build_pack_table(const dbm_model& m, bool want_lazy, PackJob** d_job
 
 void dbm_model::ensure_packed(hipStream_t on) {
   if (!packed_dirty) return;
+  static const int abl_nopack = getenv("DBM_ABL_NOPACK") ? atoi(getenv("DBM_ABL_NOPACK")) : 0;  // measurement aid (results wrong)
+  if (pack_tables_built && type == 1 && (abl_nopack & 1)) { packed_dirty = false; return; }
+  if (pack_tables_built && type == 0 && (abl_nopack & 6)) {
+    hipStream_t s2 = on ? on : ctx->stream;
+    if (!(abl_nopack & 2) && n_pack_jobs) launch_pack_jobs(d_pack_jobs, n_pack_jobs, n_pack_blocks, s2);
+    if (!(abl_nopack & 4)) pack_extra(s2);
+    packed_dirty = false;
+    return;
+  }
   hipStream_t s = on ? on : ctx->stream;
   if (!pack_tables_built) {  // the job tables only depend on the layer list: build and upload them once
     build_pack_table(*this, false, &d_pack_jobs, &n_pack_jobs, &n_pack_blocks);

@@ -635,29 +635,36 @@ __global__ __launch_bounds__(512) void trunk_fused_kernel(Args a) {
   }
 }
 
-// dst-driven gather of the trunk's weights into the per-wavefront streams (one launch per optimizer step)
-__global__ void pack_trunk_fused_kernel(const float* const* wsrc, const float* const* bsrc, float* wstream, float* bstream,
-                                        int nrdb) {
-  const long total = (long)nrdb * NWAVE * WAVE_RDB;
-  for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
-    const int w = (int)(f / ((long)nrdb * WAVE_RDB));
-    const int j = (int)((f / WAVE_RDB) % nrdb);
-    const int x0 = (int)(f % WAVE_RDB);
-    const int bidx = x0 / UNIT, x = x0 % UNIT;
+// The trunk's weights into the per-wavefront streams (one launch per optimizer step).  One wavefront per (unit, tile) block:
+// a lane's eighteen values are two runs of nine consecutive floats of the OIHW tensor (its output channel, input channels
+// 2 ks + (lane >> 5) of the quad, all taps), written as the four 16-byte + one 8-byte pieces issue_loads reads back -- no
+// LDS, no per-element index arithmetic (the element-wise gather this replaces: 47 us, 1.4 TB/s).
+__global__ __launch_bounds__(256) void pack_trunk_fused_kernel(const float* const* wsrc, const float* const* bsrc, float* wstream,
+                                                               float* bstream, int nrdb) {
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);       // (wavefront w, dense block j, block bidx)
+  const int ntask = nrdb * NWAVE * 26;
+  if (task < ntask) {
+    const int w = task / (nrdb * 26), j = (task / 26) % nrdb, bidx = task % 26;
     int K, u, mt = 0;
     if (bidx < 2) { K = 0; u = bidx; }
     else if (bidx < 5) { K = 1; u = bidx - 2; }
     else if (bidx < 9) { K = 2; u = bidx - 5; }
     else if (bidx < 14) { K = 3; u = bidx - 9; }
     else { K = 4; u = (bidx - 14) / 2; mt = (bidx - 14) % 2; }
-    int lane, i;
-    if (x < 1024) { lane = (x % 256) / 4; i = 4 * (x / 256) + x % 4; }
-    else { lane = (x - 1024) / 2; i = 16 + (x - 1024) % 2; }
-    const int tap = i / 2, ks = i % 2;
-    const int cin = 4 * (w + 8 * u) + 2 * ks + (lane >> 5);
-    const int cout = mt * 32 + (lane & 31);
     const int Cin = 64 + 32 * K;
-    wstream[f] = wsrc[j * 5 + K][((long)cout * Cin + cin) * 9 + tap];
+    const int cout = mt * 32 + (lane & 31);
+    const float* src = wsrc[j * 5 + K] + ((long)cout * Cin + 4 * (w + 8 * u) + (lane >> 5)) * 9;
+    float A[18];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) A[tap * 2 + ks] = src[ks * 18 + tap];
+    float* dst = wstream + ((size_t)w * nrdb + j) * WAVE_RDB + (size_t)bidx * UNIT;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      *reinterpret_cast<f4v*>(dst + c * 256 + lane * 4) = (f4v){A[4 * c], A[4 * c + 1], A[4 * c + 2], A[4 * c + 3]};
+    *reinterpret_cast<f2v*>(dst + 1024 + lane * 2) = (f2v){A[16], A[17]};
   }
   const long nb = (long)nrdb * 192;
   for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < nb; f += (long)gridDim.x * blockDim.x) {
@@ -677,7 +684,7 @@ size_t trunk_fused_inbox_bytes(int nimg) {
 
 void launch_pack_trunk_fused(const float* const* d_wsrc, const float* const* d_bsrc, float* wstream, float* bstream, int nrdb,
                              hipStream_t s) {
-  hipLaunchKernelGGL(pack_trunk_fused_kernel, dim3(1024), dim3(256), 0, s, d_wsrc, d_bsrc, wstream, bstream, nrdb);
+  hipLaunchKernelGGL(pack_trunk_fused_kernel, dim3((nrdb * NWAVE * 26 + 3) / 4), dim3(256), 0, s, d_wsrc, d_bsrc, wstream, bstream, nrdb);
   DBM_HIP(hipGetLastError());
 }
 

@@ -358,34 +358,41 @@ struct PackTab {
   int cum[NPAIR][6];      // ... and where conv_layer5 .. conv_layer1 start inside them
   int nsub[NPAIR][5];
 };
-__global__ void pack_trunk_fused_bwd_kernel(const float* const* wsrc, float* wstream, int nrdb, PackTab tab) {
-  const long total = tab.base[NPAIR];
-  for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (long)gridDim.x * blockDim.x) {
-    int w = 0;  // pair index
+// One wavefront per weight unit: a lane's AU values are QU runs of nine consecutive floats of the OIHW tensor (its gradient
+// output channel = forward input channel, forward output channels 4 (QU u + q) + (lane >> 4), taps reversed), written as
+// the 16-byte pieces issue_unit reads back (the element-wise gather this replaces: 47 us).
+__global__ __launch_bounds__(256) void pack_trunk_fused_bwd_kernel(const float* const* wsrc, float* wstream, int nrdb, PackTab tab,
+                                                                   int total_units) {
+  static_assert(AU % 4 == 0, "unit pieces are 16 bytes");
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= total_units) return;
+  int w = 0;  // pair index: pair k's units start at tab.base[k] / BUNIT
 #pragma unroll
-    for (int k = 1; k < NPAIR; ++k) w += f >= tab.base[k] ? 1 : 0;
-    const long rem = f - tab.base[w];
-    const int upr = tab.upr[w];
-    const int rblk = (int)(rem / ((long)upr * BUNIT));     // dense blocks in processing order: j = nrdb - 1 - rblk
-    const int ui = (int)((rem / BUNIT) % upr);
-    const int x = (int)(rem % BUNIT);
-    const int j = nrdb - 1 - rblk;
-    // unit -> (layer, sub-tile s, unit u); the wavefront walks its sub-tiles from the highest channels down
-    int l = 0;
+  for (int k = 1; k < NPAIR; ++k) w += (long)task * BUNIT >= tab.base[k] ? 1 : 0;
+  const int rem = task - (int)(tab.base[w] / BUNIT);
+  const int upr = tab.upr[w];
+  const int rblk = rem / upr, ui = rem % upr;              // dense blocks in processing order: j = nrdb - 1 - rblk
+  const int j = nrdb - 1 - rblk;
+  // unit -> (layer, sub-tile s, unit u); the wavefront walks its sub-tiles from the highest channels down
+  int l = 0;
 #pragma unroll
-    for (int k = 1; k < 5; ++k) l += ui >= tab.cum[w][k] ? 1 : 0;
-    const int KL = 4 - l, nu = layer_units(l), ul = ui - tab.cum[w][l];
-    const int s = tab.nsub[w][l] - 1 - ul / nu, u = ul % nu;
-    int lane, i;
-    if (x < (AU / 4) * 256) { lane = (x % 256) / 4; i = 4 * (x / 256) + x % 4; }
-    else { lane = (x - (AU / 4) * 256) / 2; i = (AU / 4) * 4 + (x - (AU / 4) * 256) % 2; }
-    const int q = i / 9, tap = i % 9;
-    const int mt = w + (NWAVE / 2) * s;
-    const int ci = 16 * mt + (lane & 15);                   // forward input channel = gradient output channel
-    const int co = 4 * (QU * u + q) + (lane >> 4);          // forward output channel = K index
-    const int Cin = 64 + 32 * KL;
-    wstream[f] = wsrc[j * 5 + KL][((long)co * Cin + ci) * 9 + (8 - tap)];
-  }
+  for (int k = 1; k < 5; ++k) l += ui >= tab.cum[w][k] ? 1 : 0;
+  const int KL = 4 - l, nu = layer_units(l), ul = ui - tab.cum[w][l];
+  const int s = tab.nsub[w][l] - 1 - ul / nu, u = ul % nu;
+  const int mt = w + (NWAVE / 2) * s;
+  const int ci = 16 * mt + (lane & 15);                   // forward input channel = gradient output channel
+  const int Cin = 64 + 32 * KL;
+  const float* src = wsrc[j * 5 + KL] + ((long)(4 * QU * u + (lane >> 4)) * Cin + ci) * 9;
+  float A[AU];
+#pragma unroll
+  for (int q = 0; q < QU; ++q)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) A[q * 9 + tap] = src[(long)q * 4 * Cin * 9 + (8 - tap)];
+  float* dst = wstream + (size_t)task * BUNIT;
+#pragma unroll
+  for (int c = 0; c < AU / 4; ++c)
+    *reinterpret_cast<f4v*>(dst + c * 256 + lane * 4) = (f4v){A[4 * c], A[4 * c + 1], A[4 * c + 2], A[4 * c + 3]};
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -412,7 +419,8 @@ void launch_pack_trunk_fused_bwd(const float* const* d_wsrc, float* wstream, int
     base += (long)nrdb * tab.upr[q] * BUNIT;
   }
   tab.base[NPAIR] = base;
-  hipLaunchKernelGGL(pack_trunk_fused_bwd_kernel, dim3(2048), dim3(256), 0, s, d_wsrc, wstream, nrdb, tab);
+  const int total_units = (int)(base / BUNIT);
+  hipLaunchKernelGGL(pack_trunk_fused_bwd_kernel, dim3((total_units + 3) / 4), dim3(256), 0, s, d_wsrc, wstream, nrdb, tab, total_units);
   DBM_HIP(hipGetLastError());
 }
 
