@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void smallcin_conv_fwd_kernel(const SmallConvD
 }
 
 void launch_smallcin_conv_fwd(const SmallConvDesc& d, hipStream_t s) {
+  if (dbm_abl_skip() & 128) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
   DBM_CHECK(d.Cout % 8 == 0, "smallcin conv: Cout must be a multiple of 8");
   const long total = (long)d.N * d.OH * d.OW;
   dim3 grid((unsigned)((total + 63) / 64), (unsigned)((d.Cout + 31) / 32));
@@ -103,45 +104,58 @@ __global__ __launch_bounds__(256) void smallcin_conv_wgrad_kernel(const SmallCon
 // Few taps (Cin * KH * KW <= 9: conv_layer0 of the discriminator): a workgroup per (output channel, position slice) keeps
 // all nine sums and the bias sum in registers, so dy is read ONCE instead of ten times; the slices' partial sums go to
 // a scratch buffer and a second kernel adds them in slice order (reproducible like the kernel above; 249 -> ~30 us).
-constexpr int SCW_SLICES = 16;
+constexpr int SCW_SLICES = 64;
+constexpr int SCW_OG = 8;  // output channels per workgroup of the 3 x 3 form
 // K3 = true: the geometry is known at compile time (one input channel, 3 x 3, stride 1, pad 1 = conv_layer0): without it
-// every tap decodes (c, ky, kx) with runtime integer divisions -- ~600 VALU instructions per position against ten FMAs
-// (64 -> 17 us per launch).
+// every tap decodes (c, ky, kx) with runtime integer divisions -- ~600 VALU instructions per position against ten FMAs.
+// The 3 x 3 form also takes SCW_OG output channels per workgroup (blockIdx.x = channel group): a position's nine input
+// values are loaded once for all of them (the loads of x, not of dy, were the bulk of the instructions: 49 -> ~15 us).
 template <bool K3>
 __global__ __launch_bounds__(256) void smallcin_wgrad_partial_kernel(const SmallConvDesc d, const float* __restrict__ dy,
                                                                      long dysn, float* __restrict__ partial) {
-  __shared__ float sh[4][10];
+  constexpr int OG = K3 ? SCW_OG : 1;
+  __shared__ float sh[4][OG * 10];
   const int K = K3 ? 9 : d.Cin * d.KH * d.KW;  // <= 9
-  const int o = blockIdx.x, z = blockIdx.y;
+  const int o0 = blockIdx.x * OG, z = blockIdx.y;
   const int plane = d.OH * d.OW;
   const unsigned total = (unsigned)d.N * (unsigned)plane;
   const unsigned chunk = (total + SCW_SLICES - 1) / SCW_SLICES;
   const unsigned p0 = z * chunk, p1 = min(total, p0 + chunk);
   const unsigned planeM = 0xffffffffu / (unsigned)plane, owM = 0xffffffffu / (unsigned)d.OW;
-  float acc[10];
+  float acc[OG][10];
 #pragma unroll
-  for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+  for (int oo = 0; oo < OG; ++oo)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[oo][k] = 0.f;
   for (unsigned P = p0 + threadIdx.x; P < p1; P += 256) {
     unsigned n = __umulhi(P, planeM);
     unsigned r = P - n * (unsigned)plane;
     if (r >= (unsigned)plane) { ++n; r -= (unsigned)plane; }
-    const float g = dy[(long)n * dysn + (long)o * plane + r];
-    acc[9] += g;
     unsigned a = __umulhi(r, owM);
     unsigned b = r - a * (unsigned)d.OW;
     if (b >= (unsigned)d.OW) { ++a; b -= (unsigned)d.OW; }
     const float* xn = d.x + (long)n * d.xsn;
+    const float* dyp = dy + (long)n * dysn + (long)o0 * plane + r;
     if constexpr (K3) {
       const float* xc = xn + (int)a * d.Win + (int)b;
+      float xv[9];
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
           const int iy = (int)a - 1 + ky, ix = (int)b - 1 + kx;
-          if ((unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
-            acc[ky * 3 + kx] = fmaf(g, xc[(ky - 1) * d.Win + (kx - 1)], acc[ky * 3 + kx]);
+          xv[ky * 3 + kx] = ((unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win) ? xc[(ky - 1) * d.Win + (kx - 1)] : 0.f;
         }
+#pragma unroll
+      for (int oo = 0; oo < OG; ++oo) {
+        const float g = dyp[(long)oo * plane];
+        acc[oo][9] += g;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[oo][k] = fmaf(g, xv[k], acc[oo][k]);
+      }
     } else {
+      const float g = dyp[0];
+      acc[0][9] += g;
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
         if (k < K) {
@@ -149,21 +163,23 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_partial_kernel(const Small
           const int ky = kr / d.KW, kx = kr - ky * d.KW;
           const int iy = (int)a * d.stride - d.pad + ky, ix = (int)b * d.stride - d.pad + kx;
           if ((unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
-            acc[k] = fmaf(g, xn[(long)c * d.Hin * d.Win + (long)iy * d.Win + ix], acc[k]);
+            acc[0][k] = fmaf(g, xn[(long)c * d.Hin * d.Win + (long)iy * d.Win + ix], acc[0][k]);
         }
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 10; ++k) {
-    float v = acc[k];
-    for (int s2 = 32; s2 > 0; s2 >>= 1) v += __shfl_down(v, s2, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][k] = v;
-  }
+  for (int oo = 0; oo < OG; ++oo)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      float v = acc[oo][k];
+      for (int s2 = 32; s2 > 0; s2 >>= 1) v += __shfl_down(v, s2, 64);
+      if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][oo * 10 + k] = v;
+    }
   __syncthreads();
-  if (threadIdx.x < 10) {
-    const int k = threadIdx.x;
-    partial[((long)z * d.Cout + o) * 10 + k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
+  if (threadIdx.x < OG * 10) {
+    const int k = threadIdx.x;  // (channel oo = k / 10, sum k % 10)
+    partial[((long)z * d.Cout + o0) * 10 + k] = (sh[0][k] + sh[1][k]) + (sh[2][k] + sh[3][k]);
   }
 }
 
@@ -181,10 +197,11 @@ size_t smallcin_wgrad_scratch_floats(int Cout) { return (size_t)SCW_SLICES * Cou
 
 void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dysn, float* gW, float* gb,
                                 hipStream_t s, float* scratch) {
+  if (dbm_abl_skip() & 128) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
   const int K = d.Cin * d.KH * d.KW;
   if (scratch && K <= 9 && (long)d.N * d.OH * d.OW >= 16384) {
-    if (d.Cin == 1 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1)
-      hipLaunchKernelGGL(smallcin_wgrad_partial_kernel<true>, dim3(d.Cout, SCW_SLICES), dim3(256), 0, s, d, dy, dysn, scratch);
+    if (d.Cin == 1 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Cout % SCW_OG == 0)
+      hipLaunchKernelGGL(smallcin_wgrad_partial_kernel<true>, dim3(d.Cout / SCW_OG, SCW_SLICES), dim3(256), 0, s, d, dy, dysn, scratch);
     else
       hipLaunchKernelGGL(smallcin_wgrad_partial_kernel<false>, dim3(d.Cout, SCW_SLICES), dim3(256), 0, s, d, dy, dysn, scratch);
     hipLaunchKernelGGL(smallcin_wgrad_fold_kernel, dim3(d.Cout), dim3(64), 0, s, scratch, d.Cout, K, gW, gb);
@@ -220,6 +237,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
 
 void launch_im2col(const float* x, float* col, int N, int Cin, int Hin, int Win, int KH, int KW, int stride, int OH, int OW,
                    int KP, hipStream_t s) {
+  if (dbm_abl_skip() & 256) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
   const long total = (long)N * KP * OH * OW;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;

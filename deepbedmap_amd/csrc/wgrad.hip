@@ -1807,9 +1807,11 @@ void WgradBatch::launch(hipStream_t s) {
     else if (g == 8) launch_dma(wgrad_direct_kernel<2>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
     else launch_dma(wgrad_1x1_kernel, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
     if (fold_wgs[g]) {
-      if (pair_mode[g])
-        hipLaunchKernelGGL(wgrad_pair_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);
-      else
+      static const bool abl_fold = getenv("DBM_ABL_SKIP") && (atoi(getenv("DBM_ABL_SKIP")) & 8);  // measurement aid
+      if (pair_mode[g]) {
+        if (!abl_fold)
+          hipLaunchKernelGGL(wgrad_pair_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);
+      } else
         hipLaunchKernelGGL(wgrad_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);
       DBM_HIP(hipGetLastError());
     }
