@@ -453,9 +453,22 @@ __global__ __launch_bounds__(128, 2) void wgrad_wave_dma_kernel(const WgradPlan*
     WG_T(tB);
     WG_TACC(tS, tA, tB);
     if (d.gb && ct == 0) {  // bias gradient: lane (j, kh) sums every other position of dy plane j
-      float part = 0.f;
-      for (int pix = kh; pix < p.BP; pix += 2) part += ldsY[(pinfo[pix] & 0xffff) + j * plane];
-      bsum += part;
+      // (straight from the slab, eight independent reads in flight: the position table's dependent read per element made
+      // this loop a third of a band's time for the wavefront that owns it)
+      float part[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) part[u] = 0.f;
+      for (int ib = 0; ib < p.IB; ++ib) {
+        const float* yp = ldsY + ib * slab + j * plane;
+        const int first = (kh + ib * plane) & 1;  // parity of this image's first position inside the band
+        int e = first;
+        for (; e + 14 < plane; e += 16) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) part[u] += yp[e + 2 * u];
+        }
+        for (; e < plane; e += 2) part[0] += yp[e];
+      }
+      bsum += ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
     }
     if (wave_active) {
       // K loop, software pipelined by one full step: all eleven LDS reads of step k+1 (and the table entry of step
@@ -479,6 +492,9 @@ __global__ __launch_bounds__(128, 2) void wgrad_wave_dma_kernel(const WgradPlan*
       auto half = [&](int kp, float& ac, float (&bc)[T], float& an, float (&bn)[T], int& ie) {
         // consumes (ac, bc) = step kp; fetches (an, bn) = step kp + 2 (table entry ie) and the entry of step kp + 6
         __builtin_amdgcn_sched_barrier(0);
+        // (the padding position's A value is zeroed HERE, where the wait for `ac` is due anyway: placed behind the load
+        // of `an` it cost a full `lgkmcnt(0)` -- one exposed LDS latency -- in every other step)
+        if (odd_tail && kh == 1 && kp + 2 >= BPp) ac = 0.f;
         const int inf = ie;
         ie = pinfo[kp + 6 + kh];
         an = arow[inf & 0xffff];  // (past the end: the guard entries)
@@ -486,7 +502,6 @@ __global__ __launch_bounds__(128, 2) void wgrad_wave_dma_kernel(const WgradPlan*
         for (int t = 0; t < T; ++t) bn[t] = xrow[(inf >> 16) + toff[t]];
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, bc[t], acc[t], 0, 0, 0);
-        if (odd_tail && kh == 1 && kp + 4 >= BPp) an = 0.f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
