@@ -23,6 +23,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         kn = r["Kernel_Name"]
         k = ("igemm_conv_kernel" if ("igemm_conv_kernel" in kn or "deform_conv64_fused" in kn or "deform_bwd64_fused" in kn)
              else "trunk_fused_bwd_kernel" if "trunk_fused_bwd_kernel" in kn
+             else "trunk_fused_kernel_helper" if "trunk_fused_kernel<27, true>" in kn  # the form with a helper workgroup per image
              else "trunk_fused_kernel" if "trunk_fused_kernel" in kn and "pack" not in kn else "wgrad_kernel" if "wgrad_" in kn else None)
         if k:
             acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
