@@ -698,7 +698,14 @@ void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
   // (measured: 8.82 ms per step without helpers, 8.75 with bit 0, 9.2 with both).
   static const int TP = getenv("DBM_TRUNK_TP") ? atoi(getenv("DBM_TRUNK_TP")) : 27;
   static const int helper_mask = getenv("DBM_TRUNK_HELPER") ? atoi(getenv("DBM_TRUNK_HELPER")) : 1;
-  const bool helper = TP == 27 && (helper_mask & (L.cat ? 2 : 1)) != 0;
+  static const int n_cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return prop.multiProcessorCount;
+  }();
+  // (four workgroups per image, all resident at once, one per CU: only if the device has that many)
+  const bool helper = TP == 27 && (helper_mask & (L.cat ? 2 : 1)) != 0 && 4 * L.nimg <= n_cus;
   DBM_CHECK(TP == 27 || TP == 32, "DBM_TRUNK_TP must be 27 or 32");
   static bool attr = false;
   if (!attr) {
