@@ -227,3 +227,19 @@ def test_config5_sweep_slice_two_ranks_bf16(dbm, gold):
     err = np.abs(y16[m] - y32[m]).max() / np.abs(y32[m]).max()
     assert 1e-5 < err < TOL_BF16, err
     assert np.array_equal(np.nan_to_num(dbm.merge_ranks(parts), nan=-1.0), np.nan_to_num(y16, nan=-1.0))
+
+@pytest.mark.parametrize("form", ["helpers_in_every_pass", "no_helpers", "tiles_of_32_positions"])
+def test_config3_other_forms_of_the_trunk_forward_match_the_fixture(form):
+    """The trunk forward kernel's other forms (DBM_TRUNK_HELPER / DBM_TRUNK_TP, read once per process) against the same
+    batch-64 oracle fixtures: the config 3 iteration and the tight generator-step check, in a process of their own."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DBM_TRUNK_")}
+    env.update({"helpers_in_every_pass": {"DBM_TRUNK_HELPER": "3"}, "no_helpers": {"DBM_TRUNK_HELPER": "0"},
+                "tiles_of_32_positions": {"DBM_TRUNK_TP": "32"}}[form])
+    here = os.path.abspath(__file__)
+    res = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider", "-k",
+                          "config3_full_iteration or config3_generator_step_reference_init"],
+                         env=env, cwd=os.path.dirname(os.path.dirname(here)), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "2 passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
