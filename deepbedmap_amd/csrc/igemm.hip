@@ -683,7 +683,9 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   static const int mt2_mode = getenv("DBM_IGEMM_MT2") ? atoi(getenv("DBM_IGEMM_MT2")) : 2;
   static const int ks_enable = getenv("DBM_IGEMM_KSPLIT") ? atoi(getenv("DBM_IGEMM_KSPLIT")) : 1;
   static const int ks_target = getenv("DBM_IGEMM_KSTARGET") ? atoi(getenv("DBM_IGEMM_KSTARGET")) : 1024;
-  static const int mt2_tiles = getenv("DBM_IGEMM_MT2_TILES") ? atoi(getenv("DBM_IGEMM_MT2_TILES")) : 1024;
+  // (2048: conv_layer2 of the discriminator -- 1296 two-tile workgroups = 5.06 per CU, a sixth round on sixteen CUs -- stays
+  // on one tile per wavefront, the 36 x 36 generator layers (2592) take two: 8.56 -> 8.47 ms per step against 1024)
+  static const int mt2_tiles = getenv("DBM_IGEMM_MT2_TILES") ? atoi(getenv("DBM_IGEMM_MT2_TILES")) : 2048;
   const bool mt2_ok = mt2_mode && !d.wp16 && d.CoutP % 64 == 0 && grid.y % 2 == 0 && !igemm_tap_skip(d);
   bool mt2 = mt2_ok && tiles / 2 >= mt2_tiles;
   if (!mt2 && mt2_ok && mt2_mode >= 2 && ks_enable && (long)d.Cin * d.T >= 1024 && tiles / 2 <= 512 && tiles >= 64) mt2 = true;
