@@ -20,9 +20,13 @@
 //    the newest channels' halo-free taps first (TP = 27: the middle kernel row; TP = 32: the centre tap);
 //  * split-K partial tiles are reduced through LDS; the epilogue (bias, LeakyReLU, `a5*rs + a0`, `a3*rs + x`) writes the
 //    LDS planes, the global concat buffers the backward pass reads (training) and the neighbours' granules.
+//  * helper mode (HM, TP = 27, passes that keep nothing): a fourth workgroup per image computes output channels 32..63 of
+//    every conv_layer5 for the three bands (helper_trunk), which hand it every layer output and take its channels back
+//    through the same kind of granules: 360 instead of 468 MFMAs per wavefront and dense block.
 // Every spin is bounded (an error word is raised instead of a hang); workgroups never wait for anything but the two
-// neighbouring tiles.  241 VGPRs: one workgroup per CU, a 64-image launch (192 / 162 workgroups) is resident at once on
-// the 256 CUs; kernels of other streams only delay it (they finish).
+// neighbouring tiles (and their image's helper).  <= 248 VGPRs: one workgroup per CU, a 64-image launch (192 / 162 / 256
+// workgroups) is resident at once on the 256 CUs; kernels of other streams only delay it (they finish), and persistent
+// launches are serialised among themselves (dbm_ctx::persist_begin).
 #include "model.h"
 
 namespace {
