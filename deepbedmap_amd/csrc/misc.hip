@@ -183,12 +183,14 @@ __global__ __launch_bounds__(256) void smallcin_wgrad_partial_kernel(const Small
   }
 }
 
-__global__ __launch_bounds__(64) void smallcin_wgrad_fold_kernel(const float* __restrict__ partial, int Cout, int K, float* gW,
-                                                                 float* gb) {
-  const int o = blockIdx.x, k = threadIdx.x;
-  if (k >= 10) return;
-  float v = 0.f;
-  for (int z = 0; z < SCW_SLICES; ++z) v += partial[((long)z * Cout + o) * 10 + k];  // slice order
+// one wavefront per (output channel, sum): lane z holds slice z, the shuffle tree adds them in a fixed order
+static_assert(SCW_SLICES == 64, "smallcin_wgrad_fold_kernel: one lane per slice");
+__global__ __launch_bounds__(640) void smallcin_wgrad_fold_kernel(const float* __restrict__ partial, int Cout, int K, float* gW,
+                                                                  float* gb) {
+  const int o = blockIdx.x, k = threadIdx.x >> 6, z = threadIdx.x & 63;
+  float v = partial[((long)z * Cout + o) * 10 + k];
+  for (int s2 = 32; s2 > 0; s2 >>= 1) v += __shfl_down(v, s2, 64);
+  if (z != 0) return;
   if (k == 9) { if (gb) atomicAdd(gb + o, v); }
   else if (k < K) atomicAdd(gW + o * K + k, v);
 }
@@ -204,7 +206,7 @@ void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dy
       hipLaunchKernelGGL(smallcin_wgrad_partial_kernel<true>, dim3(d.Cout / SCW_OG, SCW_SLICES), dim3(256), 0, s, d, dy, dysn, scratch);
     else
       hipLaunchKernelGGL(smallcin_wgrad_partial_kernel<false>, dim3(d.Cout, SCW_SLICES), dim3(256), 0, s, d, dy, dysn, scratch);
-    hipLaunchKernelGGL(smallcin_wgrad_fold_kernel, dim3(d.Cout), dim3(64), 0, s, scratch, d.Cout, K, gW, gb);
+    hipLaunchKernelGGL(smallcin_wgrad_fold_kernel, dim3(d.Cout), dim3(640), 0, s, scratch, d.Cout, K, gW, gb);
     DBM_HIP(hipGetLastError());
     return;
   }
