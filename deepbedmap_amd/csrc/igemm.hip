@@ -25,6 +25,7 @@
 // pair are issued before the T MFMAs of the current one.
 #include "dbm_internal.h"
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -650,6 +651,32 @@ static unsigned igemm_magic(unsigned long long dv) {  // floor(2^32 / dv), satur
   return (unsigned)(m > 0xffffffffULL ? 0xffffffffULL : m);
 }
 
+// Per-shape launch configuration (measured inside the training step, where the neighbours decide what a workgroup count costs):
+// key = (taps, Cin, Cout, positions of the widest phase, phases) -> two tiles per wavefront / wavefronts per tile / K split;
+// -1 = what the rules below say.  DBM_IGEMM_OVERRIDE="T:Cin:Cout:positions:phases=mt2,waves,ks;..." adds entries (tuning aid),
+// DBM_IGEMM_LOG=1 prints every distinct launch once.
+struct IgemmForce { int mt2, waves, ks; };
+typedef std::array<long, 5> IgemmKey;
+static const std::map<IgemmKey, IgemmForce>& igemm_overrides() {
+  static std::map<IgemmKey, IgemmForce> tab = [] {
+    std::map<IgemmKey, IgemmForce> t;
+    if (const char* e = getenv("DBM_IGEMM_OVERRIDE")) {
+      std::string str(e);
+      size_t pos = 0;
+      while (pos < str.size()) {
+        size_t end = str.find(';', pos);
+        if (end == std::string::npos) end = str.size();
+        long k[5]; int f[3];
+        if (sscanf(str.substr(pos, end - pos).c_str(), "%ld:%ld:%ld:%ld:%ld=%d,%d,%d", &k[0], &k[1], &k[2], &k[3], &k[4], &f[0], &f[1], &f[2]) == 8)
+          t[IgemmKey{k[0], k[1], k[2], k[3], k[4]}] = IgemmForce{f[0], f[1], f[2]};
+        pos = end + 1;
+      }
+    }
+    return t;
+  }();
+  return tab;
+}
+
 void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   { static const bool abl = getenv("DBM_ABL_SKIP") && (atoi(getenv("DBM_ABL_SKIP")) & 512); if (abl) return; }  // measurement aid
   ConvDesc d = d_in;
@@ -689,6 +716,13 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   const bool mt2_ok = mt2_mode && !d.wp16 && d.CoutP % 64 == 0 && grid.y % 2 == 0 && !igemm_tap_skip(d);
   bool mt2 = mt2_ok && tiles / 2 >= mt2_tiles;
   if (!mt2 && mt2_ok && mt2_mode >= 2 && ks_enable && (long)d.Cin * d.T >= 1024 && tiles / 2 <= 512 && tiles >= 64) mt2 = true;
+  const IgemmKey key{d.T, d.Cin, d.Cout, total, nph};
+  IgemmForce force{-1, -1, -1};
+  if (!d.wp16) {
+    auto it = igemm_overrides().find(key);
+    if (it != igemm_overrides().end()) force = it->second;
+  }
+  if (force.mt2 >= 0) mt2 = force.mt2 && mt2_ok;
   if (mt2) { grid.y /= 2; tiles /= 2; }
   // few tiles -> more wavefronts per tile (Cin % 32 == 0 keeps Cin / WAVES even for every choice)
   // (1536 -- eight wavefronts for the 1296-tile layers, 5.06 four-wavefront workgroups per CU -- measured -0.04 ms per step; not
@@ -701,12 +735,14 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   static const int min_pairs = getenv("DBM_IGEMM_MINPAIRS") ? atoi(getenv("DBM_IGEMM_MINPAIRS")) : 4;  // (re-measured at the end of round 2: 6 -> 4, -0.08 ms per step)
   static const int min_tiles = getenv("DBM_IGEMM_MINTILES") ? atoi(getenv("DBM_IGEMM_MINTILES")) : 96;
   while (tiles > min_tiles && waves > 4 && d.Cin / (2 * waves) < min_pairs) waves >>= 1;
+  if (force.waves > 0 && !(mt2 && force.waves != 4)) waves = force.waves;
   // Few tiles and a long K (the deep discriminator layers: 32..512 tiles, K = 2048..8192): the input channels are also split
   // across workgroups of four wavefronts, about 1024 workgroups per launch; partial tiles are folded deterministically by
   // the last workgroup of each tile (igemm_epilogue).  The bf16 inference images keep the one-workgroup form.
-  if (ks_enable && tiles <= 512 && (long)d.Cin * d.T >= 1024 && !d.wp16) {
+  if (ks_enable && (force.ks > 1 || (force.ks < 0 && tiles <= 512 && (long)d.Cin * d.T >= 1024)) && !d.wp16) {
     int ks = 1;
     while (ks < 32 && tiles * ks * 2 <= ks_target && (d.Cin / (ks * 2)) % 8 == 0 && d.Cin / (ks * 2) >= 32) ks *= 2;
+    if (force.ks > 1 && (d.Cin / force.ks) % 8 == 0 && d.Cin / force.ks >= 32) ks = force.ks;
     const size_t slots = (size_t)tiles * (mt2 ? 2 : 1);
     if (ks > 1 && slots * ks * 1024 <= KS_PART_FLOATS && slots <= KS_COUNTERS) {
       KsWorkspace& w = ks_workspace(s);
@@ -718,6 +754,17 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
     }
   }
   if (mt2 && waves != 4) { mt2 = false; grid.y *= 2; }
+  {
+    static const bool log = getenv("DBM_IGEMM_LOG") != nullptr;
+    if (log) {
+      static std::map<IgemmKey, int> seen;
+      if (!seen.count(key)) {
+        seen[key] = 1;
+        fprintf(stderr, "igemm %ld:%ld:%ld:%ld:%ld tiles=%ld mt2_ok=%d -> mt2=%d waves=%d ks=%d\n", key[0], key[1], key[2], key[3], key[4],
+                (long)grid.x * grid.y * nph, (int)mt2_ok, (int)mt2, waves, d.ksplit);
+      }
+    }
+  }
   // bf16 inference on large grids (>= 2048 position tiles: the crops of the area sweep): no split-K at all -- each of a
   // workgroup's four wavefronts owns a position tile of its own over the whole K; no LDS reduction, no barrier, the
   // accumulators go out from the registers.  (With sixteen channels per 32-cycle MFMA a K slice is a handful of
