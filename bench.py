@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 def _traffic_json():  # tools/pmc_traffic.sh (separate --pmc passes); the newest round's file
-    for r in ("r2", "r1"):
+    for r in ("r3", "r2", "r1"):
         p = os.path.join(ROOT, "profiles", r, "traffic_pmc.json")
         if os.path.exists(p):
             return p
@@ -33,6 +33,9 @@ def _traffic_json():  # tools/pmc_traffic.sh (separate --pmc passes); the newest
 
 TRAFFIC_JSON = _traffic_json()
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (the sweep's arithmetic, BASELINE config 5)
+PEAK_HBM_GBS = 8000.0
+G_FWD_MAC_PER_TILE = 845360064  # generator forward, 12 RRDB, one 11x11 -> 36x36 tile (81 trunk pixels)
 BATCH_PER_GPU = 64
 N_RRDB = 12
 GFLOP_PER_TILE = 8.43  # 2 G-fwd + 3 D-fwd + G-bwd + 2 D-bwd ~ 4 G_f + 7 D_f at 12 RRDB
@@ -64,12 +67,13 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(threads=None):
-    """The oracle (NumPy restatement of the Chainer CPU path: im2col + BLAS sgemm) on this box's host cores, on a bounded
-    sample of the same workload: the full D-step + G-step (forward, backward, Adam), 12 RRDB, at batch 8 (one warm-up,
-    median of three) and batch 16 (once); the cost model t(N) = a + b N through those two points gives the batch-64 rate
-    (the oracle's batch-64 iteration itself takes minutes on most hosts).  Beside it the same iteration in torch-CPU
-    fp32 (oneDNN convolutions, autograd), a strong-CPU yardstick.  BLAS / torch threads are pinned and reported."""
+def cpu_baseline(threads=None, batch=BATCH_PER_GPU):
+    """The oracle (NumPy restatement of the Chainer CPU path: im2col + BLAS sgemm) on this box's host cores: ONE MEASURED
+    full iteration (D-step + G-step: forward, backward, Adam; 12 RRDB) at the benchmark's own batch 64 -- `value` is that
+    measurement, not a model -- after a warm-up iteration at batch 8, whose time is reported beside it (BASELINE.md section 3
+    asks for more repetitions; one batch-64 iteration of the port takes minutes on most hosts, so the sample is bounded to
+    one).  Beside it the same iteration in torch-CPU fp32 (oneDNN convolutions, autograd) at the same batch 64, a strong-CPU
+    yardstick.  BLAS / torch threads are pinned and reported."""
     import statistics
 
     from oracle import model as omodel
@@ -96,17 +100,14 @@ def cpu_baseline(threads=None):
 
     t_all = time.perf_counter()
     port_step(8)  # warm-up: BLAS thread pool, page faults of the im2col buffers
-    t8 = statistics.median(port_step(8) for _ in range(3))
-    t16 = port_step(16)
-    b = max((t16 - t8) / 8.0, 1e-9)
-    a = max(t8 - 8.0 * b, 0.0)
-    out = {"value": 64.0 / (a + 64.0 * b), "unit": "tiles/s", "cores": threads, "kind": "port",
+    t8 = port_step(8)
+    tN = port_step(batch)
+    out = {"value": batch / tN, "unit": "tiles/s", "cores": threads, "kind": "port",
            "host_cpus": ncpu, "cpu_model": _cpu_model(), "blas_threads": threads,
-           "measured": {"batch8_s_median_of_3": t8, "batch16_s": t16, "tiles_per_s_at_batch8": 8.0 / t8,
-                        "tiles_per_s_at_batch16": 16.0 / t16},
-           "sample": f"full D-step+G-step (fwd+bwd+Adam), 12 RRDB, NumPy/BLAS oracle: 1 warm-up + median of 3 at batch 8 "
-                     f"({t8:.1f} s), 1 at batch 16 ({t16:.1f} s); value = batch-64 rate from t(N) = {a:.2f} + {b:.3f} N s"}
-    try:  # torch-CPU (oneDNN) fp32, same iteration at batch 8
+           "measured": {f"batch{batch}_s": tN, "batch8_s": t8, "tiles_per_s_at_batch8": 8.0 / t8},
+           "sample": f"ONE measured full iteration (D-step + G-step, fwd+bwd+Adam, 12 RRDB) of the NumPy/BLAS oracle at batch {batch} "
+                     f"({tN:.1f} s) after a batch-8 warm-up; batch 8 beside it: {t8:.1f} s"}
+    try:  # torch-CPU (oneDNN) fp32, the same iteration at the same batch
         import torch
 
         from oracle import torch_ref as tr
@@ -116,7 +117,7 @@ def cpu_baseline(threads=None):
         od = omodel.DiscriminatorModel(seed=2)
         Pg, Pd = tr.tp(og.params, torch.float32), tr.tp(od.params, torch.float32)
         Sd = {k: torch.tensor(np.asarray(v, np.float32)) for k, v in od.persistent.items() if not k.endswith("/N")}
-        arrays = {k: torch.tensor(v) for k, v in synthetic_batch(8, 42).items()}
+        arrays = {k: torch.tensor(v) for k, v in synthetic_batch(batch, 42).items()}
 
         def torch_step():
             t0 = time.perf_counter()
@@ -125,8 +126,8 @@ def cpu_baseline(threads=None):
 
         torch_step()
         tt = statistics.median(torch_step() for _ in range(3))
-        out["torch_cpu"] = {"value": 8.0 / tt, "unit": "tiles/s", "threads": threads,
-                            "sample": f"same iteration, torch {torch.__version__} CPU fp32 (oneDNN, autograd), batch 8, "
+        out["torch_cpu"] = {"value": batch / tt, "unit": "tiles/s", "threads": threads,
+                            "sample": f"same iteration, torch {torch.__version__} CPU fp32 (oneDNN, autograd), batch {batch}, "
                                       f"1 warm-up + median of 3 ({tt:.2f} s)"}
     except Exception as e:  # pragma: no cover
         out["torch_cpu"] = {"error": repr(e)}
@@ -134,6 +135,46 @@ def cpu_baseline(threads=None):
         limit.restore_original_limits() if hasattr(limit, "restore_original_limits") else None
     out["wall_s"] = time.perf_counter() - t_all
     return out
+
+
+def sweep_leg(dbm, ctx, g, crops=5):
+    """BASELINE config 5's unit of work, measured: one INTERIOR 288 x 288 crop of the continent sweep (deepbedmap.py:706-728;
+    320 of the 396 crops are this size) -> 1144 x 1144, generator forward with resident inputs, fp32 and bf16, timed with HIP
+    events on the library's stream over `crops` back-to-back crops after one warm-up.  FLOPs: SURVEY Appendix C's forward
+    MACs per trunk pixel x the crop's 286 x 286 trunk pixels."""
+    lib = dbm._lib.lib()
+    h = w = 288
+    r = np.random.RandomState(7)
+    ins = [dbm.to_device(r.rand(1, c, m * h, m * w).astype(np.float32), ctx) for c, m in ((1, 1), (1, 10), (2, 2), (1, 1))]
+    flop = 2.0 * G_FWD_MAC_PER_TILE / 81.0 * (h - 2) * (w - 2)
+    in_bytes = 4.0 * h * w * (1 + 100 + 8 + 1)
+    out_bytes = 4.0 * 16 * (h - 2) * (w - 2)
+    res = {"crop": [h, w], "output": [4 * (h - 2), 4 * (w - 2)], "algorithmic_tflop_per_crop": flop / 1e12,
+           "compulsory_bytes_per_crop": in_bytes + out_bytes, "crops_timed": crops,
+           "crops_per_continent": 396, "resident_bytes_whole_continent": 4.0 * (2 * 4500 * 5500 + 45020 * 55020 + 2 * 9000 * 11000 + 18000 * 22000)}
+    y = dbm.DeviceArray((1, 1, 4 * (h - 2), 4 * (w - 2)), ctx)  # (allocated once: dbm_malloc synchronises the device)
+
+    def fwd(flags):
+        dbm._lib.check(lib.dbm_gen_forward(g._h, 1, h, w, ins[0].ptr, ins[1].ptr, ins[2].ptr, ins[3].ptr, y.ptr,
+                                           dbm._lib.DEVICE_PTRS | flags), ctx.handle)
+
+    for name, flags in (("fp32", 0), ("bf16", dbm._lib.BF16)):
+        fwd(flags)
+        ctx.synchronize()
+        dbm._lib.check(lib.dbm_timer(ctx.handle, 0, None), ctx.handle)
+        for _ in range(crops):
+            fwd(flags)
+        dbm._lib.check(lib.dbm_timer(ctx.handle, 1, None), ctx.handle)
+        ms = C.c_double(0.0)
+        dbm._lib.check(lib.dbm_timer(ctx.handle, 2, C.byref(ms)), ctx.handle)
+        per = ms.value / crops
+        tf = flop / (per * 1e-3) / 1e12
+        res[name] = {"ms_per_crop": per, "tflops": tf,
+                     "frac_of_mfma_peak": tf / (PEAK_BF16_MFMA_TFLOPS if name == "bf16" else PEAK_FP32_MFMA_TFLOPS),
+                     "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS if name == "bf16" else PEAK_FP32_MFMA_TFLOPS,
+                     "compulsory_gbs": (in_bytes + out_bytes) / (per * 1e-3) / 1e9,
+                     "s_per_continent_one_gpu": 396 * per * 1e-3}
+    return res
 
 
 def spawn_ranks(n_gpus):
@@ -210,6 +251,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="tiles per GPU (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the inference leg (extras.sweep: ms per 288x288 crop, fp32 and bf16)")
     ap.add_argument("--no-deterministic", action="store_true",
                     help="cudnn_deterministic=False: fp32 atomics instead of ordered gradient folds (the reference trains "
                          "with cudnn_deterministic=True, srgan_train.py:69, and so does the headline configuration)")
@@ -223,8 +265,8 @@ def main():
                     help="N > 1: rccl (default) = libdbm's native communicator, gradient buckets overlapped with the backward "
                          "passes; nccl = torch.distributed's RCCL, one all-reduce after each backward (round-1 form)")
     ap.add_argument("--no-fused-iteration", action="store_true",
-                    help="the two step calls + two optimizer calls per minibatch instead of dbm_train_iteration (N = 1 only uses "
-                         "the fused call; data-parallel runs always use the step calls)")
+                    help="the two step calls + two optimizer calls per minibatch instead of dbm_train_iteration (which, since "
+                         "round 3, also serves data-parallel runs on the rccl / gloo-hook backends)")
     ap.add_argument("--sync-metrics", action="store_true",
                     help="fetch the five metrics to the host after every minibatch (the reference's float(...) pattern) instead "
                          "of once at the end of the run")
@@ -339,6 +381,14 @@ def main():
                     "achieved_standalone": (flop / (ms_s * 1e-3) / 1e12) if ms_s > 0 else 0.0})
     dom = max(fam, key=lambda f: f["ms_per_step"])  # the dominant kernel = most summed launch time in one step
 
+    # ---- inference leg (outside the timed region, rank 0 of a single-GPU run): BASELINE config 5's unit of work ----
+    sweep = None
+    if rank == 0 and world == 1 and not args.no_sweep:
+        try:
+            sweep = sweep_leg(dbm, ctx, g)
+        except Exception as e:  # pragma: no cover
+            sweep = {"error": repr(e)}
+
     if rank == 0:
         tiles = args.batch * world * args.steps
         out = {
@@ -362,7 +412,8 @@ def main():
                        "generator_forwards_per_iteration": 1 if args.share_generator_forward else 2,
                        "g_step_forward_prefetched_under_d_step": bool(prefetch),
                        "cudnn_deterministic": bool(dbm.global_config.cudnn_deterministic),
-                       "fused_iteration_call": bool(not args.no_fused_iteration and comm is None and prefetch),
+                       "fused_iteration_call": bool(not args.no_fused_iteration and prefetch and
+                                                    (comm is None or (comm.exchanges_in_step(ctx) and not args.sync_batch_stats))),
                        "metrics_read_back": "every minibatch" if args.sync_metrics else "once per run (device-resident log)",
                        "sync_batch_stats": bool(args.sync_batch_stats and world > 1)},
             "roofline": {
@@ -400,6 +451,8 @@ def main():
             pass
         if comm_stats is not None:
             out["config"]["gradient_exchange"] = comm_stats
+        if sweep is not None:
+            out["extras"] = {"sweep": sweep}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

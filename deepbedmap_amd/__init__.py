@@ -8,7 +8,7 @@ from ._lib import DbmError, Context, default_context, build  # noqa: F401
 from .srgan import (  # noqa: F401
     Adam, DeepbedmapInputBlock, DeviceArray, DiscriminatorModel, GeneratorModel, ResidualDenseBlock,
     ResInResDenseBlock, Variable, calculate_discriminator_loss, calculate_generator_loss, config, global_config,
-    load_npz, optimizers, psnr, save_npz, serializers, ssim_loss_func, to_device, using_config,
+    infer_num_residual_blocks, load_npz, load_trained_model, optimizers, psnr, save_npz, serializers, ssim_loss_func, to_device, using_config,
 )
 from .training import (  # noqa: F401
     METRIC_NAMES, MetricsLog, SerialIterator, TrialPruned, compile_srgan_model, concat_examples, dataset_to_device, device_batch, get_train_dev_iterators,

@@ -53,6 +53,9 @@ SIGNATURES = {
     "dbm_lzw_encode_tiles": [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int],
     "dbm_lzw_decode": [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)],
     "dbm_debug_inject_timeout": [C.c_void_p],
+    "dbm_debug_inject_timeout_async": [C.c_void_p],
+    "dbm_check_timeout": [C.c_void_p],
+    "dbm_timeout_info": [C.c_void_p, C.POINTER(C.c_long), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "dbm_timer": [C.c_void_p, C.c_int, C.POINTER(C.c_double)],
     "dbm_phase_marks": [C.c_void_p, C.c_int, C.c_char_p, C.c_int],
     "dbm_malloc": [C.c_void_p, C.c_size_t, c_void_pp],
@@ -80,6 +83,12 @@ SIGNATURES = {
     "dbm_disc_backward": [C.c_void_p, C.c_int, C.c_void_p, C.c_int],
     "dbm_discriminator_loss": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_int],
+    "dbm_discriminator_loss_t": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int],
+    "dbm_generator_loss_t": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                             C.c_int, c_float_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int],
+    "dbm_ssim_ex": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                    C.c_int],
     "dbm_generator_loss": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                            C.c_int, c_float_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int],
     "dbm_psnr": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p, C.c_int],
@@ -102,7 +111,10 @@ _lib = None
 
 
 class DbmError(RuntimeError):
-    code = None  # libdbm status (7: a persistent kernel timed out, the optimizer steps were skipped: repeat the iteration)
+    # libdbm status.  7: a persistent kernel timed out; the call that reports it enqueued nothing (re-issue it), the
+    # optimizer updates queued since the event were skipped (`Context.timeout_info()`).  8: the same in a data-parallel
+    # run -- fatal, the replicas have diverged.
+    code = None
 
 
 def build(verbose=False):
@@ -167,6 +179,16 @@ class Context:
 
     def synchronize(self):
         check(lib().dbm_synchronize(self.handle), self.handle)
+
+    def check_timeout(self):
+        """Raises DbmError (code 7 / 8) if a persistent kernel gave up since the last step call (include/dbm.h)."""
+        check(lib().dbm_check_timeout(self.handle), self.handle)
+
+    def timeout_info(self):
+        """(events, discriminator updates skipped, generator updates skipped, persistent kernels paused) of the last event."""
+        ev, d, g, off = C.c_long(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().dbm_timeout_info(self.handle, C.byref(ev), C.byref(d), C.byref(g), C.byref(off)), self.handle)
+        return int(ev.value), int(d.value), int(g.value), bool(off.value)
 
     def malloc(self, nbytes):
         p = C.c_void_p()

@@ -7,36 +7,70 @@ static thread_local std::string g_last_error;
 #define DBM_API_BEGIN(ctxptr) \
   dbm_ctx* _ectx = (ctxptr);  \
   try {
-// A persistent trunk kernel that gives up waiting for a neighbouring workgroup (another process starving the GPU, a
-// partitioned device) raises the context's error word.  The optimizer kernels have skipped their updates since (device
-// flag), so no parameter or moment was touched by the invalid pass: the flags are cleared, the persistent kernels are
-// switched off for the rest of the process (the layer-by-layer trunk path takes over) and the call that observes the
-// word returns status 7: the caller repeats the iteration.
+// ---- a persistent trunk kernel that gives up (bounded spins: another process starving the GPU, a partitioned device) ----
+// It raises the context's error word (host-mapped) and a STICKY device flag.  While the flag is up, every kernel that commits
+// training state is a no-op: the optimizer launches (gated ONCE per launch by adam_gate_kernel, so an update is all or
+// nothing) and BatchNorm's running-average writes -- no parameter, moment or running statistic ever absorbs an invalid
+// pass.  The condition is HANDLED only at the entry of the step entry points (dbm_train_iteration, dbm_discriminator_step,
+// dbm_generator_step, dbm_adam_update) and by dbm_check_timeout: nothing of the observing call has been enqueued yet, the
+// device is drained, the optimizers' step counters take back the launches that were no-ops (reported: dbm_timeout_info), the
+// persistent kernels are switched off for DBM_TRUNK_REARM iterations (default 64, doubled by every further event), and the
+// call returns status 7 WITHOUT having done anything -- the caller re-issues it.  What is lost are the updates of the
+// minibatches that were queued between the event and its observation (their count is reported; their metric rows are
+// invalid).  Other entry points (copies, tensor reads) neither observe nor clear the condition.  In a data-parallel run the
+// ranks can no longer be kept identical by a local retry: status 8, fatal.
+static int trunk_rearm_after() {
+  static const int v = getenv("DBM_TRUNK_REARM") ? atoi(getenv("DBM_TRUNK_REARM")) : 64;
+  return v;
+}
 static void dbm_handle_persistent_timeout(dbm_ctx* c) {
   (void)hipDeviceSynchronize();
-  *(volatile int*)c->dev_err = 0;
-  if (c->dev_err_flag) (void)hipMemset(c->dev_err_flag, 0, sizeof(int));
+  c->timeout_events += 1;
+  c->timeout_skipped[0] = c->timeout_skipped[1] = 0;
   for (dbm_model* m : c->models) {  // optimizer launches that found the condition up did nothing: take their step counts back
     int n = 0;
-    if (m->d_adam_skipped && hipMemcpy(&n, m->d_adam_skipped, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && n > 0) {
+    if (m->type == 0) static_cast<Generator*>(m)->graph_version = -1;  // retained / prefetched passes are void
+    if (m->is_view || !m->d_adam_skipped) continue;
+    if (hipMemcpy(&n, m->d_adam_skipped, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && n > 0) {
       m->adam_t -= n;
+      c->timeout_skipped[m->type == 1 ? 0 : 1] += n;
       (void)hipMemset(m->d_adam_skipped, 0, sizeof(int));
     }
   }
+  *(volatile int*)c->dev_err = 0;
+  if (c->dev_err_flag) (void)hipMemset(c->dev_err_flag, 0, sizeof(int));
   (void)hipDeviceSynchronize();
-  if (!g_trunk_fused_off) {
-    g_trunk_fused_off = true;
-    fprintf(stderr, "libdbm: a persistent trunk kernel gave up waiting for a neighbouring workgroup; the optimizer step was "
-                    "skipped and the layer-by-layer trunk path is used from now on (repeat the iteration)\n");
+  const long pause = trunk_rearm_after() <= 0 ? -1 : (long)trunk_rearm_after() << (c->timeout_events > 16 ? 16 : c->timeout_events - 1);
+  g_trunk_fused_off = true;
+  g_trunk_rearm_at = pause < 0 ? -1 : g_step_serial + pause;
+  fprintf(stderr, "libdbm: a persistent trunk kernel gave up waiting for a neighbouring workgroup (event %ld); %d discriminator / %d "
+                  "generator optimizer updates were skipped; the layer-by-layer trunk path is used for the next %ld iterations\n",
+          c->timeout_events, c->timeout_skipped[0], c->timeout_skipped[1], pause);
+}
+
+// entry of a step entry point: re-arm the persistent kernels when their pause is over, then observe the condition
+static void dbm_step_entry(dbm_ctx* c, bool counts_as_iteration) {
+  if (counts_as_iteration) g_step_serial += 1;
+  if (g_trunk_fused_off && g_trunk_rearm_at >= 0 && g_step_serial >= g_trunk_rearm_at) {
+    g_trunk_fused_off = false;
+    for (dbm_model* m : c->models)
+      if (m->type == 0 && !m->is_view) m->packed_dirty = true;  // the trunk's weight streams were not maintained meanwhile
+    fprintf(stderr, "libdbm: persistent trunk kernels re-armed (iteration %ld)\n", g_step_serial);
+  }
+  if (c->dev_err && *(volatile int*)c->dev_err) {
+    const bool dp = c->comm_active();
+    dbm_handle_persistent_timeout(c);
+    if (dp)
+      throw DbmError(8, "a persistent kernel gave up waiting for a neighbouring workgroup in a data-parallel run: this rank skipped "
+                        "optimizer updates the other ranks may have applied -- the replicas are no longer identical; abort the job");
+    throw DbmError(7, "a persistent kernel gave up waiting for a neighbouring workgroup: " + std::to_string(c->timeout_skipped[0]) +
+                          " discriminator / " + std::to_string(c->timeout_skipped[1]) +
+                          " generator updates queued since were skipped (dbm_timeout_info); nothing of this call was enqueued -- "
+                          "re-issue it (the layer-by-layer trunk path is active for a while)");
   }
 }
 
 #define DBM_API_END                                   \
-  if (_ectx && _ectx->dev_err && *(volatile int*)_ectx->dev_err) {                                    \
-    dbm_handle_persistent_timeout(_ectx);                                                             \
-    throw DbmError(7, "a persistent kernel gave up waiting for a neighbouring workgroup: the last iteration is invalid, " \
-                      "its optimizer steps were skipped; repeat it (the layer-by-layer trunk path is active now)");        \
-  }                                                   \
   return 0;                                           \
   }                                                   \
   catch (const DbmError& e) {                         \
@@ -165,6 +199,7 @@ int dbm_shutdown(dbm_ctx* ctx) {
   if (ctx->ev_persist) (void)hipEventDestroy(ctx->ev_persist);
   if (ctx->ev_comm) (void)hipEventDestroy(ctx->ev_comm);
   if (ctx->ev_comm_done) (void)hipEventDestroy(ctx->ev_comm_done);
+  for (auto& e : ctx->comm_ev_pool) (void)hipEventDestroy(e);
   ctx->loss_tmp.release();
   for (auto& b : ctx->stage) b.release();
   (void)hipStreamSynchronize(ctx->side);
@@ -334,6 +369,35 @@ int dbm_debug_inject_timeout(dbm_ctx* ctx) {
   const int one = 1;
   DBM_HIP(hipMemcpy(ctx->dev_err_flag, &one, sizeof(int), hipMemcpyHostToDevice));
   *(volatile int*)ctx->dev_err = 1;
+  DBM_API_END
+}
+
+__global__ void debug_raise_timeout_kernel(int* err_host, int* err_dev) {
+  *err_dev = 1;
+  *err_host = 1;
+}
+int dbm_debug_inject_timeout_async(dbm_ctx* ctx) {
+  DBM_API_BEGIN(nullptr)
+  DBM_CHECK(ctx != nullptr, "dbm_debug_inject_timeout_async: ctx is NULL");
+  hipLaunchKernelGGL(debug_raise_timeout_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->dev_err_d, ctx->dev_err_flag);
+  DBM_HIP(hipGetLastError());
+  DBM_API_END
+}
+
+int dbm_check_timeout(dbm_ctx* ctx) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(ctx != nullptr, "dbm_check_timeout: ctx is NULL");
+  dbm_step_entry(ctx, false);
+  DBM_API_END
+}
+
+int dbm_timeout_info(dbm_ctx* ctx, long* events, int* d_updates_skipped, int* g_updates_skipped, int* persistent_off) {
+  DBM_API_BEGIN(nullptr)
+  DBM_CHECK(ctx != nullptr, "dbm_timeout_info: ctx is NULL");
+  if (events) *events = ctx->timeout_events;
+  if (d_updates_skipped) *d_updates_skipped = ctx->timeout_skipped[0];
+  if (g_updates_skipped) *g_updates_skipped = ctx->timeout_skipped[1];
+  if (persistent_off) *persistent_off = g_trunk_fused_off ? 1 : 0;
   DBM_API_END
 }
 
@@ -510,7 +574,7 @@ int dbm_gen_forward(dbm_model* gm, int N, int H, int W, const float* x, const fl
   DBM_CHECK(N >= 1 && x && w1 && w2 && w3 && y, "dbm_gen_forward: bad arguments");
   Generator* g = static_cast<Generator*>(gm);
   const bool keep = flags & DBM_KEEP_GRAPH;
-  const size_t n = (size_t)N, hw = (size_t)H * W, P4 = 16 * (size_t)(H - 2) * (W - 2);
+  const size_t n = (size_t)N, hw = (size_t)H * W, P4 = 16 * (size_t)(H - 2) * (W - 2) * (size_t)g->out_ch;
   struct Bf16Scope {  // DBM_BF16: the convolution descriptors of this call point at the bf16 weight images
     Generator* g;
     Bf16Scope(Generator* gen, bool on) : g(on ? gen : nullptr) {
@@ -579,20 +643,37 @@ int dbm_disc_backward(dbm_model* dm, int slot, const float* glogits, int flags) 
 }
 
 // ---- losses ----
-int dbm_discriminator_loss(dbm_ctx* ctx, const float* real, const float* fake, int N, int t_rf, int t_fr, float* out2,
-                           float* g_real, float* g_fake, int flags) {
+static int discriminator_loss_impl(dbm_ctx* ctx, const float* real, const float* fake, int N, int t_rf, int t_fr,
+                                   const int* t_rf_arr, const int* t_fr_arr, float* out2, float* g_real, float* g_fake,
+                                   int flags) {
   DBM_API_BEGIN(ctx)
+  DBM_CHECK(N >= 1 && real && fake && out2, "dbm_discriminator_loss: bad arguments");
   const float* dr = stage_in(ctx, 0, real, N, flags);
   const float* df = stage_in(ctx, 1, fake, N, flags);
   float* dout = stage_out(ctx, 2, out2, 2, flags);
   float* dgr = stage_out(ctx, 3, g_real, N, flags);
   float* dgf = stage_out(ctx, 4, g_fake, N, flags);
-  launch_ragan_loss(dr, df, N, t_rf, t_fr, dout, dgr, dgf, ctx->stream);
+  const int* dt1 = (const int*)stage_in(ctx, 5, (const float*)t_rf_arr, N, flags);  // (int32: the same four bytes per element)
+  const int* dt2 = (const int*)stage_in(ctx, 6, (const float*)t_fr_arr, N, flags);
+  launch_ragan_loss(dr, df, N, t_rf, t_fr, dout, dgr, dgf, ctx->stream, dt1, dt2);
   finish_out(ctx, 2, out2, 2, flags);
   finish_out(ctx, 3, g_real, N, flags);
   finish_out(ctx, 4, g_fake, N, flags);
   finish_sync(ctx, flags);
   DBM_API_END
+}
+int dbm_discriminator_loss(dbm_ctx* ctx, const float* real, const float* fake, int N, int t_rf, int t_fr, float* out2,
+                           float* g_real, float* g_fake, int flags) {
+  return discriminator_loss_impl(ctx, real, fake, N, t_rf, t_fr, nullptr, nullptr, out2, g_real, g_fake, flags);
+}
+int dbm_discriminator_loss_t(dbm_ctx* ctx, const float* real, const float* fake, int N, const int* t_rf, const int* t_fr,
+                             float* out2, float* g_real, float* g_fake, int flags) {
+  if (!t_rf || !t_fr) {
+    g_last_error = "dbm_discriminator_loss_t: both target arrays are required";
+    if (ctx) ctx->err = g_last_error;
+    return 1;
+  }
+  return discriminator_loss_impl(ctx, real, fake, N, 1, 0, t_rf, t_fr, out2, g_real, g_fake, flags);
 }
 
 // device-side generator loss; all pointers are device pointers.  out3: [g_loss, psnr, ssim].
@@ -609,7 +690,8 @@ static void gen_loss_terms(dbm_ctx* ctx, const float* y, const float* t, const f
   launch_gen_loss(y, t, X, N, H, W, w[0], w[2], w[3], ctx->ssim_win[win], sums, gy, s);
 }
 // adversarial term: calculate_discriminator_loss(real=ones, fake=D(fake) detached, targets swapped) (:874-879, :1233-1237)
-static void gen_loss_adv(dbm_ctx* ctx, const float* real_logits, const float* fake_logits, int N, int t_rf, int t_fr) {
+static void gen_loss_adv(dbm_ctx* ctx, const float* real_logits, const float* fake_logits, int N, int t_rf, int t_fr,
+                         const int* t_rf_arr = nullptr, const int* t_fr_arr = nullptr) {
   hipStream_t s = ctx->stream;
   float* adv = ctx->loss_tmp.p + 8;    // [8..9]
   float* ones = ctx->loss_tmp.p + 16;  // N
@@ -617,7 +699,7 @@ static void gen_loss_adv(dbm_ctx* ctx, const float* real_logits, const float* fa
     launch_fill(ones, N, 1.f, s);
     real_logits = ones;
   }
-  launch_ragan_loss(real_logits, fake_logits, N, t_rf, t_fr, adv, nullptr, nullptr, s);
+  launch_ragan_loss(real_logits, fake_logits, N, t_rf, t_fr, adv, nullptr, nullptr, s, t_rf_arr, t_fr_arr);
 }
 static void gen_loss_finish(dbm_ctx* ctx, int N, int H, int W, const float w[4], float* out3) {
   hipStream_t s = ctx->stream;
@@ -629,15 +711,15 @@ static void gen_loss_finish(dbm_ctx* ctx, int N, int H, int W, const float w[4],
 }
 static void gen_loss_device(dbm_ctx* ctx, const float* y, const float* t, const float* X, const float* real_logits,
                             const float* fake_logits, int N, int H, int W, const float w[4], int t_rf, int t_fr,
-                            int win, float* out3, float* gy) {
+                            int win, float* out3, float* gy, const int* t_rf_arr = nullptr, const int* t_fr_arr = nullptr) {
   gen_loss_terms(ctx, y, t, X, N, H, W, w, win, gy);
-  gen_loss_adv(ctx, real_logits, fake_logits, N, t_rf, t_fr);
+  gen_loss_adv(ctx, real_logits, fake_logits, N, t_rf, t_fr, t_rf_arr, t_fr_arr);
   gen_loss_finish(ctx, N, H, W, w, out3);
 }
 
-int dbm_generator_loss(dbm_ctx* ctx, const float* y_pred, const float* y_true, const float* x, const float* real_logits,
-                       const float* fake_logits, int N, int H, int W, const float weights[4], int t_rf, int t_fr,
-                       int ssim_window, float* out3, float* gy, int flags) {
+static int generator_loss_impl(dbm_ctx* ctx, const float* y_pred, const float* y_true, const float* x, const float* real_logits,
+                               const float* fake_logits, int N, int H, int W, const float weights[4], int t_rf, int t_fr,
+                               const int* t_rf_arr, const int* t_fr_arr, int ssim_window, float* out3, float* gy, int flags) {
   DBM_API_BEGIN(ctx)
   const size_t n = (size_t)N, hw = (size_t)H * W, xhw = (size_t)(H / 4 + 2) * (W / 4 + 2);
   const float* dy = stage_in(ctx, 0, y_pred, n * hw, flags);
@@ -647,11 +729,41 @@ int dbm_generator_loss(dbm_ctx* ctx, const float* y_pred, const float* y_true, c
   const float* dr = stage_in(ctx, 6, real_logits, n, flags);
   float* dout = stage_out(ctx, 4, out3, 3, flags);
   float* dgy = stage_out(ctx, 5, gy, n * hw, flags);
-  gen_loss_device(ctx, dy, dt, dx, dr, dl, N, H, W, weights, t_rf, t_fr, ssim_window, dout, dgy);
+  // (slot 7 holds both target arrays back to back: the eight staging slots are otherwise taken)
+  const int* dt1 = nullptr;
+  const int* dt2 = nullptr;
+  if (t_rf_arr && t_fr_arr) {
+    if (flags & DBM_DEVICE_PTRS) {
+      dt1 = t_rf_arr; dt2 = t_fr_arr;
+    } else {
+      ctx->stage[7].ensure(2 * n);
+      DBM_HIP(hipMemcpyAsync(ctx->stage[7].p, t_rf_arr, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+      DBM_HIP(hipMemcpyAsync(ctx->stage[7].p + n, t_fr_arr, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+      dt1 = (const int*)ctx->stage[7].p; dt2 = dt1 + n;
+    }
+  }
+  gen_loss_device(ctx, dy, dt, dx, dr, dl, N, H, W, weights, t_rf, t_fr, ssim_window, dout, dgy, dt1, dt2);
   finish_out(ctx, 4, out3, 3, flags);
   finish_out(ctx, 5, gy, n * hw, flags);
   finish_sync(ctx, flags);
   DBM_API_END
+}
+int dbm_generator_loss(dbm_ctx* ctx, const float* y_pred, const float* y_true, const float* x, const float* real_logits,
+                       const float* fake_logits, int N, int H, int W, const float weights[4], int t_rf, int t_fr,
+                       int ssim_window, float* out3, float* gy, int flags) {
+  return generator_loss_impl(ctx, y_pred, y_true, x, real_logits, fake_logits, N, H, W, weights, t_rf, t_fr, nullptr, nullptr,
+                             ssim_window, out3, gy, flags);
+}
+int dbm_generator_loss_t(dbm_ctx* ctx, const float* y_pred, const float* y_true, const float* x, const float* real_logits,
+                         const float* fake_logits, int N, int H, int W, const float weights[4], const int* t_rf, const int* t_fr,
+                         int ssim_window, float* out3, float* gy, int flags) {
+  if (!t_rf || !t_fr) {
+    g_last_error = "dbm_generator_loss_t: both target arrays are required";
+    if (ctx) ctx->err = g_last_error;
+    return 1;
+  }
+  return generator_loss_impl(ctx, y_pred, y_true, x, real_logits, fake_logits, N, H, W, weights, 0, 1, t_rf, t_fr, ssim_window,
+                             out3, gy, flags);
 }
 
 __global__ void psnr_finish_kernel(const float* part, int blocks, float* out, float n, float range) {
@@ -702,6 +814,27 @@ int dbm_ssim(dbm_ctx* ctx, const float* y_pred, const float* y_true, int N, int 
   DBM_API_END
 }
 
+int dbm_ssim_ex(dbm_ctx* ctx, const float* y_pred, const float* y_true, int N, int H, int W, int window_size, int stride,
+                int ssim_window, float* out, int flags) {
+  if (window_size == 9 && stride == 1) return dbm_ssim(ctx, y_pred, y_true, N, H, W, ssim_window, out, flags);
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(ssim_window == 0 || ssim_window == 1, "ssim_window must be 0 (gaussian) or 1 (uniform)");
+  DBM_CHECK(window_size >= 1 && window_size <= 64 && stride >= 1, "dbm_ssim_ex: window_size in [1, 64], stride >= 1");
+  DBM_CHECK(H >= window_size && W >= window_size, "dbm_ssim_ex: the images are smaller than the window");
+  const size_t cnt = (size_t)N * H * W;
+  const float* a = stage_in(ctx, 0, y_pred, cnt, flags);
+  const float* b = stage_in(ctx, 1, y_true, cnt, flags);
+  float* dout = stage_out(ctx, 2, out, 1, flags);
+  ctx->loss_tmp.ensure(32 + 4 * (size_t)N);
+  float* sums = ctx->loss_tmp.p + 32;
+  launch_ssim_general(a, b, N, H, W, window_size, stride, ssim_window, sums, ctx->stream);
+  const float nwin = (float)N * (float)((H - window_size) / stride + 1) * (float)((W - window_size) / stride + 1);
+  hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, sums, N, nwin, dout);
+  finish_out(ctx, 2, out, 1, flags);
+  finish_sync(ctx, flags);
+  DBM_API_END
+}
+
 // ---- optimizer ----
 int dbm_adam_setup(dbm_model* m, double alpha, double beta1, double beta2, double eps) {
   DBM_API_BEGIN(m->ctx)
@@ -720,6 +853,7 @@ static void adam_update_impl(dbm_model* m, double grad_scale) {
   const double fix2 = 1.0 - std::pow(m->beta2, (double)m->adam_t);
   const double alpha_t = m->alpha * std::sqrt(fix2) / fix1;  // AdamRule.alpha_t
   DBM_MARK(m->ctx->stream, m->type == 0 ? "G:optimizer_begin" : "D:optimizer_begin");
+  // (the sticky timeout flag is sampled ONCE per launch into the model's gate word: the update is all or nothing)
   launch_adam(m->params, m->grads, m->adam_m, m->adam_v, (long)m->nparam, (float)alpha_t, (float)(1.0 - m->beta1),
               (float)(1.0 - m->beta2), (float)m->eps, (float)grad_scale, m->ctx->stream, m->ctx->dev_err_flag,
               m->d_adam_skipped);
@@ -735,6 +869,7 @@ static void adam_update_impl(dbm_model* m, double grad_scale) {
 
 int dbm_adam_update(dbm_model* m, double grad_scale) {
   DBM_API_BEGIN(m->ctx)
+  dbm_step_entry(m->ctx, false);
   adam_update_impl(m, grad_scale);
   DBM_API_END
 }
@@ -747,6 +882,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   Generator* g = static_cast<Generator*>(gm);
   Discriminator* d = static_cast<Discriminator*>(dm);
   dbm_ctx* c = g->ctx;
+  dbm_step_entry(c, (train & 1) != 0);
   hipStream_t s = c->stream;
   const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
   const bool share = (train & 2) != 0;  // opt-in: keep this forward's graph for the G-step of the same iteration
@@ -898,6 +1034,7 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
   Generator* g = static_cast<Generator*>(gm);
   Discriminator* d = static_cast<Discriminator*>(dm);
   dbm_ctx* c = g->ctx;
+  dbm_step_entry(c, false);
   hipStream_t s = c->stream;
   const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
   const bool share = (train & 2) != 0;
@@ -989,6 +1126,11 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
 // anything the D-step computes (the adversarial term is detached, :1228-1229), so it is enqueued behind the prefetched
 // forward on chain[1] and runs underneath the discriminator's backward passes and weight gradients, whose chains of
 // small kernels leave most of the chip idle.  Bitwise the same result as the two step calls + two dbm_adam_update calls.
+// Data-parallel run (a communicator on the context, round 3): the same schedule; the gradient buckets of BOTH models are
+// summed over ranks on chain[0] -- the discriminator's big bucket (conv_layer6..9) behind the fake-batch backward pass
+// that stream carries, its remainder after the join, then the generator's buckets (tail, trunk groups, input block) as
+// its backward pass on chain[1] finishes them -- and both Adam launches take 1 / world.  Same collectives in the same order
+// as the two step calls, hence the same numbers bit for bit.
 int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const float* X, const float* W1, const float* W2,
                         const float* W3, const float* Y, const float weights[4], int ssim_window, int flags, float* metrics) {
   DBM_API_BEGIN(gm->ctx)
@@ -996,13 +1138,17 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   Generator* g = static_cast<Generator*>(gm);
   Discriminator* d = static_cast<Discriminator*>(dm);
   dbm_ctx* c = g->ctx;
+  dbm_step_entry(c, true);
   DBM_CHECK(g->adam_ready && d->adam_ready, "dbm_train_iteration: both optimizers must be set up (dbm_adam_setup)");
-  DBM_CHECK(!c->comm_active() && !c->sync_stats(), "dbm_train_iteration: data-parallel runs use the two step calls");
+  DBM_CHECK(!c->sync_stats(), "dbm_train_iteration: sync_batch_stats runs use the two step calls (their statistics collectives "
+                              "are enqueued on the main stream between the layers)");
   DBM_CHECK(ssim_window == 0 || ssim_window == 1, "ssim_window must be 0 (gaussian) or 1 (uniform)");
   (void)flags;
   hipStream_t s = c->stream;
   hipStream_t pf = c->chain[1];
   const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
+  const bool dp = c->comm_active();
+  const double gscale = dp ? 1.0 / c->comm_world : 1.0;
   g->graph_version = -1;
   if (g->twin) g->twin->graph_version = -1;
   g->ensure_ws(N, H, W, false);
@@ -1013,10 +1159,17 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   float* gf = gr + N;
   float* lf_eval = gf + N;  // logits of the G-step's eval-mode pass (lf / gf are still being read by the backward passes)
   if (!c->ev_iter[0]) for (auto& e : c->ev_iter) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  struct StreamScope {  // every helper below enqueues on ctx->stream: restore it whatever happens
-    dbm_ctx* c; hipStream_t s;
-    ~StreamScope() { c->stream = s; }
-  } scope{c, s};
+  if (!g->ev_prefetch) DBM_HIP(hipEventCreateWithFlags(&g->ev_prefetch, hipEventDisableTiming));
+  struct Scope {  // every helper below enqueues on ctx->stream / reads the exchange switches: restore them whatever happens
+    dbm_ctx* c; hipStream_t s; Discriminator* d; Generator* t = nullptr;
+    ~Scope() {
+      c->stream = s; c->comm_in_step = false; c->comm_defer = false; c->comm_stream = nullptr; c->comm_pending.clear();
+      d->merge_slots = false;
+      if (t) { t->grads_cleared = false; t->use_aux = true; t->max_split = 2; }
+    }
+  } scope{c, s, d};
+  c->comm_in_step = dp;
+  c->comm_stream = dp ? c->chain[0] : nullptr;
   DBM_MARK(s, "D:begin");
   // ---- D(real) forward on the side stream, underneath the generator forward (:1145) ----
   c->fork_to_side(0);
@@ -1028,11 +1181,13 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   DBM_MARK(s, "D:generator_forward");
   // ---- the G-step's own forward (:1222-1227), retained graph, second workspace, on chain[1] ----
   Generator* t = g->get_twin();
+  scope.t = t;
   t->ensure_ws(N, H, W, true);
   t->max_split = 1;
   c->fork(s, pf, 6);
   c->stream = pf;
   t->forward(N, H, W, X, W1, W2, W3, t->yout.p, true);
+  DBM_HIP(hipEventRecord(g->ev_prefetch, pf));  // the twin's fakes are final (the G-step's eval-mode discriminator pass reads them)
   c->stream = s;
   t->max_split = 2;
   // ---- D(fake) forward, RaGAN loss, cleargrads (:1146-1162) ----
@@ -1046,46 +1201,52 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   d->merge_slots = true;
   d->merge_launcher = 1;
   d->comm_sent_lo = d->comm_sent_hi = 0;
-  try {
-    d->backward(0, gr, false);
-    c->stream = c->chain[0];
-    d->backward(1, gf, false);
-    c->stream = s;
-  } catch (...) {
-    d->merge_slots = false;
-    throw;
-  }
+  c->comm_defer = dp;  // (chain[0] is the exchange stream AND carries the fake-batch pass: its bucket goes out behind the pass)
+  d->backward(0, gr, false);
+  c->stream = c->chain[0];
+  d->backward(1, gf, false);
+  c->stream = s;
   d->merge_slots = false;
+  c->comm_defer = false;
+  if (dp) c->comm_flush();
   c->fork(c->chain[0], s, 7);
   c->join_side();  // (the discriminator's weight gradients: everything on the side stream so far)
   DBM_MARK(s, "D:weight_gradients_joined");
+  if (dp) {  // what launch_group has not sent yet: [0, lo) and [hi, nparam) in one fused group; then the optimizer's wait
+    float* p[2] = {d->grads, d->grads + d->comm_sent_hi};
+    size_t n[2] = {d->comm_sent_lo, d->nparam - d->comm_sent_hi};
+    if (d->comm_sent_hi == 0) { n[0] = d->nparam; n[1] = 0; }
+    c->comm_bucket(p, n, n[1] ? 2 : 1, s);
+    c->comm_join(s);
+    DBM_MARK(s, "D:gradients_exchanged");
+  }
   // ---- the generator's loss terms and backward pass (:1248-1256) on chain[1], behind its forward ----
   c->stream = pf;
   gen_loss_terms(c, t->yout.p, Y, X, N, H4, W4, weights, ssim_window, t->g_y.p);
   DBM_HIP(hipEventRecord(c->ev_iter[0], pf));
   DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), pf));  // cleargrads (:1255)
   t->grads_cleared = true;
-  t->use_aux = false;  // (chain[0] carries the discriminator's fake-batch pass)
-  try {
-    t->backward(t->g_y.p);
-  } catch (...) {
-    t->grads_cleared = false; t->use_aux = true;
-    throw;
-  }
+  t->use_aux = false;  // (chain[0] carries the discriminator's fake-batch pass and the gradient exchange)
+  t->backward(t->g_y.p);
   t->grads_cleared = false;
   t->use_aux = true;
   t->graph_version = -1;
   DBM_HIP(hipEventRecord(c->ev_iter[1], pf));
   c->stream = s;
   // ---- discriminator update (:1164), then the G-step's detached eval-mode discriminator pass (:1228-1237) ----
-  adam_update_impl(d, 1.0);
+  adam_update_impl(d, gscale);
+  DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));  // the twin's fakes (written on chain[1]: nothing else orders this read)
   d->forward(N, H4, W4, t->yout.p, lf_eval, false, false, 1);
   DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[0], 0));  // the loss scratch was cleared on chain[1]
   gen_loss_adv(c, nullptr, lf_eval, N, 0, 1);
   DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[1], 0));  // generator backward (and its weight gradients) done
+  if (dp) {
+    c->comm_join(s);  // ... and its last bucket summed over ranks
+    DBM_MARK(s, "G:gradients_exchanged");
+  }
   gen_loss_finish(c, N, H4, W4, weights, metrics + 2);
   DBM_MARK(s, "G:generator_backward_joined");
-  adam_update_impl(g, 1.0);  // (:1257)
+  adam_update_impl(g, gscale);  // (:1257)
   DBM_API_END
 }
 
@@ -1180,8 +1341,8 @@ int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const f
     xt.ensure((size_t)N * C * H * W);
     launch_nchw_to_nhwc64(x, xt.p, N, H * W, ctx->stream);
   }
-  if (fused && O == 1) {
-    launch_deform_conv_fused(xt.p, off, w, b, y, nullptr, nullptr, N, C, H, W, 18L * H * W, 1, 0, 0.2f, ctx->stream);
+  if (fused && O <= 16) {  // (the few-output-channel form reads the OIHW weights directly, one launch per output channel)
+    launch_deform_conv_fused(xt.p, off, w, b, y, nullptr, nullptr, N, C, H, W, 18L * H * W, O, 0, 0.2f, ctx->stream);
   } else if (O == 1) {
     launch_gemv_cols(col.p, w, b, y, N, C * 9, H * W, ctx->stream);
   } else {

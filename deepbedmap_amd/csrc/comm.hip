@@ -91,6 +91,7 @@ void dbm_ctx::comm_set_hook(int rank, int world, void (*fn)(void*, float*, size_
 void dbm_ctx::comm_destroy() {
   if (nccl_comm) {
     (void)hipStreamSynchronize(chain[1]);
+    (void)hipStreamSynchronize(chain[0]);
     (void)hipStreamSynchronize(stream);
     (void)rccl().CommDestroy((ncclComm_t)nccl_comm);
     nccl_comm = nullptr;
@@ -133,24 +134,49 @@ void dbm_ctx::comm_broadcast(float* p, size_t n, int root, hipStream_t on) {
   DBM_NCCL(rccl().Broadcast(p, p, n, ncclFloat32, root, (ncclComm_t)nccl_comm, on));
 }
 
-// Bucket of the gradient arena whose producers have all been enqueued on `producer`: the exchange stream (chain[1])
-// waits for them and takes the all-reduce; nobody else waits (comm_join at the end of the step).
+// Bucket of the gradient arena whose producers have all been enqueued on `producer`: the exchange stream waits for them
+// and takes the all-reduce; nobody else waits (comm_join at the end of the step).  The exchange stream is chain[1] in the
+// two step calls (idle while the backward passes run) and chain[0] in dbm_train_iteration, where chain[1] carries the
+// generator's own forward and backward pass (dbm_ctx::comm_stream).  With comm_defer set the collective is NOT enqueued
+// yet -- the producers' event is recorded now, the all-reduce goes out with comm_flush(): a bucket that becomes ready
+// while its exchange stream still receives the kernels of a backward pass must not cut that pass in two.
 void dbm_ctx::comm_bucket(float* const* p, const size_t* n, int nranges, hipStream_t producer) {
   if (!comm_active()) return;
-  hipStream_t cs = chain[1];
-  if (producer != cs) {
-    if (!ev_comm) DBM_HIP(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
-    DBM_HIP(hipEventRecord(ev_comm, producer));
-    DBM_HIP(hipStreamWaitEvent(cs, ev_comm, 0));
+  PendingBucket b;
+  b.nranges = nranges < 2 ? nranges : 2;
+  for (int i = 0; i < b.nranges; ++i) { b.p[i] = p[i]; b.n[i] = n[i]; }
+  b.ev = nullptr;
+  hipStream_t cs = comm_stream ? comm_stream : chain[1];
+  if (producer != cs || comm_defer) {
+    if (comm_ev_used == comm_ev_pool.size()) {
+      hipEvent_t e;
+      DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      comm_ev_pool.push_back(e);
+    }
+    b.ev = comm_ev_pool[comm_ev_used++];
+    DBM_HIP(hipEventRecord(b.ev, producer));
   }
-  DBM_MARK(cs, "  comm:bucket_begin");
-  comm_allreduce(p, n, nranges, cs);
-  DBM_MARK(cs, "  comm:bucket_end");
+  comm_pending.push_back(b);
+  if (!comm_defer) comm_flush();
+}
+
+void dbm_ctx::comm_flush() {
+  hipStream_t cs = comm_stream ? comm_stream : chain[1];
+  for (const PendingBucket& b : comm_pending) {
+    if (b.ev) DBM_HIP(hipStreamWaitEvent(cs, b.ev, 0));
+    DBM_MARK(cs, "  comm:bucket_begin");
+    comm_allreduce(b.p, b.n, b.nranges, cs);
+    DBM_MARK(cs, "  comm:bucket_end");
+  }
+  comm_pending.clear();
 }
 
 void dbm_ctx::comm_join(hipStream_t consumer) {
   if (!comm_active()) return;
+  comm_flush();
+  comm_ev_used = 0;  // (every event of the pool has been waited for by the exchange stream: free for the next pass)
+  hipStream_t cs = comm_stream ? comm_stream : chain[1];
   if (!ev_comm_done) DBM_HIP(hipEventCreateWithFlags(&ev_comm_done, hipEventDisableTiming));
-  DBM_HIP(hipEventRecord(ev_comm_done, chain[1]));
+  DBM_HIP(hipEventRecord(ev_comm_done, cs));
   DBM_HIP(hipStreamWaitEvent(consumer, ev_comm_done, 0));
 }

@@ -202,7 +202,9 @@ __global__ __launch_bounds__(256) void deform_conv64_fused_kernel(const float* _
 // nine taps, the sixteen quads of a position fold with a fixed xor tree.
 __global__ __launch_bounds__(256) void deform_conv1_fused_kernel(const float* __restrict__ xt, const float* __restrict__ off,
                                                                  const float* __restrict__ w, const float* __restrict__ bias,
-                                                                 float* __restrict__ y, int N, int H, int W, long offsn) {
+                                                                 float* __restrict__ y, int N, int H, int W, long offsn, int oc,
+                                                                 int co) {
+  // (oc > 1: GeneratorModel(out_channels=oc), forward only -- one launch per output channel co, w / bias already offset)
   __shared__ TileGeometry geo;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int plane = H * W;
@@ -246,7 +248,10 @@ __global__ __launch_bounds__(256) void deform_conv1_fused_kernel(const float* __
     v += __shfl_xor(v, 4, 64);
     v += __shfl_xor(v, 8, 64);
     const long P = P0 + 16 * wave + 4 * i + pi;
-    if (q == 0 && P < total) y[P] = v + (bias ? bias[0] : 0.f);
+    if (q == 0 && P < total) {
+      const long n = P / plane;
+      y[(n * oc + co) * plane + (P - n * plane)] = v + (bias ? bias[0] : 0.f);
+    }
   }
 }
 
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(256) void deform_wgrad1_fold_kernel(const float* __
 
 }  // namespace
 
-bool deform_conv_fused_ok(int C, int O) { return C == 64 && (O == 64 || O == 1); }
+bool deform_conv_fused_ok(int C, int O) { return C == 64 && (O == 64 || (O >= 1 && O <= 16)); }
 
 void launch_nchw_to_nhwc64(const float* x, float* xt, int N, int plane, hipStream_t s) {
   const long total = (long)N * plane;
@@ -528,7 +533,7 @@ void launch_nchw_to_nhwc64(const float* x, float* xt, int N, int plane, hipStrea
 // (IgLayer::wf, k = c * 9 + t); O == 1: w = the canonical (1, 64, 3, 3) tensor.  y (N, O, H, W) is overwritten.
 void launch_deform_conv_fused(const float* xt, const float* off, const float* w, const float* bias, float* y, float* yt, float* colout,
                               int N, int C, int H, int W, long offsn, int O, int act, float slope, hipStream_t s) {
-  DBM_CHECK(deform_conv_fused_ok(C, O), "fused deformable convolution: 64 input channels, 64 or 1 output channels");
+  DBM_CHECK(deform_conv_fused_ok(C, O), "fused deformable convolution: 64 input channels, 64 or <= 16 output channels");
   const long total = (long)N * H * W;
   DBM_CHECK(total < (1L << 31), "fused deformable convolution: more than 2^31 positions");
   const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
@@ -536,7 +541,9 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
   if (O == 64)
     hipLaunchKernelGGL(deform_conv64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, bias, y, yt, colout, N, H, W, offsn, act, slope);
   else
-    hipLaunchKernelGGL(deform_conv1_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, bias, y, N, H, W, offsn);
+    for (int co = 0; co < O; ++co)  // (w: OIHW (O, 64, 3, 3))
+      hipLaunchKernelGGL(deform_conv1_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w + (long)co * 576, bias ? bias + co : nullptr,
+                         y, N, H, W, offsn, O, co);
   if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
 }

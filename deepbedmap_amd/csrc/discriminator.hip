@@ -86,10 +86,10 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
       launch_bn_sync_stats(c.z[i].p, ctx->sync_buf.p, N, DC_O[i], ho * wo, s);
       ctx->allreduce(ctx->sync_buf.p, 3 * DC_O[i]);
       launch_bn_sync_fwd_apply(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), ctx->sync_buf.p, c.mean[i].p, c.istd[i].p,
-                               S(T_bn[i][2]), S(T_bn[i][3]), N, DC_O[i], ho * wo, ctx->sync_world, 1e-5f, 0.9f, SLOPE, s);
+                               S(T_bn[i][2]), S(T_bn[i][3]), N, DC_O[i], ho * wo, ctx->sync_world, 1e-5f, 0.9f, SLOPE, s, ctx->dev_err_flag);
     } else if (bn_train)
       launch_bn_train_fwd(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, S(T_bn[i][2]),
-                          S(T_bn[i][3]), N, DC_O[i], ho * wo, 1e-5f, 0.9f, SLOPE, s);
+                          S(T_bn[i][3]), N, DC_O[i], ho * wo, 1e-5f, 0.9f, SLOPE, s, ctx->dev_err_flag);
     else
       launch_bn_eval_fwd(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), S(T_bn[i][2]), S(T_bn[i][3]), N, DC_O[i],
                          ho * wo, 1e-5f, SLOPE, s);

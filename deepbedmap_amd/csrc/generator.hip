@@ -11,7 +11,9 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
   rs = r;
   out_ch = oc;
   DBM_CHECK(n >= 1, "num_residual_blocks must be >= 1");
-  DBM_CHECK(oc == 1, "only out_channels == 1 (the reference's value) is implemented");
+  // out_channels > 1 (srgan_train.py:450-457 allows it): forward only -- the reference's own training step fails its
+  // F.mean_absolute_error shape check against the one-channel x_topo (:882-883) and the discriminator takes one channel
+  DBM_CHECK(oc >= 1 && oc <= 16, "out_channels must be in [1, 16]");
   auto conv = [&](const std::string& name, int O, int C, int KH, int KW) {
     add_tensor(name + "/W", {O, C, KH, KW}, DBM_KIND_PARAM);
     add_tensor(name + "/b", {O}, DBM_KIND_PARAM);
@@ -73,6 +75,7 @@ Generator::~Generator() {
 
 // ---- fused 9x9 trunk forward (trunk_fused.hip) ----
 bool g_trunk_fused_off = false;
+long g_step_serial = 0, g_trunk_rearm_at = -1;
 static bool trunk_fused_enabled() {
   static const bool on = !(getenv("DBM_TRUNK_FUSED") && atoi(getenv("DBM_TRUNK_FUSED")) == 0);
   return on && !g_trunk_fused_off;
@@ -187,8 +190,10 @@ void Generator::ensure_ws(int N, int H, int W, bool train) {
   a51.ensure(n * 64 * 16 * hw);
   a42t.ensure(n * 64 * 16 * hw);
   a51t.ensure(n * 64 * 16 * hw);
-  yout.ensure(n * 16 * hw);
+  yout.ensure(n * out_ch * 16 * hw);
   if (tr) {
+    DBM_CHECK(out_ch == 1, "a retained (training) forward needs out_channels == 1: the reference's training step itself fails "
+                           "with more (mean_absolute_error against the one-channel x_topo, srgan_train.py:882-883)");
     col1.ensure(n * 576 * 16 * hw);  // sample matrix of the 64 -> 64 deformable layer: retained passes only (its weight gradient)
     if ((int)dA.size() < nrdb + 1) dA.resize(nrdb + 1);
     for (int i = 0; i <= nrdb; ++i) dA[i].ensure(n * (i == nrdb ? 64 : 192) * hw);
@@ -228,6 +233,18 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   const int h = H - 2, w = W - 2;
   const long hw = (long)h * w;
   const int nrdb = 3 * n_rrdb;
+  // bf16 sweep mode (DBM_BF16): layers that keep the fp32 arithmetic.  Bits: 1 input-block GEMMs, 2 pre- / post-residual
+  // convs, 4 trunk, 8 upsampling convs, 16 offset convs of the deformable layers (the deformable GEMMs are always fp32).
+  // Default 27 = ONLY THE TRUNK multiplies in bf16 (83 % of the forward FLOPs).  Measured in metres at the reference's data
+  // range (tools/bf16_error_study.py, DESIGN.md "bf16 at the data range"): the trunk's residual branches enter the signal
+  // through two 0.1 scalings, its bf16 rounding costs 1 m rms of 2000 m of relief; every layer ON the signal path costs
+  // 65-120 m rms in bf16 (all of them: 190 m), because the two deformable layers turn a 0.1 % error of their input and of
+  // their sampling offsets into sampling-position errors on steep data.
+  static const int bf16_keep32 = getenv("DBM_BF16_FP32_LAYERS") ? atoi(getenv("DBM_BF16_FP32_LAYERS")) : 27;
+  auto prec = [&](ConvDesc d, int bit) {
+    if (bf16_keep32 & bit) d.wp16 = nullptr;
+    return d;
+  };
   // ---- input block: four valid convolutions written straight into the 128-channel concat (:256-266) ----
   {
     struct { const float* in; int Cin, Hin, Win, K, stride; } br[4] = {
@@ -245,7 +262,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
         const IgLayer& L = layers[L_in[i]];
         float* col = (i == 1 ? colW1 : colW2).p;
         launch_im2col(br[i].in, col, N, br[i].Cin, br[i].Hin, br[i].Win, br[i].K, br[i].K, br[i].stride, h, w, L.CinP, s);
-        ConvDesc g = fwd_desc(L, col, (long)L.CinP * hw, h, w, 0, d.y, 128 * hw, N);
+        ConvDesc g = prec(fwd_desc(L, col, (long)L.CinP * hw, h, w, 0, d.y, 128 * hw, N), 1);
         launch_igemm_conv(g, s);
       } else {
         launch_smallcin_conv_fwd(d, s);
@@ -265,7 +282,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   // ---- pre-residual conv + LeakyReLU -> cat[0][:, :64]  (:541-542) ----
   for (int c = 0; c < nsplit; ++c) {
     const long n0 = cn0(c);
-    ConvDesc d = fwd_desc(layers[L_pre], a0.p + n0 * 128 * hw, 128 * hw, h, w, 0, cat[0].p + n0 * 192 * hw, 192 * hw, cnc(c));
+    ConvDesc d = prec(fwd_desc(layers[L_pre], a0.p + n0 * 128 * hw, 128 * hw, h, w, 0, cat[0].p + n0 * 192 * hw, 192 * hw, cnc(c)), 2);
     d.act = 1;
     launch_igemm_conv(d, cstream(c));
   }
@@ -287,6 +304,8 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       L.inbox = tf_inbox; L.err = ctx->dev_err_d; L.err_dev = ctx->dev_err_flag;
       L.nrdb = nrdb; L.nimg = std::min(IMGS, N - i0); L.img0 = i0; L.epoch = ++tf_epoch;
       L.rs = rs; L.slope = SLOPE;
+      // data-parallel: at most 192 resident workgroups, so that RCCL's kernels (and everything else) keep 64 compute units
+      L.no_helper = ctx->comm_active() ? 1 : 0;
       if (src->ev_pack[1]) DBM_HIP(hipStreamWaitEvent(s, src->ev_pack[1], 0));  // the weight streams (pack_extra)
       ctx->persist_begin(s);
       launch_trunk_fused(L, s);
@@ -302,12 +321,12 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
         float* C = cat[slot(j)].p + n0;
         if (k < 4) {
           const int cin = 64 + 32 * k;
-          ConvDesc d = fwd_desc(layers[L_rdb[j * 5 + k]], C, 192 * hw, h, w, 0, C + (long)cin * hw, 192 * hw, Nc);
+          ConvDesc d = prec(fwd_desc(layers[L_rdb[j * 5 + k]], C, 192 * hw, h, w, 0, C + (long)cin * hw, 192 * hw, Nc), 4);
           d.act = 1;
           launch_igemm_conv(d, cstream(c));
         } else {
           float* Cn = cat[slot(j + 1)].p + n0;
-          ConvDesc d = fwd_desc(layers[L_rdb[j * 5 + 4]], C, 192 * hw, h, w, 0, Cn, 192 * hw, Nc);
+          ConvDesc d = prec(fwd_desc(layers[L_rdb[j * 5 + 4]], C, 192 * hw, h, w, 0, Cn, 192 * hw, Nc), 4);
           d.s1 = rs; d.r1 = C; d.r1sn = 192 * hw; d.r1_nch = 64; d.r1s = 1.f;  // a6 = a5*rs + a0  (:358)
           if (j % 3 == 2) {  // a4 = a3*rs + x  (:402)
             d.r2 = cat[slot(j - 2)].p + n0; d.r2sn = 192 * hw; d.s2 = rs;
@@ -320,7 +339,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   // ---- post-residual conv, a3 = a1 + conv(a2)  (:550-551) ----
   for (int c = 0; c < nsplit; ++c) {
     const long n0 = cn0(c);
-    ConvDesc d = fwd_desc(layers[L_post], cat[slot(nrdb)].p + n0 * 192 * hw, 192 * hw, h, w, 0, a3.p + n0 * 64 * hw, 64 * hw, cnc(c));
+    ConvDesc d = prec(fwd_desc(layers[L_post], cat[slot(nrdb)].p + n0 * 192 * hw, 192 * hw, h, w, 0, a3.p + n0 * 64 * hw, 64 * hw, cnc(c)), 2);
     d.r1 = cat[0].p + n0 * 192 * hw; d.r1sn = 192 * hw; d.r1_nch = 64;
     launch_igemm_conv(d, cstream(c));
   }
@@ -328,10 +347,10 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   DBM_MARK(s, "  gen_forward:9x9_stage");
   // ---- nearest x2 + conv + LeakyReLU, twice; the resize is folded into the conv's gather (:556-568) ----
   {
-    ConvDesc d = fwd_desc(layers[L_up1], a3.p, 64 * hw, h, w, 1, a41.p, 64 * 4 * hw, N);
+    ConvDesc d = prec(fwd_desc(layers[L_up1], a3.p, 64 * hw, h, w, 1, a41.p, 64 * 4 * hw, N), 8);
     d.act = 1;
     launch_igemm_conv(d, s);
-    ConvDesc e = fwd_desc(layers[L_up2], a41.p, 64 * 4 * hw, 2 * h, 2 * w, 1, a42.p, 64 * 16 * hw, N);
+    ConvDesc e = prec(fwd_desc(layers[L_up2], a41.p, 64 * 4 * hw, 2 * h, 2 * w, 1, a42.p, 64 * 16 * hw, N), 8);
     e.act = 1;
     launch_igemm_conv(e, s);
   }
@@ -350,7 +369,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     if (keep) col2.ensure((size_t)N * 576 * P4);
   }
   {
-    ConvDesc d = fwd_desc(layers[L_off1], a42.p, 64 * P4, H4, W4, 0, off1.p, 32 * P4, N);
+    ConvDesc d = prec(fwd_desc(layers[L_off1], a42.p, 64 * P4, H4, W4, 0, off1.p, 32 * P4, N), 16);
     launch_igemm_conv(d, s);
     if (dfused) {
       launch_nchw_to_nhwc64(a42.p, a42t.p, N, (int)P4, s);
@@ -365,7 +384,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   }
   // ---- deformable conv 2 (:574) ----
   {
-    ConvDesc d = fwd_desc(layers[L_off2], a51.p, 64 * P4, H4, W4, 0, off2.p, 32 * P4, N);
+    ConvDesc d = prec(fwd_desc(layers[L_off2], a51.p, 64 * P4, H4, W4, 0, off2.p, 32 * P4, N), 16);
     launch_igemm_conv(d, s);
     if (dfused) {
       launch_deform_conv_fused(a51t.p, off2.p, P(T_def2W), P(T_def2b), y, nullptr, nullptr, N, 64, H4, W4, 32 * P4, out_ch, 0, SLOPE, s);
@@ -375,6 +394,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
         launch_deform_sample(a51.p, off2.p, col2.p, N, 64, H4, W4, 32 * P4, s);
       }
     } else {
+      DBM_CHECK(out_ch == 1, "DBM_DEFORM_FUSED=0 serves out_channels == 1 only");
       float* col = keep ? col2.p : col1.p;
       launch_deform_sample(a51.p, off2.p, col, N, 64, H4, W4, 32 * P4, s);
       launch_gemv_cols(col, P(T_def2W), P(T_def2b), y, N, 576, (int)P4, s);

@@ -53,7 +53,7 @@ void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int
 // then y = lrelu(gamma*(z-mean)*inv_std + beta).
 void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* inv_std,
                          float* avg_mean, float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
-                         hipStream_t s);
+                         hipStream_t s, const int* hold = nullptr);  // hold: device word; non-zero = no running-average update
 void launch_bn_eval_fwd(const float* z, float* y, const float* gamma, const float* beta, const float* avg_mean,
                         const float* avg_var, int N, int C, int plane, float eps, float slope, hipStream_t s);
 // backward through lrelu + BN(train): gz = d loss/d z ; ggamma/gbeta accumulated (+=)
@@ -70,8 +70,13 @@ void launch_linear_bwd(const float* x, const float* W, const float* gy, const fl
 
 // RaGAN discriminator loss (srgan_train.py:960-1009) on N real + N fake logits.
 // out[0] = loss, out[1] = binary accuracy (train_eval_discriminator :1156-1158); g_real/g_fake may be null.
+// real_targets / fake_targets (device int32[N], may be null): per-sample targets (-1 = ignored) instead of the constants.
 void launch_ragan_loss(const float* real, const float* fake, int N, int real_target, int fake_target, float* out,
-                       float* g_real, float* g_fake, hipStream_t s);
+                       float* g_real, float* g_fake, hipStream_t s, const int* real_targets = nullptr,
+                       const int* fake_targets = nullptr);
+// mean SSIM's per-image sums (sums[4 n + 2]) for any window_size <= 64 / stride (metric only; the loss kernel is 9 / 1)
+void launch_ssim_general(const float* y, const float* t, int N, int H, int W, int ws, int stride, int uniform, float* sums,
+                         hipStream_t s);
 
 // Generator loss terms on y_pred vs y_true [N,1,H,W] and x_topo = X[:, :, 1:-1, 1:-1] (srgan_train.py:841-902).
 // sums[0..4] = sum|y-t|, sum|pool4(y)-x|, sum ssim_map, sum (y-t)^2, (unused); gy (may be null) receives
@@ -81,10 +86,11 @@ void launch_gen_loss(const float* y, const float* t, const float* X, int N, int 
 
 // Adam (Chainer form, srgan_train.py:1043-1048): one fused pass over the flat arenas.
 // skip (may be null): device word; while it is non-zero the update is a no-op (a persistent kernel gave up: the
-// gradients of this iteration are invalid, parameters and moments must not be touched)
+// gradients of this iteration are invalid, parameters and moments must not be touched).  It is sampled once per launch
+// into skipped[1] (adam_gate_kernel): an update is all or nothing.
 void launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha_t, float one_minus_beta1,
                  float one_minus_beta2, float eps, float gscale, hipStream_t s, const int* skip = nullptr,
-                 int* skipped = nullptr);  // *skipped counts the no-op launches
+                 int* skipped = nullptr);  // skipped[0] counts the no-op launches, skipped[1] is the launch's gate word
 void launch_fill(float* p, long n, float v, hipStream_t s);
 void launch_gather_rows(const void* src, void* dst, const int* d_idx, int n, size_t row_bytes, hipStream_t s);
 int sqdiff_blocks(long n);  // partial sums launch_sqdiff writes to out[0..blocks)
@@ -103,6 +109,7 @@ struct TrunkFusedLaunch {
   int* err_dev;          // the same flag in device memory: the optimizer kernels skip their update while it is set
   int nrdb, nimg, img0, epoch;
   float rs, slope;
+  int no_helper = 0;     // 1: never the four-workgroups-per-image form (data-parallel runs: RCCL's kernels need compute units too)
 };
 size_t trunk_fused_stream_floats(int nrdb);
 size_t trunk_fused_inbox_bytes(int nimg);
@@ -133,7 +140,7 @@ void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s);
 void launch_bn_sync_stats(const float* z, float* buf, int N, int C, int plane, hipStream_t s);
 void launch_bn_sync_fwd_apply(const float* z, float* y, const float* gamma, const float* beta, const float* buf, float* mean,
                               float* inv_std, float* avg_mean, float* avg_var, int N, int C, int plane, int world, float eps,
-                              float decay, float slope, hipStream_t s);
+                              float decay, float slope, hipStream_t s, const int* hold = nullptr);
 void launch_bn_sync_bwd_sums(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
                              const float* inv_std, float* buf, float* ggamma, float* gbeta, int N, int C, int plane, float slope,
                              hipStream_t s);

@@ -39,6 +39,13 @@ struct dbm_ctx {
   void (*comm_hook)(void* user, float* dev, size_t n, void* hip_stream) = nullptr;  // dbm_comm_set_hook
   void* comm_user = nullptr;
   bool comm_in_step = false;  // set by the fused steps: the backward passes hand finished buckets to comm_bucket
+  hipStream_t comm_stream = nullptr;  // stream the collectives are enqueued on (null: chain[1]; dbm_train_iteration: chain[0])
+  bool comm_defer = false;    // comm_bucket only records the producers' event; the all-reduce goes out with comm_flush()
+  struct PendingBucket { float* p[2]; size_t n[2]; int nranges; hipEvent_t ev; };
+  std::vector<PendingBucket> comm_pending;
+  std::vector<hipEvent_t> comm_ev_pool;  // one event per bucket of a pass (reused from pass to pass)
+  size_t comm_ev_used = 0;
+  void comm_flush();
   hipEvent_t ev_comm = nullptr, ev_comm_done = nullptr;
   hipEvent_t ev_timer[2] = {nullptr, nullptr};  // dbm_timer
   hipEvent_t ev_iter[2] = {nullptr, nullptr};   // dbm_train_iteration: loss scratch cleared / generator backward done
@@ -64,7 +71,10 @@ struct dbm_ctx {
   long data_epoch = 0;        // bumped by every entry point that writes / frees caller-visible device memory
   int* dev_err = nullptr;     // host-mapped word a persistent kernel raises when a bounded spin runs out (checked by every API call)
   int* dev_err_d = nullptr;   // its device address
-  int* dev_err_flag = nullptr;  // the same flag in device memory (read by the optimizer kernels: no update while it is set)
+  int* dev_err_flag = nullptr;  // the same flag in device memory, STICKY until the host handles it (the optimizer launches and
+                                // BatchNorm's running-average writes are no-ops while it is set)
+  long timeout_events = 0;      // persistent-kernel timeouts handled so far (dbm_timeout_info)
+  int timeout_skipped[2] = {0, 0};  // optimizer updates (discriminator, generator) that were no-ops in the last event
   float* zeros = nullptr;     // 256 B of zeros (igemm out-of-image taps)
   float* ssim_win[2] = {nullptr, nullptr};  // 9-tap 1-D windows: gaussian(1.5), uniform
   DevBuf loss_tmp;            // scratch for the loss entry points
@@ -72,7 +82,10 @@ struct dbm_ctx {
 };
 
 void dbm_comm_unique_id_impl(void* out128);  // comm.hip: ncclGetUniqueId
-extern bool g_trunk_fused_off;  // set when a persistent trunk kernel timed out: the layer-by-layer path from then on
+// A persistent trunk kernel timed out: the layer-by-layer trunk path serves until iteration g_trunk_rearm_at (-1: for good);
+// g_step_serial counts the training iterations entered (api.hip: dbm_step_entry).
+extern bool g_trunk_fused_off;
+extern long g_step_serial, g_trunk_rearm_at;
 
 struct Tensor {
   std::string key;

@@ -34,7 +34,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void bn_train_fwd_kernel(const float* __restrict__ z, float* __restrict__ y,
                                                           const float* gamma, const float* beta, float* mean_o,
                                                           float* istd_o, float* avg_mean, float* avg_var, int N, int C,
-                                                          int plane, float eps, float decay, float slope) {
+                                                          int plane, float eps, float decay, float slope, const int* hold) {
   __shared__ float sh[NT / 64];
   const int c = blockIdx.x;
   const long m = (long)N * plane;
@@ -90,9 +90,11 @@ __global__ __launch_bounds__(NT) void bn_train_fwd_kernel(const float* __restric
   if (threadIdx.x == 0) {
     mean_o[c] = mean;
     istd_o[c] = istd;
-    const float adjust = (float)((double)m / (m - 1 > 1 ? (double)(m - 1) : 1.0));
-    avg_mean[c] = avg_mean[c] * decay + (1.f - decay) * mean;
-    avg_var[c] = avg_var[c] * decay + ((1.f - decay) * adjust) * var;
+    if (!(hold && *hold)) {  // (no running-average update from a pass the timeout flag has declared void)
+      const float adjust = (float)((double)m / (m - 1 > 1 ? (double)(m - 1) : 1.0));
+      avg_mean[c] = avg_mean[c] * decay + (1.f - decay) * mean;
+      avg_var[c] = avg_var[c] * decay + ((1.f - decay) * adjust) * var;
+    }
   }
   const float g = gamma[c], b = beta[c];
   if (cached) {
@@ -110,14 +112,14 @@ __global__ __launch_bounds__(NT) void bn_train_fwd_kernel(const float* __restric
 
 void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* inv_std,
                          float* avg_mean, float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
-                         hipStream_t s) {
+                         hipStream_t s, const int* hold) {
   if (dbm_abl_skip() & 1) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
   if (plane >= 64 && C <= 256)
     hipLaunchKernelGGL(bn_train_fwd_kernel<1024>, dim3(C), dim3(1024), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean,
-                       avg_var, N, C, plane, eps, decay, slope);
+                       avg_var, N, C, plane, eps, decay, slope, hold);
   else
     hipLaunchKernelGGL(bn_train_fwd_kernel<256>, dim3(C), dim3(256), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean,
-                       avg_var, N, C, plane, eps, decay, slope);
+                       avg_var, N, C, plane, eps, decay, slope, hold);
   DBM_HIP(hipGetLastError());
 }
 
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void bn_sync_fwd_apply_kernel(const float* __r
                                                                 const float* gamma, const float* beta, const float* buf,
                                                                 float* mean_o, float* istd_o, float* avg_mean, float* avg_var,
                                                                 int N, int C, int plane, int world, float eps, float decay,
-                                                                float slope) {
+                                                                float slope, const int* hold) {
   const int c = blockIdx.x;
   const long m = (long)N * plane;
   const double mg = (double)m * world;
@@ -279,9 +281,11 @@ __global__ __launch_bounds__(256) void bn_sync_fwd_apply_kernel(const float* __r
   if (threadIdx.x == 0) {
     mean_o[c] = mean;
     istd_o[c] = istd;
-    const float adjust = (float)(mg / (mg - 1 > 1 ? mg - 1 : 1.0));
-    avg_mean[c] = avg_mean[c] * decay + (1.f - decay) * mean;
-    avg_var[c] = avg_var[c] * decay + ((1.f - decay) * adjust) * var;
+    if (!(hold && *hold)) {
+      const float adjust = (float)(mg / (mg - 1 > 1 ? mg - 1 : 1.0));
+      avg_mean[c] = avg_mean[c] * decay + (1.f - decay) * mean;
+      avg_var[c] = avg_var[c] * decay + ((1.f - decay) * adjust) * var;
+    }
   }
   const float g = gamma[c], b = beta[c];
   BN_SYNC_FOR_EACH(const float v = g * ((z[idx] - mean) * istd) + b; y[idx] = v >= 0.f ? v : slope * v;)
@@ -326,9 +330,9 @@ void launch_bn_sync_stats(const float* z, float* buf, int N, int C, int plane, h
 }
 void launch_bn_sync_fwd_apply(const float* z, float* y, const float* gamma, const float* beta, const float* buf, float* mean,
                               float* inv_std, float* avg_mean, float* avg_var, int N, int C, int plane, int world, float eps,
-                              float decay, float slope, hipStream_t s) {
+                              float decay, float slope, hipStream_t s, const int* hold) {
   hipLaunchKernelGGL(bn_sync_fwd_apply_kernel, dim3(C), dim3(256), 0, s, z, y, gamma, beta, buf, mean, inv_std, avg_mean, avg_var,
-                     N, C, plane, world, eps, decay, slope);
+                     N, C, plane, world, eps, decay, slope, hold);
   DBM_HIP(hipGetLastError());
 }
 void launch_bn_sync_bwd_sums(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
@@ -424,26 +428,33 @@ __device__ __forceinline__ float sce_elem(float x, float t) {
   return -(x * (t - (x >= 0.f ? 1.f : 0.f)) - log1pf(expf(-fabsf(x))));
 }
 
+// tr_arr / tf_arr (may be null): per-sample int32 targets of the two F.sigmoid_cross_entropy calls (-1 = ignored; the
+// reference's signature accepts any int array, srgan_train.py:995-1004); null = the constant tr / tf for every sample.
+// Each call normalises by max(count(t != -1), 1) (normalize=True).
 __global__ __launch_bounds__(256) void ragan_loss_kernel(const float* __restrict__ real, const float* __restrict__ fake,
-                                                         int N, float tr, float tf, float* out, float* g_real,
+                                                         int N, float tr, float tf, const int* __restrict__ tr_arr,
+                                                         const int* __restrict__ tf_arr, float* out, float* g_real,
                                                          float* g_fake) {
   __shared__ float sh[4];
-  float sr = 0.f, sf = 0.f;
+  float sr = 0.f, sf = 0.f, c1 = 0.f, c2 = 0.f;
   for (int i = threadIdx.x; i < N; i += 256) {
     sr += real[i];
     sf += fake[i];
+    c1 += (tr_arr && tr_arr[i] == -1) ? 0.f : 1.f;
+    c2 += (tf_arr && tf_arr[i] == -1) ? 0.f : 1.f;
   }
   const float mr = block_sum_256(sr, sh) / (float)N;
   const float mf = block_sum_256(sf, sh) / (float)N;
-  float l = 0.f, acc = 0.f, s1 = 0.f, s2 = 0.f;
+  const float n1 = fmaxf(block_sum_256(c1, sh), 1.f), n2 = fmaxf(block_sum_256(c2, sh), 1.f);
+  float l1 = 0.f, l2 = 0.f, acc = 0.f, s1 = 0.f, s2 = 0.f;
   for (int i = threadIdx.x; i < N; i += 256) {
     const float xr = real[i] - mf, xf = fake[i] - mr;
-    l += sce_elem(xr, tr) + sce_elem(xf, tf);
+    const float t1 = tr_arr ? (float)tr_arr[i] : tr, t2 = tf_arr ? (float)tf_arr[i] : tf;
+    if (t1 != -1.f) { l1 += sce_elem(xr, t1); s1 += (1.f / (1.f + expf(-xr)) - t1) / n1; }
+    if (t2 != -1.f) { l2 += sce_elem(xf, t2); s2 += (1.f / (1.f + expf(-xf)) - t2) / n2; }
     acc += (real[i] >= 0.f ? 1.f : 0.f) + (fake[i] >= 0.f ? 0.f : 1.f);
-    s1 += (1.f / (1.f + expf(-xr)) - tr) / (float)N;
-    s2 += (1.f / (1.f + expf(-xf)) - tf) / (float)N;
   }
-  const float L = block_sum_256(l, sh) / (float)N;
+  const float L = block_sum_256(l1, sh) / n1 + block_sum_256(l2, sh) / n2;
   const float A = block_sum_256(acc, sh) / (float)(2 * N);
   const float S1 = block_sum_256(s1, sh);
   const float S2 = block_sum_256(s2, sh);
@@ -454,8 +465,9 @@ __global__ __launch_bounds__(256) void ragan_loss_kernel(const float* __restrict
   if (g_real && g_fake) {
     for (int i = threadIdx.x; i < N; i += 256) {
       const float xr = real[i] - mf, xf = fake[i] - mr;
-      g_real[i] = (1.f / (1.f + expf(-xr)) - tr) / (float)N - S2 / (float)N;
-      g_fake[i] = (1.f / (1.f + expf(-xf)) - tf) / (float)N - S1 / (float)N;
+      const float t1 = tr_arr ? (float)tr_arr[i] : tr, t2 = tf_arr ? (float)tf_arr[i] : tf;
+      g_real[i] = (t1 != -1.f ? (1.f / (1.f + expf(-xr)) - t1) / n1 : 0.f) - S2 / (float)N;
+      g_fake[i] = (t2 != -1.f ? (1.f / (1.f + expf(-xf)) - t2) / n2 : 0.f) - S1 / (float)N;
     }
   }
 }
@@ -517,9 +529,9 @@ void launch_ragan_sync_grad(const float* real, const float* fake, int N, int wor
 }
 
 void launch_ragan_loss(const float* real, const float* fake, int N, int real_target, int fake_target, float* out,
-                       float* g_real, float* g_fake, hipStream_t s) {
+                       float* g_real, float* g_fake, hipStream_t s, const int* real_targets, const int* fake_targets) {
   hipLaunchKernelGGL(ragan_loss_kernel, dim3(1), dim3(256), 0, s, real, fake, N, (float)real_target, (float)fake_target,
-                     out, g_real, g_fake);
+                     real_targets, fake_targets, out, g_real, g_fake);
   DBM_HIP(hipGetLastError());
 }
 
@@ -680,17 +692,87 @@ void launch_gen_loss(const float* y, const float* t, const float* X, int N, int 
   DBM_HIP(hipGetLastError());
 }
 
+// ssim_loss_func(y_pred, y_true, window_size, stride) for OTHER windows than the loss's 9 / 1 (srgan_train.py:932-956 passes
+// both through to ssim.functions.ssim_loss): metric only, one workgroup per image, the two mean-shifted images in LDS when
+// they fit (else read from memory), every output window by one thread.  Window = normalised gaussian(sigma 1.5) of
+// `ws` taps centred at ws / 2 (pytorch-ssim lineage) or uniform; valid windows only; sums[4 n + 2] = sum of the SSIM map.
+__global__ __launch_bounds__(256) void ssim_general_kernel(const float* __restrict__ y, const float* __restrict__ t, int H, int W,
+                                                           int ws, int stride, int uniform, int in_lds, float* sums) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ float sh[4];
+  __shared__ float g1[64];
+  const int n = blockIdx.x, tid = threadIdx.x, HW = H * W;
+  const float* yn = y + (long)n * HW;
+  const float* tn = t + (long)n * HW;
+  if (tid == 0) {
+    float s = 0.f;
+    for (int i = 0; i < ws; ++i) {
+      const float d = (float)(i - ws / 2);
+      g1[i] = uniform ? 1.f : expf(-(d * d) / (2.f * 1.5f * 1.5f));
+      s += g1[i];
+    }
+    for (int i = 0; i < ws; ++i) g1[i] /= s;
+  }
+  float ys = 0.f, ts = 0.f;
+  for (int e = tid; e < HW; e += 256) { ys += yn[e]; ts += tn[e]; }
+  const float shy = block_sum_256(ys, sh) / (float)HW;
+  const float sht = block_sum_256(ts, sh) / (float)HW;
+  float* sY = sm;
+  float* sT = sm + HW;
+  if (in_lds) {
+    for (int e = tid; e < HW; e += 256) { sY[e] = yn[e] - shy; sT[e] = tn[e] - sht; }
+  }
+  __syncthreads();
+  const int OH = (H - ws) / stride + 1, OW = (W - ws) / stride + 1;
+  const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  float ss = 0.f;
+  for (int e = tid; e < OH * OW; e += 256) {
+    const int i0 = (e / OW) * stride, j0 = (e % OW) * stride;
+    float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    for (int a = 0; a < ws; ++a) {
+      float h1 = 0.f, h2 = 0.f, h11 = 0.f, h22 = 0.f, h12 = 0.f;
+      for (int b = 0; b < ws; ++b) {
+        const int q = (i0 + a) * W + j0 + b;
+        const float u = in_lds ? sY[q] : yn[q] - shy, v = in_lds ? sT[q] : tn[q] - sht, w = g1[b];
+        h1 += w * u; h2 += w * v; h11 += w * (u * u); h22 += w * (v * v); h12 += w * (u * v);
+      }
+      const float w = g1[a];
+      m1 += w * h1; m2 += w * h2; e11 += w * h11; e22 += w * h22; e12 += w * h12;
+    }
+    const float s11 = e11 - m1 * m1, s22 = e22 - m2 * m2, s12 = e12 - m1 * m2;
+    const float u1 = m1 + shy, u2 = m2 + sht;
+    ss += ((2.f * u1 * u2 + C1) * (2.f * s12 + C2)) / ((u1 * u1 + u2 * u2 + C1) * (s11 + s22 + C2));
+  }
+  const float SS = block_sum_256(ss, sh);
+  if (tid == 0) { sums[4 * n + 0] = 0.f; sums[4 * n + 1] = 0.f; sums[4 * n + 2] = SS; sums[4 * n + 3] = 0.f; }
+}
+
+void launch_ssim_general(const float* y, const float* t, int N, int H, int W, int ws, int stride, int uniform, float* sums,
+                         hipStream_t s) {
+  DBM_CHECK(ws >= 1 && ws <= 64 && stride >= 1, "ssim: window_size must be in [1, 64], stride >= 1");
+  DBM_CHECK(H >= ws && W >= ws, "ssim: the images are smaller than the window");
+  const size_t lds = 2 * sizeof(float) * (size_t)H * W;
+  const int in_lds = lds <= 60 * 1024;
+  hipLaunchKernelGGL(ssim_general_kernel, dim3(N), dim3(256), in_lds ? lds : 0, s, y, t, H, W, ws, stride, uniform, in_lds, sums);
+  DBM_HIP(hipGetLastError());
+}
+
 // ----------------------------------------------------------------------------------------------
 // chainer.optimizers.Adam  (srgan_train.py:1043-1048; AdamRule.update_core)
 // ----------------------------------------------------------------------------------------------
+// The sticky timeout flag is sampled ONCE per optimizer launch (a persistent kernel on another stream may raise it while
+// the update runs: per-block reads would leave a model half updated): gate[0] = flag, and a no-op launch is counted so
+// that the host can take the step count back (adam_t).
+__global__ void adam_gate_kernel(const int* flag, int* gate, int* skipped) {
+  const int f = *flag;
+  *gate = f;
+  if (f) *skipped += 1;
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n, float alpha_t,
-                                                   float omb1, float omb2, float eps, float gscale, const int* skip,
-                                                   int* skipped) {
-  if (skip && *skip) {  // (wave-uniform scalar load, L2-resident)
-    if (skipped && blockIdx.x == 0 && threadIdx.x == 0) *skipped += 1;  // the host takes the step count back (adam_t)
-    return;
-  }
+                                                   float omb1, float omb2, float eps, float gscale, const int* gate) {
+  if (gate && *gate) return;  // (wave-uniform scalar load; written by adam_gate_kernel just before this launch)
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
     const float gr = g[e] * gscale;
     float mm = m[e], vv = v[e];
@@ -707,8 +789,13 @@ void launch_adam(float* p, const float* g, float* m, float* v, long n, float alp
   if (dbm_abl_skip() & 4) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  const int* gate = nullptr;
+  if (skip && skipped) {  // skipped[0] = count of no-op launches, skipped[1] = this launch's gate word
+    hipLaunchKernelGGL(adam_gate_kernel, dim3(1), dim3(1), 0, s, skip, skipped + 1, skipped);
+    gate = skipped + 1;
+  }
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, alpha_t, one_minus_beta1,
-                     one_minus_beta2, eps, gscale, skip, skipped);
+                     one_minus_beta2, eps, gscale, gate);
   DBM_HIP(hipGetLastError());
 }
 

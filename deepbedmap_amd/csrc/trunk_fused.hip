@@ -709,7 +709,7 @@ void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
     return prop.multiProcessorCount;
   }();
   // (four workgroups per image, all resident at once, one per CU: only if the device has that many)
-  const bool helper = TP == 27 && (helper_mask & (L.cat ? 2 : 1)) != 0 && 4 * L.nimg <= n_cus;
+  const bool helper = TP == 27 && (helper_mask & (L.cat ? 2 : 1)) != 0 && 4 * L.nimg <= n_cus && !L.no_helper;
   DBM_CHECK(TP == 27 || TP == 32, "DBM_TRUNK_TP must be 27 or 32");
   static bool attr = false;
   if (!attr) {

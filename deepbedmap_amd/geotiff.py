@@ -77,6 +77,28 @@ def _tiles_of(band, th, tw):
     return padded.reshape(ny, th, nx, tw).transpose(0, 2, 1, 3).reshape(ny * nx, th, tw), ny, nx
 
 
+def _epsg_of(crs):
+    """EPSG code of `crs`: an int, "EPSG:3031", or the reference's default PROJ string for Antarctic polar stereographic
+    (data_prep.py:784: "+proj=stere +lat_0=-90 +lat_ts=-71 +lon_0=0 ... +datum=WGS84 ..." = EPSG:3031).  Other PROJ strings
+    would need a projection database: refused with a clear message."""
+    if isinstance(crs, (int, np.integer)):
+        return int(crs)
+    text = str(crs).strip()
+    if text.isdigit():
+        return int(text)
+    if text.upper().startswith("EPSG:") and text[5:].strip().isdigit():
+        return int(text[5:])
+    if text.startswith("+"):
+        kv = dict((t.lstrip("+").split("=") + [""])[:2] for t in text.split())
+        f = lambda k, d=0.0: float(kv.get(k, d) or d)  # noqa: E731
+        if (kv.get("proj") == "stere" and f("lat_0") == -90.0 and f("lat_ts") == -71.0 and f("lon_0") == 0.0 and f("k", 1.0) == 1.0
+                and f("x_0") == 0.0 and f("y_0") == 0.0 and kv.get("datum", kv.get("ellps", "WGS84")) == "WGS84"
+                and kv.get("units", "m") == "m"):
+            return EPSG_ANTARCTIC_POLAR_STEREOGRAPHIC
+    raise ValueError(f"save_array_to_grid: crs {crs!r} is not an EPSG code, 'EPSG:n' or the Antarctic polar stereographic "
+                     "PROJ string of the reference (EPSG:3031)")
+
+
 def save_array_to_grid(outfilepath, window_bound, array, save_netcdf=False, crs=EPSG_ANTARCTIC_POLAR_STEREOGRAPHIC, dtype=None,
                        nodataval=-2000, tiled=False, compression="none", bigtiff=True, nthreads=None):
     """data_prep.py:779-834 without rasterio: writes `{outfilepath}.tif` and returns its path.
@@ -105,19 +127,31 @@ def save_array_to_grid(outfilepath, window_bound, array, save_netcdf=False, crs=
         sample_format = 1
     else:
         raise ValueError(f"unsupported dtype {dt}")
+    epsg = _epsg_of(crs)
     th, tw = (TILE, TILE) if tiled else (min(TILE, H), W)
     blocks, ny, nx = _tiles_of(band, th, tw)
     raw = blocks.reshape(len(blocks), -1).view(np.uint8)
+    # strips: the last one holds only the rows that exist (TIFF 6.0: StripByteCounts of H % RowsPerStrip rows, what GDAL
+    # writes); tiles are always whole (zero padded)
+    last_rows = H - (ny - 1) * th
+    short_last = (not tiled) and last_rows < th
     if str(compression).lower() == "lzw":
-        streams, comp = lzw_encode_tiles(raw, nthreads), 5
+        if short_last:
+            streams = lzw_encode_tiles(raw[:-1], nthreads) if ny > 1 else []
+            streams += lzw_encode_tiles(np.ascontiguousarray(raw[-1:, :last_rows * tw * dt.itemsize]), nthreads)
+        else:
+            streams = lzw_encode_tiles(raw, nthreads)
+        comp = 5
     elif str(compression).lower() in ("none", "1"):
         streams, comp = [r.tobytes() for r in raw], 1
+        if short_last:
+            streams[-1] = streams[-1][:last_rows * tw * dt.itemsize]
     else:
         raise ValueError(f"unsupported compression {compression!r} (none, lzw)")
     minx, miny, maxx, maxy = (float(v) for v in window_bound)
     px, py = (maxx - minx) / W, (maxy - miny) / H  # rasterio.transform.from_bounds
     nodata = (repr(int(nodataval)) if float(nodataval).is_integer() else repr(float(nodataval))).encode() + b"\0"
-    geokeys = [1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, int(crs)]  # projected, PixelIsArea, ProjectedCSType
+    geokeys = [1, 1, 0, 3, 1024, 0, 1, 1, 1025, 0, 1, 1, 3072, 0, 1, epsg]  # projected, PixelIsArea, ProjectedCSType
     off_t = 16 if bigtiff else 4  # LONG8 / LONG
     tags = [
         (256, 4, [W]), (257, 4, [H]), (258, 3, [8 * dt.itemsize]), (259, 3, [comp]), (262, 3, [1]), (277, 3, [1]),
@@ -201,9 +235,10 @@ def read_geotiff(path):
     out = np.zeros((ny * th, nx * tw), dtype=dt)
     nbytes = th * tw * dt.itemsize
     for i, (o, c) in enumerate(zip(offs, cnts)):
-        raw = lzw_decode(buf[o:o + c], nbytes) if comp == 5 else np.frombuffer(buf[o:o + c], dtype=np.uint8)
         ty, tx = divmod(i, nx)
-        out[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw] = raw.view(dt).reshape(th, tw)
+        rows = th if 322 in tags else min(th, H - ty * th)  # (the last strip holds only the rows that exist)
+        raw = lzw_decode(buf[o:o + c], rows * tw * dt.itemsize) if comp == 5 else np.frombuffer(buf[o:o + c], dtype=np.uint8)
+        out[ty * th:ty * th + rows, tx * tw:(tx + 1) * tw] = raw.view(dt).reshape(rows, tw)
     info = {"pixel_scale": tags.get(33550), "tiepoint": tags.get(33922), "geokeys": tags.get(34735),
             "nodata": tags.get(42113, b"").rstrip(b"\0").decode(), "bigtiff": big, "compression": comp, "tile": (th, tw)}
     return out[None, :H, :W], info

@@ -338,6 +338,7 @@ class GeneratorModel(_Link):
             raise ValueError("GeneratorModel: only resblock_class=ResInResDenseBlock is implemented (srgan_train.py:364-404)")
         self.num_residual_blocks = num_residual_blocks
         self.residual_scaling = residual_scaling
+        self.out_channels = int(out_channels)  # > 1: forward only (the reference's own training step fails with it)
         _lib.check(_lib.lib().dbm_gen_create(self.ctx.handle, int(num_residual_blocks), float(residual_scaling),
                                              int(out_channels), C.byref(self._h)), self.ctx.handle)
         self._index()
@@ -360,8 +361,11 @@ class GeneratorModel(_Link):
         for name, arr in (("w1", w1), ("w2", w2), ("w3", w3)):
             if tuple(arr.shape) != exp[name]:
                 raise ValueError(f"Invalid shape for {name}: expected {exp[name]}, got {tuple(arr.shape)}")
-        oshape = (n, 1, 4 * (h - 2), 4 * (w - 2))
+        oshape = (n, self.out_channels, 4 * (h - 2), 4 * (w - 2))
         l = _lib.lib()
+        if keep and self.out_channels != 1:
+            raise ValueError("out_channels > 1 is forward-only: use using_config('enable_backprop', False) (the reference's "
+                             "training step fails with it too: mean_absolute_error against the one-channel x_topo)")
         if device:
             y = DeviceArray(oshape, self.ctx)
             self._held_inputs = (x, w1, w2, w3)  # the input-block weight gradient reads them in backward
@@ -476,10 +480,46 @@ def save_npz(file, obj, compression=True):
     (np.savez_compressed if compression else np.savez)(file, **d)
 
 
+def infer_num_residual_blocks(file):
+    """Number of ResInResDenseBlocks in a generator .npz: the reference does NOT serialise `num_residual_blocks`
+    (a plain attribute, srgan_train.py:459-460; deepbedmap.py:397-405 recovers it from Comet's experiment parameters) --
+    but the keys `residual_network/{i}/...` of chainer's Sequential say it."""
+    with np.load(file) as f:
+        idx = {int(k.split("/")[1]) for k in f.files if k.startswith("residual_network/")}
+    if not idx or idx != set(range(len(idx))):
+        raise ValueError(f"{file}: no contiguous residual_network/0..n-1 keys (not a GeneratorModel .npz?)")
+    return len(idx)
+
+
+def load_trained_model(model_weights_path, num_residual_blocks=None, residual_scaling: float = 0.1, ctx=None):
+    """The construct + load part of deepbedmap.py:381-410 (`load_trained_model`, minus the Comet.ML download):
+    GeneratorModel(num_residual_blocks=..., residual_scaling=...) + chainer.serializers.load_npz.  num_residual_blocks=None
+    reads the block count from the file's keys; residual_scaling is not recoverable from the weights (pass the value the
+    model was trained with; the reference's default is 0.1)."""
+    n = infer_num_residual_blocks(model_weights_path) if num_residual_blocks is None else int(num_residual_blocks)
+    model = GeneratorModel(num_residual_blocks=n, residual_scaling=float(residual_scaling), ctx=ctx, initialize=False)
+    load_npz(model_weights_path, model)
+    return model
+
+
+class BlockCountMismatch(KeyError, ValueError):
+    """load_npz of a generator file into a model built with another num_residual_blocks.  Chainer raises a bare KeyError
+    for the first missing key (strict mode); this subclass says what is actually wrong."""
+
+    def __str__(self):
+        return str(self.args[0]) if self.args else ""
+
+
 def load_npz(file, obj, strict=True):
     """chainer.serializers.load_npz (deepbedmap.py:408, srgan_train.py:1566-1574)."""
     with np.load(file) as f:
         keys = set(f.files)
+        if isinstance(obj, GeneratorModel):  # a clear message instead of a KeyError deep in the key list
+            idx = {int(k.split("/")[1]) for k in keys if k.startswith("residual_network/")}
+            if idx and len(idx) != int(obj.num_residual_blocks) and strict:
+                raise BlockCountMismatch(f"{file} holds {len(idx)} residual blocks, the model was built with "
+                                         f"num_residual_blocks={obj.num_residual_blocks} (load_trained_model() reads the count "
+                                         "from the file)")
         for name, p in obj._tensors.items():
             if name not in keys:
                 if strict:
@@ -502,12 +542,15 @@ class serializers:  # namespace parity with chainer.serializers
 # --------------------------------------------------------------------------------------
 # losses / metrics
 # --------------------------------------------------------------------------------------
-def _const_target(t, name):
-    t = np.asarray(t)
-    v = int(t.reshape(-1)[0])
-    if not np.all(t == v) or v not in (0, 1):
-        raise NotImplementedError(f"{name}: only constant 0/1 target arrays (what the reference passes) are supported")
-    return v
+def _targets(t, n, name):
+    """int32 target array of F.sigmoid_cross_entropy (srgan_train.py:995-1004): any array of 0 / 1 / -1 (ignored) with one
+    entry per logit, as Chainer's type check demands."""
+    t = np.ascontiguousarray(np.asarray(t).reshape(-1), dtype=np.int32)
+    if t.size != n:
+        raise ValueError(f"{name}: {t.size} targets for {n} logits")
+    if not np.isin(t, (-1, 0, 1)).all():
+        raise ValueError(f"{name}: targets must be 0, 1 or -1 (ignored)")
+    return t
 
 
 def _arr(v):
@@ -518,15 +561,15 @@ def calculate_discriminator_loss(real_labels_pred, fake_labels_pred, real_minus_
     """srgan_train.py:960-1009.  Returns a Variable; `.backward()` back-propagates into the discriminator(s)
     whose retained forwards produced the two logits arrays."""
     real, fake = _arr(real_labels_pred), _arr(fake_labels_pred)
-    t_rf = _const_target(real_minus_fake_target, "real_minus_fake_target")
-    t_fr = _const_target(fake_minus_real_target, "fake_minus_real_target")
     ctx = _lib.default_context()
     l = _lib.lib()
     n = int(np.prod(real.shape))
+    t_rf = _targets(real_minus_fake_target, n, "real_minus_fake_target")
+    t_fr = _targets(fake_minus_real_target, n, "fake_minus_real_target")
     out = np.empty(2, dtype=np.float32)
     r, f = _f32(np.asarray(real)).reshape(-1), _f32(np.asarray(fake)).reshape(-1)
     gr, gf = np.empty(n, np.float32), np.empty(n, np.float32)
-    _lib.check(l.dbm_discriminator_loss(ctx.handle, _hp(r), _hp(f), n, t_rf, t_fr, _hp(out), _hp(gr), _hp(gf), 0),
+    _lib.check(l.dbm_discriminator_loss_t(ctx.handle, _hp(r), _hp(f), n, _hp(t_rf), _hp(t_fr), _hp(out), _hp(gr), _hp(gf), 0),
                ctx.handle)
     v = Variable(np.float32(out[0]))
     v.accuracy = float(out[1])
@@ -552,7 +595,8 @@ def _gen_loss_call(y_pred, y_true, x_full, real_labels, fake_labels, t_rf, t_fr,
     if yp.shape != yt.shape:
         raise ValueError("Input images must have the same dimensions.")  # srgan_train.py:950-951
     n, c, h, w = yp.shape
-    assert c == 1
+    if c != 1:  # chainer: F.mean_absolute_error(pooled (N, c, h/4, w/4), x_topo (N, 1, h/4, w/4)) fails its shape check
+        raise ValueError(f"calculate_generator_loss: y_pred has {c} channels, x_topo has 1 (mean_absolute_error needs equal shapes)")
     xf = _f32(x_full)
     fl = _f32(np.asarray(fake_labels)).reshape(-1)
     rl = None if real_labels is None else _f32(np.asarray(real_labels)).reshape(-1)
@@ -560,8 +604,8 @@ def _gen_loss_call(y_pred, y_true, x_full, real_labels, fake_labels, t_rf, t_fr,
     gy = np.empty_like(yp) if want_grad else None
     wts = (C.c_float * 4)(*[float(v) for v in weights])
     win = {"gaussian": 0, "uniform": 1}[global_config.ssim_window]
-    _lib.check(l.dbm_generator_loss(ctx.handle, _hp(yp), _hp(yt), _hp(xf), None if rl is None else _hp(rl), _hp(fl), n,
-                                    h, w, wts, t_rf, t_fr, win, _hp(out), None if gy is None else _hp(gy), 0),
+    _lib.check(l.dbm_generator_loss_t(ctx.handle, _hp(yp), _hp(yt), _hp(xf), None if rl is None else _hp(rl), _hp(fl), n,
+                                      h, w, wts, _hp(t_rf), _hp(t_fr), win, _hp(out), None if gy is None else _hp(gy), 0),
                ctx.handle)
     return out, gy
 
@@ -572,8 +616,9 @@ def calculate_generator_loss(y_pred, y_true, fake_labels, real_labels, fake_minu
                              structural_loss_weighting: float = 5.25e-0):
     """srgan_train.py:841-902.  `.backward()` on the result runs the generator backward when y_pred came from a
     retained GeneratorModel.forward."""
-    t_fr = _const_target(fake_minus_real_target, "fake_minus_real_target")
-    t_rf = _const_target(real_minus_fake_target, "real_minus_fake_target")
+    n_logits = int(np.prod(np.asarray(_arr(fake_labels)).shape))
+    t_fr = _targets(fake_minus_real_target, n_logits, "fake_minus_real_target")
+    t_rf = _targets(real_minus_fake_target, n_logits, "real_minus_fake_target")
     xt = _f32(np.asarray(x_topo))
     x_full = np.pad(xt, ((0, 0), (0, 0), (1, 1), (1, 1)))  # the kernel reads x[:, :, 1:-1, 1:-1]
     weights = (content_loss_weighting, adversarial_loss_weighting, topographic_loss_weighting,
@@ -596,17 +641,20 @@ def psnr(y_pred, y_true, data_range=2 ** 32):
 
 
 def ssim_loss_func(y_pred, y_true, window_size: int = 9, stride: int = 1):
-    """srgan_train.py:932-956: mean SSIM over valid 9x9 windows; ValueError on shape mismatch."""
+    """srgan_train.py:932-956: mean SSIM over the valid window_size x window_size windows taken every `stride` pixels
+    (ssim.functions.ssim_loss); ValueError on shape mismatch.  Any window_size in [1, 64] and stride >= 1."""
     yp = np.asarray(_arr(y_pred))
     yt = np.asarray(y_true)
     if not yp.shape == yt.shape:
         raise ValueError("Input images must have the same dimensions.")
-    if window_size != 9 or stride != 1:
-        raise NotImplementedError("only window_size=9, stride=1 (the reference's values) are implemented")
+    window_size, stride = int(window_size), int(stride)
     yp, yt = _f32(yp), _f32(yt)
     n, c, h, w = yp.shape
+    if not (1 <= window_size <= 64) or stride < 1 or h < window_size or w < window_size:
+        raise ValueError(f"ssim_loss_func: window_size {window_size} / stride {stride} do not fit {h} x {w} images")
     ctx = _lib.default_context()
     out = np.empty(1, dtype=np.float32)
     win = {"gaussian": 0, "uniform": 1}[global_config.ssim_window]
-    _lib.check(_lib.lib().dbm_ssim(ctx.handle, _hp(yp), _hp(yt), n * c, h, w, win, _hp(out), 0), ctx.handle)
+    _lib.check(_lib.lib().dbm_ssim_ex(ctx.handle, _hp(yp), _hp(yt), n * c, h, w, window_size, stride, win, _hp(out), 0),
+               ctx.handle)
     return Variable(np.float32(out[0]))

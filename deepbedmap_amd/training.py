@@ -65,9 +65,15 @@ def _check_batch(arrs):
 
 def _repeat_after_timeout(fn):
     """libdbm status 7: a persistent trunk kernel gave up waiting for a neighbouring workgroup (another process starving
-    the GPU).  The library has skipped the optimizer updates of the invalid pass, cleared the condition and switched to
-    the layer-by-layer trunk path: the step is simply run again."""
+    the GPU).  The library reports it ONLY at the entry of a step call (or from Context.check_timeout()), before anything
+    of that call has been enqueued: the device is drained, the optimizer launches and BatchNorm running-average writes
+    queued since the event were no-ops (no parameter, moment or statistic absorbed an invalid pass; their count is
+    reported), the layer-by-layer trunk kernels take over for a while.  The call is therefore simply issued again -- it has
+    not run yet.  What is lost are the updates of the minibatches queued between the event and this call: a warning says how
+    many, and a MetricsLog passed as `log=` / `metrics=` marks their rows invalid (NaN).  Status 8 (the same in a
+    data-parallel run: the replicas have diverged) is not retried."""
     import functools
+    import warnings
 
     @functools.wraps(fn)
     def wrapper(*args, **kwargs):
@@ -76,9 +82,24 @@ def _repeat_after_timeout(fn):
         except _lib.DbmError as e:
             if e.code != 7:
                 raise
+            g_model = args[1] if len(args) > 1 else kwargs.get("g_model")
+            ctx = getattr(g_model, "ctx", None) or _lib.default_context()
+            _, nd, ng, _ = ctx.timeout_info()
+            _dropped[id(ctx)] = _dropped.get(id(ctx), 0) + max(nd, ng)
+            warnings.warn(f"libdbm: a persistent kernel timed out; {nd} discriminator / {ng} generator updates queued since "
+                          "were skipped (their minibatches are lost); continuing on the layer-by-layer trunk kernels",
+                          RuntimeWarning, stacklevel=2)
             return fn(*args, **kwargs)
 
     return wrapper
+
+
+_dropped = {}  # id(ctx) -> optimizer updates dropped by timeouts since the last `pop_dropped_updates`
+
+
+def pop_dropped_updates(ctx):
+    """Number of minibatch updates lost to persistent-kernel timeouts on `ctx` since the last call (0 in a healthy run)."""
+    return _dropped.pop(id(ctx), 0)
 
 
 @_repeat_after_timeout
@@ -117,6 +138,7 @@ def train_eval_discriminator(input_arrays, g_model, d_model, d_optimizer=None, t
     if not sync:
         return m
     out = m.get()
+    g_model.ctx.check_timeout()  # (synchronous form: a timeout during THIS call is reported by this call, which is then repeated)
     return float(out[0]), float(out[1])
 
 
@@ -144,6 +166,7 @@ def train_eval_generator(input_arrays, g_model, d_model, g_optimizer=None, train
     if not sync:
         return m
     out = m.get()
+    g_model.ctx.check_timeout()
     return float(out[2]), float(out[3]), float(out[4])
 
 
@@ -259,16 +282,27 @@ class MetricsLog:
         self.n += 1
         return row
 
+    invalid = ()  # row indices whose minibatch was computed by / after a timed-out persistent kernel (their update was skipped)
+
+    def invalidate_last(self, k, keep_last=0):
+        """Marks the k rows before the last `keep_last` ones invalid: fetch() returns them as NaN."""
+        hi = self.n - keep_last
+        self.invalid = tuple(sorted(set(self.invalid) | set(range(max(0, hi - k), hi))))
+
     def fetch(self):
-        """(n, 8) float32 array of the rows written so far (synchronises the stream)."""
-        return self.buf.get()[:self.n].copy()
+        """(n, 8) float32 array of the rows written so far (synchronises the stream); invalidated rows are NaN."""
+        rows = self.buf.get()[:self.n].copy()
+        for r in self.invalid:
+            rows[r] = np.nan
+        return rows
 
 
 @_repeat_after_timeout
 def train_iteration(train_arrays, g_model, g_optimizer, d_model, d_optimizer, metrics=None):
     """dbm_train_iteration: D-step, discriminator update, G-step, generator update of one minibatch of DEVICE arrays as one
     library call.  Returns the device metrics buffer [d_loss, d_accu, g_loss, g_psnr, g_ssim, ...] (no host
-    synchronisation)."""
+    synchronisation).  On a context with a communicator (DataParallel.attach: "rccl", or "gloo" on a GPU) the call is one
+    data-parallel iteration: both gradient arenas are summed over ranks inside it and both updates take 1 / world."""
     global_config.train = True
     assert d_optimizer is not None and g_optimizer is not None  # Optimizer required for neural network training
     n, h, w = _check_batch(train_arrays)
@@ -294,7 +328,11 @@ def train_minibatch(train_arrays, g_model, g_optimizer, d_model, d_optimizer, co
     row = log.next_row() if log is not None else None
     if fused is None:
         fused = bool(global_config.fused_iteration)
-    if (fused and prefetch and comm is None and g_optimizer is not None and d_optimizer is not None
+    # (a communicator the library drives itself -- DataParallel "rccl", or "gloo" on a GPU -- is exchanged inside the call;
+    # torch's own all-reduce ("nccl") and sync_batch_stats need the two step calls)
+    comm_ok = comm is None or (hasattr(comm, "exchanges_in_step") and comm.exchanges_in_step(g_model.ctx)
+                               and not getattr(comm, "sync_batch_stats", False))
+    if (fused and prefetch and comm_ok and g_optimizer is not None and d_optimizer is not None
             and all(_is_device(train_arrays[k]) for k in _KEYS)):
         # ONE library call for the whole minibatch (dbm_train_iteration): the same numbers as the two calls below, bit for
         # bit, with the generator's backward pass scheduled underneath the discriminator's
@@ -320,10 +358,22 @@ def trainer(i: int, columns: list, train_iter, dev_iter, g_model, g_optimizer, d
         # both steps of every minibatch are enqueued back to back; the metrics stay on the device until the epoch ends
         # (the reference's `float(...)` after each step is a host round trip during which the GPU idles; its only
         # consumer is the per-epoch mean)
+        lost = pop_dropped_updates(g_model.ctx)
+        if lost:  # a timeout was observed by the previous call: the rows of the minibatches whose updates were skipped
+            log.invalidate_last(lost, keep_last=1)  # (the last row is the re-issued, valid, minibatch)
         train_minibatch(train_arrays, g_model, g_optimizer, d_model, d_optimizer, comm=comm, log=log)
     rows = log.fetch()
+    try:  # the epoch's last iterations have no following step call that would notice a timeout
+        g_model.ctx.check_timeout()
+    except _lib.DbmError as e:
+        if e.code != 7:
+            raise
+        _, nd, ng, _ = g_model.ctx.timeout_info()
+        log.invalidate_last(max(nd, ng))
+        rows = log.fetch()
+    keep = [r for r in range(len(rows)) if r not in set(log.invalid)]  # (rows of minibatches a timeout made void are left out)
     for col, name in enumerate(("discriminator_loss", "discriminator_accu", "generator_loss", "generator_psnr", "generator_ssim")):
-        metrics_dict[name].extend(float(v) for v in rows[:, col])
+        metrics_dict[name].extend(float(v) for v in rows[keep, col])
     while i == dev_iter.epoch:
         dev_arrays = concat_examples(dev_iter.dataset, dev_iter.next())
         d_dev_loss, d_dev_accu = train_eval_discriminator(dev_arrays, g_model, d_model, train=False)

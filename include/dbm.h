@@ -6,9 +6,14 @@
  * binding a reference maintainer would add.  Conventions:
  *   - every function returns 0 on success, non-zero on error; dbm_last_error() gives the text;
  *     nothing throws across the boundary.  Status 7 is recoverable: a persistent kernel gave up waiting for a
- *     neighbouring workgroup (the GPU is shared or partitioned), the optimizer updates of that iteration were skipped
- *     (parameters and Adam moments untouched) and the layer-by-layer kernels serve the trunk from now on -- repeat
- *     the iteration;
+ *     neighbouring workgroup (the GPU is shared or partitioned).  From that moment a sticky device flag turns every
+ *     optimizer launch and every BatchNorm running-average write into a no-op, so no parameter, moment or running
+ *     statistic absorbs the invalid pass.  The condition is observed ONLY at the entry of the step entry points
+ *     (dbm_train_iteration, dbm_discriminator_step, dbm_generator_step, dbm_adam_update) and by dbm_check_timeout: the call
+ *     drains the device, gives the skipped launches' step counts back, switches to the layer-by-layer trunk kernels for a
+ *     while (re-armed after DBM_TRUNK_REARM = 64 iterations, doubling) and returns 7 WITHOUT having enqueued anything --
+ *     re-issue it; dbm_timeout_info says how many queued updates were dropped.  Status 8: the same in a data-parallel run,
+ *     where a local retry cannot keep the replicas identical -- fatal, abort the job;
  *   - tensors are NCHW float32, C-contiguous; weights OIHW, exactly the arrays stored by
  *     chainer.serializers.save_npz (key layout: SURVEY.md Appendix B);
  *   - pointers are HOST pointers unless flags contains DBM_DEVICE_PTRS, in which case they are
@@ -96,9 +101,20 @@ int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam);
  * Ended by dbm_profile_end_ex. */
 int dbm_profile_begin_serial(dbm_ctx* ctx);
 /* testing aid: raises the condition a persistent trunk kernel raises when it gives up waiting for a neighbouring
- * workgroup.  From then on the optimizer kernels skip their updates; the next API call that completes returns status 7
- * ("repeat the iteration"), clears the condition and switches the process to the layer-by-layer trunk path. */
+ * workgroup.  From then on the optimizer launches and BatchNorm's running-average writes are no-ops; the next STEP entry
+ * point (or dbm_check_timeout) returns status 7 without enqueuing anything. */
 int dbm_debug_inject_timeout(dbm_ctx* ctx);
+/* the same raised by a kernel ENQUEUED on the context's stream (no host synchronisation): the condition comes up in stream
+ * order, as a persistent kernel's would, with whatever the host has queued behind it running under the raised flag */
+int dbm_debug_inject_timeout_async(dbm_ctx* ctx);
+/* Observes a pending persistent-kernel timeout like the step entry points do (status 7 / 8, see the conventions above); 0
+ * when there is none.  For the end of an epoch: the last iterations of a run have no following step call that would
+ * notice.  (srgan_train.py has no counterpart: Chainer's kernels cannot time out.) */
+int dbm_check_timeout(dbm_ctx* ctx);
+/* What the last handled timeout cost: number of events so far, optimizer updates of the discriminator / generator that
+ * were no-ops (= minibatches whose update was dropped), and whether the persistent trunk kernels are currently paused.
+ * Any pointer may be NULL. */
+int dbm_timeout_info(dbm_ctx* ctx, long* events, int* d_updates_skipped, int* g_updates_skipped, int* persistent_off);
 /* measurement aid: HIP-event stopwatch on the context's stream.  op 0 = record the start event, 1 = record the stop
  * event (both asynchronous), 2 = wait for the stop event and write the elapsed milliseconds to *ms. */
 int dbm_timer(dbm_ctx* ctx, int op, double* ms);
@@ -121,7 +137,9 @@ int dbm_gather_rows(dbm_ctx* ctx, void* dst_dev, const void* src_dev, const int*
 
 /* ---- models ---- */
 /* GeneratorModel.__init__(num_residual_blocks=12, residual_scaling=0.1, out_channels=1): srgan_train.py:450-523.
- * Parameters are created zero; the caller uploads them (HeNormal init or load_npz) with dbm_model_set_tensor. */
+ * Parameters are created zero; the caller uploads them (HeNormal init or load_npz) with dbm_model_set_tensor.
+ * out_channels in [1, 16]; more than one channel is forward-only (y is (N, out_channels, 4(H-2), 4(W-2))): the reference's
+ * own training step fails with it (F.mean_absolute_error against the one-channel x_topo, srgan_train.py:882-883). */
 int dbm_gen_create(dbm_ctx* ctx, int num_residual_blocks, float residual_scaling, int out_channels, dbm_model** out);
 /* DiscriminatorModel.__init__(): srgan_train.py:611-647 */
 int dbm_disc_create(dbm_ctx* ctx, dbm_model** out);
@@ -163,6 +181,12 @@ int dbm_disc_backward(dbm_model* d, int slot, const float* glogits, int flags);
 int dbm_discriminator_loss(dbm_ctx* ctx, const float* real_logits, const float* fake_logits, int N,
                            int real_minus_fake_target, int fake_minus_real_target, float* out2, float* g_real,
                            float* g_fake, int flags);
+/* the same with per-sample int32 target arrays (N each; 0, 1 or -1 = ignored), what the reference's signature accepts
+ * (srgan_train.py:960-1004: `real_minus_fake_target`, `fake_minus_real_target` are arrays handed to
+ * F.sigmoid_cross_entropy, each call normalised by its count of targets != -1) */
+int dbm_discriminator_loss_t(dbm_ctx* ctx, const float* real_logits, const float* fake_logits, int N,
+                             const int* real_minus_fake_target, const int* fake_minus_real_target, float* out2, float* g_real,
+                             float* g_fake, int flags);
 /* calculate_generator_loss: srgan_train.py:841-902, psnr :906-928, ssim_loss_func :932-956.
  * y_pred,y_true (N,1,H,W); x (N,1,H/4+2,W/4+2) is the full BEDMAP2 tile (x_topo = x[:,:,1:-1,1:-1], :1248);
  * fake_logits (N) from the discriminator in eval mode, real_logits (N) or NULL for the reference's ones(N) (:1233);
@@ -174,6 +198,11 @@ int dbm_generator_loss(dbm_ctx* ctx, const float* y_pred, const float* y_true, c
                        const float* real_logits, const float* fake_logits, int N, int H, int W,
                        const float weights[4], int real_minus_fake_target, int fake_minus_real_target,
                        int ssim_window, float* out3, float* gy, int flags);
+/* the same with per-sample int32 target arrays for the adversarial term (see dbm_discriminator_loss_t) */
+int dbm_generator_loss_t(dbm_ctx* ctx, const float* y_pred, const float* y_true, const float* x,
+                         const float* real_logits, const float* fake_logits, int N, int H, int W,
+                         const float weights[4], const int* real_minus_fake_target, const int* fake_minus_real_target,
+                         int ssim_window, float* out3, float* gy, int flags);
 
 /* psnr(y_pred, y_true, data_range=2**32): srgan_train.py:906-928 over n elements; out[0] = 20*log10(range/sqrt(mse)) */
 int dbm_psnr(dbm_ctx* ctx, const float* y_pred, const float* y_true, size_t n, double data_range, float* out,
@@ -181,6 +210,10 @@ int dbm_psnr(dbm_ctx* ctx, const float* y_pred, const float* y_true, size_t n, d
 /* ssim_loss_func(y_pred, y_true, window_size=9, stride=1): srgan_train.py:932-956; (N,1,H,W), H,W >= 9 */
 int dbm_ssim(dbm_ctx* ctx, const float* y_pred, const float* y_true, int N, int H, int W, int ssim_window,
              float* out, int flags);
+/* ssim_loss_func with any window_size (1..64, gaussian(1.5) centred at window_size / 2 or uniform) and stride >= 1:
+ * the metric for other windows than the loss's 9 / 1 (valid windows only; N counts images x channels) */
+int dbm_ssim_ex(dbm_ctx* ctx, const float* y_pred, const float* y_true, int N, int H, int W, int window_size, int stride,
+                int ssim_window, float* out, int flags);
 
 /* ---- optimizer ---- */
 /* chainer.optimizers.Adam(alpha, eps=1e-8).setup(model): srgan_train.py:1043-1048 */
@@ -238,8 +271,10 @@ int dbm_lzw_decode(const void* src, size_t nbytes, void* dst, size_t cap, size_t
  * (dbm_adam_setup).  Numerically the two step calls + two dbm_adam_update calls, bit for bit; scheduled as a whole: the
  * generator's backward pass -- independent of everything the D-step computes, since the adversarial term is detached
  * (:1228-1229) -- runs on a library stream underneath the discriminator's backward passes.  metrics_dev (device, >= 8
- * floats) receives [d_loss, d_accu, g_loss, psnr, ssim].  Single-GPU form: with a communicator or sync_batch_stats on the
- * context the call is refused (use the two step calls). */
+ * floats) receives [d_loss, d_accu, g_loss, psnr, ssim].  With a communicator on the context (dbm_comm_init /
+ * dbm_comm_set_hook) the call is one data-parallel iteration: both models' gradient buckets are summed over ranks inside
+ * it (on library stream chain[0], underneath the generator's backward pass) and both updates take 1 / world -- the same
+ * collectives in the same order as the two step calls.  Refused with sync_batch_stats (use the two step calls). */
 int dbm_train_iteration(dbm_model* g, dbm_model* d, int N, int H, int W, const float* X, const float* W1, const float* W2,
                         const float* W3, const float* Y, const float weights[4], int ssim_window, int flags,
                         float* metrics_dev);

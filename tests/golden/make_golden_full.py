@@ -39,6 +39,20 @@ a multiple of the WORST deviation the float32 oracle shows on any tensor there, 
 kernels is c3lin.
 
     python tests/golden/make_golden_full.py c3lin c2      # recompute only these, keep the rest of the file
+
+Round 3 -- tests/golden/esrgan_dem.npz (`python tests/golden/make_golden_full.py dem dem5 dlin`):
+
+  dem   the full iteration of config 3 at the REFERENCE'S DATA RANGE (SURVEY 8d "DEM-like"): the reference feeds raw metres,
+        m/yr and kg/m2/yr (deepbedmap.py:164-169 gap-fills BEDMAP2 with -5000 m; paper/tc-2020-74.tex:192-197): X ~ U[-2000, 2000]
+        with -5000 blocks, W1 ~ U[0, 4000], W2 ~ U[0, 1000], W3 ~ U[0, 500].  The weights are scaled so that activations
+        STAY in that range through the network the way a trained model's do (`models_dem`), and the target Y is correlated
+        with the prediction (0.8 x the oracle's float64 forward + U[-300, 300] m, stored), so that the SSIM term works on
+        tiles whose mean (thousands of metres) dwarfs their variance -- the regime where E[x^2] - mu^2 in float32 fails;
+  dem5  one interior 288 x 288 crop of the continent sweep at the same data range (fp32 oracle; the bf16 mode's error is
+        reported in metres against it);
+  dlin  the D-step of config 3 with a discriminator whose every LeakyReLU input is dominated by its bias / beta
+        (no slope hangs on a rounding error, cf. c3lin): the float32 oracle is a tight reference for EVERY discriminator
+        gradient, BatchNorm running statistic and the loss at batch 64; mid-size tensors are stored in full.
 """
 import os
 import sys
@@ -122,6 +136,107 @@ def models_c5():
 
 def target_c2():
     return np.random.RandomState(77).rand(32, 1, 36, 36).astype(np.float32)
+
+
+# ---- the reference's data range (SURVEY 8d "DEM-like"; deepbedmap.py:164-169, 663-665) ----
+PATH_DEM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "esrgan_dem.npz")
+
+
+def arrays_dem(n, seed, h=11, w=11):
+    """Raw physical units as the reference feeds them: X = BEDMAP2 bed elevation [m] with -5000 m gap-fill blocks
+    (deepbedmap.py:164-169), W1 = ice surface elevation [m], W2 = ice velocity [m/yr], W3 = accumulation [kg/m2/yr]
+    (W1..W3 clipped to >= 0 by the caller, deepbedmap.py:663-665).  Y here is a placeholder of the same range: the
+    fixtures replace it by a target correlated with the prediction (`dem/Y`)."""
+    r = [np.random.RandomState(seed + i) for i in range(6)]
+    f = np.float32
+    a = {"X": r[0].uniform(-2000, 2000, (n, 1, h, w)).astype(f), "W1": r[1].uniform(0, 4000, (n, 1, 10 * h, 10 * w)).astype(f),
+         "W2": r[2].uniform(0, 1000, (n, 2, 2 * h, 2 * w)).astype(f), "W3": r[3].uniform(0, 500, (n, 1, h, w)).astype(f),
+         "Y": r[4].uniform(-2000, 2000, (n, 1, 4 * (h - 2), 4 * (w - 2))).astype(f)}
+    for i in range(0, n, 3):  # gap-fill blocks in every third tile (a few per large crop)
+        for _ in range(1 if h < 64 else 6):
+            bh, bw = r[5].randint(2, max(3, h // 4)), r[5].randint(2, max(3, w // 4))
+            y0, x0 = r[5].randint(0, h - bh + 1), r[5].randint(0, w - bw + 1)
+            a["X"][i, 0, y0:y0 + bh, x0:x0 + bw] = -5000.0
+    return a
+
+
+def oracle_generator_dem(n_blocks, seed):
+    """A generator whose activations stay at the data's magnitude (O(10^3)) from the input block to the output, like a
+    trained model's: the layers on the main path (input block, pre-residual, upsampling, deformable GEMMs) are
+    variance-preserving (HeNormal x 10 = He scale 1), the residual branches (trunk, post-residual) contribute a third of their
+    input per conv (x 3), and the offset convolutions produce offsets of about a pixel (x 10 x 1e-3) instead of thousands."""
+    g = omodel.GeneratorModel(num_residual_blocks=n_blocks, seed=seed)
+    r = np.random.RandomState(seed + 1)
+    for k in sorted(g.params):
+        if k.endswith("/W"):
+            sc = 3.0 if (k.startswith("residual_network/") or k.startswith("post_residual")) else 10.0
+            if "offset_conv" in k:
+                sc *= 1e-3
+            g.params[k] *= np.float32(sc)
+        else:
+            g.params[k] += r.normal(0, 0.1, g.params[k].shape).astype(np.float32)
+    return g
+
+
+def models_dem():
+    """The discriminator is the LINEAR-regime one (oracle_discriminator_lin, scaled for images in metres): at this data range
+    the generator's own float32 rounding (2e-5 of a +-9000 m output, ten times c3's) flips ~100 LeakyReLU slopes of a
+    natural discriminator from one implementation to the next and its gradients then agree to 20 % only (measured:
+    identical fakes -> 1e-5, fakes perturbed by 2e-5 of the range -> 0.03 median / 0.19 worst); in the linear regime the
+    same perturbation moves them by < 1e-4, so every discriminator gradient is held to 5e-4 here too."""
+    return oracle_generator_dem(12, 707), oracle_discriminator_lin(808, img_sigma=2000.0)
+
+
+def models_dem5():
+    return oracle_generator_dem(12, 909)
+
+
+def oracle_discriminator_lin(seed, img_sigma=0.29):
+    """A discriminator in the LINEAR regime (img_sigma: standard deviation of the images it will see -- 0.29 for U[0, 1),
+    ~2000 for elevations in metres: conv_layer0's bias is scaled with it, everything behind BatchNorm is scale free): every LeakyReLU input is held away from zero by its bias / beta
+    (pre-activation = gamma x_hat + beta with gamma ~ 1, |beta| ~ 4: the density of values within a rounding error of
+    zero is 1.3e-4 of the natural one -- ~1e-4 expected slope flips per batch-64 iteration instead of ~10), so float32
+    implementations agree to ~1e-6 on every gradient and the float32 oracle is a TIGHT reference at full size.
+    A constant per-channel offset would, through the zero padding, turn into positional variance that BatchNorm then
+    normalises by (the per-sample signal dies within a few layers): every convolution / linear weight is therefore made
+    orthogonal, tap by tap, to the vector of its input channels' means (= lrelu(beta) of the layer below), so that only
+    the variation of the activations travels."""
+    d = omodel.DiscriminatorModel(seed=seed)
+    r = np.random.RandomState(seed + 1)
+    P = d.params
+    lrelu = lambda v: np.where(v > 0, v, 0.2 * v)  # noqa: E731
+    signed = lambda shape, lo, hi: (r.randint(0, 2, shape) * 2 - 1) * r.uniform(lo, hi, shape)  # noqa: E731
+    W0 = P["conv_layer0/W"].astype(np.float64) * 3.0
+    W0 -= W0.mean(axis=(1, 2, 3), keepdims=True)  # zero-sum kernels: the image's mean level does not reach conv_layer1
+    b0 = signed((64,), 1.5, 2.0) * (img_sigma / 0.29)  # (|W0 * img| has sigma ~0.12 at img_sigma 0.29: the bias is > 12 sigma)
+    P["conv_layer0/W"], P["conv_layer0/b"] = W0.astype(np.float32), b0.astype(np.float32)
+    m = lrelu(b0)
+    for i in range(1, 10):
+        W = P[f"conv_layer{i}/W"].astype(np.float64) * 3.0
+        coef = np.einsum("ocyx,c->oyx", W, m) / float((m * m).sum())
+        W -= coef[:, None, :, :] * m[None, :, None, None]
+        P[f"conv_layer{i}/W"] = W.astype(np.float32)
+        c = W.shape[0]
+        beta = signed((c,), 3.5, 4.5)
+        P[f"batch_norm{i}/gamma"] = r.uniform(0.8, 1.2, (c,)).astype(np.float32)
+        P[f"batch_norm{i}/beta"] = beta.astype(np.float32)
+        m = lrelu(beta)
+    W1 = P["linear_1/W"].astype(np.float64) * 10.0
+    W1 -= np.outer(W1 @ m / float(m @ m), m)
+    P["linear_1/W"] = W1.astype(np.float32)
+    P["linear_1/b"] = signed((100,), 3.5, 4.5).astype(np.float32)
+    P["linear_2/W"] = (P["linear_2/W"].astype(np.float64) * 10.0).astype(np.float32)  # logits differ by O(1) between samples
+    P["linear_2/b"] = r.normal(0, 0.1, (1,)).astype(np.float32)
+    return d
+
+
+def models_dlin():
+    return oracle_generator(12, 101, scale=8.0), oracle_discriminator_lin(1202)
+
+
+DLIN_FLOOR = 1e-3  # gradients below this fraction of the largest one carry rounding noise only (three are exactly zero in theory)
+DLIN_FULL = ("conv_layer0/W", "conv_layer0/b", "conv_layer1/W", "conv_layer2/W", "linear_1/W", "linear_1/b", "linear_2/W",
+             "linear_2/b") + tuple(f"batch_norm{i}/{p}" for i in range(1, 10) for p in ("gamma", "beta"))
 
 
 # ---- digests ----
@@ -265,16 +380,99 @@ def compute_c5():
             "c5/samples": s, "c5/stats": st, "c5/shape": np.array(y.shape, np.int64)}
 
 
+def _iteration_dem(f64, Y=None):
+    a = arrays_dem(64, 7100)
+    g, d = models_dem()
+    if f64:
+        to_float64(g), to_float64(d)
+        a = {k: v.astype(np.float64) for k, v in a.items()}
+    out = {"g_forward": g.forward(a["X"], a["W1"], a["W2"], a["W3"])}
+    if Y is None:  # the target: correlated with the prediction, a few hundred metres of independent relief on top
+        Y = (0.8 * out["g_forward"] + np.random.RandomState(7199).uniform(-300, 300, out["g_forward"].shape)).astype(np.float32)
+    a["Y"] = Y.astype(a["X"].dtype)
+    out["Y"] = Y
+    out["d_step"] = np.array(otrain.train_eval_discriminator(a, g, d, otrain.Adam(d.params, alpha=ALPHA, eps=EPS)), np.float64)
+    out["gradD"] = {k: v.copy() for k, v in d.grads.items()}
+    out["persD"] = {k: np.asarray(v, np.float64) for k, v in d.persistent.items() if not k.endswith("/N")}
+    out["g_step"] = np.array(otrain.train_eval_generator(a, g, d, otrain.Adam(g.params, alpha=ALPHA, eps=EPS)), np.float64)
+    out["gradG"] = {k: v.copy() for k, v in g.grads.items()}
+    return out
+
+
+def compute_dem():
+    r64 = _iteration_dem(True)
+    r32 = _iteration_dem(False, Y=r64["Y"])
+    y64 = r64["g_forward"]
+    out = {"dem/g_forward": y64.astype(np.float32), "dem/Y": r64["Y"],
+           "dem/g_forward_dev": np.array(np.abs(r32["g_forward"] - y64).max() / np.abs(y64).max()),
+           "dem/d_step": r64["d_step"], "dem/d_step_f32": r32["d_step"],
+           "dem/g_step": r64["g_step"], "dem/g_step_f32": r32["g_step"]}
+    for name, floor in (("gradD", DLIN_FLOOR), ("persD", G_FLOOR), ("gradG", G_FLOOR)):
+        part = digest_dict(f"dem/{name}/", r64[name])
+        out.update(with_dev(part, f"dem/{name}/", r32[name], floor))
+    print("dem: forward dev", float(out["dem/g_forward_dev"]), "range", float(y64.min()), float(y64.max()), "d", r64["d_step"],
+          r32["d_step"], "g", r64["g_step"], r32["g_step"], "gradD dev", out["dem/gradD/dev"].max(0), "gradG dev",
+          out["dem/gradG/dev"].max(0), "persD dev", out["dem/persD/dev"].max(0), flush=True)
+    return out
+
+
+def compute_dem5():
+    a = arrays_dem(1, 7500, h=288, w=288)
+    g = models_dem5()
+    y = g.forward(a["X"], a["W1"], a["W2"], a["W3"])  # (1, 1, 1144, 1144), metres
+    s, st = digest("dem5/y", y)
+    c = y.shape[2] // 2 - C5_BLOCK // 2
+    print("dem5: range", float(y.min()), float(y.max()), "std", float(y.std()), flush=True)
+    return {"dem5/grid": y[0, 0, ::C5_STRIDE, ::C5_STRIDE].copy(), "dem5/centre": y[0, 0, c:c + C5_BLOCK, c:c + C5_BLOCK].copy(),
+            "dem5/samples": s, "dem5/stats": st, "dem5/shape": np.array(y.shape, np.int64),
+            "dem5/std": np.array(float(y.std()), np.float64)}
+
+
+def _dstep_dlin(f64):
+    a = arrays(64, 8200)
+    g, d = models_dlin()
+    if f64:
+        to_float64(g), to_float64(d)
+        a = {k: v.astype(np.float64) for k, v in a.items()}
+    m = np.array(otrain.train_eval_discriminator(a, g, d, otrain.Adam(d.params, alpha=ALPHA, eps=EPS)), np.float64)
+    return m, {k: v.copy() for k, v in d.grads.items()}, {k: np.asarray(v, np.float64) for k, v in d.persistent.items()
+                                                            if not k.endswith("/N")}
+
+
+def compute_dlin():
+    """Reference = the float32 oracle (what the HIP path restates); its distance from the float64 oracle is recorded and
+    must be tiny -- that is what makes this fixture a TIGHT check."""
+    m64, g64, p64 = _dstep_dlin(True)
+    m32, g32, p32 = _dstep_dlin(False)
+    out = {"dlin/d_step": m32, "dlin/d_step_f64": m64}
+    out.update(digest_dict("dlin/gradD/", g32))
+    out.update(digest_dict("dlin/persD/", p32))
+    part64 = digest_dict("dlin/gradD/", g64)
+    dev = with_dev(part64, "dlin/gradD/", g32, DLIN_FLOOR)["dlin/gradD/dev"]
+    out["dlin/gradD/dev"] = dev
+    for k in DLIN_FULL:
+        out["dlin/full/" + k] = g32[k].astype(np.float32)
+    print("dlin: d_step", m32, m64, "worst float32-vs-float64 deviation (sample, projection)", dev.max(0), flush=True)
+    print("dlin: per tensor", {k: tuple(float(f"{v:.1e}") for v in dev[i]) for i, k in enumerate(sorted(g32))}, flush=True)
+    assert dev.max() < 2e-4, "dlin is meant to be well conditioned"  # (measured: <= 2e-5 on every conv / linear weight, 1.3e-4 on conv_layer0/b)
+    return out
+
+
 if __name__ == "__main__":
     import time
 
     todo = {"c3": compute_c3, "c3lin": compute_c3lin, "c2": compute_c2, "c5": compute_c5}
+    todo_dem = {"dem": compute_dem, "dem5": compute_dem5, "dlin": compute_dlin}  # round 3: esrgan_dem.npz
     want = sys.argv[1:] or list(todo)
-    out = dict(np.load(PATH)) if (sys.argv[1:] and os.path.exists(PATH)) else {}
-    for name in want:
-        t0 = time.time()
-        out = {k: v for k, v in out.items() if not k.startswith(name + "/")}
-        out.update(todo[name]())
-        print(name, f"{time.time() - t0:.0f} s", flush=True)
-    np.savez_compressed(PATH, **out)
-    print("wrote", PATH, os.path.getsize(PATH), "bytes")
+    for path, table in ((PATH, todo), (PATH_DEM, todo_dem)):
+        mine = [n for n in want if n in table]
+        if not mine:
+            continue
+        out = dict(np.load(path)) if (sys.argv[1:] and os.path.exists(path)) else {}
+        for name in mine:
+            t0 = time.time()
+            out = {k: v for k, v in out.items() if not k.startswith(name + "/")}
+            out.update(table[name]())
+            print(name, f"{time.time() - t0:.0f} s", flush=True)
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path), "bytes")

@@ -87,3 +87,42 @@ def test_float32_grid_and_errors(tmp_path):
         geotiff.save_array_to_grid(str(tmp_path / "g"), (0, 0, 1, 1), z, compression="zstd")
     with pytest.raises(AssertionError):
         geotiff.save_array_to_grid(str(tmp_path / "g"), (0, 0, 1, 1), z[0])
+
+
+def test_crs_forms_of_the_reference(tmp_path):
+    """data_prep.py:784's default `crs` is the PROJ string of Antarctic polar stereographic; callers also pass "EPSG:3031"."""
+    z = np.nan_to_num(_dem(20, 20), nan=0.0)
+    proj = "+proj=stere +lat_0=-90 +lat_ts=-71 +lon_0=0 +k=1 +x_0=0 +y_0=0 +datum=WGS84 +units=m +no_defs"
+    for crs in (proj, "EPSG:3031", "epsg:3031", 3031, "3031"):
+        path = geotiff.save_array_to_grid(str(tmp_path / "c"), (0, 0, 20, 20), z, crs=crs)
+        assert geotiff.read_geotiff(path)[1]["geokeys"][-4:] == [3072, 0, 1, 3031]
+    assert geotiff.read_geotiff(geotiff.save_array_to_grid(str(tmp_path / "c"), (0, 0, 20, 20), z, crs="EPSG:4326"))[1]["geokeys"][-1] == 4326
+    for bad in ("+proj=stere +lat_0=90 +lat_ts=70 +lon_0=-45 +datum=WGS84", "+proj=utm +zone=33", "WGS 84"):
+        with pytest.raises(ValueError, match="EPSG"):
+            geotiff.save_array_to_grid(str(tmp_path / "c"), (0, 0, 20, 20), z, crs=bad)
+
+
+@pytest.mark.parametrize("compression", ["none", "lzw"])
+def test_last_strip_holds_only_the_rows_that_exist(tmp_path, compression):
+    """Strip mode (tiled=False): 300 rows in strips of 256 -> the second strip is 44 rows, and its StripByteCounts says so
+    (what GDAL writes; libtiff reads the file back)."""
+    import struct
+
+    dem = np.nan_to_num(_dem(300, 61, seed=2), nan=-2000.0)
+    path = geotiff.save_array_to_grid(str(tmp_path / "s"), (0.0, 0.0, 61.0, 300.0), dem, dtype=np.int16, tiled=False,
+                                      compression=compression, bigtiff=False)
+    got, info = geotiff.read_geotiff(path)
+    assert np.array_equal(got, dem.astype(np.int16))
+    if compression == "none":
+        buf = open(path, "rb").read()
+        ifd = struct.unpack_from("<I", buf, 4)[0]
+        n = struct.unpack_from("<H", buf, ifd)[0]
+        counts = None
+        for i in range(n):
+            tag, typ, count, val = struct.unpack_from("<HHII", buf, ifd + 2 + 12 * i)
+            if tag == 279:
+                counts = list(struct.unpack_from("<%dI" % count, buf, val)) if count > 1 else [val]
+        assert counts == [256 * 61 * 2, 44 * 61 * 2]
+    PIL = pytest.importorskip("PIL.Image")
+    with PIL.open(path) as im:
+        assert np.array_equal(np.array(im).astype(np.int16), dem[0].astype(np.int16))

@@ -1,0 +1,211 @@
+"""-m gpu: parity at the REFERENCE'S DATA RANGE and the tight full-size discriminator step, against
+tests/golden/esrgan_dem.npz (made by `python tests/golden/make_golden_full.py dlin dem dem5`).
+
+The reference feeds raw physical units (deepbedmap.py:164-169 gap-fills BEDMAP2 with -5000 m): bed
+elevation X in metres, ice surface elevation W1 in metres, velocity W2 in m/yr, accumulation W3 in kg/m2/yr.  Rounds 1-2
+tested everything on U[0, 1).  Here: the generator forward at batch 64, one full config-3 iteration, and one 288 x 288 crop
+of the continent sweep in fp32 AND bf16 -- the bf16 error is reported in METRES.
+
+dlin: `train_eval_discriminator` at batch 64 with a discriminator in the linear regime (no LeakyReLU slope hangs on a
+rounding error): every gradient, BatchNorm running statistic and the loss against the float32 oracle at 5e-4 / 1e-4, in
+both cudnn_deterministic modes, mid-size tensors element by element.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden_full as mgf  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL_FWD, TOL_GRAD = 1e-4, 5e-4
+DEV, DEV_G = 3.0, 5.0  # as in test_gpu_fullsize.py: multiples of the float32 oracle's own distance from the float64 oracle
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(mgf.PATH_DEM))
+
+
+@pytest.fixture(scope="module")
+def dbm():
+    import deepbedmap_amd as d
+
+    return d
+
+
+@pytest.fixture(autouse=True)
+def _reset_config(dbm):
+    dbm.global_config.train = True
+    dbm.global_config.enable_backprop = True
+    dbm.global_config.ssim_window = "gaussian"
+    dbm.global_config.cudnn_deterministic = True
+    dbm.global_config.dtype = "float32"
+    yield
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def copy_params(dst, src_params, persistent=None):
+    for name, p in dst._tensors.items():
+        if name in src_params:
+            p.array = src_params[name]
+        elif persistent is not None and name in persistent:
+            p.array = np.asarray(persistent[name], dtype=np.float32)
+    return dst
+
+
+def grads_of(model):
+    return {k: t.grad for k, t in model._tensors.items() if t.kind == 0}
+
+
+def _close(got, ref64, ref32, rtol, atol=1e-6):
+    got, ref64, ref32 = (np.asarray(v, np.float64) for v in (got, ref64, ref32))
+    tol = np.maximum(rtol * np.abs(ref64) + atol, DEV * np.abs(ref32 - ref64))
+    return bool(np.all(np.abs(got - ref64) <= tol))
+
+
+def _note(name, **values):
+    """Measured numbers for DESIGN.md (written next to the test run when gpurun_out/ exists)."""
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "dem_parity_notes.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **{k: float(v) for k, v in values.items()}}) + "\n")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _dem_models(dbm):
+    og, od = mgf.models_dem()
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=12, initialize=False), og.params)
+    d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+    d_opt = dbm.optimizers.Adam(alpha=mgf.ALPHA, eps=mgf.EPS).setup(d)
+    g_opt = dbm.optimizers.Adam(alpha=mgf.ALPHA, eps=mgf.EPS).setup(g)
+    return g, d, g_opt, d_opt
+
+
+def _dem_batch(gold):
+    a = mgf.arrays_dem(64, 7100)
+    a["Y"] = gold["dem/Y"]
+    return a
+
+
+def test_dem_generator_forward_batch64(dbm, gold):
+    """Generator forward, batch 64, 12 RRDB, inputs in metres / m/yr / kg/m2/yr, activations of O(10^3) throughout: within
+    1e-4 of the output range of the float64 oracle (BASELINE north_star's bar at the reference's data range)."""
+    g, _, _, _ = _dem_models(dbm)
+    a = _dem_batch(gold)
+    ref = gold["dem/g_forward"]
+    assert np.abs(ref).max() > 5000 and ref.std() > 1000  # really metres
+    with dbm.using_config("enable_backprop", False):
+        y_host = g.forward(a["X"], a["W1"], a["W2"], a["W3"]).array
+        y_dev = g.forward(*[dbm.to_device(a[k]) for k in ("X", "W1", "W2", "W3")]).array.get()
+    e = rel(y_host, ref)
+    _note("dem_forward_b64", rel_err=e, oracle_f32_dev=float(gold["dem/g_forward_dev"]), max_abs_m=np.abs(y_host - ref).max())
+    assert e < max(TOL_FWD, DEV * float(gold["dem/g_forward_dev"])), e
+    assert np.array_equal(y_host, y_dev)
+
+
+def test_dem_full_iteration_matches_oracle_fixture(dbm, gold):
+    """One config-3 iteration (D-step + G-step, batch 64, prefetched forward, cudnn_deterministic) on the DEM-range batch
+    against the float64 oracle: metrics at 2e-4, BatchNorm running statistics at 1e-4, every DISCRIMINATOR gradient at 5e-4
+    (linear-regime discriminator: no slope hangs on the generator's rounding), every GENERATOR gradient within a multiple
+    of what the float32 oracle itself needs (`dev`: its LeakyReLU slopes do flip; make_golden_full, Conditioning)."""
+    g, d, g_opt, d_opt = _dem_models(dbm)
+    batch = dbm.device_batch(_dem_batch(gold))
+    got_d = dbm.train_eval_discriminator(batch, g, d, d_opt, prefetch_generator_forward=True)
+    assert _close(got_d[0], gold["dem/d_step"][0], gold["dem/d_step_f32"][0], 2e-4), (got_d, gold["dem/d_step"])
+    assert abs(got_d[1] - gold["dem/d_step"][1]) <= 2.0 / 128 + 1e-6
+    # the discriminator of this fixture is in the linear regime (make_golden_full.models_dem): every gradient at 5e-4
+    worst = mgf.check_digest_dict(gold, "dem/gradD/", grads_of(d), TOL_GRAD, TOL_GRAD, floor=mgf.DLIN_FLOOR, dev_factor=DEV)
+    assert worst[0] < 1.0, worst
+    pers = {k: t.array for k, t in d._tensors.items() if t.kind == 1 and not k.endswith("/N")}
+    worst = mgf.check_digest_dict(gold, "dem/persD/", pers, 1e-4, 1e-4, floor=mgf.G_FLOOR, dev_factor=DEV)
+    assert worst[0] < 1.0, worst
+    got_g = dbm.train_eval_generator(batch, g, d, g_opt)
+    # (PSNR / SSIM / loss in float32 on metres: the SSIM kernel's mean-shifted tiles are what keeps them at 1e-5)
+    assert _close(got_g, gold["dem/g_step"], gold["dem/g_step_f32"], 2e-4, 1e-5), (got_g, gold["dem/g_step"])
+    dev = gold["dem/gradG/dev"]
+    worst = mgf.check_digest_dict(gold, "dem/gradG/", grads_of(g), max(TOL_GRAD, DEV_G * float(dev[:, 0].max())),
+                                  max(TOL_GRAD, DEV_G * float(dev[:, 1].max())), floor=mgf.G_FLOOR)
+    assert worst[0] < 1.0, worst
+    _note("dem_iteration", d_loss=got_d[0], g_loss=got_g[0], psnr=got_g[1], ssim=got_g[2])
+
+
+def _crop_errors(y, gold):
+    assert tuple(y.shape) == tuple(gold["dem5/shape"])
+    c = y.shape[2] // 2 - mgf.C5_BLOCK // 2
+    d_grid = y[0, 0, ::mgf.C5_STRIDE, ::mgf.C5_STRIDE].astype(np.float64) - gold["dem5/grid"]
+    d_centre = y[0, 0, c:c + mgf.C5_BLOCK, c:c + mgf.C5_BLOCK].astype(np.float64) - gold["dem5/centre"]
+    s, st = mgf.digest("dem5/y", y)
+    d_s = s.astype(np.float64) - gold["dem5/samples"]
+    both = np.concatenate([d_grid.ravel(), d_centre.ravel(), d_s.ravel()])
+    e_proj = np.abs(st[2:] - gold["dem5/stats"][2:]).max() / gold["dem5/stats"][0]  # = relative rms error of the whole crop
+    return float(np.abs(both).max()), float(np.sqrt((both ** 2).mean())), float(e_proj)
+
+
+def test_dem_crop_fp32_and_bf16_error_in_metres(dbm, gold):
+    """One interior 288 x 288 crop of the continent sweep (deepbedmap.py:706-728) on DEM-range grids: fp32 within 1e-4 of the
+    output range; the bf16 sweep mode's error in METRES (8 significand bits on 3000 m is +-12 m before the first conv)."""
+    og = mgf.models_dem5()
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=12, initialize=False), og.params)
+    a = mgf.arrays_dem(1, 7500, h=288, w=288)
+    ins = [dbm.to_device(a[k]) for k in ("X", "W1", "W2", "W3")]
+    with dbm.using_config("enable_backprop", False):
+        y32 = g.forward(*ins).array.get()
+        with dbm.using_config("dtype", "bfloat16"):
+            y16 = g.forward(*ins).array.get()
+    rng = float(gold["dem5/stats"][1])   # largest |elevation| of the crop, metres
+    std = float(gold["dem5/std"])
+    m32, r32, p32 = _crop_errors(y32, gold)
+    m16, r16, p16 = _crop_errors(y16, gold)
+    _note("dem_crop", range_m=rng, std_m=std, fp32_max_m=m32, fp32_rms_m=r32, fp32_rel_rms=p32, bf16_max_m=m16, bf16_rms_m=r16,
+          bf16_rel_rms=p16)
+    # fp32: every compared pixel within 1e-4 of the output range (measured 6.5e-5: 0.9 m of 14 km); the +-1 projections are
+    # the relative RMS error of the whole crop against the float32 ORACLE, i.e. the sum of two float32 rounding fields
+    assert m32 / rng < TOL_FWD and p32 < 2 * TOL_FWD, (m32, rng, p32)
+    # bf16 sweep mode (the trunk multiplies in bf16, the layers on the signal path keep fp32: DESIGN.md "bf16 at the data
+    # range"): measured 1.0 m rms / 10 m worst pixel on this crop of 2000 m relief and +-14 km range -- white-noise grids,
+    # the worst case for the deformable sampler; all-bf16 is 190 m rms here (tools/bf16_error_study.py).
+    assert 1e-6 < p16 and r16 < 2e-3 * std and m16 < 5e-3 * rng, (m16, r16, p16, rng, std)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("deterministic", [True, False])
+@pytest.mark.parametrize("path", ["device_prefetch", "host_sequential"])
+def test_dlin_discriminator_step_tight(dbm, gold, deterministic, path):
+    """train_eval_discriminator at batch 64 (srgan_train.py:1084-1166) in the linear regime: the loss at 1e-4, EVERY
+    discriminator gradient at 5e-4 of its largest entry (digests + the mid-size tensors element by element), BatchNorm
+    running statistics at 1e-4 -- merged weight-gradient launches, wgrad_s2tiny_kernel, the cross-workgroup split-K and the
+    1024-wide BatchNorm backward at full size, in both cudnn_deterministic modes."""
+    og, od = mgf.models_dlin()
+    with dbm.using_config("cudnn_deterministic", deterministic):
+        g = copy_params(dbm.GeneratorModel(num_residual_blocks=12, initialize=False), og.params)
+        d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+        d_opt = dbm.optimizers.Adam(alpha=mgf.ALPHA, eps=mgf.EPS).setup(d)
+        a = mgf.arrays(64, 8200)
+        if path == "device_prefetch":
+            got = dbm.train_eval_discriminator(dbm.device_batch(a), g, d, d_opt, prefetch_generator_forward=True)
+        else:
+            got = dbm.train_eval_discriminator(a, g, d, d_opt)
+        grads = grads_of(d)
+        pers = {k: t.array for k, t in d._tensors.items() if t.kind == 1 and not k.endswith("/N")}
+    ref = gold["dlin/d_step"]
+    assert abs(got[0] - ref[0]) <= 1e-4 * abs(ref[0]) and got[1] == ref[1], (got, ref)
+    worst = mgf.check_digest_dict(gold, "dlin/gradD/", grads, TOL_GRAD, TOL_GRAD, floor=mgf.DLIN_FLOOR)
+    assert worst[0] < 1.0, worst
+    worst_p = mgf.check_digest_dict(gold, "dlin/persD/", pers, 1e-4, 1e-4)
+    assert worst_p[0] < 1.0, worst_p
+    gmax = max(float(np.abs(gold["dlin/full/" + k]).max()) for k in mgf.DLIN_FULL)
+    for k in mgf.DLIN_FULL:  # element by element
+        r = gold["dlin/full/" + k].astype(np.float64)
+        scale = max(float(np.abs(r).max()), mgf.DLIN_FLOOR * gmax)
+        e = float(np.abs(grads[k].astype(np.float64) - r).max()) / scale
+        assert e < TOL_GRAD, (k, e)
+    _note(f"dlin_{path}_{int(deterministic)}", worst_digest=worst[0] * TOL_GRAD, worst_pers=worst_p[0] * 1e-4)

@@ -749,7 +749,7 @@ def test_prefetched_forward_is_not_reused_for_refilled_arrays(dbm):
 
 
 _TIMEOUT_SCRIPT = r"""
-import sys, numpy as np
+import sys, warnings, numpy as np
 sys.path.insert(0, sys.argv[1])
 import deepbedmap_amd as d
 from deepbedmap_amd import _lib
@@ -760,7 +760,8 @@ batch = d.device_batch({"X": rs.rand(4, 1, 11, 11), "W1": rs.rand(4, 1, 110, 110
                         "W3": rs.rand(4, 1, 11, 11), "Y": rs.rand(4, 1, 36, 36)})
 inject = sys.argv[3] == "1"
 if inject:
-    # a retained generator gradient that is NOT zero, then the condition: the optimizer launch must be a no-op
+    # a retained generator gradient that is NOT zero, then the condition: the optimizer entry point observes it, returns
+    # status 7 and has done nothing
     with d.using_config("enable_backprop", True):
         y = g.forward(batch["X"], batch["W1"], batch["W2"], batch["W3"])
     g.cleargrads()
@@ -768,24 +769,31 @@ if inject:
     assert max(float(np.abs(p.grad).max()) for p in g.params()) > 0
     before = {k: np.array(v) for k, v in g.serialize_dict().items()}
     _lib.check(_lib.lib().dbm_debug_inject_timeout(g.ctx.handle), g.ctx.handle)
+    # entry points that are not steps neither observe nor clear the condition
+    assert g.count_params() > 0 and np.isfinite(next(iter(before.values()))).all()
+    _ = d.to_device(np.zeros(4, np.float32)).get()
     try:
         g_opt.update()
         raise SystemExit("status 7 expected")
     except _lib.DbmError as e:
         assert e.code == 7, e
     assert all(np.array_equal(before[k], v) for k, v in g.serialize_dict().items())
+    assert g.ctx.timeout_info()[0] == 1 and g.ctx.timeout_info()[3]
     g.cleargrads()
     _lib.check(_lib.lib().dbm_debug_inject_timeout(g.ctx.handle), g.ctx.handle)
-m = list(d.train_eval_discriminator(batch, g, dm, d_opt, prefetch_generator_forward=True))   # observes, recovers, repeats
-m += list(d.train_eval_generator(batch, g, dm, g_opt))
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    m = list(d.train_eval_discriminator(batch, g, dm, d_opt, prefetch_generator_forward=True))   # observes, recovers, is re-issued
+    m += list(d.train_eval_generator(batch, g, dm, g_opt))
+    assert (len([x for x in w if "timed out" in str(x.message)]) == 1) == inject
 np.savez(sys.argv[2], m=np.array(m), **{"g/" + k: v for k, v in g.serialize_dict().items()})
 """
 
 
 def test_persistent_kernel_timeout_is_recovered(dbm, tmp_path):
     """A persistent trunk kernel that gives up (injected: dbm_debug_inject_timeout) must not corrupt anything: the
-    optimizer kernels skip their update while the condition is up, the observing call returns status 7, the Python
-    mirror repeats the step on the layer-by-layer trunk path, and training ends where an undisturbed run with
+    condition is observed at the entry of a step call, which returns status 7 without having enqueued anything; the Python
+    mirror re-issues it on the layer-by-layer trunk path, and training ends where an undisturbed run with
     DBM_TRUNK_FUSED=0 ends."""
     import subprocess
     import sys
@@ -805,10 +813,97 @@ def test_persistent_kernel_timeout_is_recovered(dbm, tmp_path):
     assert np.allclose(outs[0]["m"], outs[1]["m"], rtol=2e-4, atol=1e-6)
     for k in outs[0]:
         if k != "m":
-            # the skipped optimizer launch gave its step count back: the same Adam step as the undisturbed run, except
-            # where a gradient is rounding noise (its first step is alpha * sign(g))
+            # nothing was applied by the call that reported the condition: the same Adam step as the undisturbed run,
+            # except where a gradient is rounding noise (its first step is alpha * sign(g))
             assert np.abs(outs[0][k] - outs[1][k]).max() <= 2.1e-3, k
             assert np.mean(np.abs(outs[0][k] - outs[1][k]) < 2e-5) > 0.97, k
+
+
+_TIMEOUT_QUEUED_SCRIPT = r"""
+import os, sys, warnings, numpy as np
+sys.path.insert(0, sys.argv[1])
+import deepbedmap_amd as d
+from deepbedmap_amd import _lib, training
+total, inject_after = int(sys.argv[3]), int(sys.argv[4])
+np.random.seed(4)
+g, g_opt, dm, d_opt = d.compile_srgan_model(num_residual_blocks=2, residual_scaling=0.3, learning_rate=2e-4)
+rs = np.random.RandomState(5)
+n = 16
+batch = d.device_batch({"X": rs.rand(n, 1, 11, 11), "W1": rs.rand(n, 1, 110, 110), "W2": rs.rand(n, 2, 22, 22),
+                        "W3": rs.rand(n, 1, 11, 11), "Y": rs.rand(n, 1, 36, 36)})
+log = d.MetricsLog(g.ctx, rows=64)
+dropped = 0
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    for it in range(total):
+        lost = training.pop_dropped_updates(g.ctx)
+        if lost:
+            dropped += lost
+            log.invalidate_last(lost, keep_last=1)
+        d.train_minibatch(batch, g, g_opt, dm, d_opt, log=log)      # dbm_train_iteration, nothing synchronises the host
+        if it + 1 == inject_after:
+            _lib.check(_lib.lib().dbm_debug_inject_timeout_async(g.ctx.handle), g.ctx.handle)
+    rows = log.fetch()
+    try:
+        g.ctx.check_timeout()
+    except _lib.DbmError as e:   # raised behind the last step call: only the epoch-end check can see it
+        assert e.code == 7
+        k = max(g.ctx.timeout_info()[1:3])
+        dropped += k
+        log.invalidate_last(k)
+        rows = log.fetch()
+dropped += training.pop_dropped_updates(g.ctx)
+events = g.ctx.timeout_info()[0]
+np.savez(sys.argv[2], dropped=dropped, events=events, rows=rows, invalid=np.array(log.invalid, np.int64),
+         **{"g/" + k: v for k, v in g.serialize_dict().items()}, **{"d/" + k: v for k, v in dm.serialize_dict().items()})
+"""
+
+
+def test_timeout_with_several_iterations_queued(dbm, tmp_path):
+    """The condition comes up in STREAM order (a kernel enqueued behind iteration 3 raises it) while the host keeps enqueuing
+    iterations: every optimizer launch and BatchNorm running-average write queued behind it is a no-op, a later step call
+    (or the epoch-end check) observes it, reports how many updates were dropped, and training continues.  The run must end
+    where an undisturbed run of (total - dropped) iterations on the same minibatch ends -- parameters of BOTH models and the
+    discriminator's running statistics (nothing half-applied, nothing applied twice) -- and the dropped iterations' metric
+    rows are marked invalid."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "queued.py"
+    script.write_text(_TIMEOUT_QUEUED_SCRIPT)
+    total = 12
+
+    def run(name, total_, inject_after, fused="1"):
+        out = str(tmp_path / f"{name}.npz")
+        res = subprocess.run([sys.executable, str(script), root, out, str(total_), str(inject_after)],
+                             env=dict(os.environ, DBM_TRUNK_FUSED=fused, DBM_TRUNK_REARM="1"), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        return dict(np.load(out)), res.stderr
+
+    hit, err = run("hit", total, 3)
+    dropped = int(hit["dropped"])
+    assert int(hit["events"]) == 1 and 0 <= dropped <= total - 3, (hit["events"], dropped)
+    assert "layer-by-layer trunk path" in err
+    if total - 3 - dropped >= 2:  # (paused for one iteration, then the persistent kernels again)
+        assert "re-armed" in err
+    assert len(hit["invalid"]) == dropped and np.isnan(hit["rows"][hit["invalid"].astype(int), :5]).all()
+    valid = np.setdiff1d(np.arange(total), hit["invalid"].astype(int))
+    assert np.isfinite(hit["rows"][valid, :5]).all()
+    clean, _ = run("clean", total - dropped, -1)
+    for k in clean:
+        if k in ("dropped", "events", "rows", "invalid") or k.endswith("/N"):
+            continue
+        a, b = hit[k], clean[k]
+        if k.endswith("avg_mean") or k.endswith("avg_var"):
+            # running statistics: exactly (total - dropped) valid real + fake updates went in -- an extra or a missing one
+            # would move them by ~10 %
+            assert np.abs(a - b).max() <= 2e-3 * max(1.0, float(np.abs(b).max())), k
+            continue
+        # parameters: the same number of Adam steps from the same gradients (a few iterations ran on the layer-by-layer
+        # trunk kernels: last-bit differences, amplified where a gradient is rounding noise)
+        assert np.abs(a - b).max() <= 6 * 2e-4 * 2 + 1e-6, (k, float(np.abs(a - b).max()))
+        assert np.mean(np.abs(a - b) < 5e-5) > 0.95, k
 
 
 def test_api_refuses_what_it_does_not_implement(dbm, tmp_path):

@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, fused=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import deepbedmap_amd as dbm
@@ -44,11 +44,19 @@ def _worker(rank, world, port, out_dir):
     batch = dbm.device_batch({k: v.astype(np.float32) for k, v in dbm.shard_batch(full, rank, world).items()}, ctx)
     metrics = []
     for _ in range(2):
-        metrics += list(dbm.train_eval_discriminator(batch, g, d, d_opt, comm=comm, prefetch_generator_forward=True))
-        metrics += list(dbm.train_eval_generator(batch, g, d, g_opt, comm=comm))
+        if fused:  # ONE library call per minibatch (dbm_train_iteration) with the communicator on the context
+            assert comm.exchanges_in_step(ctx)
+            metrics += list(dbm.train_minibatch(batch, g, g_opt, d, d_opt, comm=comm, fused=True))
+        else:
+            metrics += list(dbm.train_eval_discriminator(batch, g, d, d_opt, comm=comm, prefetch_generator_forward=True))
+            metrics += list(dbm.train_eval_generator(batch, g, d, g_opt, comm=comm))
     assert np.isfinite(metrics).all()
+    import ctypes as C
+    cw, cb, cc = C.c_int(0), C.c_size_t(0), C.c_size_t(0)
+    dbm._lib.check(dbm._lib.lib().dbm_comm_stats(ctx.handle, C.byref(cw), C.byref(cb), C.byref(cc), 0), ctx.handle)
     changed = any(not np.array_equal(start[k], v) for k, v in g.serialize_dict().items())
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), changed=np.asarray(changed),
+    np.savez(os.path.join(out_dir, f"{'fused' if fused else 'rank'}{rank}.npz"), changed=np.asarray(changed), metrics=np.array(metrics),
+             comm=np.array([cw.value, cb.value, cc.value], np.float64),
              **{"g/" + k: v for k, v in g.serialize_dict().items()}, **{"d/" + k: v for k, v in d.serialize_dict().items()})
     comm.barrier()
     torch.distributed.destroy_process_group()
@@ -61,9 +69,33 @@ def test_two_ranks_on_one_gpu_stay_identical(tmp_path):
     r1 = dict(np.load(tmp_path / "rank1.npz"))
     assert bool(r0["changed"]) and bool(r1["changed"])
     for k in r0:
-        if k.endswith("avg_mean") or k.endswith("avg_var") or k.endswith("/N") or k == "changed":
-            continue  # BatchNorm running statistics are per-rank (standard data parallelism)
+        if k.endswith("avg_mean") or k.endswith("avg_var") or k.endswith("/N") or k in ("changed", "metrics", "comm"):
+            continue  # BatchNorm running statistics (and the metrics of a rank's own tiles) are per-rank (standard data parallelism)
         assert np.array_equal(r0[k], r1[k]), k
+
+
+def test_fused_iteration_with_a_communicator_equals_the_two_step_calls(tmp_path):
+    """dbm_train_iteration on a context with a communicator (round 3): the data-parallel rank runs the SAME fused schedule a
+    single GPU runs -- gradient buckets of both models on chain[0], the discriminator's big bucket deferred behind the
+    fake-batch pass that stream carries, 1 / world in both Adam launches.  Two ranks on one GPU (hook backend), two
+    iterations: bitwise the two step calls + optimizer calls on every rank -- parameters, BatchNorm statistics, metrics --
+    with the same bytes exchanged."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), False), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    for rank in range(world):
+        a, b = dict(np.load(tmp_path / f"rank{rank}.npz")), dict(np.load(tmp_path / f"fused{rank}.npz"))
+        assert bool(b["changed"])
+        assert a["comm"][0] == b["comm"][0] == world and a["comm"][1] == b["comm"][1] > 0  # same world, same bytes
+        for k in a:
+            if k == "comm":
+                continue
+            assert np.array_equal(a[k], b[k]), (rank, k)
+    f0, f1 = dict(np.load(tmp_path / "fused0.npz")), dict(np.load(tmp_path / "fused1.npz"))
+    for k in f0:
+        if k.endswith("avg_mean") or k.endswith("avg_var") or k.endswith("/N") or k in ("changed", "metrics", "comm"):
+            continue
+        assert np.array_equal(f0[k], f1[k]), k
 
 
 # ---- sync_batch_stats: 2 ranks x batch 2 == 1 process x batch 4 (BatchNorm / RaGAN statistics of the global batch) ----
