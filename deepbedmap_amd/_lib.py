@@ -43,6 +43,7 @@ SIGNATURES = {
     "dbm_set_deterministic": [C.c_void_p, C.c_int],
     "dbm_memcpy2d_d2d": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t],
     "dbm_fill_f32": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float],
+    "dbm_clip_min_f32": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float],
     "dbm_gather_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_size_t],
     "dbm_profile_begin": [C.c_void_p],
     "dbm_profile_begin_serial": [C.c_void_p],
@@ -103,6 +104,7 @@ SIGNATURES = {
                             C.c_void_p, C.c_void_p, c_float_p, C.c_int, C.c_int, C.c_void_p],
     "dbm_op_conv2d": [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int] * 10,
     "dbm_op_conv2d_backward": [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int] * 9,
+    "dbm_op_conv2d_cl16": [C.c_void_p] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p] + [C.c_int] * 6,
     "dbm_op_deform_conv2d": [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int] * 5,
     "dbm_op_deform_conv2d_backward": [C.c_void_p] + [C.c_void_p] * 8 + [C.c_int] * 5,
 }

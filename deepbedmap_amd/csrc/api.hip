@@ -362,6 +362,13 @@ int dbm_fill_f32(dbm_ctx* ctx, float* dst, size_t n, float value) {
   DBM_API_END
 }
 
+int dbm_clip_min_f32(dbm_ctx* ctx, float* dst, size_t n, float lo) {
+  DBM_API_BEGIN(ctx)
+  ctx->data_epoch++;  // caller-visible device memory changes: retained generator forwards keyed on it go stale
+  if (n) launch_clip_min(dst, (long)n, lo, ctx->stream);
+  DBM_API_END
+}
+
 int dbm_debug_inject_timeout(dbm_ctx* ctx) {
   DBM_API_BEGIN(nullptr)  // (not observed by this call itself)
   DBM_CHECK(ctx != nullptr, "dbm_debug_inject_timeout: ctx is NULL");
@@ -1322,6 +1329,41 @@ int dbm_op_conv2d_backward(dbm_ctx* ctx, const float* x, const float* w, const f
     }
     DBM_HIP(hipStreamSynchronize(ctx->stream));
   }
+  DBM_API_END
+}
+
+// 3x3 / stride 1 / pad 1 convolution through the channels-last bf16 kernel of the sweep's trunk (conv_cl16.hip), for the parity
+// tests: x (N, C, H, W) fp32 is rounded to bf16 NHWC, y = [lrelu](s1 * (conv + b) + r1), fp32 out.  All DEVICE pointers.
+int dbm_op_conv2d_cl16(dbm_ctx* ctx, const float* x, const float* w, const float* b, const float* r1, float s1, float* y, int N,
+                       int C, int H, int W, int O, int lrelu) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(C % 32 == 0 && C >= 32 && C <= 256 && (O == 32 || O == 64), "cl16 conv op: C % 32 == 0, O 32 or 64");
+  DBM_CHECK(r1 == nullptr || O == 64, "cl16 conv op: the residual input has 64 channels");
+  hipStream_t s = ctx->stream;
+  const int plane = H * W;
+  const size_t P = (size_t)N * plane;
+  DevBuf act, res, out, wimg, bias;
+  act.ensure(P * C / 2 + 8);
+  out.ensure(P * 64);
+  wimg.ensure(cl16_packed_elems(C, O) / 2 + 8);
+  bias.ensure(64);
+  if (b) DBM_HIP(hipMemcpyAsync(bias.p, b, sizeof(float) * O, hipMemcpyDeviceToDevice, s));
+  for (int c0 = 0; c0 < C; c0 += 64)
+    launch_nchw_to_cl(x + (size_t)c0 * plane, (long)C * plane, nullptr, (char*)act.p + 2 * (size_t)c0, C, N, plane, s, std::min(64, C - c0));
+  if (r1) {
+    res.ensure(P * 64);
+    launch_nchw_to_cl(r1, 64L * plane, res.p, nullptr, 0, N, plane, s);
+  }
+  launch_pack_cl16(w, wimg.p, O, C, s);
+  ClConvLaunch q;
+  memset(&q, 0, sizeof(q));
+  q.x = act.p; q.xc = C; q.Cin = C; q.Cout = O; q.w = wimg.p; q.bias = bias.p; q.y32 = out.p;
+  q.r1 = r1 ? res.p : nullptr; q.s1 = r1 ? s1 : 1.f; q.s2 = 1.f; q.act = lrelu; q.slope = 0.2f; q.N = N; q.H = H; q.W = W;
+  q.zeros = ctx->zeros;
+  launch_conv_cl16(q, s);
+  launch_cl_to_nchw(out.p, y, (long)O * plane, N, plane, s, O);
+  DBM_HIP(hipStreamSynchronize(s));
+  act.release(); res.release(); out.release(); wimg.release(); bias.release();
   DBM_API_END
 }
 

@@ -1,0 +1,398 @@
+// 3x3 / stride 1 / pad 1 convolution on CHANNELS-LAST bf16 activations, LDS-tiled, v_mfma_f32_32x32x16_bf16: the RRDB trunk
+// (srgan_train.py:333-360, 393-404, 546) of the bf16 area sweep (BASELINE config 5; deepbedmap.py:689-741) on planes too
+// large for the persistent 9x9 kernels -- a 288 x 288 crop has a 286 x 286 trunk plane, 81 796 pixels.
+//
+// Why not the per-layer implicit GEMM of igemm.hip in its bf16 form: it gathers fp32 NCHW activations straight from L1
+// into MFMA operands (one dword per lane, channel and tap) and rounds them in registers.  At the bf16 MFMA rate (32 cycles
+// per 32 x 32 x 16) the vector L1 then bounds the kernel at 5 % of the matrix peak.  Here
+//   * activations live in HBM as NHWC bf16 (the dense block's concat: 192 channels = 384 bytes per pixel; the 64-channel
+//     residual stream additionally as NHWC fp32, so that the 36 residual additions never round to 8 bits): a lane's eight K
+//     values of the B operand are ONE 16-byte LDS read, for every tap, and a layer's output is written once, in bf16;
+//   * a workgroup owns a tile of 16 columns x 2 * nslots rows (nslots <= 12: chosen by the launcher so that the plane is one
+//     round of <= 256 workgroups) and stages, per chunk of 32 input channels, the tile's zero-framed halo block
+//     ((TH + 2) x 18 pixels x 64 bytes) AND the chunk's weights (9 taps x 32 x Cout, in fragment order) into LDS, double
+//     buffered: one barrier per chunk; the loads of chunk c + 1 are issued before the MFMAs of chunk c and written after them;
+//   * both land by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass (measured: the register-staged
+//     first version spent a quarter of a chunk's cycles in ds_write_b128);
+//   * the MFMA's N axis (32 lanes) is a patch of 2 rows x 16 columns, dealt to the lanes so that every 16-lane group of a
+//     ds_read_b128 ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: MI355X_MICROARCH.md, LDS) reads sixteen CONSECUTIVE pixels
+//     of one row; a pixel's four 16-byte parts sit at slot (part ^ ((pixel >> 2) & 3)) of its 64 bytes, so sixteen
+//     consecutive pixels cover the sixteen slots of the 256-byte bank row: conflict-free for every tap, no padding;
+//   * wave w owns patches w and w + 8: waves w and w + 4 share a SIMD, so a tile of 12 patches is three per SIMD; the weight
+//     fragment of a K step is read once per wave and used for both patches (and for both 32-channel output tiles of
+//     conv_layer5): 1.0-1.5 KB of LDS reads per MFMA against the 2 KB an unblocked wave would need (LDS: 256 B / clk).
+// Epilogues: bias + LeakyReLU -> bf16 into the concat's next 32 channels (conv_layer1..4); conv_layer5: fp32
+// `a5 * rs + a0` (and `... * rs + x` for every third block, :358 / :402) against the fp32 residual stream, written as fp32
+// AND as the next block's bf16 channels 0..63.
+// Numerics = the bf16 mode of igemm.hip: operands rounded to nearest-even bf16, fp32 accumulation, fp32 residual stream.
+#include "dbm_internal.h"
+#include "kernels.h"
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CL_TW = 16;            // tile width (pixels)
+constexpr int CL_HW = CL_TW + 2;     // halo block width
+constexpr int CL_NT = 512;           // threads per workgroup (8 wavefronts)
+constexpr int CL_MAXSLOTS = 12;
+constexpr int CL_ACT_BYTES = (((2 * CL_MAXSLOTS + 2) * CL_HW * 4 + 63) / 64) * 1024;  // one buffer of staged activations
+
+struct ClConvArgs {
+  const __bf16* x; int xc;           // input: NHWC bf16, xc channels per pixel; channels [0, Cin) are read
+  int Cin;                           // multiple of 32
+  const bf16x8* w;                   // packed weights [chunk][tap][k half][mtile][lane][8]  (launch_pack_cl16)
+  const float* bias;                 // Cout floats
+  __bf16* y16; int yc, y0;           // bf16 output: NHWC, yc channels per pixel, first output channel y0 (may be null)
+  float* y32;                        // fp32 output: NHWC, 64 channels per pixel (may be null)
+  const float* r1; float s1;         // v = s1 * (acc + bias) + r1   (r1: NHWC fp32, 64 channels; may be null)
+  const float* r2; float s2;         // then v = s2 * v + r2         (may be null)
+  int act; float slope;
+  int N, H, W, nslots, tilesX, tilesY;
+  const void* zeros;                 // >= 16 bytes of device zeros (out-of-plane pixels of the halo block)
+};
+
+// half-lane h (0..31) -> (row 0/1, column 0..15) of the wavefront's 2 x 16 patch: each 16-lane group of a ds_read_b128
+// covers one row
+__device__ __forceinline__ void patch_of(int h, int& g, int& i) {
+  if (h < 4) { g = 0; i = h; }
+  else if (h < 12) { g = 1; i = h - 4; }
+  else if (h < 16) { g = 0; i = h - 8; }
+  else if (h < 20) { g = 1; i = h - 8; }
+  else if (h < 28) { g = 0; i = h - 12; }
+  else { g = 1; i = h - 16; }
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <int MT>
+__global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int TH = 2 * a.nslots, HR = TH + 2, NPIX = HR * CL_HW;
+  const int AINS = (NPIX * 4 + 63) >> 6;         // LDS-DMA wave-instructions (1 KB each) per chunk of activations
+  constexpr int ACT_BYTES = CL_ACT_BYTES;        // (the layout is the same for every tile height: compile-time offsets)
+  constexpr int WINS = 18 * MT;                  // ... and of weights
+  constexpr int W_BYTES = WINS * 1024;
+  // (byte offsets into smem, not pointers: a pointer picked from an array by a run-time index loses its LDS address space
+  // and every access turns into a flat_load)
+  constexpr int WGT0 = 2 * ACT_BYTES;
+
+  int b = blockIdx.x;
+  const int tx = b % a.tilesX; b /= a.tilesX;
+  const int ty = b % a.tilesY;
+  const int n = b / a.tilesY;
+  const int gy0 = ty * TH - 1, gx0 = tx * CL_TW - 1;   // plane coordinates of halo pixel (0, 0)
+  const long img = (long)n * a.H * a.W;
+
+  // ---- staging by LDS-DMA (global_load_lds_dwordx4: per-lane source, lane-linear destination; no staging registers, no
+  // ds_write pass).  Activations: 64 bytes per pixel, the four 16-byte parts of pixel q stored at slot (part ^ ((q >> 2) & 3))
+  // -- sixteen consecutive pixels then cover the sixteen slots of the 256-byte bank row whatever the part: the fragment
+  // reads below stay conflict-free without padding; the permutation is applied on the SOURCE side (lane -> part), the
+  // destination stays linear.  Out-of-plane pixels are fetched from a zero block. ----
+  constexpr int ASTEPS = (30 + 7) / 8;           // AINS <= ceil(26 * 18 * 4 / 64) = 30 instructions over eight wavefronts
+  constexpr int WSTEPS = (WINS + 7) / 8;
+  const __bf16* asrc[ASTEPS];
+  const __bf16* zsrc = reinterpret_cast<const __bf16*>(a.zeros);
+#pragma unroll
+  for (int s = 0; s < ASTEPS; ++s) {
+    const int u = 64 * (wave + 8 * s) + lane;
+    const int q = u >> 2, part = (u & 3) ^ ((q >> 2) & 3);
+    const int hy = q / CL_HW, hx = q - hy * CL_HW;
+    const int gy = gy0 + hy, gx = gx0 + hx;
+    const bool inside = q < NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    asrc[s] = inside ? a.x + (img + (long)gy * a.W + gx) * a.xc + 8 * part : nullptr;
+  }
+  const int nchunk = a.Cin >> 5;
+  auto stage = [&](int c, auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
+#pragma unroll
+    for (int s = 0; s < ASTEPS; ++s) {
+      const int k = wave + 8 * s;
+      if (k < AINS)
+        __builtin_amdgcn_global_load_lds(asrc[s] ? asrc[s] + 32 * c : zsrc, (lds_ptr)(smem + buf * ACT_BYTES + k * 1024), 16, 0, 0);
+    }
+    const u4v* wsrc = reinterpret_cast<const u4v*>(a.w) + (long)c * (WINS * 64) + lane;
+#pragma unroll
+    for (int s = 0; s < WSTEPS; ++s) {
+      const int k = wave + 8 * s;
+      if (k < WINS) __builtin_amdgcn_global_load_lds(wsrc + k * 64, (lds_ptr)(smem + WGT0 + buf * W_BYTES + k * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- this lane's patches ----
+  int g, i;
+  patch_of(lane & 31, g, i);
+  const bool has0 = wave < a.nslots, has1 = wave + 8 < a.nslots;   // wave-uniform
+  const int prow0 = 2 * wave + g, prow1 = 2 * (wave + 8) + g;
+  // B operand addresses (K half 0; K half 1 = the same ^ 32): pixel q = (prow + ky) * 18 + i + kx, part = lane >> 5
+  int bad0[9], bad1[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int q0 = (prow0 + t / 3) * CL_HW + i + t % 3, q1 = (prow1 + t / 3) * CL_HW + i + t % 3;
+    bad0[t] = q0 * 64 + (((lane >> 5) ^ ((q0 >> 2) & 3)) << 4);
+    bad1[t] = q1 * 64 + (((lane >> 5) ^ ((q1 >> 2) & 3)) << 4);
+  }
+
+  f32x16 acc[2][MT];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
+
+  auto compute = [&](auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
+    if (!has0) return;
+    const unsigned char* ab = smem + buf * ACT_BYTES;
+    const unsigned char* wb = smem + WGT0 + buf * W_BYTES + lane * 16;
+    if (has1) {   // (wave-uniform: two patches share every weight fragment)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          bf16x8 av[MT];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const bf16x8*>(wb + ((t * 2 + kh) * MT + m) * 1024);
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ab + (bad0[t] ^ (kh << 5)));
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ab + (bad1[t] ^ (kh << 5)));
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], b0, acc[0][m], 0, 0, 0);
+            acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], b1, acc[1][m], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ab + (bad0[t] ^ (kh << 5)));
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(wb + ((t * 2 + kh) * MT + m) * 1024);
+            acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc[0][m], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+
+  stage(0, B0{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // chunk c is computed from buffer c & 1 while chunk c + 1 lands in the other one (two chunks per trip: the buffer
+  // offsets are compile-time constants, so that hipcc can tell the DMA's destination from the fragment reads' source)
+  for (int c = 0; c < nchunk; c += 2) {
+    if (c + 1 < nchunk) stage(c + 1, B1{});
+    compute(B0{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c + 1 has landed (this wavefront's pieces; the barrier covers the rest)
+    __syncthreads();
+    if (c + 1 >= nchunk) break;
+    if (c + 2 < nchunk) stage(c + 2, B0{});
+    compute(B1{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane = (pixel, 4 * (lane >> 5) + 8 * (reg >> 2) + (reg & 3) inside each 32-channel tile) ----
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (!(s == 0 ? has0 : has1)) continue;
+    const int prow = s == 0 ? prow0 : prow1;
+    const int gy = ty * TH + prow, gx = tx * CL_TW + i;
+    if (gy >= a.H || gx >= a.W) continue;
+    const long pix = img + (long)gy * a.W + gx;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = 32 * m + 8 * rg + 4 * (lane >> 5);
+        const f4v bv = (f4v){a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
+        f4v v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[s][m][4 * rg + e] + bv[e];
+        if (a.r1) {
+          const f4v r = *reinterpret_cast<const f4v*>(a.r1 + pix * 64 + co);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = a.s1 * v[e] + r[e];
+        }
+        if (a.r2) {
+          const f4v r = *reinterpret_cast<const f4v*>(a.r2 + pix * 64 + co);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = a.s2 * v[e] + r[e];
+        }
+        if (a.act) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : a.slope * v[e];
+        }
+        if (a.y32) *reinterpret_cast<f4v*>(a.y32 + pix * 64 + co) = v;
+        if (a.y16) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+          *reinterpret_cast<bf16x4*>(a.y16 + pix * a.yc + a.y0 + co) = o;
+        }
+      }
+    }
+  }
+}
+
+// dst[chunk][tap][k half][mtile][lane][8] = bf16(W[cout = 32 mtile + (lane & 31)][cin = 32 chunk + 16 khalf + 8 (lane >> 5) + e][tap])
+__global__ __launch_bounds__(256) void pack_cl16_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int O, int C, int MT,
+                                                        long total) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int i8 = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    long r = e >> 9;
+    const int m = (int)(r % MT); r /= MT;
+    const int kh = (int)(r & 1); r >>= 1;
+    const int t = (int)(r % 9);
+    const int chunk = (int)(r / 9);
+    const int co = 32 * m + (lane & 31), ci = 32 * chunk + 16 * kh + 8 * (lane >> 5) + i8;
+    dst[e] = (__bf16)((co < O && ci < C) ? w[((long)co * C + ci) * 9 + t] : 0.f);
+  }
+}
+
+// x (N, 64, plane) fp32 with image stride xsn  ->  res (N * plane, 64) fp32  and  act (N * plane, ac) bf16 channels 0..63
+__global__ __launch_bounds__(256) void nchw_to_cl_kernel(const float* __restrict__ x, long xsn, float* __restrict__ res,
+                                                         __bf16* __restrict__ act, int ac, long total, int plane, int nch) {
+  __shared__ float tile[64 * 65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long P0 = (long)blockIdx.x * 64;
+  for (int c = wave; c < nch; c += 4) {   // coalesced along positions
+    const long P = P0 + lane;
+    float v = 0.f;
+    if (P < total) {
+      const long n = P / plane;
+      v = x[n * xsn + (long)c * plane + (P - n * plane)];
+    }
+    tile[c * 65 + lane] = v;
+  }
+  __syncthreads();
+  for (int p = wave; p < 64; p += 4) {    // coalesced along channels
+    const long P = P0 + p;
+    if (P >= total) break;
+    if (lane >= nch) continue;
+    const float v = tile[lane * 65 + p];
+    if (res) res[P * 64 + lane] = v;
+    if (act) act[P * ac + lane] = (__bf16)v;
+  }
+}
+
+// res (N * plane, 64) fp32 -> y (N, 64, plane) fp32 with image stride ysn
+__global__ __launch_bounds__(256) void cl_to_nchw_kernel(const float* __restrict__ res, float* __restrict__ y, long ysn, long total,
+                                                         int plane, int nch) {
+  __shared__ float tile[64 * 65];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long P0 = (long)blockIdx.x * 64;
+  for (int p = wave; p < 64; p += 4) {
+    const long P = P0 + p;
+    tile[lane * 65 + p] = P < total ? res[P * 64 + lane] : 0.f;
+  }
+  __syncthreads();
+  for (int c = wave; c < nch; c += 4) {
+    const long P = P0 + lane;
+    if (P < total) {
+      const long n = P / plane;
+      y[n * ysn + (long)c * plane + (P - n * plane)] = tile[c * 65 + lane];
+    }
+  }
+}
+
+}  // namespace
+
+size_t cl16_packed_elems(int Cin, int Cout) { return (size_t)(Cin / 32) * 9 * 2 * ((Cout + 31) / 32) * 64 * 8; }
+
+void launch_pack_cl16(const float* w, void* dst, int O, int C, hipStream_t s) {
+  DBM_CHECK(C % 32 == 0 && O >= 1 && O <= 64, "cl16 pack: Cin % 32 == 0, Cout <= 64");
+  const int MT = (O + 31) / 32;
+  const long total = (long)cl16_packed_elems(C, O);
+  long nb = (total + 2047) / 2048;
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(pack_cl16_kernel, dim3((unsigned)nb), dim3(256), 0, s, w, (__bf16*)dst, O, C, MT, total);
+  DBM_HIP(hipGetLastError());
+}
+
+void launch_nchw_to_cl(const float* x, long xsn, float* res, void* act, int ac, int N, int plane, hipStream_t s, int nch) {
+  const long total = (long)N * plane;
+  DBM_CHECK(nch >= 1 && nch <= 64, "nchw_to_cl: 1..64 channels per call");
+  hipLaunchKernelGGL(nchw_to_cl_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, x, xsn, res, (__bf16*)act, ac, total, plane,
+                     nch);
+  DBM_HIP(hipGetLastError());
+}
+
+void launch_cl_to_nchw(const float* res, float* y, long ysn, int N, int plane, hipStream_t s, int nch) {
+  const long total = (long)N * plane;
+  DBM_CHECK(nch >= 1 && nch <= 64, "cl_to_nchw: 1..64 channels per call");
+  hipLaunchKernelGGL(cl_to_nchw_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, res, y, ysn, total, plane, nch);
+  DBM_HIP(hipGetLastError());
+}
+
+// patches (of 2 rows) per tile: the plane in as few rounds of <= n_cus workgroups as possible, then the least work per SIMD
+static int cl16_choose_slots(int N, int H, int W, int n_cus) {
+  static const int forced = getenv("DBM_CL16_SLOTS") ? atoi(getenv("DBM_CL16_SLOTS")) : 0;
+  if (forced >= 1 && forced <= CL_MAXSLOTS) return forced;
+  const int tilesX = (W + CL_TW - 1) / CL_TW;
+  int best = 8;
+  double best_cost = 1e30;
+  for (int ns = 2; ns <= CL_MAXSLOTS; ++ns) {
+    const int tilesY = (H + 2 * ns - 1) / (2 * ns);
+    const long wgs = (long)N * tilesX * tilesY;
+    const long rounds = (wgs + n_cus - 1) / n_cus;
+    int load = 0;  // patches on the busiest SIMD: waves s and s + 4 share one, wave w owns patches w and w + 8
+    for (int sd = 0; sd < 4; ++sd) {
+      int l = 0;
+      for (int p = sd; p < ns; p += 4) ++l;
+      load = l > load ? l : load;
+    }
+    const double cost = (double)rounds * (1.0 + load);  // (one unit of fixed cost per tile: staging, barriers, epilogue)
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = ns; }
+  }
+  return best;
+}
+
+void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
+  DBM_CHECK(L.Cin % 32 == 0 && L.Cin >= 32 && (L.Cout == 32 || L.Cout == 64), "cl16 conv: Cin % 32 == 0, Cout 32 or 64");
+  DBM_CHECK(L.xc % 8 == 0 && (!L.y16 || (L.yc % 4 == 0 && L.y0 % 4 == 0)), "cl16 conv: channel strides must keep 16- / 8-byte alignment");
+  static const int n_cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount;
+  }();
+  ClConvArgs a;
+  a.x = (const __bf16*)L.x; a.xc = L.xc; a.Cin = L.Cin; a.w = (const bf16x8*)L.w; a.bias = L.bias;
+  a.y16 = (__bf16*)L.y16; a.yc = L.yc; a.y0 = L.y0; a.y32 = L.y32;
+  a.r1 = L.r1; a.s1 = L.s1; a.r2 = L.r2; a.s2 = L.s2; a.act = L.act; a.slope = L.slope;
+  a.N = L.N; a.H = L.H; a.W = L.W;
+  a.nslots = cl16_choose_slots(L.N, L.H, L.W, n_cus);
+  a.tilesX = (L.W + CL_TW - 1) / CL_TW;
+  a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
+  const int MT = L.Cout / 32;
+  const size_t lds = 2 * (size_t)CL_ACT_BYTES + 2 * (size_t)18 * MT * 1024;
+  a.zeros = L.zeros;
+  DBM_CHECK(L.zeros != nullptr, "cl16 conv: a device zero block is required");
+  static bool attr = false;
+  if (!attr) {
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  const unsigned grid = (unsigned)((long)L.N * a.tilesX * a.tilesY);
+  if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)L.N * L.H * L.W * L.Cout * L.Cin * 9);
+  if (MT == 1)
+    hipLaunchKernelGGL(conv_cl16_kernel<1>, dim3(grid), dim3(CL_NT), lds, s, a);
+  else
+    hipLaunchKernelGGL(conv_cl16_kernel<2>, dim3(grid), dim3(CL_NT), lds, s, a);
+  if (g_profiler.enabled) g_profiler.end(s);
+  DBM_HIP(hipGetLastError());
+}

@@ -41,6 +41,7 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
                                  "/conv_layer" + std::to_string(k);
         conv(name, cout[k - 1], cin[k - 1], 3, 3);
         L_rdb.push_back(add_iglayer(name, cout[k - 1], cin[k - 1], 3, 1, 1, true));
+        layers.back().want_cl16 = true;
       }
   conv("post_residual_conv_layer", 64, 64, 3, 3);  // :478-485
   L_post = add_iglayer("post_residual_conv_layer", 64, 64, 3, 1, 1, true);
@@ -312,8 +313,40 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       ctx->persist_end(s);
     }
   }
-  if (!fused) (owner ? owner : this)->ensure_packed_lazy();
-  for (int j = 0; j < (fused ? 0 : nrdb); ++j) {
+  // bf16 sweep mode on planes the persistent kernels do not serve: the trunk on channels-last bf16 activations
+  // (conv_cl16.hip).  DBM_CL16=0 (read per call): the per-layer implicit GEMM in its bf16 form instead.
+  const bool cl16 = !fused && use_bf16 && !(bf16_keep32 & 4) && layers[L_rdb[0]].wcl16 != nullptr &&
+                    !(getenv("DBM_CL16") && atoi(getenv("DBM_CL16")) == 0);
+  if (cl16) {
+    const size_t n = (size_t)N;
+    for (auto& b : catb) b.ensure(n * 96 * hw);   // 192 bf16 = 96 floats per pixel
+    for (auto& b : resb) b.ensure(n * 64 * hw);
+    for (int c = 1; c < nsplit; ++c) ctx->fork(cstream(c), s, 4 + c);  // (the pre-residual conv's image ranges)
+    launch_nchw_to_cl(cat[0].p, 192 * hw, resb[0].p, catb[0].p, 192, N, (int)hw, s);
+    for (int j = 0; j < nrdb; ++j) {
+      void* C16 = catb[j & 1].p;
+      for (int k = 0; k < 5; ++k) {
+        const IgLayer& L = layers[L_rdb[j * 5 + k]];
+        ClConvLaunch q;
+        memset(&q, 0, sizeof(q));
+        q.x = C16; q.xc = 192; q.Cin = 64 + 32 * k; q.Cout = k < 4 ? 32 : 64; q.w = L.wcl16; q.bias = P(L.bi);
+        q.N = N; q.H = h; q.W = w; q.slope = SLOPE; q.s1 = 1.f; q.s2 = 1.f; q.zeros = ctx->zeros;
+        if (k < 4) {
+          q.y16 = C16; q.yc = 192; q.y0 = q.Cin; q.act = 1;
+        } else {
+          q.y16 = catb[(j + 1) & 1].p; q.yc = 192; q.y0 = 0;
+          q.y32 = resb[(j + 1) & 3].p;
+          q.r1 = resb[j & 3].p; q.s1 = rs;                                    // a6 = a5*rs + a0  (:358)
+          if (j % 3 == 2) { q.r2 = resb[(3 * (j / 3)) & 3].p; q.s2 = rs; }    // a4 = a3*rs + x   (:402)
+        }
+        launch_conv_cl16(q, s);
+      }
+    }
+    launch_cl_to_nchw(resb[nrdb & 3].p, cat[slot(nrdb)].p, 192 * hw, N, (int)hw, s);
+    for (int c = 1; c < nsplit; ++c) ctx->fork(s, cstream(c), c);  // the post-residual conv's ranges continue behind it
+  }
+  if (!fused && !cl16) (owner ? owner : this)->ensure_packed_lazy();
+  for (int j = 0; j < ((fused || cl16) ? 0 : nrdb); ++j) {
     for (int c = 0; c < nsplit; ++c) {  // one dense block per range at a time: fewer stream switches on the host
       for (int k = 0; k < 5; ++k) {
         const long n0 = cn0(c) * 192 * hw;

@@ -92,6 +92,7 @@ void launch_adam(float* p, const float* g, float* m, float* v, long n, float alp
                  float one_minus_beta2, float eps, float gscale, hipStream_t s, const int* skip = nullptr,
                  int* skipped = nullptr);  // skipped[0] counts the no-op launches, skipped[1] is the launch's gate word
 void launch_fill(float* p, long n, float v, hipStream_t s);
+void launch_clip_min(float* p, long n, float lo, hipStream_t s);  // p = max(p, lo) in place, NaN kept (np.clip)
 void launch_gather_rows(const void* src, void* dst, const int* d_idx, int n, size_t row_bytes, hipStream_t s);
 int sqdiff_blocks(long n);  // partial sums launch_sqdiff writes to out[0..blocks)
 void launch_sqdiff(const float* a, const float* b, long n, float* out, hipStream_t s);
@@ -152,3 +153,25 @@ void launch_ragan_sync_loss(const float* real, const float* fake, int N, int wor
                             float* out, hipStream_t s);
 void launch_ragan_sync_grad(const float* real, const float* fake, int N, int world, int real_target, int fake_target,
                             const float* buf, float* g_real, float* g_fake, hipStream_t s);
+
+// ---- channels-last bf16 3x3 convolution for the trunk of the bf16 area sweep on large planes (conv_cl16.hip) ----
+struct ClConvLaunch {
+  const void* x; int xc;     // input NHWC bf16 (xc channels per pixel), channels [0, Cin) are read
+  int Cin, Cout;             // Cin % 32 == 0, Cout 32 or 64
+  const void* w;             // packed by launch_pack_cl16
+  const float* bias;
+  void* y16; int yc, y0;     // bf16 output (NHWC, yc channels per pixel, first channel y0) or null
+  float* y32;                // fp32 output (NHWC, 64 channels per pixel) or null
+  const float* r1; float s1; // v = s1 * (acc + bias) + r1 (NHWC fp32, 64 channels), if r1
+  const float* r2; float s2; // v = s2 * v + r2, if r2
+  int act; float slope;
+  int N, H, W;
+  const void* zeros;         // >= 16 bytes of device zeros (dbm_ctx::zeros)
+};
+size_t cl16_packed_elems(int Cin, int Cout);   // bf16 elements of a layer's packed image
+void launch_pack_cl16(const float* w_oihw, void* dst, int O, int C, hipStream_t s);
+void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s);
+// (N, 64, plane) fp32 [image stride xsn] -> NHWC fp32 (res, may be null) and NHWC bf16 channels 0..63 of a buffer with `ac`
+// channels per pixel (act, may be null); and back
+void launch_nchw_to_cl(const float* x, long xsn, float* res, void* act, int ac, int N, int plane, hipStream_t s, int nch = 64);
+void launch_cl_to_nchw(const float* res, float* y, long ysn, int N, int plane, hipStream_t s, int nch = 64);

@@ -59,6 +59,7 @@ dbm_model::~dbm_model() {
   for (auto& L : layers) {
     if (L.wf) (void)hipFree(L.wf);
     if (L.wf16) (void)hipFree(L.wf16);
+    if (L.wcl16) (void)hipFree(L.wcl16);
     for (int i = 0; i < 4; ++i)
       if (L.wb[i]) (void)hipFree(L.wb[i]);
   }
@@ -274,6 +275,10 @@ void dbm_model::ensure_packed_bf16() {
     if (nb > 256) nb = 256;
     hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, s, P(L.wi), (__bf16*)L.wf16, L.O, L.Cview, L.Kview, L.CinP,
                        L.CoutP);
+    if (L.want_cl16 && L.K == 3 && L.C % 32 == 0 && (L.O == 32 || L.O == 64)) {  // fragment-ordered image (conv_cl16.hip)
+      if (!L.wcl16) DBM_HIP(hipMalloc(&L.wcl16, cl16_packed_elems(L.C, L.O) * sizeof(__bf16)));
+      launch_pack_cl16(P(L.wi), L.wcl16, L.O, L.C, s);
+    }
   }
   DBM_HIP(hipGetLastError());
   packed16_version = param_version;

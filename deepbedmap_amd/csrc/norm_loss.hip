@@ -811,6 +811,22 @@ void launch_fill(float* p, long n, float v, hipStream_t s) {
   DBM_HIP(hipGetLastError());
 }
 
+// np.clip(a, a_min=lo, a_max=None) in place (deepbedmap.py:663-665: W1, W2, W3 clipped to >= 0 before the sweep); NaN stays NaN
+__global__ __launch_bounds__(256) void clip_min_kernel(float* __restrict__ p, long n, float lo) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const float v = p[e];
+    if (v < lo) p[e] = lo;
+  }
+}
+
+void launch_clip_min(float* p, long n, float lo, hipStream_t s) {
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(clip_min_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n, lo);
+  DBM_HIP(hipGetLastError());
+}
+
 // sum of squared differences (psnr, srgan_train.py:906-928)
 __global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
                                                      float* out) {

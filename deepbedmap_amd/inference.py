@@ -24,9 +24,18 @@ class Shape:  # deepbedmap.py:680-684
 
 
 def clip_inputs(W1_tile, W2_tile, W3_tile):
-    """deepbedmap.py:663-665: ice surface elevation, velocity and accumulation clipped to >= 0."""
-    return (np.clip(a=W1_tile, a_min=0.0, a_max=None), np.clip(a=W2_tile, a_min=0.0, a_max=None),
-            np.clip(a=W3_tile, a_min=0.0, a_max=None))
+    """deepbedmap.py:663-665: ice surface elevation, velocity and accumulation clipped to >= 0.  NumPy arrays are clipped
+    on the host (new arrays, like np.clip); grids that already live in HBM (DeviceArray) are clipped there, in place
+    (dbm_clip_min_f32) -- nothing crosses PCIe."""
+    out = []
+    for a in (W1_tile, W2_tile, W3_tile):
+        if isinstance(a, DeviceArray):
+            _lib.check(_lib.lib().dbm_clip_min_f32(a.ctx.handle, C.c_void_p(a.ptr), a.size, 0.0), a.ctx.handle)
+            a._gen += 1
+            out.append(a)
+        else:
+            out.append(np.clip(a=a, a_min=0.0, a_max=None))
+    return tuple(out)
 
 
 def tile_steps(final_shape: Shape, stride: Shape):
@@ -72,12 +81,15 @@ def predict_tiled(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=
 
 def predict_tiled_resident(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=18000, x=22000),
                            ary_shape=Shape(y=1000, x=1000), stride=Shape(y=1000, x=1000), xtrapad=Shape(y=18, x=18), rank=0,
-                           world=1, download=True, dtype="float32"):
+                           world=1, download=True, dtype="float32", clip=False):
     """predict_tiled with the grids resident in HBM.  Inputs are NumPy arrays (uploaded once) or DeviceArrays of the
-    same shapes as for predict_tiled.  Returns Y_hat as a NumPy array (download=True) or as the device canvas."""
+    same shapes as for predict_tiled.  Returns Y_hat as a NumPy array (download=True) or as the device canvas.
+    clip=True: W1, W2, W3 are clipped to >= 0 (deepbedmap.py:663-665) on the device, after the upload (DeviceArrays: in place)."""
     ctx = model.ctx
     lib = _lib.lib()
     grids = [a if isinstance(a, DeviceArray) else to_device(a, ctx) for a in (X_tile, W1_tile, W2_tile, W3_tile)]
+    if clip:
+        grids[1:] = clip_inputs(*grids[1:])
     scale = (1, 10, 2, 1)  # pixels of each grid per low-resolution pixel
     canvas = DeviceArray((1, final_shape.y, final_shape.x), ctx)
     _lib.check(lib.dbm_fill_f32(ctx.handle, C.c_void_p(canvas.ptr), canvas.size, float("nan")), ctx.handle)

@@ -131,6 +131,9 @@ int dbm_memcpy_d2h(dbm_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
 int dbm_memcpy2d_d2d(dbm_ctx* ctx, void* dst_dev, size_t dst_pitch, const void* src_dev, size_t src_pitch,
                      size_t width_bytes, size_t height);
 int dbm_fill_f32(dbm_ctx* ctx, float* dst_dev, size_t n, float value);
+/* `np.clip(a=W_tile, a_min=0.0, a_max=None)` (deepbedmap.py:663-665: ice surface elevation, velocity and accumulation are
+ * clipped to >= 0 before the sweep) on a grid that already lives in HBM: in place, NaN stays NaN.  Asynchronous. */
+int dbm_clip_min_f32(dbm_ctx* ctx, float* dst_dev, size_t n, float lo);
 /* chainer.dataset.concat_examples over a dataset that lives on the device (srgan_train.py:107-121 `to_gpu`, 1286-1288):
  * dst row i = src row idx[i], rows of row_bytes (a multiple of 4) bytes; idx is a HOST array of n ints.  Asynchronous. */
 int dbm_gather_rows(dbm_ctx* ctx, void* dst_dev, const void* src_dev, const int* idx_host, int n, size_t row_bytes);
@@ -286,6 +289,11 @@ int dbm_op_conv2d(dbm_ctx* ctx, const float* x, const float* w, const float* b, 
 /* data gradient (gx, may be NULL) and weight/bias gradient (gw, gb accumulated; may be NULL) of the same layer */
 int dbm_op_conv2d_backward(dbm_ctx* ctx, const float* x, const float* w, const float* gy, float* gx, float* gw,
                            float* gb, int N, int C, int H, int W, int O, int k, int stride, int pad, int upsample2);
+/* the same L.Convolution2D (3x3, stride 1, pad 1: the RRDB trunk's layers, srgan_train.py:292-331) on the channels-last
+ * bf16 kernel of the area sweep (conv_cl16.hip): x is rounded to bf16, fp32 accumulation, y = [lrelu](s1 * (conv + b) + r1)
+ * with r1 (N,64,H,W) or NULL; C % 32 == 0, O = 32 or 64 */
+int dbm_op_conv2d_cl16(dbm_ctx* ctx, const float* x, const float* w, const float* b, const float* r1, float s1, float* y, int N,
+                       int C, int H, int W, int O, int lrelu);
 /* L.DeformableConvolution2D sampler + GEMM (stride 1, pad 1, 3x3): off (N,18,H,W) */
 int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y,
                          int N, int C, int H, int W, int O);

@@ -186,3 +186,31 @@ def test_generator_loss_terms_at_the_reference_data_range(dbm, window):
         assert abs(float(dbm.ssim_loss_func(dbm.Variable(y), t)) - ssim_ref) < 2e-5
         assert abs(float(dbm.ssim_loss_func(dbm.Variable(y), t, window_size=7, stride=2)) - float(ops.ssim(y64, t64, 7, 2, window))) < 2e-5
     assert abs(dbm.psnr(y, t) - float(ops.psnr(y64, t64))) < 1e-3
+
+
+def test_clip_of_resident_grids_on_the_device(dbm):
+    """deepbedmap.py:663-665 (`np.clip(a=W_tile, a_min=0.0, a_max=None)` before the sweep) on grids that already live in HBM:
+    clip_inputs on DeviceArrays runs dbm_clip_min_f32 in place, with np.clip's treatment of NaN; predict_tiled_resident(clip=True)
+    gives the canvas of the host-clipped call."""
+    rs = np.random.RandomState(5)
+    a = (rs.normal(size=(1, 1, 70, 90)) * 50).astype(np.float32)
+    a[0, 0, 3, 4] = np.nan
+    a[0, 0, 5, 6] = -0.0
+    dev = dbm.to_device(a)
+    out = dbm.clip_inputs(dev, dev, dev)[0]
+    assert out is dev
+    got, ref = dev.get(), np.clip(a, 0.0, None)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.nan_to_num(got), np.nan_to_num(ref))
+    # the resident sweep with clip=True == the host-clipped sweep
+    np.random.seed(12)
+    g = dbm.GeneratorModel(num_residual_blocks=1)
+    H, W = 30, 34
+    X = rs.rand(1, 1, H, W).astype(np.float32)
+    W1 = (rs.rand(1, 1, 10 * H, 10 * W) - 0.3).astype(np.float32)
+    W2 = (rs.rand(1, 2, 2 * H, 2 * W) - 0.3).astype(np.float32)
+    W3 = (rs.rand(1, 1, H, W) - 0.3).astype(np.float32)
+    S = dbm.Shape
+    kw = dict(final_shape=S(y=4 * H, x=4 * W), ary_shape=S(y=40, x=40), stride=S(y=40, x=40), xtrapad=S(y=2, x=2))
+    ref = dbm.predict_tiled_resident(g, X, *dbm.clip_inputs(W1, W2, W3), **kw)
+    got = dbm.predict_tiled_resident(g, X, W1, W2, W3, clip=True, **kw)
+    assert np.array_equal(np.nan_to_num(got, nan=-7.0), np.nan_to_num(ref, nan=-7.0))

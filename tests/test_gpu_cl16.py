@@ -1,0 +1,104 @@
+"""-m gpu: the channels-last bf16 convolution of the area sweep's trunk (csrc/conv_cl16.hip, BASELINE config 5).
+
+The kernel's contract is exact: operands rounded to nearest-even bf16, products accumulated in fp32.  The oracle's im2col
+convolution on PRE-ROUNDED operands (float64 accumulation) is therefore a tight reference -- 2e-5 of the output's largest
+magnitude, the order-of-summation noise of an fp32 accumulator over K <= 1728 terms -- not a 3e-2 "bf16 tolerance".
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import model as omodel
+from oracle import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_round(a):
+    """float32 -> nearest-even bfloat16 -> float32 (what v_cvt_pk_bf16_f32 does)."""
+    a = np.ascontiguousarray(a, np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).reshape(a.shape)
+
+
+@pytest.fixture(scope="module")
+def dbm():
+    import deepbedmap_amd as d
+    from deepbedmap_amd import _lib
+
+    return d, _lib, _lib.default_context()
+
+
+CASES = [
+    # N, C, H, W, O, lrelu, residual
+    (1, 64, 40, 37, 32, 1, False),     # conv_layer1: ragged tiles in both directions
+    (2, 96, 18, 50, 32, 1, False),     # conv_layer2, two images
+    (1, 128, 9, 9, 32, 1, False),      # a plane smaller than one tile
+    (1, 160, 23, 16, 32, 0, False),    # conv_layer4, exactly one tile column
+    (1, 192, 33, 35, 64, 0, True),     # conv_layer5: two output tiles per wavefront, a5 * rs + a0 epilogue
+    (1, 64, 286, 286, 32, 1, False),   # the sweep's trunk plane: 234 workgroups of eleven patches
+    (1, 192, 286, 286, 64, 0, True),
+]
+
+
+@pytest.mark.parametrize("N,Cc,H,W,O,lrelu,resid", CASES)
+def test_cl16_conv_matches_oracle_on_rounded_operands(dbm, N, Cc, H, W, O, lrelu, resid):
+    d, _lib, ctx = dbm
+    rs = np.random.RandomState(Cc * 7 + H)
+    x = rs.normal(size=(N, Cc, H, W)).astype(np.float32) * 3.0
+    w = rs.normal(size=(O, Cc, 3, 3)).astype(np.float32) / np.sqrt(9 * Cc)
+    b = rs.normal(size=(O,)).astype(np.float32)
+    r1 = rs.normal(size=(N, 64, H, W)).astype(np.float32) if resid else None
+    s1 = 0.1 if resid else 1.0
+    ref = ops.conv2d(bf16_round(x).astype(np.float64), bf16_round(w).astype(np.float64), b.astype(np.float64), 1, 1)
+    if resid:
+        ref = s1 * ref + r1
+    if lrelu:
+        ref = np.where(ref >= 0, ref, 0.2 * ref)
+    dx, dw, db = d.to_device(x), d.to_device(w), d.to_device(b)
+    dr = d.to_device(r1) if resid else None
+    y = d.DeviceArray((N, O, H, W))
+    _lib.check(_lib.lib().dbm_op_conv2d_cl16(ctx.handle, dx.ptr, dw.ptr, db.ptr, dr.ptr if resid else None, s1, y.ptr, N, Cc, H, W, O,
+                                             lrelu), ctx.handle)
+    got = y.get()
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 2e-5, err
+
+
+def test_cl16_trunk_equals_the_per_layer_bf16_path(dbm):
+    """GeneratorModel.forward in the bf16 sweep mode with the trunk on conv_cl16 (default) against the same mode on the
+    per-layer implicit GEMM (DBM_CL16=0): both round the same operands at the same places (the dense block's activations
+    to bf16, the residual stream in fp32), so they agree to accumulation-order noise -- on a plane with ragged tiles,
+    three RRDBs (every `x` skip of :402), two images."""
+    d, _lib, ctx = dbm
+    og = omodel.GeneratorModel(num_residual_blocks=3, seed=31)
+    r = np.random.RandomState(32)
+    for k in sorted(og.params):
+        og.params[k] = (og.params[k] * np.float32(3.0) if k.endswith("/W") else r.normal(0, 0.1, og.params[k].shape).astype(np.float32))
+    g = d.GeneratorModel(num_residual_blocks=3, initialize=False)
+    for name, p in g._tensors.items():
+        p.array = og.params[name]
+    h, w = 45, 61
+    ins = [d.to_device(r.rand(2, c, m * h, m * w).astype(np.float32)) for c, m in ((1, 1), (1, 10), (2, 2), (1, 1))]
+    old = os.environ.get("DBM_CL16")
+    try:
+        with d.using_config("enable_backprop", False):
+            y32 = g.forward(*ins).array.get()
+            with d.using_config("dtype", "bfloat16"):
+                os.environ["DBM_CL16"] = "1"
+                y_cl = g.forward(*ins).array.get()
+                os.environ["DBM_CL16"] = "0"
+                y_ig = g.forward(*ins).array.get()
+    finally:
+        if old is None:
+            os.environ.pop("DBM_CL16", None)
+        else:
+            os.environ["DBM_CL16"] = old
+    scale = np.abs(y32).max()
+    assert np.abs(y_cl - y_ig).max() / scale < 1e-4, np.abs(y_cl - y_ig).max() / scale
+    e = np.abs(y_cl - y32).max() / scale
+    assert 1e-7 < e < 3e-2, e  # really bf16 arithmetic, within the mode's tolerance of the fp32 forward
+    assert not np.array_equal(y_cl, y_ig)  # (two different kernels did run)

@@ -193,8 +193,11 @@ def test_config5_full_crop_fp32_and_bf16_match_oracle_fixture(dbm, gold):
         with dbm.using_config("dtype", "bfloat16"):
             y16 = g.forward(*ins).array.get()
     _c5_check(y32, gold, TOL_FWD)
-    e16 = _c5_check(y16, gold, TOL_BF16)
-    assert e16 > 1e-5  # really the bf16 arithmetic
+    _c5_check(y16, gold, TOL_BF16)
+    # really the bf16 arithmetic -- in the TRUNK only since round 3 (DBM_BF16_FP32_LAYERS = 27: the layers on the signal path
+    # keep fp32, DESIGN.md "bf16 at the data range"), whose residual branches enter through two 0.1 scalings: at the
+    # reference's initialisation the two outputs differ in the seventh digit
+    assert not np.array_equal(y16, y32) and np.abs(y16 - y32).max() / np.abs(y32).max() < 1e-3
 
 
 def test_config5_sweep_slice_two_ranks_bf16(dbm, gold):
@@ -225,7 +228,7 @@ def test_config5_sweep_slice_two_ranks_bf16(dbm, gold):
     assert m[:, frame:-frame, frame:-frame].all() and not m[:, :frame].any()
     assert np.array_equal(np.isnan(y16), ~m)
     err = np.abs(y16[m] - y32[m]).max() / np.abs(y32[m]).max()
-    assert 1e-5 < err < TOL_BF16, err
+    assert 0 < err < TOL_BF16, err  # (bf16 in the trunk only: see test_config5_full_crop_fp32_and_bf16_match_oracle_fixture)
     assert np.array_equal(np.nan_to_num(dbm.merge_ranks(parts), nan=-1.0), np.nan_to_num(y16, nan=-1.0))
 
 @pytest.mark.parametrize("form", ["helpers_in_every_pass", "no_helpers", "tiles_of_32_positions"])
