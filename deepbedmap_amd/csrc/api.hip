@@ -1422,6 +1422,40 @@ int dbm_op_conv2d_cl16(dbm_ctx* ctx, const float* x, const float* w, const float
   DBM_API_END
 }
 
+// The split-bf16 form (conv_cl16x3_kernel: three bf16 MFMAs per product) of the same convolution, optionally on the nearest x2
+// resize of x: x (N, 64, H >> ups, W >> ups), y (N, O, H, W), O <= 64; planar != 0 writes y through the kernel's channel-plane
+// epilogue (the offset tensors' form) instead of NHWC + transpose.  All DEVICE pointers.
+int dbm_op_conv2d_cl16x3(dbm_ctx* ctx, const float* x, const float* w, const float* b, float* y, int N, int H, int W, int O, int ups,
+                         int lrelu, int planar) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(O >= 1 && O <= 64 && (ups == 0 || ups == 1), "cl16x3 conv op: O <= 64, ups 0 / 1");
+  hipStream_t s = ctx->stream;
+  const int Hs = H >> ups, Ws = W >> ups, plane = H * W, splane = Hs * Ws;
+  DevBuf xin, out, wimg, bias;
+  xin.ensure((size_t)N * splane * 64);
+  out.ensure((size_t)N * plane * 64);
+  wimg.ensure(cl16x3_packed_elems(64, O) / 2 + 8);
+  bias.ensure(64);
+  if (b) DBM_HIP(hipMemcpyAsync(bias.p, b, sizeof(float) * O, hipMemcpyDeviceToDevice, s));
+  launch_nchw_to_cl(x, 64L * splane, xin.p, nullptr, 0, N, splane, s);
+  launch_pack_cl16x3(w, wimg.p, O, 64, s);
+  ClX3Launch q;
+  memset(&q, 0, sizeof(q));
+  q.x = xin.p; q.xc = 64; q.Cin = 64; q.Cout = O; q.ups = ups; q.w = wimg.p; q.bias = bias.p; q.act = lrelu; q.slope = 0.2f;
+  q.N = N; q.H = H; q.W = W;
+  if (planar) {
+    DBM_HIP(hipMemsetAsync(y, 0, sizeof(float) * (size_t)N * O * plane, s));
+    q.yp = y; q.ysn = (long)O * plane; q.ypc = O;
+  } else {
+    q.y32 = out.p; q.yc = 64;
+  }
+  launch_conv_cl16x3(q, s);
+  if (!planar) launch_cl_to_nchw(out.p, y, (long)O * plane, N, plane, s, O);
+  DBM_HIP(hipStreamSynchronize(s));
+  xin.release(); out.release(); wimg.release(); bias.release();
+  DBM_API_END
+}
+
 int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y,
                          int N, int C, int H, int W, int O) {
   DBM_API_BEGIN(ctx)

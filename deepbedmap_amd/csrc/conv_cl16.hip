@@ -247,6 +247,223 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16 x 3") form for the layers ON the signal path of the sweep -- the two upsampling convolutions and the two
+// offset convolutions of the deformable layers (srgan_train.py:488-514, 556-572): plain bf16 operands cost them 65-120 m rms
+// at the reference's data range (DESIGN.md "bf16 at the data range"), fp32 MFMA runs at 1/16 of the bf16 rate.  Every fp32
+// operand is split x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (sixteen significand bits), and a product is three bf16
+// MFMAs: hi*hi + hi*lo + lo*hi (the dropped lo*lo term is 2^-18 relative) -- fp32 accumulation; 3/16 of the fp32 MFMA time at
+// 2^-16 instead of 2^-9 operand precision.
+//   * input: NHWC fp32 (64 channels), optionally the nearest x2 resize folded into the staging (source pixel = (y >> 1, x >> 1)
+//     of the half-size plane); the split happens while a chunk of 16 channels is staged through registers (one 16-byte load
+//     = 4 channels -> 8 bytes of hi and 8 bytes of lo, two ds_write_b64);
+//   * LDS pixel record = 64 bytes [hi k0 | hi k1 | lo k0 | lo k1] with the same slot swizzle as above (conflict-free
+//     ds_read_b128 fragment reads), weights [chunk][tap][mtile][hi | lo][lane][8] by LDS-DMA;
+//   * output: NHWC fp32 (what the next layer of this kind and the fused deformable sampler read) or channel planes (the
+//     offset tensors the deformable kernels consume).
+// ---------------------------------------------------------------------------------------------------------------------
+struct ClX3Args {
+  const float* x; int xc;            // input NHWC fp32, xc channels per pixel; channels [0, Cin) are read
+  int Cin;                           // multiple of 16
+  int ups;                           // 1: x is the (H / 2, W / 2) plane, nearest x2 folded in
+  const bf16x8* w;                   // packed [chunk][tap][mtile][hi | lo][lane][8]  (launch_pack_cl16x3)
+  const float* bias;
+  float* y32; int yc;                // NHWC fp32 output, yc channels per pixel (may be null)
+  float* yp; long ysn; int ypc;      // channel-plane output yp[n * ysn + co * H * W + pixel], co < ypc (may be null)
+  int act; float slope;
+  int N, H, W, nslots, tilesX, tilesY;
+};
+
+__device__ __forceinline__ void split_bf16(const f4v v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+}
+
+template <int MT>
+__global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int TH = 2 * a.nslots, HR = TH + 2, NPIX = HR * CL_HW;
+  constexpr int ACT_BYTES = CL_ACT_BYTES;
+  constexpr int WINS = 9 * MT * 2;               // LDS-DMA instructions (1 KB) of a 16-channel chunk's weights
+  constexpr int W_BYTES = WINS * 1024;
+  constexpr int WGT0 = 2 * ACT_BYTES;
+
+  int b = blockIdx.x;
+  const int tx = b % a.tilesX; b /= a.tilesX;
+  const int ty = b % a.tilesY;
+  const int n = b / a.tilesY;
+  const int gy0 = ty * TH - 1, gx0 = tx * CL_TW - 1;
+  const int Hs = a.H >> a.ups, Ws = a.W >> a.ups;   // source plane
+  const long simg = (long)n * Hs * Ws;
+
+  // ---- activations: 16-byte pieces (4 channels) through registers; piece idx = (pixel q, quarter p) ----
+  constexpr int ASTEPS = (26 * CL_HW * 4 + CL_NT - 1) / CL_NT;
+  constexpr int WSTEPS = (WINS + 7) / 8;
+  const float* asrc[ASTEPS];
+  int ahi[ASTEPS];   // LDS byte of the piece's hi half (-1: no piece); lo half = the same ^ 32
+#pragma unroll
+  for (int s = 0; s < ASTEPS; ++s) {
+    const int idx = tid + CL_NT * s;
+    const int q = idx >> 2, p = idx & 3;
+    const int hy = q / CL_HW, hx = q - hy * CL_HW;
+    const int gy = gy0 + hy, gx = gx0 + hx;
+    const bool have = q < NPIX;
+    const bool inside = have && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    asrc[s] = inside ? a.x + (simg + (long)(gy >> a.ups) * Ws + (gx >> a.ups)) * a.xc + 4 * p : nullptr;
+    ahi[s] = have ? q * 64 + ((((p >> 1)) ^ ((q >> 2) & 3)) << 4) + (p & 1) * 8 : -1;
+  }
+  f4v areg[ASTEPS];
+  const int nchunk = a.Cin >> 4;
+  auto issue = [&](int c, auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
+#pragma unroll
+    for (int s = 0; s < ASTEPS; ++s) areg[s] = asrc[s] ? *reinterpret_cast<const f4v*>(asrc[s] + 16 * c) : (f4v){0.f, 0.f, 0.f, 0.f};
+    const u4v* wsrc = reinterpret_cast<const u4v*>(a.w) + (long)c * (WINS * 64) + lane;
+#pragma unroll
+    for (int s = 0; s < WSTEPS; ++s) {
+      const int k = wave + 8 * s;
+      if (k < WINS) __builtin_amdgcn_global_load_lds(wsrc + k * 64, (lds_ptr)(smem + WGT0 + buf * W_BYTES + k * 1024), 16, 0, 0);
+    }
+  };
+  auto commit = [&](auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
+#pragma unroll
+    for (int s = 0; s < ASTEPS; ++s) {
+      if (ahi[s] < 0) continue;
+      bf16x4 hi, lo;
+      split_bf16(areg[s], hi, lo);
+      *reinterpret_cast<bf16x4*>(smem + buf * ACT_BYTES + ahi[s]) = hi;
+      *reinterpret_cast<bf16x4*>(smem + buf * ACT_BYTES + (ahi[s] ^ 32)) = lo;
+    }
+  };
+
+  int g, i;
+  patch_of(lane & 31, g, i);
+  const bool has0 = wave < a.nslots, has1 = wave + 8 < a.nslots;
+  const int prow0 = 2 * wave + g, prow1 = 2 * (wave + 8) + g;
+  int bad0[9], bad1[9];   // hi fragment of tap t (K half = lane >> 5); lo fragment = the same ^ 32
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int q0 = (prow0 + t / 3) * CL_HW + i + t % 3, q1 = (prow1 + t / 3) * CL_HW + i + t % 3;
+    bad0[t] = q0 * 64 + (((lane >> 5) ^ ((q0 >> 2) & 3)) << 4);
+    bad1[t] = q1 * 64 + (((lane >> 5) ^ ((q1 >> 2) & 3)) << 4);
+  }
+  f32x16 acc[2][MT];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
+
+  auto compute = [&](auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
+    if (!has0) return;
+    const unsigned char* ab = smem + buf * ACT_BYTES;
+    const unsigned char* wb = smem + WGT0 + buf * W_BYTES + lane * 16;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      bf16x8 ah[MT], al[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        ah[m] = *reinterpret_cast<const bf16x8*>(wb + ((t * MT + m) * 2 + 0) * 1024);
+        al[m] = *reinterpret_cast<const bf16x8*>(wb + ((t * MT + m) * 2 + 1) * 1024);
+      }
+      const bf16x8 bh0 = *reinterpret_cast<const bf16x8*>(ab + bad0[t]);
+      const bf16x8 bl0 = *reinterpret_cast<const bf16x8*>(ab + (bad0[t] ^ 32));
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh0, acc[0][m], 0, 0, 0);   // (small terms first)
+        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl0, acc[0][m], 0, 0, 0);
+        acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh0, acc[0][m], 0, 0, 0);
+      }
+      if (has1) {
+        const bf16x8 bh1 = *reinterpret_cast<const bf16x8*>(ab + bad1[t]);
+        const bf16x8 bl1 = *reinterpret_cast<const bf16x8*>(ab + (bad1[t] ^ 32));
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh1, acc[1][m], 0, 0, 0);
+          acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl1, acc[1][m], 0, 0, 0);
+          acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh1, acc[1][m], 0, 0, 0);
+        }
+      }
+    }
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+
+  issue(0, B0{});
+  commit(B0{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int c = 0; c < nchunk; c += 2) {
+    if (c + 1 < nchunk) issue(c + 1, B1{});
+    compute(B0{});
+    if (c + 1 < nchunk) commit(B1{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (c + 1 >= nchunk) break;
+    if (c + 2 < nchunk) issue(c + 2, B0{});
+    compute(B1{});
+    if (c + 2 < nchunk) commit(B0{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const long plane = (long)a.H * a.W;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (!(s == 0 ? has0 : has1)) continue;
+    const int prow = s == 0 ? prow0 : prow1;
+    const int gy = ty * TH + prow, gx = tx * CL_TW + i;
+    if (gy >= a.H || gx >= a.W) continue;
+    const long pin = (long)gy * a.W + gx;
+    const long pix = (long)n * plane + pin;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = 32 * m + 8 * rg + 4 * (lane >> 5);
+        f4v v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[s][m][4 * rg + e] + a.bias[co + e];
+          if (a.act) v[e] = v[e] >= 0.f ? v[e] : a.slope * v[e];
+        }
+        if (a.y32) *reinterpret_cast<f4v*>(a.y32 + pix * a.yc + co) = v;
+        if (a.yp) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < a.ypc) a.yp[(long)n * a.ysn + (long)(co + e) * plane + pin] = v[e];
+        }
+      }
+    }
+  }
+}
+
+// dst[chunk][tap][mtile][hi | lo][lane][8]: W[cout = 32 mtile + (lane & 31)][cin = 16 chunk + 8 (lane >> 5) + e][tap] split in two
+__global__ __launch_bounds__(256) void pack_cl16x3_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int O, int C, int MT,
+                                                          long total) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int i8 = (int)(e & 7), lane = (int)((e >> 3) & 63);
+    long r = e >> 9;
+    const int part = (int)(r & 1); r >>= 1;
+    const int m = (int)(r % MT); r /= MT;
+    const int t = (int)(r % 9);
+    const int chunk = (int)(r / 9);
+    const int co = 32 * m + (lane & 31), ci = 16 * chunk + 8 * (lane >> 5) + i8;
+    const float v = (co < O && ci < C) ? w[((long)co * C + ci) * 9 + t] : 0.f;
+    const __bf16 h = (__bf16)v;
+    dst[e] = part == 0 ? h : (__bf16)(v - (float)h);
+  }
+}
+
 // dst[chunk][tap][k half][mtile][lane][8] = bf16(W[cout = 32 mtile + (lane & 31)][cin = 32 chunk + 16 khalf + 8 (lane >> 5) + e][tap])
 __global__ __launch_bounds__(256) void pack_cl16_kernel(const float* __restrict__ w, __bf16* __restrict__ dst, int O, int C, int MT,
                                                         long total) {
@@ -393,6 +610,53 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
     hipLaunchKernelGGL(conv_cl16_kernel<1>, dim3(grid), dim3(CL_NT), lds, s, a);
   else
     hipLaunchKernelGGL(conv_cl16_kernel<2>, dim3(grid), dim3(CL_NT), lds, s, a);
+  if (g_profiler.enabled) g_profiler.end(s);
+  DBM_HIP(hipGetLastError());
+}
+
+size_t cl16x3_packed_elems(int Cin, int Cout) { return (size_t)(Cin / 16) * 9 * ((Cout + 31) / 32) * 2 * 64 * 8; }
+
+void launch_pack_cl16x3(const float* w, void* dst, int O, int C, hipStream_t s) {
+  DBM_CHECK(C % 16 == 0 && O >= 1 && O <= 64, "cl16x3 pack: Cin % 16 == 0, Cout <= 64");
+  const int MT = (O + 31) / 32;
+  const long total = (long)cl16x3_packed_elems(C, O);
+  long nb = (total + 2047) / 2048;
+  if (nb > 512) nb = 512;
+  hipLaunchKernelGGL(pack_cl16x3_kernel, dim3((unsigned)nb), dim3(256), 0, s, w, (__bf16*)dst, O, C, MT, total);
+  DBM_HIP(hipGetLastError());
+}
+
+void launch_conv_cl16x3(const ClX3Launch& L, hipStream_t s) {
+  DBM_CHECK(L.Cin % 16 == 0 && L.Cin >= 16 && L.Cout >= 1 && L.Cout <= 64, "cl16x3 conv: Cin % 16 == 0, Cout <= 64");
+  DBM_CHECK(L.xc % 4 == 0 && (!L.y32 || L.yc % 4 == 0), "cl16x3 conv: channel strides must keep 16-byte alignment");
+  DBM_CHECK(!L.ups || (L.H % 2 == 0 && L.W % 2 == 0), "cl16x3 conv: the folded resize doubles both sides");
+  static const int n_cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount;
+  }();
+  ClX3Args a;
+  a.x = L.x; a.xc = L.xc; a.Cin = L.Cin; a.ups = L.ups; a.w = (const bf16x8*)L.w; a.bias = L.bias;
+  a.y32 = L.y32; a.yc = L.yc; a.yp = L.yp; a.ysn = L.ysn; a.ypc = L.ypc; a.act = L.act; a.slope = L.slope;
+  a.N = L.N; a.H = L.H; a.W = L.W;
+  a.nslots = cl16_choose_slots(L.N, L.H, L.W, n_cus);
+  a.tilesX = (L.W + CL_TW - 1) / CL_TW;
+  a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
+  const int MT = (L.Cout + 31) / 32;
+  const size_t lds = 2 * (size_t)CL_ACT_BYTES + 2 * (size_t)9 * MT * 2 * 1024;
+  static bool attr = false;
+  if (!attr) {
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  const unsigned grid = (unsigned)((long)L.N * a.tilesX * a.tilesY);
+  if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)L.N * L.H * L.W * L.Cout * L.Cin * 9);
+  if (MT == 1)
+    hipLaunchKernelGGL(conv_cl16x3_kernel<1>, dim3(grid), dim3(CL_NT), lds, s, a);
+  else
+    hipLaunchKernelGGL(conv_cl16x3_kernel<2>, dim3(grid), dim3(CL_NT), lds, s, a);
   if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
 }

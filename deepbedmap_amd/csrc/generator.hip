@@ -47,14 +47,18 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
   L_post = add_iglayer("post_residual_conv_layer", 64, 64, 3, 1, 1, true);
   conv("post_upsample_conv_layer_1", 64, 64, 3, 3);  // :488-495
   L_up1 = add_iglayer("post_upsample_conv_layer_1", 64, 64, 3, 1, 1, true);
+  layers.back().want_x3 = true;
   conv("post_upsample_conv_layer_2", 64, 64, 3, 3);  // :496-503
   L_up2 = add_iglayer("post_upsample_conv_layer_2", 64, 64, 3, 1, 1, true);
+  layers.back().want_x3 = true;
   conv("final_conv_layer1/offset_conv", 18, 64, 3, 3);  // :506-514
   L_off1 = add_iglayer("final_conv_layer1/offset_conv", 18, 64, 3, 1, 1, true);
+  layers.back().want_x3 = true;
   conv("final_conv_layer1/deform_conv", 64, 64, 3, 3);
   L_def1 = add_iglayer("final_conv_layer1/deform_conv", 64, 64, 3, 1, 0, true, /*as_1x1=*/true);
   conv("final_conv_layer2/offset_conv", 18, 64, 3, 3);  // :515-523
   L_off2 = add_iglayer("final_conv_layer2/offset_conv", 18, 64, 3, 1, 1, true);
+  layers.back().want_x3 = true;
   conv("final_conv_layer2/deform_conv", oc, 64, 3, 3);
   T_def2W = tid("final_conv_layer2/deform_conv/W");
   T_def2b = tid("final_conv_layer2/deform_conv/b");
@@ -379,7 +383,32 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   for (int c = 1; c < nsplit; ++c) ctx->fork(cstream(c), s, 4 + c);
   DBM_MARK(s, "  gen_forward:9x9_stage");
   // ---- nearest x2 + conv + LeakyReLU, twice; the resize is folded into the conv's gather (:556-568) ----
-  {
+  const int H4 = 4 * h, W4 = 4 * w;
+  const long P4 = 16 * hw;
+  // The sampler is fused into the GEMM (deform_fused.hip), fed from a channels-last copy of the layer input; the
+  // (N, 576, H, W) sample matrices exist only in a retained pass, as a by-product for the two weight gradients.
+  static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  const bool dfused = fused_env && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch);
+  // bf16 sweep mode: the upsampling and offset convolutions -- on the signal path, where plain bf16 costs ~100 m rms at the
+  // data range -- run in split-bf16 arithmetic (conv_cl16x3_kernel: three bf16 MFMAs per product, 2^-16 operand precision) on
+  // NHWC fp32 activations, which is also what the fused deformable sampler reads.  DBM_CL16X3=0 (read per call): fp32 igemm.
+  const bool x3 = use_bf16 && !keep && dfused && layers[L_up1].wx3 != nullptr && !(getenv("DBM_CL16X3") && atoi(getenv("DBM_CL16X3")) == 0);
+  auto x3_launch = [&](const IgLayer& L, const float* xin, int ups, int Ho, int Wo, float* y32, float* yp, int act) {
+    ClX3Launch q;
+    memset(&q, 0, sizeof(q));
+    q.x = xin; q.xc = 64; q.Cin = 64; q.Cout = L.O; q.ups = ups; q.w = L.wx3; q.bias = P(L.bi);
+    q.y32 = y32; q.yc = 64; q.yp = yp; q.ysn = 32L * Ho * Wo; q.ypc = L.O; q.act = act; q.slope = SLOPE; q.N = N; q.H = Ho; q.W = Wo;
+    launch_conv_cl16x3(q, s);
+  };
+  if (x3) {
+    a3t.ensure((size_t)N * 64 * hw);
+    a41t.ensure((size_t)N * 64 * 4 * hw);
+    a42t.ensure((size_t)N * 64 * P4);
+    a51t.ensure((size_t)N * 64 * P4);
+    launch_nchw_to_cl(a3.p, 64 * hw, a3t.p, nullptr, 0, N, (int)hw, s);
+    x3_launch(layers[L_up1], a3t.p, 1, 2 * h, 2 * w, a41t.p, nullptr, 1);
+    x3_launch(layers[L_up2], a41t.p, 1, H4, W4, a42t.p, nullptr, 1);
+  } else {
     ConvDesc d = prec(fwd_desc(layers[L_up1], a3.p, 64 * hw, h, w, 1, a41.p, 64 * 4 * hw, N), 8);
     d.act = 1;
     launch_igemm_conv(d, s);
@@ -388,12 +417,6 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     launch_igemm_conv(e, s);
   }
   // ---- deformable conv 1 + LeakyReLU (:572-573): offset conv, sampler -> col, GEMM over 576 columns ----
-  const int H4 = 4 * h, W4 = 4 * w;
-  const long P4 = 16 * hw;
-  // The sampler is fused into the GEMM (deform_fused.hip), fed from a channels-last copy of the layer input; the
-  // (N, 576, H, W) sample matrices exist only in a retained pass, as a by-product for the two weight gradients.
-  static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
-  const bool dfused = fused_env && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch);
   if (dfused) {
     a42t.ensure((size_t)N * 64 * P4);
     a51t.ensure((size_t)N * 64 * P4);
@@ -401,7 +424,11 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     col1.ensure((size_t)N * 576 * P4);
     if (keep) col2.ensure((size_t)N * 576 * P4);
   }
-  {
+  if (x3) {
+    x3_launch(layers[L_off1], a42t.p, 0, H4, W4, nullptr, off1.p, 0);
+    launch_deform_conv_fused(a42t.p, off1.p, layers[L_def1].wf, P(layers[L_def1].bi), a51.p, a51t.p, nullptr, N, 64, H4, W4, 32 * P4, 64, 1,
+                             SLOPE, s);
+  } else {
     ConvDesc d = prec(fwd_desc(layers[L_off1], a42.p, 64 * P4, H4, W4, 0, off1.p, 32 * P4, N), 16);
     launch_igemm_conv(d, s);
     if (dfused) {
@@ -417,8 +444,12 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   }
   // ---- deformable conv 2 (:574) ----
   {
-    ConvDesc d = prec(fwd_desc(layers[L_off2], a51.p, 64 * P4, H4, W4, 0, off2.p, 32 * P4, N), 16);
-    launch_igemm_conv(d, s);
+    if (x3) {
+      x3_launch(layers[L_off2], a51t.p, 0, H4, W4, nullptr, off2.p, 0);
+    } else {
+      ConvDesc d = prec(fwd_desc(layers[L_off2], a51.p, 64 * P4, H4, W4, 0, off2.p, 32 * P4, N), 16);
+      launch_igemm_conv(d, s);
+    }
     if (dfused) {
       launch_deform_conv_fused(a51t.p, off2.p, P(T_def2W), P(T_def2b), y, nullptr, nullptr, N, 64, H4, W4, 32 * P4, out_ch, 0, SLOPE, s);
       // (unfused backward only: the 64 -> 1 layer's weight gradient then reads its sample matrix)

@@ -175,3 +175,20 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s);
 // channels per pixel (act, may be null); and back
 void launch_nchw_to_cl(const float* x, long xsn, float* res, void* act, int ac, int N, int plane, hipStream_t s, int nch = 64);
 void launch_cl_to_nchw(const float* res, float* y, long ysn, int N, int plane, hipStream_t s, int nch = 64);
+
+// split-bf16 (three bf16 MFMAs per product: 2^-16 operand precision) 3x3 convolution on NHWC fp32 activations: the layers on
+// the signal path of the bf16 sweep (upsampling and offset convolutions)
+struct ClX3Launch {
+  const float* x; int xc;    // input NHWC fp32 (xc channels per pixel), channels [0, Cin) are read
+  int Cin, Cout;             // Cin % 16 == 0, Cout <= 64
+  int ups;                   // 1: x is the (H / 2, W / 2) plane (nearest x2 folded in)
+  const void* w;             // packed by launch_pack_cl16x3
+  const float* bias;
+  float* y32; int yc;        // NHWC fp32 output (yc channels per pixel; all 32 * ceil(Cout / 32) channels are written) or null
+  float* yp; long ysn; int ypc;  // channel planes yp[n * ysn + co * H * W + pixel], co < ypc, or null
+  int act; float slope;
+  int N, H, W;               // output plane
+};
+size_t cl16x3_packed_elems(int Cin, int Cout);
+void launch_pack_cl16x3(const float* w_oihw, void* dst, int O, int C, hipStream_t s);
+void launch_conv_cl16x3(const ClX3Launch& L, hipStream_t s);

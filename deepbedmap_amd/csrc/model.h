@@ -116,6 +116,8 @@ struct IgLayer {
   void* wf16 = nullptr;      // bf16 [T][CinP/16][2][CoutP][8]: a lane's eight K values of one MFMA are one 16-byte load
   bool want_cl16 = false;    // also a fragment-ordered bf16 image for the channels-last kernel (conv_cl16.hip): trunk layers
   void* wcl16 = nullptr;     // bf16 [chunk][tap][k half][mtile][lane][8]
+  bool want_x3 = false;      // ... and a split-bf16 (hi | lo) image for conv_cl16x3_kernel: the sweep's upsampling / offset convs
+  void* wx3 = nullptr;       // bf16 [chunk][tap][mtile][hi | lo][lane][8]
   int OP = 0, CP = 0;
   float* wb[4] = {nullptr, nullptr, nullptr, nullptr};  // dgrad packs [Tb][OP][CP]
   int Tb = 0;
@@ -200,6 +202,7 @@ struct Generator : dbm_model {
   // bf16 sweep mode on large planes (conv_cl16.hip): the dense block's concat as NHWC bf16 (two buffers in ping-pong, 192
   // channels per pixel) and the 64-channel residual stream as NHWC fp32 (block input, block output, RRDB input)
   DevBuf catb[2], resb[4];
+  DevBuf a3t, a41t;  // NHWC fp32 inputs of the two upsampling convolutions in the sweep's split-bf16 tail (conv_cl16x3_kernel)
   DevBuf g_a0, g_a3, g_u1, g_z41, g_u2, g_a42, goff1, goff2, gcol, g_a51, g_y;
   // A second workspace on the same parameters: the G-step's generator forward can be enqueued while the D-step's
   // discriminator passes are still running (dbm_discriminator_step, prefetch flag).  The twin aliases this model's

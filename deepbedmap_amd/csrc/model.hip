@@ -60,6 +60,7 @@ dbm_model::~dbm_model() {
     if (L.wf) (void)hipFree(L.wf);
     if (L.wf16) (void)hipFree(L.wf16);
     if (L.wcl16) (void)hipFree(L.wcl16);
+    if (L.wx3) (void)hipFree(L.wx3);
     for (int i = 0; i < 4; ++i)
       if (L.wb[i]) (void)hipFree(L.wb[i]);
   }
@@ -278,6 +279,10 @@ void dbm_model::ensure_packed_bf16() {
     if (L.want_cl16 && L.K == 3 && L.C % 32 == 0 && (L.O == 32 || L.O == 64)) {  // fragment-ordered image (conv_cl16.hip)
       if (!L.wcl16) DBM_HIP(hipMalloc(&L.wcl16, cl16_packed_elems(L.C, L.O) * sizeof(__bf16)));
       launch_pack_cl16(P(L.wi), L.wcl16, L.O, L.C, s);
+    }
+    if (L.want_x3 && L.K == 3 && L.Kview == 3 && L.C % 16 == 0 && L.O <= 64) {  // split-bf16 image (conv_cl16x3_kernel)
+      if (!L.wx3) DBM_HIP(hipMalloc(&L.wx3, cl16x3_packed_elems(L.C, L.O) * sizeof(__bf16)));
+      launch_pack_cl16x3(P(L.wi), L.wx3, L.O, L.C, s);
     }
   }
   DBM_HIP(hipGetLastError());

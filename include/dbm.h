@@ -294,6 +294,12 @@ int dbm_op_conv2d_backward(dbm_ctx* ctx, const float* x, const float* w, const f
  * with r1 (N,64,H,W) or NULL; C % 32 == 0, O = 32 or 64 */
 int dbm_op_conv2d_cl16(dbm_ctx* ctx, const float* x, const float* w, const float* b, const float* r1, float s1, float* y, int N,
                        int C, int H, int W, int O, int lrelu);
+/* ... and in the sweep's split-bf16 arithmetic (three bf16 MFMAs per product: operands carry 16 significand bits) for the
+ * layers on the signal path -- post_upsample_conv_layer_1/2 behind F.resize_images (srgan_train.py:553-568; ups = 1: x is the
+ * (H/2, W/2) plane) and the deformable layers' offset convolutions (:506-523; planar = 1: channel-plane output):
+ * x (N,64,H>>ups,W>>ups) -> y (N,O,H,W), O <= 64 */
+int dbm_op_conv2d_cl16x3(dbm_ctx* ctx, const float* x, const float* w, const float* b, float* y, int N, int H, int W, int O, int ups,
+                         int lrelu, int planar);
 /* L.DeformableConvolution2D sampler + GEMM (stride 1, pad 1, 3x3): off (N,18,H,W) */
 int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y,
                          int N, int C, int H, int W, int O);

@@ -102,3 +102,39 @@ def test_cl16_trunk_equals_the_per_layer_bf16_path(dbm):
     e = np.abs(y_cl - y32).max() / scale
     assert 1e-7 < e < 3e-2, e  # really bf16 arithmetic, within the mode's tolerance of the fp32 forward
     assert not np.array_equal(y_cl, y_ig)  # (two different kernels did run)
+
+
+X3_CASES = [
+    # N, H, W (output plane), O, ups, lrelu, planar
+    (1, 40, 37, 64, 0, 1, 0),      # ragged tiles
+    (2, 36, 52, 64, 1, 1, 0),      # post_upsample: nearest x2 folded into the staging, two images
+    (1, 33, 35, 18, 0, 0, 1),      # offset convolution: 18 channel planes
+    (1, 572, 572, 64, 1, 1, 0),    # the sweep's first upsampling layer: 286 -> 572
+]
+
+
+@pytest.mark.parametrize("N,H,W,O,ups,lrelu,planar", X3_CASES)
+def test_split_bf16_conv_is_fp32_class(dbm, N, H, W, O, ups, lrelu, planar):
+    """conv_cl16x3_kernel (three bf16 MFMAs per product) against the float64 oracle on the UN-rounded fp32 operands: 3e-5 of
+    the output's largest magnitude -- sixteen significand bits per operand; the plain bf16 kernel on the same data is two
+    orders of magnitude further away (asserted: the split is what buys the accuracy, not the test's tolerance)."""
+    d, _lib, ctx = dbm
+    rs = np.random.RandomState(H * 3 + O)
+    Hs, Ws = H >> ups, W >> ups
+    x = (rs.normal(size=(N, 64, Hs, Ws)) * 300.0 + 1000.0).astype(np.float32)   # un-normalised, offset data
+    w = (rs.normal(size=(O, 64, 3, 3)) / np.sqrt(9 * 64)).astype(np.float32)
+    b = rs.normal(size=(O,)).astype(np.float32)
+    xu = ops.upsample_nearest2(x) if ups else x
+    ref = ops.conv2d(xu.astype(np.float64), w.astype(np.float64), b.astype(np.float64), 1, 1)
+    if lrelu:
+        ref = np.where(ref >= 0, ref, 0.2 * ref)
+    dx, dw, db = d.to_device(x), d.to_device(w), d.to_device(b)
+    y = d.DeviceArray((N, O, H, W))
+    _lib.check(_lib.lib().dbm_op_conv2d_cl16x3(ctx.handle, dx.ptr, dw.ptr, db.ptr, y.ptr, N, H, W, O, ups, lrelu, planar), ctx.handle)
+    err = np.abs(y.get() - ref).max() / np.abs(ref).max()
+    assert err < 3e-5, err
+    if not ups and O in (32, 64):  # the one-MFMA bf16 kernel on the same data
+        y1 = d.DeviceArray((N, O, H, W))
+        _lib.check(_lib.lib().dbm_op_conv2d_cl16(ctx.handle, dx.ptr, dw.ptr, db.ptr, None, 1.0, y1.ptr, N, 64, H, W, O, lrelu), ctx.handle)
+        err1 = np.abs(y1.get() - ref).max() / np.abs(ref).max()
+        assert err1 > 30 * err, (err1, err)
