@@ -137,6 +137,31 @@ def cpu_baseline(threads=None, batch=BATCH_PER_GPU):
     return out
 
 
+def shape_table(recs, recs_s, keys):
+    """Per launch shape (family, tag): launches per step, in-step and standalone time, TFLOP/s and fraction of the fp32 MFMA
+    roof (standalone), algorithmic bytes per launch and the GB/s they imply.  recs / recs_s: Context.profile_records() of an
+    in-step and of a serialised step (same launches, same order)."""
+    rows = {}
+    for src, col in ((recs, "ms"), (recs_s, "ms_standalone")):
+        for r in src:
+            row = rows.setdefault((r["family"], r["tag"], r["flops"], r["bytes"]),
+                                  {"kernel": keys[r["family"]], "shape": r["tag"], "workgroups": r["wgs"], "launches": 0, "ms": 0.0, "ms_standalone": 0.0,
+                                   "gflop_per_launch": r["flops"] / 1e9, "algorithmic_bytes_per_launch": r["bytes"]})
+            row[col] += r["ms"]
+            if col == "ms":
+                row["launches"] += 1
+    out = []
+    for row in rows.values():
+        n, ms = max(row["launches"], 1), row["ms_standalone"]
+        row["avg_us_standalone"] = 1e3 * ms / n
+        row["tflops_standalone"] = row["gflop_per_launch"] * n / ms if ms > 0 else 0.0
+        row["frac_mfma_standalone"] = row["tflops_standalone"] / PEAK_FP32_MFMA_TFLOPS
+        row["algorithmic_gbps_standalone"] = row["algorithmic_bytes_per_launch"] * n / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        row["flop_per_byte"] = row["gflop_per_launch"] * 1e9 / max(row["algorithmic_bytes_per_launch"], 1.0)
+        out.append({k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items()})
+    return sorted(out, key=lambda r: -r["ms_standalone"])
+
+
 def sweep_leg(dbm, ctx, g, crops=5):
     """BASELINE config 5's unit of work, measured: one INTERIOR 288 x 288 crop of the continent sweep (deepbedmap.py:706-728;
     320 of the 396 crops are this size) -> 1144 x 1144, generator forward with resident inputs, fp32 and bf16, timed with HIP
@@ -174,6 +199,29 @@ def sweep_leg(dbm, ctx, g, crops=5):
                      "mfma_peak_tflops": PEAK_BF16_MFMA_TFLOPS if name == "bf16" else PEAK_FP32_MFMA_TFLOPS,
                      "compulsory_gbs": (in_bytes + out_bytes) / (per * 1e-3) / 1e9,
                      "s_per_continent_one_gpu": 396 * per * 1e-3}
+        # one more crop with every MFMA launch bracketed (device synchronised around each): per-shape standalone durations with
+        # their algorithmic FLOP / bytes; launches that are not MFMA kernels (im2col of the 10x input, packing, the bilinear
+        # sampler's transposes) are the difference between `bracketed_ms` and ms_per_crop
+        dbm._lib.check(lib.dbm_profile_begin_serial(ctx.handle), ctx.handle)
+        fwd(flags)
+        recs = ctx.profile_records()
+        peak = PEAK_BF16_MFMA_TFLOPS if name == "bf16" else PEAK_FP32_MFMA_TFLOPS
+        shapes = {}
+        for r_ in recs:
+            row = shapes.setdefault((r_["tag"], r_["flops"], r_["bytes"]), {"shape": r_["tag"], "workgroups": r_["wgs"], "launches": 0, "ms": 0.0, "gflop_per_launch": r_["flops"] / 1e9,
+                                                                           "algorithmic_bytes_per_launch": r_["bytes"]})
+            row["launches"] += 1
+            row["ms"] += r_["ms"]
+        rows = []
+        for row in sorted(shapes.values(), key=lambda q: -q["ms"]):
+            row["avg_us"] = 1e3 * row["ms"] / row["launches"]
+            row["tflops"] = row["gflop_per_launch"] * row["launches"] / row["ms"] if row["ms"] > 0 else 0.0
+            row["frac_of_fp32_mfma_peak" if (name == "fp32" or row["shape"].startswith(("deform", "x3_"))) else "frac_of_bf16_mfma_peak"] = \
+                row["tflops"] / (PEAK_FP32_MFMA_TFLOPS if (name == "fp32" or row["shape"].startswith(("deform", "x3_"))) else peak)
+            row["algorithmic_gbps"] = row["algorithmic_bytes_per_launch"] * row["launches"] / (row["ms"] * 1e-3) / 1e9 if row["ms"] > 0 else 0.0
+            rows.append({k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items()})
+        res[name]["bracketed_ms"] = sum(r_["ms"] for r_ in recs)
+        res[name]["per_shape_standalone"] = rows
     return res
 
 
@@ -352,15 +400,14 @@ def main():
                       "collectives_per_step": cc.value / max(args.steps + args.warmup, 1)}
 
     # ---- roofline leg (outside the timed region): hipEvent-bracketed launches of the dominant kernel ----
-    prof = (C.c_double * 15)()
     assert metrics_rows is None or (len(metrics_rows) == args.steps + args.warmup and np.isfinite(metrics_rows[:, :5]).all())
     dbm._lib.check(lib.dbm_profile_begin(ctx.handle), ctx.handle)
     step()
-    dbm._lib.check(lib.dbm_profile_end_ex(ctx.handle, prof, 5), ctx.handle)
-    prof_s = (C.c_double * 15)()   # the same brackets with the device synchronised around each launch: standalone durations
+    recs = ctx.profile_records()
+    # the same brackets with the device synchronised around each launch: standalone durations
     dbm._lib.check(lib.dbm_profile_begin_serial(ctx.handle), ctx.handle)
     step()
-    dbm._lib.check(lib.dbm_profile_end_ex(ctx.handle, prof_s, 5), ctx.handle)
+    recs_s = ctx.profile_records()
     FAMILIES = [
         ("igemm_conv_kernel + the fused deformable-convolution GEMMs (per-layer conv forward + data gradient, v_mfma_f32_32x32x2_f32)", "igemm_conv_kernel"),
         ("weight gradients (wgrad_wave_dma_kernel, wgrad_band_dma_kernel, wgrad_kernel)", "wgrad_kernel"),
@@ -372,13 +419,16 @@ def main():
     ]
     fam = []
     for i, (label, key) in enumerate(FAMILIES):
-        ms, flop, n = prof[3 * i], prof[3 * i + 1], prof[3 * i + 2]
-        ms_s = prof_s[3 * i]
+        mine, mine_s = [r for r in recs if r["family"] == i], [r for r in recs_s if r["family"] == i]
+        ms, flop, byt, n = (sum(r["ms"] for r in mine), sum(r["flops"] for r in mine), sum(r["bytes"] for r in mine), len(mine))
+        ms_s = sum(r["ms"] for r in mine_s)
         fam.append({"kernel": label, "key": key, "ms_per_step": ms, "launches_per_step": int(n),
                     "avg_launch_us": 1e3 * ms / max(n, 1), "algorithmic_gflop_per_launch": flop / max(n, 1) / 1e9,
+                    "algorithmic_bytes_per_launch": byt / max(n, 1),
                     "achieved": (flop / (ms * 1e-3) / 1e12) if ms > 0 else 0.0,
                     "standalone_ms_per_step": ms_s, "standalone_avg_launch_us": 1e3 * ms_s / max(n, 1),
                     "achieved_standalone": (flop / (ms_s * 1e-3) / 1e12) if ms_s > 0 else 0.0})
+    per_shape = shape_table(recs, recs_s, [k for _, k in FAMILIES])
     dom = max(fam, key=lambda f: f["ms_per_step"])  # the dominant kernel = most summed launch time in one step
 
     # ---- inference leg (outside the timed region, rank 0 of a single-GPU run): BASELINE config 5's unit of work ----
@@ -431,6 +481,10 @@ def main():
                 "standalone_avg_launch_us": dom["standalone_avg_launch_us"],
                 "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
                 "algorithmic_gflop_per_launch": dom["algorithmic_gflop_per_launch"],
+                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                # every distinct launch shape of the step (tag = layer geometry): launches, standalone time, fraction of the fp32
+                # MFMA roof, algorithmic bytes and the HBM rate they imply -- sorted by standalone time
+                "per_shape": per_shape,
                 "other_kernels": [{k: f[k] for k in ("kernel", "achieved", "achieved_standalone", "ms_per_step", "standalone_ms_per_step",
                                                      "launches_per_step", "avg_launch_us")}
                                   for f in fam if f is not dom and f["launches_per_step"] > 0],
@@ -445,6 +499,7 @@ def main():
         try:  # HBM bytes per launch of the dominant kernel: PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, from the committed pass
             with open(TRAFFIC_JSON) as f:
                 out["roofline"]["traffic"] = json.load(f)[dom["key"]]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_over_algorithmic_bytes"] = out["roofline"]["traffic"] / max(dom["algorithmic_bytes_per_launch"], 1.0)
                 out["roofline"]["traffic_source"] = ("static: " + os.path.relpath(TRAFFIC_JSON, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / "
                                                      "WRITE_SIZE in separate passes of this command; not measured in this run)")
         except Exception:

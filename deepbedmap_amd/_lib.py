@@ -49,6 +49,7 @@ SIGNATURES = {
     "dbm_profile_begin_serial": [C.c_void_p],
     "dbm_profile_end": [C.c_void_p, C.POINTER(C.c_double)],
     "dbm_profile_end_ex": [C.c_void_p, C.POINTER(C.c_double), C.c_int],
+    "dbm_profile_end_records": [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)],
     "dbm_set_sync_batch_stats": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "dbm_f32_to_i16": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t],
     "dbm_lzw_encode_tiles": [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_int],
@@ -192,6 +193,18 @@ class Context:
         ev, d, g, off = C.c_long(0), C.c_int(0), C.c_int(0), C.c_int(0)
         check(lib().dbm_timeout_info(self.handle, C.byref(ev), C.byref(d), C.byref(g), C.byref(off)), self.handle)
         return int(ev.value), int(d.value), int(g.value), bool(off.value)
+
+    def profile_records(self):
+        """Ends dbm_profile_begin / _begin_serial; one dict per bracketed launch: family, flops, bytes (both algorithmic), ms, wgs (workgroups), tag."""
+        n = C.c_size_t(0)
+        check(lib().dbm_profile_end_records(self.handle, None, 0, C.byref(n)), self.handle)
+        buf = C.create_string_buffer(n.value + 1)
+        check(lib().dbm_profile_end_records(self.handle, buf, n.value + 1, C.byref(n)), self.handle)
+        recs = []
+        for line in buf.value.decode().splitlines():
+            f, fl, by, ms, wgs, tag = line.split(" ", 5)
+            recs.append({"family": int(f), "flops": float(fl), "bytes": float(by), "ms": float(ms), "wgs": int(wgs), "tag": tag})
+        return recs
 
     def malloc(self, nbytes):
         p = C.c_void_p()

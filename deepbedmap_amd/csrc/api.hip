@@ -350,6 +350,22 @@ int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam) {
   DBM_API_END
 }
 
+int dbm_profile_end_records(dbm_ctx* ctx, char* buf, size_t cap, size_t* len) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK(len != nullptr && (buf != nullptr || cap == 0), "dbm_profile_end_records: null argument");
+  g_profiler.enabled = false;
+  g_profiler.serial = false;
+  DBM_HIP(hipDeviceSynchronize());
+  static thread_local std::string pending;  // (a too-small buffer keeps the text for the retry)
+  if (pending.empty()) pending = g_profiler.dump_records();
+  *len = pending.size();
+  if (pending.size() + 1 <= cap) {
+    memcpy(buf, pending.c_str(), pending.size() + 1);
+    pending.clear();
+  }
+  DBM_API_END
+}
+
 int dbm_memcpy2d_d2d(dbm_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes,
                      size_t height) {
   DBM_API_BEGIN(ctx)

@@ -605,7 +605,16 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
     attr = true;
   }
   const unsigned grid = (unsigned)((long)L.N * a.tilesX * a.tilesY);
-  if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)L.N * L.H * L.W * L.Cout * L.Cin * 9);
+  if (g_profiler.enabled) {
+    // algorithmic bytes: Cin bf16 channels per pixel in, the packed weights, the outputs (bf16 and / or the 64-channel fp32
+    // residual stream) and the fp32 residual operands
+    const double px = (double)L.N * L.H * L.W;
+    const double bytes = px * (2.0 * L.Cin + (L.y16 ? 2.0 * L.Cout : 0.0) + (L.y32 ? 256.0 : 0.0) + (L.r1 ? 256.0 : 0.0) + (L.r2 ? 256.0 : 0.0)) +
+                         2.0 * 9 * L.Cin * L.Cout;
+    char tag[40];
+    snprintf(tag, sizeof(tag), "cl16_c%d>%d_%dx%d_n%d", L.Cin, L.Cout, L.H, L.W, L.N);
+    g_profiler.begin(s, 0, 2.0 * px * L.Cout * L.Cin * 9, bytes, tag, grid);
+  }
   if (MT == 1)
     hipLaunchKernelGGL(conv_cl16_kernel<1>, dim3(grid), dim3(CL_NT), lds, s, a);
   else
@@ -652,7 +661,15 @@ void launch_conv_cl16x3(const ClX3Launch& L, hipStream_t s) {
     attr = true;
   }
   const unsigned grid = (unsigned)((long)L.N * a.tilesX * a.tilesY);
-  if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)L.N * L.H * L.W * L.Cout * L.Cin * 9);
+  if (g_profiler.enabled) {
+    // algorithmic bytes: the fp32 NHWC source plane (a quarter of the output plane when the resize is folded in), hi + lo
+    // weight images, Cout fp32 channels out.  flops: the layer's, not the three MFMAs the split spends on each
+    const double px = (double)L.N * L.H * L.W;
+    const double bytes = px * (4.0 * L.Cin / (L.ups ? 4 : 1) + 4.0 * L.Cout) + 2.0 * 2.0 * 9 * L.Cin * L.Cout;
+    char tag[40];
+    snprintf(tag, sizeof(tag), "x3_c%d>%d_%dx%d_n%d%s", L.Cin, L.Cout, L.H, L.W, L.N, L.ups ? "u" : "");
+    g_profiler.begin(s, 0, 2.0 * px * L.Cout * L.Cin * 9, bytes, tag, grid);
+  }
   if (MT == 1)
     hipLaunchKernelGGL(conv_cl16x3_kernel<1>, dim3(grid), dim3(CL_NT), lds, s, a);
   else

@@ -102,9 +102,12 @@ void launch_igemm_conv(const ConvDesc& d, hipStream_t s);
 struct KernelProfiler {
   bool enabled = false;
   bool serial = false;   // dbm_profile_begin_serial: the host synchronises the device around every bracketed launch
-  struct Rec { hipEvent_t a, b; double flops; int family; };
+  // bytes: ALGORITHMIC bytes of the launch (operands read once + results written once: what a perfect cache hierarchy would
+  // move); tag: a short label of the launch's shape (layer geometry) for the per-shape table of bench.py / profiles
+  struct Rec { hipEvent_t a, b; double flops, bytes; int family; long wgs; char tag[40]; };
   std::vector<Rec> recs;
-  void begin(hipStream_t s, int family, double flops);
+  void begin(hipStream_t s, int family, double flops, double bytes = 0.0, const char* tag = nullptr, long wgs = 0);  // wgs: workgroups of the (first) launch -- joins a bracket to a rocprofv3 row
+  std::string dump_records();  // "family flops bytes ms wgs tag\n" per bracket, then clears (dbm_profile_records)
   void end(hipStream_t s);
   void collect(double* out, int nfam);  // [ms, flops, launches] for families 0 .. nfam-1, then clears
   // phase marks: one event per named point of a training step on the main stream (dbm_phase_marks)
@@ -201,10 +204,11 @@ struct WgradBatch {
   int fold_wgs[NCAT] = {};
   bool pair_mode[NCAT] = {};     // deterministic folding through pair buffers (WgradPlan::pairW)
   double flops[NCAT] = {};
+  double abytes[NCAT] = {};      // algorithmic bytes of a category's launch: every layer's x, dy and gW once
   // 4x4 stride-2 layers on tiny planes (wgrad_s2tiny_kernel): their own plan table, outside the categories
   void* d_tiny = nullptr;
   int n_tiny = 0, tiny_wgs = 0;
-  double tiny_flops = 0.0;
+  double tiny_flops = 0.0, tiny_bytes = 0.0;
   std::vector<int> tiny_owner;
   void add(const WgradDesc& d) { if (!built) descs.push_back(d); }
   void build();

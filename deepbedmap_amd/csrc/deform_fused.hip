@@ -537,7 +537,14 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
   const long total = (long)N * H * W;
   DBM_CHECK(total < (1L << 31), "fused deformable convolution: more than 2^31 positions");
   const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
-  if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)total * O * C * 9);
+  if (g_profiler.enabled) {
+    // algorithmic bytes: the NHWC input and the 18 offset planes once, the weights once, the output (and its NHWC twin / the
+    // kept sampled columns of a training forward) once
+    const double bytes = 4.0 * ((double)total * (C + 18 + O + (yt ? O : 0) + (colout ? 9.0 * C : 0.0)) + 9.0 * C * O);
+    char tag[40];
+    snprintf(tag, sizeof(tag), "deform%d_%dx%d_n%d%s", O, H, W, N, colout ? "_keep" : "");
+    g_profiler.begin(s, 0, 2.0 * (double)total * O * C * 9, bytes, tag, blocks);
+  }
   if (O == 64)
     hipLaunchKernelGGL(deform_conv64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, bias, y, yt, colout, N, H, W, offsn, act, slope);
   else
@@ -555,7 +562,11 @@ void launch_deform_bwd64_fused(const float* xt, const float* off, const float* w
   const long total = (long)N * H * W;
   DBM_CHECK(total < (1L << 31), "fused deformable backward: more than 2^31 positions");
   const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
-  if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * (double)total * 64 * 576);
+  if (g_profiler.enabled) {
+    char tag[40];
+    snprintf(tag, sizeof(tag), "deform_bwd64_%dx%d_n%d", H, W, N);  // in: x, offsets, gy, weights; out: gcol (576 planes), goff
+    g_profiler.begin(s, 0, 2.0 * (double)total * 64 * 576, 4.0 * ((double)total * (64 + 18 + 64 + 576 + 18) + 576.0 * 64), tag, blocks);
+  }
   hipLaunchKernelGGL(deform_bwd64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, wb, gy, gcol, goff, N, H, W, offsn);
   if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());

@@ -501,13 +501,16 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
 
 KernelProfiler g_profiler;
 
-void KernelProfiler::begin(hipStream_t s, int family, double flops) {
+void KernelProfiler::begin(hipStream_t s, int family, double flops, double bytes, const char* tag, long wgs) {
   if (serial) DBM_HIP(hipDeviceSynchronize());  // standalone durations: nothing else is running when the bracket opens
   Rec r;
   DBM_HIP(hipEventCreate(&r.a));
   DBM_HIP(hipEventCreate(&r.b));
   r.flops = flops;
+  r.bytes = bytes;
   r.family = family;
+  r.wgs = wgs;
+  snprintf(r.tag, sizeof(r.tag), "%s", tag ? tag : "-");
   DBM_HIP(hipEventRecord(r.a, s));
   recs.push_back(r);
 }
@@ -533,6 +536,22 @@ void KernelProfiler::collect(double* out, int nfam) {
     (void)hipEventDestroy(r.b);
   }
   recs.clear();
+}
+
+std::string KernelProfiler::dump_records() {
+  std::string out;
+  for (auto& r : recs) {
+    DBM_HIP(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    DBM_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+    char line[200];
+    snprintf(line, sizeof(line), "%d %.6e %.6e %.6f %ld %s\n", r.family, r.flops, r.bytes, ms, r.wgs, r.tag);
+    out += line;
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  recs.clear();
+  return out;
 }
 
 void KernelProfiler::mark(hipStream_t s, const char* name) {
@@ -777,7 +796,18 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
     d.nosplit = 1;
     grid.x = (grid.x + 3) / 4;
   }
-  if (g_profiler.enabled) g_profiler.begin(s, 0, 2.0 * flop_positions * d.Cout * d.Cin * d.T);
+  if (g_profiler.enabled) {
+    // algorithmic bytes: the input once, the weight image(s) once, the output once (+ whatever the epilogue reads)
+    const double np = d.nphase > 1 ? d.nphase : 1;
+    double bytes = 4.0 * ((double)d.N * d.Cin * d.Hin * d.Win + flop_positions * d.Cout) + (d.wp16 ? 2.0 : 4.0) * np * d.T * (double)d.Cin * d.CoutP;
+    if (d.r1) bytes += 4.0 * flop_positions * d.r1_nch;
+    if (d.r2) bytes += 4.0 * flop_positions * d.Cout;
+    if (d.mask) bytes += 4.0 * flop_positions * (d.Cout - d.mask_c0);
+    if (d.accumulate) bytes += 4.0 * flop_positions * d.Cout;
+    char tag[40];
+    snprintf(tag, sizeof(tag), "c%d>%d_k%d%s_%dx%d%s%s", d.Cin, d.Cout, d.T, d.nphase > 1 ? "p" : "", d.Hin, d.Win, d.ups ? "u" : "", d.wp16 ? "_bf16" : "");
+    g_profiler.begin(s, 0, 2.0 * flop_positions * d.Cout * d.Cin * d.T, bytes, tag, (long)grid.x * grid.y * grid.z);
+  }
   switch (d.T) {
     case 1: launch_t<1>(d, grid, waves, s, mt2); break;
     case 4: launch_t<4>(d, grid, waves, s, mt2); break;

@@ -733,7 +733,15 @@ void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
   a.off_hb = (unsigned)(3 * L.nimg * 2 * 2 * 64 * HS);
   a.off_bh = a.off_hb + (unsigned)(L.nimg * 2 * 5 * 32 * 81);
   const double flop = 2.0 * 19408896.0 * L.nrdb * L.nimg;  // 19 408 896 MAC per dense block and tile
-  if (g_profiler.enabled) g_profiler.begin(s, helper ? 4 : 2, flop);
+  if (g_profiler.enabled) {
+    // algorithmic bytes: the 26 624 x 9 weights of every dense block once, the trunk's input once, and what the launch has to
+    // leave in HBM -- the 64-channel output, plus (training: store_all) the 192-channel concatenation of every dense block
+    const double wbytes = 4.0 * 26624.0 * 9.0 * L.nrdb;
+    const double abytes = 4.0 * 81.0 * L.nimg * (64.0 + 64.0 + (L.cat ? 192.0 * L.nrdb : 0.0));
+    char tag[40];
+    snprintf(tag, sizeof(tag), "trunk_fwd_%drdb_n%d%s%s", L.nrdb, L.nimg, L.cat ? "_keep" : "", helper ? "_helper" : "");
+    g_profiler.begin(s, helper ? 4 : 2, flop, wbytes + abytes, tag, helper ? 32 * ((L.nimg + 7) / 8) : 8 * a.tpx);
+  }
   if (helper)
     hipLaunchKernelGGL((trunk_fused_kernel<27, true>), dim3(32 * ((L.nimg + 7) / 8)), dim3(NTHREADS), LDS_HELPER, s, a);
   else if (TP == 27)

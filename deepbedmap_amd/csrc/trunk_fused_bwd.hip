@@ -443,7 +443,15 @@ void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s) {
   static const int abl = getenv("DBM_TFB_ABL") ? atoi(getenv("DBM_TFB_ABL")) : 0;
   a.abl = abl;
   const int grid = ((L.nimg + 7) / 8) * 24;
-  if (g_profiler.enabled) g_profiler.begin(s, 3, 2.0 * 19408896.0 * (L.j1 - L.j0) * L.nimg);
+  if (g_profiler.enabled) {
+    // algorithmic bytes: the flipped weights of the launch's dense blocks once; per image the incoming gradient (64 channels),
+    // every block's stored concatenation (192: the LeakyReLU masks) in, every block's conv-output gradients dA (192) out
+    const double nb = L.j1 - L.j0;
+    const double bytes = 4.0 * 26624.0 * 9.0 * nb + 4.0 * 81.0 * L.nimg * (64.0 + 64.0 + 2.0 * 192.0 * nb);
+    char tag[40];
+    snprintf(tag, sizeof(tag), "trunk_bwd_%d..%d_n%d", L.j0, L.j1, L.nimg);
+    g_profiler.begin(s, 3, 2.0 * 19408896.0 * (L.j1 - L.j0) * L.nimg, bytes, tag, grid);
+  }
   hipLaunchKernelGGL(trunk_fused_bwd_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
   if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());

@@ -1586,7 +1586,7 @@ void WgradBatch::build() {
     std::vector<TinyPlan> tp;
     std::vector<int> owner(descs.size(), -1);
     int wgs = 0;
-    double fl = 0.0;
+    double fl = 0.0, tiny_bytes_acc = 0.0;
     for (size_t i = 0; i < descs.size(); ++i) {
       if (owner[i] >= 0) continue;
       const WgradDesc& d = descs[i];
@@ -1610,8 +1610,9 @@ void WgradBatch::build() {
       wgs += (d.Cout / 16) * q.ctiles;
       tp.push_back(q);
       fl += 2.0 * (double)grp.size() * d.N * d.OH * d.OW * d.Cout * d.Cin * 16;
+      tiny_bytes_acc += 4.0 * ((double)grp.size() * d.N * ((double)d.Cin * d.Hin * d.Win + (double)d.Cout * d.OH * d.OW) + (double)d.Cout * d.Cin * 16);
     }
-    n_tiny = (int)tp.size(); tiny_wgs = wgs; tiny_flops = fl;
+    n_tiny = (int)tp.size(); tiny_wgs = wgs; tiny_flops = fl; tiny_bytes = tiny_bytes_acc;
     tiny_owner = owner;
     if (d_tiny) { (void)hipFree(d_tiny); d_tiny = nullptr; }
     if (n_tiny) {
@@ -1633,7 +1634,7 @@ void WgradBatch::build() {
     std::vector<int> starts;
     int total = 0;
     size_t maxlds = 0;
-    double fl = 0.0;
+    double fl = 0.0, by = 0.0;
     // LDS-DMA forms: the K split is chosen so that the launch is ONE round of equally long two-wavefront groups
     // (four per CU for the trunk form; two or four per CU for row bands, by their LDS footprint)
     int S_fixed = 0;
@@ -1689,6 +1690,7 @@ void WgradBatch::build() {
         total += p.wg_count;
         plans.push_back(p);
         fl += 2.0 * (double)d.N * d.OH * d.OW * d.Cout * d.Cin * TT[g];
+        by += 4.0 * ((double)d.N * ((double)d.Cin * d.Hin * d.Win + (double)d.Cout * d.OH * d.OW) + (double)d.Cout * d.Cin * TT[g]);
       }
       // (deterministic mode: no finer K split than necessary -- every extra slice is a pair buffer to write and fold --
       // but a launch of a few dozen workgroups, e.g. the 4x4 layers of the deep discriminator, is split as well)
@@ -1762,6 +1764,7 @@ void WgradBatch::build() {
     total_wg[g] = total;
     lds[g] = maxlds;
     flops[g] = fl;
+    abytes[g] = by;
     if (plans.empty()) continue;
     DBM_HIP(hipMalloc((void**)&d_plans[g], plans.size() * sizeof(WgradPlan)));
     DBM_HIP(hipMalloc((void**)&d_starts[g], starts.size() * sizeof(int)));
@@ -1803,14 +1806,20 @@ void WgradBatch::launch(hipStream_t s) {
   }
   if (!built) build();
   if (n_tiny) {
-    if (g_profiler.enabled) g_profiler.begin(s, 1, tiny_flops);
+    if (g_profiler.enabled) g_profiler.begin(s, 1, tiny_flops, tiny_bytes, "wgrad_s2tiny", tiny_wgs);
     hipLaunchKernelGGL(wgrad_s2tiny_kernel, dim3(tiny_wgs), dim3(256), 0, s, (const TinyPlan*)d_tiny, n_tiny);
     DBM_HIP(hipGetLastError());
     if (g_profiler.enabled) g_profiler.end(s);
   }
   for (int g = 0; g < NCAT; ++g) {
     if (nplans[g] == 0) continue;
-    if (g_profiler.enabled) g_profiler.begin(s, 1, flops[g]);
+    if (g_profiler.enabled) {
+      static const char* const cat_name[NCAT] = {"wgrad<1,1>", "wgrad<9,9>", "wgrad<16,8>", "wave_dma", "band_dma<9,9>", "band_dma<16,8>",
+                                                 "direct<0>", "direct<1>", "direct<2>", "wgrad_1x1"};
+      char tag[40];
+      snprintf(tag, sizeof(tag), "%s_x%d", cat_name[g], nplans[g]);
+      g_profiler.begin(s, 1, flops[g], abytes[g], tag, total_wg[g]);
+    }
     if (g == 0) launch_T<1, 1>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else if (g == 1) launch_T<9, 9>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);
     else if (g == 2) launch_T<16, 8>(d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s);

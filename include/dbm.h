@@ -100,6 +100,12 @@ int dbm_profile_end_ex(dbm_ctx* ctx, double* out, int nfam);
  * (inside a training step up to four streams share the chip and every bracket also contains the neighbours' work).
  * Ended by dbm_profile_end_ex. */
 int dbm_profile_begin_serial(dbm_ctx* ctx);
+/* ends either kind of bracketing and returns EVERY bracket as a text line "family flops bytes ms wgs tag\n": family as in
+ * dbm_profile_end_ex (0..4), the launch's algorithmic FLOP and algorithmic BYTES (operands read once + results written once),
+ * its duration, its workgroup count (what joins a bracket to a rocprofv3 dispatch row) and a label of its shape (layer geometry) -- bench.py's per-shape roofline table, and the denominator of the
+ * traffic ratio in profiles/<round>/traffic_pmc.json.  *len = the text's length; if it does not fit into cap (with its NUL)
+ * nothing is copied and the text is kept for a second call with a larger buffer. */
+int dbm_profile_end_records(dbm_ctx* ctx, char* buf, size_t cap, size_t* len);
 /* testing aid: raises the condition a persistent trunk kernel raises when it gives up waiting for a neighbouring
  * workgroup.  From then on the optimizer launches and BatchNorm's running-average writes are no-ops; the next STEP entry
  * point (or dbm_check_timeout) returns status 7 without enqueuing anything. */

@@ -21,8 +21,18 @@ for r in csv.DictReader(open(f"{out}/sq_counter_collection.csv")):
     if key not in seen:
         seen.add(key); cnt[k] += 1
 res = {k: dict(v, launches=cnt[k]) for k, v in acc.items()}
+for k, v in res.items():
+    # MFMA-busy %: SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs (it equals 64 cycles x the kernel's
+    # v_mfma_f32_32x32x2_f32 count, 32 x its v_mfma_f32_32x32x16_bf16 count), GRBM_GUI_ACTIVE over the 8 XCDs: the denominator is
+    # (GRBM_GUI_ACTIVE / 8) x 1024 SIMD-cycles = GRBM_GUI_ACTIVE x 128 -- every SIMD issuing MFMAs back to back for the whole
+    # (serialised) launch = 100 %
+    if v.get("GRBM_GUI_ACTIVE"):
+        v["mfma_busy_pct"] = 100.0 * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (v["GRBM_GUI_ACTIVE"] * 128.0)
+        v["mfma_busy_denominator"] = "GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs"
+        # wavefront occupancy in the same units: SQ_WAVE_CYCLES counts quad-cycles per resident wavefront
+        v["avg_waves_per_simd"] = 4.0 * v.get("SQ_WAVE_CYCLES", 0.0) / (v["GRBM_GUI_ACTIVE"] * 128.0)
 json.dump(res, open(f"{out}/sq.json", "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0))[:12]:
-    print(k, {a: round(b) for a, b in v.items()})
+    print(k, {a: (round(b, 2) if isinstance(b, float) else b) for a, b in v.items() if a != "mfma_busy_denominator"})
 PY
 rm -f "$OUT"/*_kernel_trace.csv "$OUT"/*_counter_collection.csv
