@@ -64,6 +64,8 @@ struct Args {
   int* err_dev;
   int nrdb, nimg, img0, epoch;
   int ntiles, tpx;         // tiles of this launch; tiles per XCD (block b = tile (b % 8) * tpx + b / 8)
+  unsigned off_xcc;        // granule offset of the XCC_ID table [image][4] (xcd_handshake)
+  int local_st;            // exchange stores may stay in the XCD's L2 when the reader is on the same XCD (DBM_TRUNK_LOCAL_ST)
   unsigned off_hb, off_bh; // helper mode: granule offsets of the helpers' inboxes [image][2][5][32][81] and of the boxes the
                            // helpers fill for their bands [image][2][32][81]
   float rs, slope;
@@ -90,6 +92,7 @@ struct Wave {
   int hh_l[3];
   unsigned ep_h;
   bool st_ok, up_ok, dn_ok;
+  bool local;              // every workgroup that reads this one's granules runs on this XCD
 };
 
 #define DI __device__ __forceinline__
@@ -130,9 +133,39 @@ template <int TP, int NM, int SEL> DI void mma_taps(const float (&A)[36], int b,
 DI unsigned long long granule_load(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-DI void granule_store(unsigned long long* p, float v, unsigned tag) {
-  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+// local: the reader's workgroup runs on the SAME XCD as this one (xcd_handshake): the granule may stay in that XCD's L2 --
+// a store that is write-through only as far as the L2 (`sc0`; the reader's agent-scope load finds the dirty line there) instead
+// of an agent-scope store, which gfx950 writes through to the fabric (`sc1`): the exchange then costs no memory-side write
+// traffic at all (PMC WRITE_SIZE of a 64-image pass in helper form: 447 -> see profiles/r3) and the pass is 5 % shorter.
+// The tag travels with the value, so a granule that did NOT become visible can only delay its reader (bounded spin ->
+// status 7), never feed it a wrong value.
+DI void granule_store(unsigned long long* p, float v, unsigned tag, bool local) {
+  const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+  if (local) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Which XCD am I on, and are the workgroups I exchange granules with on the same one?  Every workgroup publishes its XCC_ID
+// (agent scope, tagged with the launch's epoch) in slot `mine` of the table and reads the slots in `mask` (bit k = slot
+// base + k).  Workgroups are dealt to the XCDs round-robin by index and the tile mapping puts an image's workgroups on one
+// XCD, so the answer is normally yes; it is CHECKED because a "no" with local stores would be a stall.  A partner that
+// does not show up within the spin bound just means agent-scope stores.
+DI bool xcd_handshake(unsigned long long* table, int base, int mine, unsigned mask, unsigned tag, int lane) {
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // hwreg(HW_REG_XCC_ID), bits 3:0
+  if (threadIdx.x == 0)
+    __hip_atomic_store(table + base + mine, ((unsigned long long)tag << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int k = lane & 3;
+  const bool partner = (mask >> k) & 1u;
+  unsigned long long v = granule_load(table + base + (partner ? k : mine));
+  int spins = 0;
+#pragma nounroll
+  while (partner && (unsigned)(v >> 32) != tag && spins < 4096) {
+    __builtin_amdgcn_s_sleep(2);
+    v = granule_load(table + base + k);
+    ++spins;
+  }
+  const bool ok = !partner || ((unsigned)(v >> 32) == tag && (unsigned)v == xcc);
+  return __all(ok);
 }
 
 }  // namespace
@@ -339,15 +372,15 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
       if (publish) {
         if (W.up_ok) {  // my first positions are what follows the previous tile
 #pragma unroll
-          for (int i = 0; i < 2; ++i) granule_store(obox + (W.ep_up + (mt * 32 + i) * HS), v[i], tag_out);
+          for (int i = 0; i < 2; ++i) granule_store(obox + (W.ep_up + (mt * 32 + i) * HS), v[i], tag_out, W.local);
         }
         if (W.dn_ok) {  // my last positions are what precedes the next tile
 #pragma unroll
-          for (int i = 0; i < 2; ++i) granule_store(obox + (W.ep_dn + (mt * 32 + i) * HS), v[i], tag_out);
+          for (int i = 0; i < 2; ++i) granule_store(obox + (W.ep_dn + (mt * 32 + i) * HS), v[i], tag_out, W.local);
         }
         if (HM) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) granule_store(hbox + (W.ep_h + i * 81), v[i], tag_out);
+          for (int i = 0; i < 2; ++i) granule_store(hbox + (W.ep_h + i * 81), v[i], tag_out, W.local);
         }
       }
     }
@@ -403,6 +436,8 @@ DI void helper_trunk(const Args& a, const int cl) {
   const int cell0 = (nq / 9 + 1) * 10 + nq % 9 + 1;   // band 0; band b: + 30 b
   const int bofs = (lane >> 5) * CSH + cell0 - 11;
   const int m0 = ((2 * w) & 3) + 8 * ((2 * w) >> 2) + 4 * (lane >> 5);
+  const unsigned xtag = ((unsigned)a.epoch << 12) | 0xFFFu;   // (layer serials stay below 0xFFF)
+  const bool local = a.local_st && xcd_handshake(a.inbox + a.off_xcc, 4 * cl, 3, 0x7u, xtag, lane);
   for (int i = t; i < 192 * CSH; i += NTHREADS) lds[i] = 0.f;
   __syncthreads();
   const float* in = a.in + (size_t)img * 192 * 81;
@@ -528,7 +563,7 @@ DI void helper_trunk(const Args& a, const int cl) {
         if (st_ok) {
           lds[lc] = v;
           if (gbase) gbase[((size_t)img * 192 + 32 + m0 + i) * 81 + 27 * b + n] = v;
-          if (!last_rdb) granule_store(obox + (m0 + i) * 81 + 27 * b + n, v, tag_out);
+          if (!last_rdb) granule_store(obox + (m0 + i) * 81 + 27 * b + n, v, tag_out, local);
         }
       }
     }
@@ -553,9 +588,15 @@ __global__ __launch_bounds__(512) void trunk_fused_kernel(Args a) {
     W.cl = cl;
   } else {
     tile = (B % 8) * a.tpx + B / 8;
-    W.cl = 0;
+    W.cl = tile / 3;   // (TP = 27: a.tpx is a multiple of three -- an image's bands are consecutive blocks of one XCD)
   }
   if (tile >= a.ntiles) return;
+  W.local = false;
+  if (TP == 27 && a.local_st) {  // partners: the bands above / below (and the image's helper)
+    const int role = tile - 3 * W.cl;
+    const unsigned mask = (role > 0 ? 1u << (role - 1) : 0u) | (role < 2 ? 1u << (role + 1) : 0u) | (HM ? 8u : 0u);
+    W.local = xcd_handshake(a.inbox + a.off_xcc, 4 * W.cl, role, mask, ((unsigned)a.epoch << 12) | 0xFFFu, W.lane);
+  }
   // the tile's own positions [P0, pend) of the launch's images laid end to end; (i0, r0) / (il, rl): image and row of the
   // first / last one.  LDS row of (image i, row r) = (i - i0) * 10 + r - r0 + 1: row 0 is the row above the first own row,
   // and between the last row of image i0 and the first row of image i0 + 1 lies one row nobody writes (zero).
@@ -683,7 +724,13 @@ size_t trunk_fused_stream_floats(int nrdb) { return (size_t)nrdb * NWAVE * WAVE_
 // the neighbour boxes [tiles][2][2][64][HS] at three tiles per image, the helpers' inboxes and the boxes they fill (the
 // backward chain's boxes are smaller)
 size_t trunk_fused_inbox_bytes(int nimg) {
-  return ((size_t)3 * nimg * 2 * 2 * 64 * HS + (size_t)nimg * 2 * 5 * 32 * 81 + (size_t)nimg * 2 * 32 * 81) * sizeof(unsigned long long);
+  return ((size_t)3 * nimg * 2 * 2 * 64 * HS + (size_t)nimg * 2 * 5 * 32 * 81 + (size_t)nimg * 2 * 32 * 81 + (size_t)4 * nimg) * sizeof(unsigned long long);
+}
+// granules in front of the XCC_ID table [image][4] at the end of an inbox buffer sized for `nimg_alloc` images
+size_t trunk_fused_xcc_offset(int nimg_alloc) { return trunk_fused_inbox_bytes(nimg_alloc) / sizeof(unsigned long long) - (size_t)4 * nimg_alloc; }
+int trunk_local_stores() {
+  static const int v = getenv("DBM_TRUNK_LOCAL_ST") ? atoi(getenv("DBM_TRUNK_LOCAL_ST")) : 1;
+  return v;
 }
 
 void launch_pack_trunk_fused(const float* const* d_wsrc, const float* const* d_bsrc, float* wstream, float* bstream, int nrdb,
@@ -729,7 +776,9 @@ void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
   a.inbox = L.inbox; a.err = L.err; a.err_dev = L.err_dev;
   a.nrdb = L.nrdb; a.nimg = L.nimg; a.img0 = L.img0; a.epoch = L.epoch & 0xFFFFF; a.rs = L.rs; a.slope = L.slope;
   a.ntiles = (L.nimg * 81 + TP - 1) / TP;
-  a.tpx = (a.ntiles + 7) / 8;
+  a.tpx = TP == 27 ? 3 * ((L.nimg + 7) / 8) : (a.ntiles + 7) / 8;
+  a.off_xcc = (unsigned)trunk_fused_xcc_offset(64);
+  a.local_st = trunk_local_stores();
   a.off_hb = (unsigned)(3 * L.nimg * 2 * 2 * 64 * HS);
   a.off_bh = a.off_hb + (unsigned)(L.nimg * 2 * 5 * 32 * 81);
   const double flop = 2.0 * 19408896.0 * L.nrdb * L.nimg;  // 19 408 896 MAC per dense block and tile

@@ -60,6 +60,8 @@ struct Args {
   int* err_dev;
   int nrdb, j0, j1, nimg, img0, epoch;
   float rs, slope;
+  unsigned off_xcc;  // XCC_ID table of the handshake (granule offset inside inbox)
+  int local_st;
   int abl;  // measurement aid (DBM_TFB_ABL): 1 = no halo exchange, 2 = no epilogue (results are then wrong)
 };
 
@@ -71,6 +73,7 @@ struct Wave {
   int bofs;         // B operand lane base: (lane >> 4) * CS + position offset
   int pofs;         // 11 + position offset: own cell inside a plane
   bool st_ok, up_ok, dn_ok;
+  bool local;       // the neighbouring bands run on this XCD: exchange stores stay in its L2
   unsigned me;      // inbox slot of this workgroup
   const float* wp;
   float skipv[4];   // gradient of the RRDB output at this thread's conv_layer1 outputs (the `x` skip of :402)
@@ -125,9 +128,28 @@ DI void mma_unit(const float (&A)[AU], int b, int b_next, float (&bq0)[9], f4v (
 DI unsigned long long granule_load(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-DI void granule_store(unsigned long long* p, float v, unsigned tag) {
-  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+// local: the reading workgroup runs on this XCD (checked at kernel start, see trunk_fused.hip): the granule stays in its L2
+DI void granule_store(unsigned long long* p, float v, unsigned tag, bool local) {
+  const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+  if (local) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+DI bool xcd_handshake(unsigned long long* table, int base, int mine, unsigned mask, unsigned tag, int lane) {
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;  // hwreg(HW_REG_XCC_ID), bits 3:0
+  if (threadIdx.x == 0)
+    __hip_atomic_store(table + base + mine, ((unsigned long long)tag << 32) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int k = lane & 3;
+  const bool partner = (mask >> k) & 1u;
+  unsigned long long v = granule_load(table + base + (partner ? k : mine));
+  int spins = 0;
+#pragma nounroll
+  while (partner && (unsigned)(v >> 32) != tag && spins < 4096) {
+    __builtin_amdgcn_s_sleep(2);
+    v = granule_load(table + base + k);
+    ++spins;
+  }
+  const bool ok = !partner || ((unsigned)(v >> 32) == tag && (unsigned)v == xcc);
+  return __all(ok);
 }
 
 // Halo rows of NCH freshly finished channels (planes from `plane0`) come from the neighbours' granules.  The loads are
@@ -247,8 +269,8 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
         gdst[gofs + r * 81] = v;
         if (publish) {
           const int pch = ch - fin0;
-          if (W.up_ok) granule_store(obox + ((size_t)(W.me - 1) * 4 + 1) * 576 + pch * 9 + W.pos, v, tag_out);
-          if (W.dn_ok) granule_store(obox + ((size_t)(W.me + 1) * 4 + 0) * 576 + pch * 9 + (W.pos - 18), v, tag_out);
+          if (W.up_ok) granule_store(obox + ((size_t)(W.me - 1) * 4 + 1) * 576 + pch * 9 + W.pos, v, tag_out, W.local);
+          if (W.dn_ok) granule_store(obox + ((size_t)(W.me + 1) * 4 + 0) * 576 + pch * 9 + (W.pos - 18), v, tag_out, W.local);
         }
       }
     }
@@ -297,6 +319,9 @@ __global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
   if (W.cl >= a.nimg) return;
   W.img = a.img0 + W.cl;
   W.me = (unsigned)(W.cl * 3 + W.band);
+  W.local = a.local_st && xcd_handshake(a.inbox + a.off_xcc, 4 * W.cl, W.band,
+                                        (W.band > 0 ? 1u << (W.band - 1) : 0u) | (W.band < 2 ? 1u << (W.band + 1) : 0u),
+                                        ((unsigned)a.epoch << 12) | 0xFFFu, W.lane);
   W.nh = W.w & 1;
   W.pos = W.nh * 16 + (W.lane & 15);
   {
@@ -442,6 +467,8 @@ void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s) {
   a.rs = L.rs; a.slope = L.slope;
   static const int abl = getenv("DBM_TFB_ABL") ? atoi(getenv("DBM_TFB_ABL")) : 0;
   a.abl = abl;
+  a.off_xcc = (unsigned)trunk_fused_xcc_offset(64);
+  a.local_st = trunk_local_stores();
   const int grid = ((L.nimg + 7) / 8) * 24;
   if (g_profiler.enabled) {
     // algorithmic bytes: the flipped weights of the launch's dense blocks once; per image the incoming gradient (64 channels),

@@ -25,4 +25,4 @@ t0 = time.perf_counter()
 for _ in range(n):
     dbm.train_minibatch(batch, g, go, d, do, log=log)
 ctx.synchronize()
-print("ms_per_step %.4f" % ((time.perf_counter() - t0) / n * 1e3))
+print("ms_per_step %.4f" % ((time.perf_counter() - t0) / n * 1e3), "timeout_info", ctx.timeout_info())
