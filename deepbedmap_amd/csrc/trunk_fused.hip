@@ -136,7 +136,9 @@ DI unsigned long long granule_load(const unsigned long long* p) {
 // local: the reader's workgroup runs on the SAME XCD as this one (xcd_handshake): the granule may stay in that XCD's L2 --
 // a store that is write-through only as far as the L2 (`sc0`; the reader's agent-scope load finds the dirty line there) instead
 // of an agent-scope store, which gfx950 writes through to the fabric (`sc1`): the exchange then costs no memory-side write
-// traffic at all (PMC WRITE_SIZE of a 64-image pass in helper form: 447 -> see profiles/r3) and the pass is 5 % shorter.
+// traffic while the line stays there (PMC, 64-image pass in helper form: WRITE_SIZE 457 -> 298 MB, FETCH_SIZE x 2 868 -> 412 MB -- the
+// weight stream evicts part of the dirty granules, 1.6 MB per dense block and XCD against a 4 MB L2 --; retained pass 739 -> 451 MB,
+// backward chain 856 -> 550 MB: profiles/r3/n_local_stores_traffic_pmc.json) and the passes are 5 % shorter.
 // The tag travels with the value, so a granule that did NOT become visible can only delay its reader (bounded spin ->
 // status 7), never feed it a wrong value.
 DI void granule_store(unsigned long long* p, float v, unsigned tag, bool local) {
