@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void deform_conv64_fused_kernel(const float* _
     const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
     v[r] = acc[r] + (bias ? bias[c] : 0.f);
     if (act) v[r] = v[r] >= 0.f ? v[r] : slope * v[r];
-    yn[(long)c * plane] = v[r];
+    if (y) yn[(long)c * plane] = v[r];
   }
   if (yt) {
 #pragma unroll
@@ -253,6 +253,86 @@ __global__ __launch_bounds__(256) void deform_conv1_fused_kernel(const float* __
       y[(n * oc + co) * plane + (P - n * plane)] = v + (bias ? bias[0] : 0.f);
     }
   }
+}
+
+// ---- the few-output-channel layer (64 -> 1: the DEM itself) with the multiplication BEFORE the sampler ----
+// Bilinear sampling is linear in the sampled plane: sum_c w[c][t] * sample(x_c, pos) = sample(sum_c w[c][t] * x_c, pos).  So the
+// layer is a 1x1 convolution 64 -> 9 (one plane z_t per tap, deform1_premul_kernel: reads the input once, coalesced) followed by
+// nine four-corner gathers of single floats per position (deform1_sample_kernel) -- instead of gathering 9 x 4 x 256 bytes per
+// position through the vector L1 (deform_conv1_fused_kernel: 12 GB of gathers for one 1144 x 1144 plane, 0.65 ms; now 0.34 + 0.05 GB).
+// The sums are associated differently (channels first, then corners and taps), i.e. equal to the other order to fp32 rounding.
+//
+// z[(n * nz + k) * plane + p] = sum_c w[k * 64 + c'] ..., k = co * 9 + t, w in its canonical OIHW order (co, c, t)
+__global__ __launch_bounds__(256) void deform1_premul_kernel(const float* __restrict__ xt, const float* __restrict__ w, float* __restrict__ z,
+                                                             long total, int plane, int nz) {
+  extern __shared__ __attribute__((aligned(16))) float pm[];  // wsh[nz][64] | zt[nz][64]
+  float* wsh = pm;
+  float* zt = pm + nz * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int e = tid; e < nz * 64; e += 256) {  // e = k * 64 + c  <-  w[(co * 64 + c) * 9 + t]
+    const int k = e >> 6, c = e & 63, co = k / 9, t = k - 9 * co;
+    wsh[e] = w[((long)co * 64 + c) * 9 + t];
+  }
+  __syncthreads();
+  const int q = lane & 15, pi = lane >> 4;
+  const long P0 = (long)blockIdx.x * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = 16 * wave + 4 * i + pi;
+    const long P = P0 + pl;
+    const float4 v = P < total ? *reinterpret_cast<const float4*>(xt + P * 64 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < nz; ++k) {
+      const float4 wr = *reinterpret_cast<const float4*>(wsh + k * 64 + 4 * q);
+      float a = wr.x * v.x;
+      a = fmaf(wr.y, v.y, a);
+      a = fmaf(wr.z, v.z, a);
+      a = fmaf(wr.w, v.w, a);
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      a += __shfl_xor(a, 4, 64);
+      a += __shfl_xor(a, 8, 64);
+      if (q == 0) zt[k * 64 + pl] = a;
+    }
+  }
+  __syncthreads();
+  const long P = P0 + lane;
+  if (P < total) {
+    const long n = P / plane;
+    float* dst = z + n * nz * plane + (P - n * plane);
+    for (int k = wave; k < nz; k += 4) dst[(long)k * plane] = zt[k * 64 + lane];
+  }
+}
+
+// y[(n * oc + co) * plane + p] = bias[co] + sum_t bilinear(z[n][co * 9 + t], p + tap_t + offset_t(p));  blockIdx.y = co
+__global__ __launch_bounds__(256) void deform1_sample_kernel(const float* __restrict__ z, const float* __restrict__ off,
+                                                             const float* __restrict__ bias, float* __restrict__ y, long total, int H, int W,
+                                                             long offsn, int oc) {
+  const long P = (long)blockIdx.x * 256 + threadIdx.x;
+  if (P >= total) return;
+  const int plane = H * W, co = blockIdx.y;
+  const int n = (int)(P / plane);
+  const int p = (int)(P - (long)n * plane);
+  const int a = p / W, b = p - a * W;
+  const float* on = off + (long)n * offsn + p;
+  const float* zn = z + ((long)n * oc + co) * 9 * plane;
+  float ox[9], oy[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { ox[t] = on[(long)t * plane]; oy[t] = on[(long)(9 + t) * plane]; }
+  float acc = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const DeformGeom g = deform_geom(ox[t], oy[t], a, b, t / 3, t % 3, H, W, 1);
+    const int o1 = deform_corner(g.v0, g.u0, H, W, 1), o2 = deform_corner(g.v0, g.u0 + 1, H, W, 1);
+    const int o3 = deform_corner(g.v0 + 1, g.u0, H, W, 1), o4 = deform_corner(g.v0 + 1, g.u0 + 1, H, W, 1);
+    const float* zt = zn + (long)t * plane;
+    const float z1 = zt[o1 >= 0 ? o1 : 0], z2 = zt[o2 >= 0 ? o2 : 0], z3 = zt[o3 >= 0 ? o3 : 0], z4 = zt[o4 >= 0 ? o4 : 0];
+    float v = (o1 >= 0 ? g.wu1 * g.wv1 : 0.f) * z1;
+    v = fmaf(o2 >= 0 ? g.wu0 * g.wv1 : 0.f, z2, v);
+    v = fmaf(o3 >= 0 ? g.wu1 * g.wv0 : 0.f, z3, v);
+    v = fmaf(o4 >= 0 ? g.wu0 * g.wv0 : 0.f, z4, v);
+    acc += v;
+  }
+  y[((long)n * oc + co) * plane + p] = acc + (bias ? bias[co] : 0.f);
 }
 
 
@@ -531,8 +611,10 @@ void launch_nchw_to_nhwc64(const float* x, float* xt, int N, int plane, hipStrea
 // xt: the layer input channels-last (launch_nchw_to_nhwc64, or the previous fused layer's `yt`).
 // O == 64: w = the packed forward image [576][64] of the layer viewed as a 1x1 convolution over (c, tap) columns
 // (IgLayer::wf, k = c * 9 + t); O == 1: w = the canonical (1, 64, 3, 3) tensor.  y (N, O, H, W) is overwritten.
+// O <= 16 with a scratch `z` of N * 9 * O * H * W floats: the premultiplied form (deform1_premul_kernel + deform1_sample_kernel);
+// z == nullptr: the gather-then-multiply kernel.  O == 64: y may be null when only the channels-last output yt is wanted.
 void launch_deform_conv_fused(const float* xt, const float* off, const float* w, const float* bias, float* y, float* yt, float* colout,
-                              int N, int C, int H, int W, long offsn, int O, int act, float slope, hipStream_t s) {
+                              int N, int C, int H, int W, long offsn, int O, int act, float slope, hipStream_t s, float* z) {
   DBM_CHECK(deform_conv_fused_ok(C, O), "fused deformable convolution: 64 input channels, 64 or <= 16 output channels");
   const long total = (long)N * H * W;
   DBM_CHECK(total < (1L << 31), "fused deformable convolution: more than 2^31 positions");
@@ -540,14 +622,19 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
   if (g_profiler.enabled) {
     // algorithmic bytes: the NHWC input and the 18 offset planes once, the weights once, the output (and its NHWC twin / the
     // kept sampled columns of a training forward) once
-    const double bytes = 4.0 * ((double)total * (C + 18 + O + (yt ? O : 0) + (colout ? 9.0 * C : 0.0)) + 9.0 * C * O);
+    const double bytes = 4.0 * ((double)total * (C + 18 + (y ? O : 0) + (yt ? O : 0) + (colout ? 9.0 * C : 0.0)) + 9.0 * C * O);
     char tag[40];
     snprintf(tag, sizeof(tag), "deform%d_%dx%d_n%d%s", O, H, W, N, colout ? "_keep" : "");
     g_profiler.begin(s, 0, 2.0 * (double)total * O * C * 9, bytes, tag, blocks);
   }
   if (O == 64)
     hipLaunchKernelGGL(deform_conv64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, bias, y, yt, colout, N, H, W, offsn, act, slope);
-  else
+  else if (z) {
+    const int nz = 9 * O;
+    hipLaunchKernelGGL(deform1_premul_kernel, dim3(blocks), dim3(256), (size_t)2 * nz * 64 * sizeof(float), s, xt, w, z, total, H * W, nz);
+    hipLaunchKernelGGL(deform1_sample_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)O), dim3(256), 0, s, z, off, bias, y, total, H, W,
+                       offsn, O);
+  } else
     for (int co = 0; co < O; ++co)  // (w: OIHW (O, 64, 3, 3))
       hipLaunchKernelGGL(deform_conv1_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w + (long)co * 576, bias ? bias + co : nullptr,
                          y, N, H, W, offsn, O, co);

@@ -426,7 +426,8 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   }
   if (x3) {
     x3_launch(layers[L_off1], a42t.p, 0, H4, W4, nullptr, off1.p, 0);
-    launch_deform_conv_fused(a42t.p, off1.p, layers[L_def1].wf, P(layers[L_def1].bi), a51.p, a51t.p, nullptr, N, 64, H4, W4, 32 * P4, 64, 1,
+    // (the split-bf16 tail reads channels-last only: the NCHW copy of this layer's output is not written)
+    launch_deform_conv_fused(a42t.p, off1.p, layers[L_def1].wf, P(layers[L_def1].bi), nullptr, a51t.p, nullptr, N, 64, H4, W4, 32 * P4, 64, 1,
                              SLOPE, s);
   } else {
     ConvDesc d = prec(fwd_desc(layers[L_off1], a42.p, 64 * P4, H4, W4, 0, off1.p, 32 * P4, N), 16);
@@ -451,7 +452,10 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       launch_igemm_conv(d, s);
     }
     if (dfused) {
-      launch_deform_conv_fused(a51t.p, off2.p, P(T_def2W), P(T_def2b), y, nullptr, nullptr, N, 64, H4, W4, 32 * P4, out_ch, 0, SLOPE, s);
+      static const bool premul = !(getenv("DBM_DEFORM1_PREMUL") && atoi(getenv("DBM_DEFORM1_PREMUL")) == 0);
+      if (premul) zdef.ensure((size_t)N * 9 * out_ch * P4);
+      launch_deform_conv_fused(a51t.p, off2.p, P(T_def2W), P(T_def2b), y, nullptr, nullptr, N, 64, H4, W4, 32 * P4, out_ch, 0, SLOPE, s,
+                               premul ? zdef.p : nullptr);
       // (unfused backward only: the 64 -> 1 layer's weight gradient then reads its sample matrix)
       if (keep && !deform_bwd_fused(H4, W4)) {
         col2.ensure((size_t)N * 576 * P4);

@@ -32,7 +32,7 @@ void launch_deform_backward(const float* x, const float* off, const float* gcol,
 bool deform_conv_fused_ok(int C, int O);
 void launch_nchw_to_nhwc64(const float* x, float* xt, int N, int plane, hipStream_t s);
 void launch_deform_conv_fused(const float* xt, const float* off, const float* w, const float* bias, float* y, float* yt, float* colout,
-                              int N, int C, int H, int W, long offsn, int O, int act, float slope, hipStream_t s);
+                              int N, int C, int H, int W, long offsn, int O, int act, float slope, hipStream_t s, float* z = nullptr);
 void launch_deform_bwd64_fused(const float* xt, const float* off, const float* wb, const float* gy, float* gcol, float* goff, int N, int H,
                                int W, long offsn, hipStream_t s);
 size_t deform_bwd1_partial_floats(int N, int H, int W);

@@ -198,6 +198,7 @@ struct Generator : dbm_model {
   DevBuf csr_ws;       // sampling lists of the deformable layers' input-gradient gather (deform_csr_build_kernel)
   DevBuf dw2_partial;  // per-workgroup partial sums of final_conv_layer2's weight gradient (deform_bwd1_fused_kernel)
   bool deform_bwd_fused(int H4, int W4) const;
+  DevBuf zdef;        // the last layer's premultiplied tap planes (N, 9 * out_ch, 4H, 4W): deform1_premul_kernel
   DevBuf a42t, a51t;  // channels-last copies of the deformable layers' inputs (what the fused sampler gathers from)
   // bf16 sweep mode on large planes (conv_cl16.hip): the dense block's concat as NHWC bf16 (two buffers in ping-pong, 192
   // channels per pixel) and the 64-channel residual stream as NHWC fp32 (block input, block output, RRDB input)
