@@ -222,6 +222,27 @@ def sweep_leg(dbm, ctx, g, crops=5):
             rows.append({k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items()})
         res[name]["bracketed_ms"] = sum(r_["ms"] for r_ in recs)
         res[name]["per_shape_standalone"] = rows
+    # equal-shape crops eight at a time (predict_tiled_resident(crops_per_batch=8)): the same work per crop in fuller launches
+    nb = 8
+    ins = [dbm.to_device(r.rand(nb, c, m * h, m * w).astype(np.float32), ctx) for c, m in ((1, 1), (1, 10), (2, 2), (1, 1))]
+    y = dbm.DeviceArray((nb, 1, 4 * (h - 2), 4 * (w - 2)), ctx)
+
+    def fwd8():
+        dbm._lib.check(lib.dbm_gen_forward(g._h, nb, h, w, ins[0].ptr, ins[1].ptr, ins[2].ptr, ins[3].ptr, y.ptr,
+                                           dbm._lib.DEVICE_PTRS | dbm._lib.BF16), ctx.handle)
+
+    fwd8()
+    ctx.synchronize()
+    dbm._lib.check(lib.dbm_timer(ctx.handle, 0, None), ctx.handle)
+    for _ in range(2):
+        fwd8()
+    dbm._lib.check(lib.dbm_timer(ctx.handle, 1, None), ctx.handle)
+    ms = C.c_double(0.0)
+    dbm._lib.check(lib.dbm_timer(ctx.handle, 2, C.byref(ms)), ctx.handle)
+    per = ms.value / (2 * nb)
+    res["bf16"]["batch8"] = {"ms_per_crop": per, "tflops": flop / (per * 1e-3) / 1e12,
+                             "frac_of_mfma_peak": flop / (per * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                             "s_per_continent_one_gpu": 396 * per * 1e-3}
     return res
 
 

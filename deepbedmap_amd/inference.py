@@ -81,10 +81,12 @@ def predict_tiled(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=
 
 def predict_tiled_resident(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=18000, x=22000),
                            ary_shape=Shape(y=1000, x=1000), stride=Shape(y=1000, x=1000), xtrapad=Shape(y=18, x=18), rank=0,
-                           world=1, download=True, dtype="float32", clip=False):
+                           world=1, download=True, dtype="float32", clip=False, crops_per_batch=1):
     """predict_tiled with the grids resident in HBM.  Inputs are NumPy arrays (uploaded once) or DeviceArrays of the
     same shapes as for predict_tiled.  Returns Y_hat as a NumPy array (download=True) or as the device canvas.
-    clip=True: W1, W2, W3 are clipped to >= 0 (deepbedmap.py:663-665) on the device, after the upload (DeviceArrays: in place)."""
+    clip=True: W1, W2, W3 are clipped to >= 0 (deepbedmap.py:663-665) on the device, after the upload (DeviceArrays: in place).
+    crops_per_batch > 1: crops of equal shape go through the generator that many at a time (the reference's loop, :704-741, is one
+    crop per forward; per crop the arithmetic is the same, so is the canvas) -- 6.5 -> 5.9 ms per 288 x 288 bf16 crop at 8."""
     ctx = model.ctx
     lib = _lib.lib()
     grids = [a if isinstance(a, DeviceArray) else to_device(a, ctx) for a in (X_tile, W1_tile, W2_tile, W3_tile)]
@@ -98,27 +100,38 @@ def predict_tiled_resident(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape
         _lib.check(lib.dbm_memcpy2d_d2d(ctx.handle, C.c_void_p(dst), 4 * dpitch, C.c_void_p(src), 4 * spitch, 4 * width,
                                         height), ctx.handle)
 
-    crops = {}
+    # the rank's tiles grouped by crop shape (320 of the continent's 396 crops are 288 x 288), each group in batches of
+    # `crops_per_batch` crops per generator forward: same arithmetic per crop, fewer and fuller launches
+    groups = {}
     for i, step in enumerate(tile_steps(final_shape, stride)):
         if i % world != rank:
             continue
         y0, y1, x0, x1 = crop_bounds(step, final_shape, ary_shape, xtrapad)
-        h, w = y1 - y0, x1 - x0
-        if (h, w) not in crops:  # crop staging buffers, reused by every tile of the same shape (320 of 396 are 288 x 288)
-            crops[(h, w)] = [DeviceArray((1, g.shape[1], k * h, k * w), ctx) for g, k in zip(grids, scale)]
-        bufs = crops[(h, w)]
-        for g, k, b in zip(grids, scale, bufs):
-            H, W = g.shape[2], g.shape[3]
-            for c in range(g.shape[1]):
-                copy2d(b.ptr + 4 * c * (k * h) * (k * w), k * w, g.ptr + 4 * (c * H * W + (k * y0) * W + k * x0), W, k * w, k * h)
-        with using_config(name="enable_backprop", value=False), using_config(name="dtype", value=dtype):
-            Y_pred = model.forward(x=bufs[0], w1=bufs[1], w2=bufs[2], w3=bufs[3])
-        Wo = 4 * (w - 2)
-        rows = 4 * (h - 2) - 8 * xtrapad.y
-        cols = Wo - 8 * xtrapad.x
-        ys, xs = (y0 + xtrapad.y + 1) * 4, (x0 + xtrapad.x + 1) * 4
-        copy2d(canvas.ptr + 4 * (ys * final_shape.x + xs), final_shape.x,
-               Y_pred.array.ptr + 4 * (4 * xtrapad.y * Wo + 4 * xtrapad.x), Wo, cols, rows)
+        groups.setdefault((y1 - y0, x1 - x0), []).append((y0, y1, x0, x1))
+    B = max(1, int(crops_per_batch))
+    for (h, w), tiles in groups.items():
+        nb_max = min(B, len(tiles))
+        # crop staging buffers, reused by every batch of this shape
+        bufs = [DeviceArray((nb_max, g.shape[1], k * h, k * w), ctx) for g, k in zip(grids, scale)]
+        Ho, Wo = 4 * (h - 2), 4 * (w - 2)
+        rows, cols = Ho - 8 * xtrapad.y, Wo - 8 * xtrapad.x
+        for b0 in range(0, len(tiles), nb_max):
+            batch = tiles[b0:b0 + nb_max]
+            nb = len(batch)
+            for j, (y0, y1, x0, x1) in enumerate(batch):
+                for g, k, b in zip(grids, scale, bufs):
+                    H, W = g.shape[2], g.shape[3]
+                    nc = g.shape[1]
+                    for c in range(nc):
+                        copy2d(b.ptr + 4 * ((j * nc + c) * (k * h) * (k * w)), k * w, g.ptr + 4 * (c * H * W + (k * y0) * W + k * x0), W,
+                               k * w, k * h)
+            ins = bufs if nb == nb_max else [DeviceArray((nb,) + b.shape[1:], ctx, ptr=b.ptr, owner=b) for b in bufs]
+            with using_config(name="enable_backprop", value=False), using_config(name="dtype", value=dtype):
+                Y_pred = model.forward(x=ins[0], w1=ins[1], w2=ins[2], w3=ins[3])
+            for j, (y0, y1, x0, x1) in enumerate(batch):
+                ys, xs = (y0 + xtrapad.y + 1) * 4, (x0 + xtrapad.x + 1) * 4
+                copy2d(canvas.ptr + 4 * (ys * final_shape.x + xs), final_shape.x,
+                       Y_pred.array.ptr + 4 * (j * Ho * Wo + 4 * xtrapad.y * Wo + 4 * xtrapad.x), Wo, cols, rows)
     return canvas.get() if download else canvas
 
 

@@ -502,6 +502,11 @@ def test_tiled_area_inference_matches_oracle_loop(dbm):
     assert np.array_equal(np.nan_to_num(Yr, nan=-1.0), np.nan_to_num(Y, nan=-1.0))
     parts = [dbm.predict_tiled_resident(g, X, W1, W2, W3, final, ary, stride, pad, rank=k, world=2) for k in range(2)]
     assert np.array_equal(np.nan_to_num(dbm.merge_ranks(parts), nan=-1.0), np.nan_to_num(Y, nan=-1.0))
+    # equal-shape crops three at a time through the generator (a partial last batch included): the same canvas up to the
+    # summation order of launches whose split depends on the batch size
+    Yb = dbm.predict_tiled_resident(g, X, W1, W2, W3, final, ary, stride, pad, crops_per_batch=3)
+    assert np.array_equal(np.isnan(Yb), np.isnan(Y))
+    assert rel(Yb[m], Y[m]) < 1e-5
 
 
 def test_trainer_epoch_no_nan(dbm):
