@@ -108,6 +108,7 @@ SIGNATURES = {
     "dbm_op_conv2d_cl16": [C.c_void_p] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p] + [C.c_int] * 6,
     "dbm_op_conv2d_cl16x3": [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int] * 7,
     "dbm_op_deform_conv2d": [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int] * 5,
+    "dbm_op_deform_conv2d_form": [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int] * 6,
     "dbm_op_deform_conv2d_backward": [C.c_void_p] + [C.c_void_p] * 8 + [C.c_int] * 5,
 }
 

@@ -1472,6 +1472,28 @@ int dbm_op_conv2d_cl16x3(dbm_ctx* ctx, const float* x, const float* w, const flo
   DBM_API_END
 }
 
+int dbm_op_deform_conv2d_form(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y, int N, int H,
+                              int W, int O, int form, int lrelu) {
+  DBM_API_BEGIN(ctx)
+  DBM_CHECK((form == 1 && O >= 1 && O <= 16) || (form == 2 && O == 64), "deform conv op: form 1 (O <= 16, premultiplied) or 2 (O = 64, split-bf16)");
+  hipStream_t s = ctx->stream;
+  const long plane = (long)H * W;
+  DevBuf xt, z, wx;
+  xt.ensure((size_t)N * 64 * plane);
+  launch_nchw_to_nhwc64(x, xt.p, N, (int)plane, s);
+  if (form == 1) {
+    z.ensure((size_t)N * 9 * O * plane);
+    launch_deform_conv_fused(xt.p, off, w, b, y, nullptr, nullptr, N, 64, H, W, 18L * plane, O, 0, 0.2f, s, z.p);
+  } else {
+    wx.ensure((deform_x3_packed_elems() + 1) / 2);
+    launch_pack_deform_x3(w, wx.p, s);
+    launch_deform_conv64_x3(xt.p, off, wx.p, b, y, nullptr, N, H, W, 18L * plane, lrelu, 0.2f, s);
+  }
+  DBM_HIP(hipStreamSynchronize(s));
+  xt.release(); z.release(); wx.release();
+  DBM_API_END
+}
+
 int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y,
                          int N, int C, int H, int W, int O) {
   DBM_API_BEGIN(ctx)

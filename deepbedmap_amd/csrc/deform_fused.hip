@@ -255,6 +255,130 @@ __global__ __launch_bounds__(256) void deform_conv1_fused_kernel(const float* __
   }
 }
 
+// ---- 64 -> 64 in split-bf16 arithmetic (the bf16 sweep, forward only) ----
+// The same sampler; the blended samples are split x = hi + lo (hi = bf16(x), lo = bf16(x - hi)) on their way into LDS and
+// the product is three v_mfma_f32_32x32x16_bf16 -- hi*hi + hi*lo + lo*hi, fp32 accumulation, 2^-16 operand precision (the
+// arithmetic of conv_cl16x3_kernel, conv_cl16.hip) -- instead of 32 fp32 MFMAs per tap: 384 instead of 2048 matrix-pipe
+// cycles per tap and wavefront.  What remains is the sampler's gathers (the 64 -> 1 layer's time before it was re-associated).
+//   LDS sample tile: [position][64 channels] bf16, one 128-byte row per position for hi and one for lo, rows 144 bytes apart
+//   (any sixteen consecutive rows -- and the lane groups of a ds_read_b128 -- then fall on distinct banks);
+//   weights: wx [tap][k step][hi | lo][channel tile][lane][8] bf16 (launch_pack_deform_x3): lane = (out channel lane & 31,
+//   k group lane >> 5), one coalesced 16-byte load per fragment.
+typedef __bf16 dbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dbf16x4 __attribute__((ext_vector_type(4)));
+constexpr int DX_ROW = 144;                 // bytes between positions of the split sample tile
+constexpr int DX_TILE = 64 * DX_ROW;        // one (hi or lo) tile
+
+__global__ __launch_bounds__(256) void deform_conv64_x3_kernel(const float* __restrict__ xt, const float* __restrict__ off,
+                                                               const dbf16x8* __restrict__ wx, const float* __restrict__ bias,
+                                                               float* __restrict__ y, float* __restrict__ yt, int N, int H, int W,
+                                                               long offsn, int act, float slope) {
+  __shared__ TileGeometry geo;
+  __shared__ __attribute__((aligned(16))) unsigned char col[2][2 * DX_TILE];  // [buffer][hi | lo][position][64 bf16 (+ pad)]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int plane = H * W;
+  const long total = (long)N * plane;
+  const long P0 = (long)blockIdx.x * DF_POS;
+  build_geometry(geo, off, offsn, P0, total, plane, H, W, tid);
+  const int q = lane & 15, pi = lane >> 4;            // sampler role
+  const float* xq = xt + 4 * q;
+  const int ct = wave & 1, pt = wave >> 1, j = lane & 31, kg = lane >> 5;   // multiplier role
+  const dbf16x8* wl = wx + ct * 64 + lane;            // + ((t * 4 + ks) * 2 + hl) * 128
+  const int boff = (pt * 32 + j) * DX_ROW + kg * 16;  // + ks * 32 (+ DX_TILE for lo)
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  __syncthreads();
+
+  float4 c1[4], c2[4], c3[4], c4[4], cw[4];
+  auto gather = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t * DF_POS + 16 * wave + 4 * i + pi;
+      const int4 id = geo.idx[e];
+      cw[i] = geo.wgt[e];
+      c1[i] = *reinterpret_cast<const float4*>(xq + (long)id.x * 64);
+      c2[i] = *reinterpret_cast<const float4*>(xq + (long)id.y * 64);
+      c3[i] = *reinterpret_cast<const float4*>(xq + (long)id.z * 64);
+      c4[i] = *reinterpret_cast<const float4*>(xq + (long)id.w * 64);
+    }
+  };
+  auto blend = [&](unsigned char* dst) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = blend4(cw[i], c1[i], c2[i], c3[i], c4[i]);
+      const float f[4] = {v.x, v.y, v.z, v.w};
+      dbf16x4 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (__bf16)f[e];
+        lo[e] = (__bf16)(f[e] - (float)hi[e]);
+      }
+      unsigned char* d = dst + (16 * wave + 4 * i + pi) * DX_ROW + 8 * q;
+      *reinterpret_cast<dbf16x4*>(d) = hi;
+      *reinterpret_cast<dbf16x4*>(d + DX_TILE) = lo;
+    }
+  };
+  gather(0);
+  blend(col[0]);
+  __syncthreads();
+  auto multiply = [&](int t, bool more) {
+    dbf16x8 ah[4], al[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ah[ks] = wl[((t * 4 + ks) * 2 + 0) * 128];
+      al[ks] = wl[((t * 4 + ks) * 2 + 1) * 128];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) gather(t + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* cb = col[t & 1] + boff;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const dbf16x8 bh = *reinterpret_cast<const dbf16x8*>(cb + ks * 32);
+      const dbf16x8 bl = *reinterpret_cast<const dbf16x8*>(cb + ks * 32 + DX_TILE);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bl, acc, 0, 0, 0);   // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) blend(col[(t + 1) & 1]);
+    __syncthreads();
+  };
+  for (int t = 0; t < 8; ++t) multiply(t, true);
+  multiply(8, false);
+  const long Pm = P0 + pt * 32 + j;
+  if (Pm >= total) return;
+  const long nm = Pm / plane;
+  float v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+    v[r] = acc[r] + (bias ? bias[c] : 0.f);
+    if (act) v[r] = v[r] >= 0.f ? v[r] : slope * v[r];
+    if (y) y[nm * 64 * plane + (Pm - nm * plane) + (long)c * plane] = v[r];
+  }
+  if (yt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(yt + Pm * 64 + ct * 32 + 8 * g + 4 * kg) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+  }
+}
+
+// w: canonical OIHW (64, 64, 3, 3) -> wx [tap][k step][hi | lo][channel tile][lane][8]
+__global__ __launch_bounds__(256) void pack_deform_x3_kernel(const float* __restrict__ w, __bf16* __restrict__ wx) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // (t, ks, ct, lane, e)
+  if (idx >= 9 * 4 * 2 * 64 * 8) return;
+  const int e = idx & 7, lane = (idx >> 3) & 63, ct = (idx >> 9) & 1, ks = (idx >> 10) & 3, t = idx >> 12;
+  const int o = ct * 32 + (lane & 31), c = 16 * ks + 8 * (lane >> 5) + e;
+  const float v = w[((long)o * 64 + c) * 9 + t];
+  const __bf16 hi = (__bf16)v;
+  const __bf16 lo = (__bf16)(v - (float)hi);
+  const long base = ((long)(t * 4 + ks) * 2) * 1024 + (ct * 64 + lane) * 8 + e;
+  wx[base] = hi;
+  wx[base + 1024] = lo;
+}
+
 // ---- the few-output-channel layer (64 -> 1: the DEM itself) with the multiplication BEFORE the sampler ----
 // Bilinear sampling is linear in the sampled plane: sum_c w[c][t] * sample(x_c, pos) = sample(sum_c w[c][t] * x_c, pos).  So the
 // layer is a 1x1 convolution 64 -> 9 (one plane z_t per tap, deform1_premul_kernel: reads the input once, coalesced) followed by
@@ -638,6 +762,29 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
     for (int co = 0; co < O; ++co)  // (w: OIHW (O, 64, 3, 3))
       hipLaunchKernelGGL(deform_conv1_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w + (long)co * 576, bias ? bias + co : nullptr,
                          y, N, H, W, offsn, O, co);
+  if (g_profiler.enabled) g_profiler.end(s);
+  DBM_HIP(hipGetLastError());
+}
+
+size_t deform_x3_packed_elems() { return (size_t)9 * 4 * 2 * 2 * 64 * 8; }
+void launch_pack_deform_x3(const float* w_oihw, void* dst, hipStream_t s) {
+  hipLaunchKernelGGL(pack_deform_x3_kernel, dim3((9 * 4 * 2 * 64 * 8 + 255) / 256), dim3(256), 0, s, w_oihw, (__bf16*)dst);
+  DBM_HIP(hipGetLastError());
+}
+// the 64 -> 64 layer in split-bf16 arithmetic (forward only): wx from launch_pack_deform_x3; y and / or yt
+void launch_deform_conv64_x3(const float* xt, const float* off, const void* wx, const float* bias, float* y, float* yt, int N, int H, int W,
+                             long offsn, int act, float slope, hipStream_t s) {
+  const long total = (long)N * H * W;
+  DBM_CHECK(total < (1L << 31), "fused deformable convolution: more than 2^31 positions");
+  const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
+  if (g_profiler.enabled) {
+    const double bytes = 4.0 * (double)total * (64 + 18 + (y ? 64 : 0) + (yt ? 64 : 0)) + 2.0 * 2.0 * 9 * 64 * 64;
+    char tag[40];
+    snprintf(tag, sizeof(tag), "deform64x3_%dx%d_n%d", H, W, N);
+    g_profiler.begin(s, 0, 2.0 * (double)total * 64 * 64 * 9, bytes, tag, blocks);
+  }
+  hipLaunchKernelGGL(deform_conv64_x3_kernel, dim3(blocks), dim3(256), 0, s, xt, off, (const dbf16x8*)wx, bias, y, yt, N, H, W, offsn, act,
+                     slope);
   if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
 }

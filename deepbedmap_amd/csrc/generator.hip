@@ -56,6 +56,7 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
   layers.back().want_x3 = true;
   conv("final_conv_layer1/deform_conv", 64, 64, 3, 3);
   L_def1 = add_iglayer("final_conv_layer1/deform_conv", 64, 64, 3, 1, 0, true, /*as_1x1=*/true);
+  layers.back().want_dx3 = true;
   conv("final_conv_layer2/offset_conv", 18, 64, 3, 3);  // :515-523
   L_off2 = add_iglayer("final_conv_layer2/offset_conv", 18, 64, 3, 1, 1, true);
   layers.back().want_x3 = true;
@@ -427,8 +428,12 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   if (x3) {
     x3_launch(layers[L_off1], a42t.p, 0, H4, W4, nullptr, off1.p, 0);
     // (the split-bf16 tail reads channels-last only: the NCHW copy of this layer's output is not written)
-    launch_deform_conv_fused(a42t.p, off1.p, layers[L_def1].wf, P(layers[L_def1].bi), nullptr, a51t.p, nullptr, N, 64, H4, W4, 32 * P4, 64, 1,
-                             SLOPE, s);
+    static const bool dx3 = !(getenv("DBM_DEFORM_X3") && atoi(getenv("DBM_DEFORM_X3")) == 0);
+    if (dx3 && layers[L_def1].wdx3)
+      launch_deform_conv64_x3(a42t.p, off1.p, layers[L_def1].wdx3, P(layers[L_def1].bi), nullptr, a51t.p, N, H4, W4, 32 * P4, 1, SLOPE, s);
+    else
+      launch_deform_conv_fused(a42t.p, off1.p, layers[L_def1].wf, P(layers[L_def1].bi), nullptr, a51t.p, nullptr, N, 64, H4, W4, 32 * P4, 64,
+                               1, SLOPE, s);
   } else {
     ConvDesc d = prec(fwd_desc(layers[L_off1], a42.p, 64 * P4, H4, W4, 0, off1.p, 32 * P4, N), 16);
     launch_igemm_conv(d, s);

@@ -118,6 +118,8 @@ struct IgLayer {
   void* wcl16 = nullptr;     // bf16 [chunk][tap][k half][mtile][lane][8]
   bool want_x3 = false;      // ... and a split-bf16 (hi | lo) image for conv_cl16x3_kernel: the sweep's upsampling / offset convs
   void* wx3 = nullptr;       // bf16 [chunk][tap][mtile][hi | lo][lane][8]
+  bool want_dx3 = false;     // the 64 -> 64 deformable layer: split-bf16 image for deform_conv64_x3_kernel (launch_pack_deform_x3)
+  void* wdx3 = nullptr;
   int OP = 0, CP = 0;
   float* wb[4] = {nullptr, nullptr, nullptr, nullptr};  // dgrad packs [Tb][OP][CP]
   int Tb = 0;

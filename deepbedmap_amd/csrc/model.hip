@@ -61,6 +61,7 @@ dbm_model::~dbm_model() {
     if (L.wf16) (void)hipFree(L.wf16);
     if (L.wcl16) (void)hipFree(L.wcl16);
     if (L.wx3) (void)hipFree(L.wx3);
+    if (L.wdx3) (void)hipFree(L.wdx3);
     for (int i = 0; i < 4; ++i)
       if (L.wb[i]) (void)hipFree(L.wb[i]);
   }
@@ -283,6 +284,10 @@ void dbm_model::ensure_packed_bf16() {
     if (L.want_x3 && L.K == 3 && L.Kview == 3 && L.C % 16 == 0 && L.O <= 64) {  // split-bf16 image (conv_cl16x3_kernel)
       if (!L.wx3) DBM_HIP(hipMalloc(&L.wx3, cl16x3_packed_elems(L.C, L.O) * sizeof(__bf16)));
       launch_pack_cl16x3(P(L.wi), L.wx3, L.O, L.C, s);
+    }
+    if (L.want_dx3 && L.K == 3 && L.C == 64 && L.O == 64) {
+      if (!L.wdx3) DBM_HIP(hipMalloc(&L.wdx3, deform_x3_packed_elems() * sizeof(__bf16)));
+      launch_pack_deform_x3(P(L.wi), L.wdx3, s);
     }
   }
   DBM_HIP(hipGetLastError());

@@ -309,6 +309,11 @@ int dbm_op_conv2d_cl16x3(dbm_ctx* ctx, const float* x, const float* w, const flo
 /* L.DeformableConvolution2D sampler + GEMM (stride 1, pad 1, 3x3): off (N,18,H,W) */
 int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y,
                          int N, int C, int H, int W, int O);
+/* the two other forms of the forward pass the generator uses, 64 input channels: form 1 = the few-output-channel layer
+ * (O <= 16; srgan_train.py:574, the DEM itself) with the multiplication BEFORE the sampler -- nine premultiplied tap planes,
+ * scalar gathers --, form 2 = the 64 -> 64 layer (:572) in the sweep's split-bf16 arithmetic (+ LeakyReLU 0.2 if lrelu) */
+int dbm_op_deform_conv2d_form(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y, int N, int H,
+                              int W, int O, int form, int lrelu);
 int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* gy,
                                   float* gx, float* goff, float* gw, float* gb, int N, int C, int H, int W, int O);
 

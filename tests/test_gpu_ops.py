@@ -147,6 +147,12 @@ def test_deform_conv_forward_backward(dbm, O, scale, shape):
     dx, doff, dw, db = dev(d, x), dev(d, off), dev(d, w), dev(d, b)
     _lib.check(l.dbm_op_deform_conv2d(ctx.handle, dx.ptr, doff.ptr, dw.ptr, db.ptr, y.ptr, N, Cc, H, W, O), ctx.handle)
     assert rel(y.get(), ref) < TOL
+    # the generator's other forms of the same forward pass: 64 -> 1 with the multiplication before the sampler (fp32: the same
+    # tolerance), 64 -> 64 in split-bf16 arithmetic (sixteen significand bits per operand: 3e-5 of the output's largest value)
+    y2 = d.DeviceArray(ref.shape)
+    _lib.check(l.dbm_op_deform_conv2d_form(ctx.handle, dx.ptr, doff.ptr, dw.ptr, db.ptr, y2.ptr, N, H, W, O, 1 if O == 1 else 2, 0), ctx.handle)
+    assert rel(y2.get(), ref) < (TOL if O == 1 else 3e-5)
+    assert not np.array_equal(y2.get(), y.get())  # (a different kernel did run)
     gy = rs.normal(size=ref.shape).astype(np.float32)
     gx_ref, goff_ref, gw_ref, gb_ref = ops.deform_conv2d_backward(x, off, w, gy)
     gx, goff = d.DeviceArray(x.shape), d.DeviceArray(off.shape)
@@ -209,3 +215,22 @@ def test_generator_loss_and_gradient(dbm, window):
     assert abs(out[1] - ops.psnr(y, t)) < 1e-3
     assert abs(out[2] - ops.ssim(y, t, kind=window)) < 1e-5
     assert rel(gy, gref) < TOL
+
+
+@pytest.mark.parametrize("O", [1, 3])
+def test_deform_conv_premultiplied_form_at_dem_range(dbm, O):
+    """The last layer of the generator at the reference's data range (un-normalised metres, offsets of a fraction of a pixel
+    up to two pixels), O = out_channels 1 and 3: premultiplied tap planes + scalar gathers against the float64 oracle --
+    1e-5 of the output's range (the re-association costs nothing measurable)."""
+    d, _lib, ctx = dbm
+    N, H, W = 2, 40, 37
+    rs = np.random.RandomState(70 + O)
+    x = (rs.normal(size=(N, 64, H, W)) * 700.0 + 500.0).astype(np.float32)
+    off = rs.normal(scale=0.7, size=(N, 18, H, W)).astype(np.float32)
+    w = (rs.normal(size=(O, 64, 3, 3)) / np.sqrt(64 * 9)).astype(np.float32)
+    b = rs.normal(size=(O,)).astype(np.float32)
+    ref = ops.deform_conv2d(x.astype(np.float64), off.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    y = d.DeviceArray(ref.shape)
+    dx, doff, dw, db = dev(d, x), dev(d, off), dev(d, w), dev(d, b)
+    _lib.check(_lib.lib().dbm_op_deform_conv2d_form(ctx.handle, dx.ptr, doff.ptr, dw.ptr, db.ptr, y.ptr, N, H, W, O, 1, 0), ctx.handle)
+    assert rel(y.get(), ref) < 1e-5
