@@ -333,6 +333,10 @@ def main():
     ap.add_argument("--dist-backend", default=None, choices=["rccl", "nccl", "gloo"],
                     help="N > 1: rccl (default) = libdbm's native communicator, gradient buckets overlapped with the backward "
                          "passes; nccl = torch.distributed's RCCL, one all-reduce after each backward (round-1 form)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="single GPU only: attach a ONE-rank native RCCL communicator and treat it as active (DBM_COMM_FORCE_WORLD1=1): "
+                         "the data-parallel schedule -- bucketed ncclAllReduce calls on the exchange stream, persistent launches at 192 "
+                         "workgroups, optimizers behind the exchange events -- measured on one GPU")
     ap.add_argument("--no-fused-iteration", action="store_true",
                     help="the two step calls + two optimizer calls per minibatch instead of dbm_train_iteration (which, since "
                          "round 3, also serves data-parallel runs on the rccl / gloo-hook backends)")
@@ -365,7 +369,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
-    comm = dbm.DataParallel(backend=args.dist_backend, sync_batch_stats=args.sync_batch_stats) if world > 1 else None
+    if args.force_comm and world == 1:
+        os.environ["DBM_COMM_FORCE_WORLD1"] = "1"   # (read by the library at its first exchange decision)
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    comm = (dbm.DataParallel(backend=args.dist_backend or ("rccl" if args.force_comm else None), sync_batch_stats=args.sync_batch_stats)
+            if (world > 1 or args.force_comm) else None)
     ctx = dbm.Context(local_rank)
     dbm._lib._default_ctx = ctx
     # multi-GPU: libdbm enqueues on the stream torch issues its RCCL collectives on (stream-ordered, no host waits);

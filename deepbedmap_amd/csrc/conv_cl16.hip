@@ -147,40 +147,55 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
 
+  // One chunk = 18 steps (tap t = s >> 1, K half kh = s & 1).  The fragments of step s + 2 are requested BEFORE the MFMAs of step
+  // s and pinned there (hipcc otherwise puts every ds_read_b128 right in front of its MFMA behind an lgkmcnt(0): one exposed LDS
+  // latency per MFMA -- the ISA of the first version); a ring of three register sets with compile-time slots.  A wavefront with
+  // one patch alternates two accumulators (a single chain would serialise on the matrix pipe's result latency); they are added
+  // in the epilogue.
   auto compute = [&](auto BUF) {
     constexpr int buf = decltype(BUF)::value;
     if (!has0) return;
     const unsigned char* ab = smem + buf * ACT_BYTES;
     const unsigned char* wb = smem + WGT0 + buf * W_BYTES + lane * 16;
+    bf16x8 fa[3][MT], fb0[3], fb1[3];
     if (has1) {   // (wave-uniform: two patches share every weight fragment)
+      auto ld = [&](int st, int slot) {
+        const int t = st >> 1, kh = st & 1;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+        for (int m = 0; m < MT; ++m) fa[slot][m] = *reinterpret_cast<const bf16x8*>(wb + ((t * 2 + kh) * MT + m) * 1024);
+        fb0[slot] = *reinterpret_cast<const bf16x8*>(ab + (bad0[t] ^ (kh << 5)));
+        fb1[slot] = *reinterpret_cast<const bf16x8*>(ab + (bad1[t] ^ (kh << 5)));
+      };
+      ld(0, 0);
+      ld(1, 1);
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-          bf16x8 av[MT];
+      for (int st = 0; st < 18; ++st) {
+        if (st + 2 < 18) ld(st + 2, (st + 2) % 3);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const bf16x8*>(wb + ((t * 2 + kh) * MT + m) * 1024);
-          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ab + (bad0[t] ^ (kh << 5)));
-          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ab + (bad1[t] ^ (kh << 5)));
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], b0, acc[0][m], 0, 0, 0);
-            acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[m], b1, acc[1][m], 0, 0, 0);
-          }
+        for (int m = 0; m < MT; ++m) {
+          acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3][m], fb0[st % 3], acc[0][m], 0, 0, 0);
+          acc[1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3][m], fb1[st % 3], acc[1][m], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
+      auto ld = [&](int st, int slot) {
+        const int t = st >> 1, kh = st & 1;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+        for (int m = 0; m < MT; ++m) fa[slot][m] = *reinterpret_cast<const bf16x8*>(wb + ((t * 2 + kh) * MT + m) * 1024);
+        fb0[slot] = *reinterpret_cast<const bf16x8*>(ab + (bad0[t] ^ (kh << 5)));
+      };
+      ld(0, 0);
+      ld(1, 1);
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ab + (bad0[t] ^ (kh << 5)));
+      for (int st = 0; st < 18; ++st) {
+        if (st + 2 < 18) ld(st + 2, (st + 2) % 3);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const bf16x8 av = *reinterpret_cast<const bf16x8*>(wb + ((t * 2 + kh) * MT + m) * 1024);
-            acc[0][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc[0][m], 0, 0, 0);
-          }
-        }
+        for (int m = 0; m < MT; ++m)
+          acc[st & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3][m], fb0[st % 3], acc[st & 1][m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -205,6 +220,12 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   }
 
   // ---- epilogue: lane = (pixel, 4 * (lane >> 5) + 8 * (reg >> 2) + (reg & 3) inside each 32-channel tile) ----
+  if (has0 && !has1) {  // (one patch: even steps went to acc[0], odd steps to acc[1])
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][m][r] += acc[1][m][r];
+  }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     if (!(s == 0 ? has0 : has1)) continue;

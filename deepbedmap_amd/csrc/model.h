@@ -67,7 +67,16 @@ struct dbm_ctx {
   void persist_begin(hipStream_t s);
   void persist_end(hipStream_t s);
   size_t comm_bytes = 0, comm_calls = 0;  // statistics (dbm_comm_stats)
-  bool comm_active() const { return comm_world > 1 && (nccl_comm != nullptr || comm_hook != nullptr); }
+  // DBM_COMM_FORCE_WORLD1=1 (testing / measuring the data-parallel schedule on ONE GPU): a one-rank communicator counts as
+  // active -- every bucket really goes through ncclAllReduce (a sum over one rank), the persistent launches keep to 192
+  // workgroups, the optimizers wait for the exchange events
+  static bool comm_force_world1() {
+    static const bool f = getenv("DBM_COMM_FORCE_WORLD1") && atoi(getenv("DBM_COMM_FORCE_WORLD1")) != 0;
+    return f;
+  }
+  bool comm_active() const {
+    return (comm_world > 1 || (comm_force_world1() && comm_world == 1 && nccl_comm != nullptr)) && (nccl_comm != nullptr || comm_hook != nullptr);
+  }
   void comm_init(int rank, int world, const void* id128);
   void comm_set_hook(int rank, int world, void (*fn)(void*, float*, size_t, void*), void* user);
   void comm_destroy();
