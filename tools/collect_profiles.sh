@@ -8,7 +8,8 @@
 #   <prefix>_phases.txt                     tools/phases.py fused (hipEvents at the phase boundaries, unprofiled)
 #   <prefix>_timeline_per_queue.txt         tools/step_timeline.sh (per-queue run-length summary of one iteration)
 #   traffic_pmc.json                        tools/pmc_traffic.sh (FETCH_SIZE / WRITE_SIZE passes; per family and per launch shape)
-#   sq_counters.json                        tools/pmc_sq.sh (MFMA-busy %, wait states per kernel)
+#   sq_counters.json                        tools/pmc_sq.sh (MFMA-busy %, wait states per kernel: the training step)
+#   sq_counters_sweep.json                  the same for the sweep's kernels (tools/sweep_crop_bench.py)
 set -e
 TAG=${1:?tag}; PFX=${2:?prefix}
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
@@ -28,5 +29,7 @@ bash tools/pmc_traffic.sh $TAG/pmc > "$OUT/pmc_traffic.log"
 cp "$OUT/pmc/traffic.json" "$OUT/traffic_pmc.json"
 bash tools/pmc_sq.sh $TAG/sq > "$OUT/pmc_sq.log"
 cp "$OUT/sq/sq.json" "$OUT/sq_counters.json"
-rm -rf "$OUT/prof" "$OUT/ser" "$OUT/tl" "$OUT/pmc" "$OUT/sq"
+SQ_CMD="tools/sweep_crop_bench.py" bash tools/pmc_sq.sh $TAG/sqs > "$OUT/pmc_sq_sweep.log"
+cp "$OUT/sqs/sq.json" "$OUT/sq_counters_sweep.json"
+rm -rf "$OUT/prof" "$OUT/ser" "$OUT/tl" "$OUT/pmc" "$OUT/sq" "$OUT/sqs"
 ls -la "$OUT"

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Runs on the GPU box: SQ-level counters (MFMA busy, wave wait states) per kernel, one pass.
-# usage: tools/pmc_sq.sh <tag>
+# usage: tools/pmc_sq.sh <tag>            (SQ_CMD="tools/sweep_crop_bench.py" tools/pmc_sq.sh <tag>: the sweep's kernels instead of the training step's)
 set -e
 TAG=${1:-pmcsq}
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd /tmp && export TMPDIR=/tmp && cd "${ROOT:?repository root not found}"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -f csv -d "$OUT" -o sq -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > "$OUT/sq.log" 2>&1 || { echo "rocprofv3 failed; last lines of "$OUT/sq.log":" >&2; tail -n 30 "$OUT/sq.log" >&2; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -f csv -d "$OUT" -o sq -- python3 ${SQ_CMD:-bench.py --no-cpu-baseline --no-sweep --steps 1 --warmup 1} > "$OUT/sq.log" 2>&1 || { echo "rocprofv3 failed; last lines of "$OUT/sq.log":" >&2; tail -n 30 "$OUT/sq.log" >&2; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, json, sys, collections, re
 out = sys.argv[1]
@@ -15,7 +15,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 seen = set()
 for r in csv.DictReader(open(f"{out}/sq_counter_collection.csv")):
-    k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", ""))[:48]
+    k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", ""))[:48]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
     key = (r["Dispatch_Id"], k)
     if key not in seen:
