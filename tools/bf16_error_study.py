@@ -8,7 +8,7 @@ to keep fp32 arithmetic?  One 288 x 288 crop (deepbedmap.py:706-728), the DEM-ra
   smooth  the same ranges as smooth relief (bilinear x8 upsampling of a coarse field + 2 % white noise): what BEDMAP2 / REMA /
           MEaSUREs grids look like at 1 km .. 100 m.
 
-Reference = the fp32 HIP path of the same process (pinned to the oracle by tests/test_gpu_dem.py).  DBM_BF16_FP32_LAYERS is
+Reference = the fp32 HIP path of the same process (pinned to the float64 oracle at this data range by tests/test_gpu_dem.py).  DBM_BF16_FP32_LAYERS is
 read once per process: run this script once per mask (tools/bf16_error_study.sh).  Prints one JSON line.
 """
 import json
@@ -20,8 +20,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-import make_golden_full as mgf  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from dem_model import dem_arrays, dem_generator  # noqa: E402
 
 
 def smooth_field(r, shape, lo, hi, coarse=8, noise=0.02):
@@ -49,12 +49,9 @@ def smooth_arrays(seed, h=288, w=288):
 def main():
     import deepbedmap_amd as dbm
 
-    og = mgf.models_dem5()
-    g = dbm.GeneratorModel(num_residual_blocks=12, initialize=False)
-    for name, p in g._tensors.items():
-        p.array = og.params[name]
+    g = dem_generator(dbm, seed=909)
     out = {"DBM_BF16_FP32_LAYERS": os.environ.get("DBM_BF16_FP32_LAYERS", "(default)")}
-    for kind, arrays in (("white", mgf.arrays_dem(1, 7500, h=288, w=288)), ("smooth", smooth_arrays(7600))):
+    for kind, arrays in (("white", dem_arrays(1, 7500)), ("smooth", smooth_arrays(7600))):
         ins = [dbm.to_device(arrays[k]) for k in ("X", "W1", "W2", "W3")]
         with dbm.using_config("enable_backprop", False):
             y32 = g.forward(*ins).array.get().astype(np.float64)
