@@ -25,7 +25,8 @@ def family(kn):
 
 def shape_class(kn):
     """the class a launch belongs to in bench.py's per-shape tables (roofline.per_shape / extras.sweep.*.per_shape_standalone)"""
-    for pat, c in (("igemm_conv_kernel", "igemm"), ("deform_conv64_fused", "deform64"), ("deform_conv1_fused", "deform1"),
+    for pat, c in (("igemm_conv_kernel", "igemm"), ("deform_conv64_fused", "deform64"), ("deform_conv64_x3", "deform64x3"), ("deform_conv1_fused", "deform1"),
+                   ("deform1_premul", "deform1"), ("deform1_sample", None),
                    ("deform_bwd64_fused", "deform_bwd64"), ("conv_cl16x3_kernel", "x3"), ("conv_cl16_kernel", "cl16"),
                    ("trunk_fused_bwd_kernel", "trunk_bwd"), ("trunk_fused_kernel", "trunk_fwd"), ("wgrad_pair_fold", None), ("wgrad_fold", None),
                    ("wgrad_", "wgrad")):
@@ -35,12 +36,21 @@ def shape_class(kn):
 
 
 def tag_class(tag):
-    for pre, c in (("deform_bwd64", "deform_bwd64"), ("deform64", "deform64"), ("deform", "deform1"), ("x3_", "x3"), ("cl16_", "cl16"),
+    for pre, c in (("deform_bwd64", "deform_bwd64"), ("deform64x3", "deform64x3"), ("deform64", "deform64"), ("deform", "deform1"), ("x3_", "x3"), ("cl16_", "cl16"),
                    ("trunk_fwd", "trunk_fwd"), ("trunk_bwd", "trunk_bwd"), ("c", "igemm")):
         if tag.startswith(pre):
             return c
     return "wgrad"
 
+
+# the launch shapes of the TRAINING step (bench.py's roofline.per_shape of the same command): the family averages below count
+# these only -- the command's inference leg launches the same kernels on much larger grids
+train_keys = None
+try:
+    _line = [l for l in open(f"{out}/FETCH_SIZE.log") if l.startswith("{")][-1]
+    train_keys = {(tag_class(r["shape"]), r["workgroups"]) for r in json.loads(_line)["roofline"].get("per_shape", [])}
+except Exception:
+    pass
 
 res = {}
 shapes = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "n": {"FETCH_SIZE": 0, "WRITE_SIZE": 0}, "kernels": set()})
@@ -51,11 +61,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
         kn = r["Kernel_Name"]
         k = family(kn)
-        if k:
-            acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
         sc = shape_class(kn)
+        wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+        if k and (train_keys is None or (sc, wgs) in train_keys):
+            acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
         if sc:
-            wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
             sh = shapes[(sc, wgs)]
             sh[c] += float(r["Counter_Value"]); sh["n"][c] += 1; sh["kernels"].add(kn.replace("void ", "").split("(")[0][:60])
     for k, (s, n) in acc.items():
@@ -98,7 +108,8 @@ per_shape.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches_sampled"])
 fam_class = {"igemm_conv_kernel": ("igemm", "deform64", "deform_bwd64"), "wgrad_kernel": ("wgrad",), "trunk_fused_kernel": ("trunk_fwd",),
              "trunk_fused_kernel_helper": ("trunk_fwd",), "trunk_fused_bwd_kernel": ("trunk_bwd",)}
 for k, v in res.items():
-    rows = [r for r in per_shape if r["class"] in fam_class.get(k, ()) and "algorithmic_bytes_per_launch" in r]
+    rows = [r for r in per_shape if r["class"] in fam_class.get(k, ()) and "algorithmic_bytes_per_launch" in r and
+            (train_keys is None or (r["class"], r["workgroups"]) in train_keys)]
     if k.startswith("trunk_fused_kernel"):
         rows = [r for r in rows if any(("helper" in s) == k.endswith("helper") for s in r["shapes"])]
     n = sum(r["launches_sampled"] for r in rows)
