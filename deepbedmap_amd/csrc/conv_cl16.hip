@@ -70,13 +70,18 @@ __device__ __forceinline__ void patch_of(int h, int& g, int& i) {
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
-template <int MT>
+__host__ __device__ constexpr int cl_act_bytes(int maxs) { return (((2 * maxs + 2) * CL_HW * 4 + 63) / 64) * 1024; }
+
+// TSLOTS: the largest tile height (in 2-row patches) the LDS layout is sized for.  12: one workgroup per CU (96 / 132 KB), what a
+// single crop wants (234 tiles of eleven patches on 256 CUs); 8: 78 KB with one output-channel tile -- two workgroups per CU, so
+// that one's staging and epilogue run under the other's MFMAs when a launch has several rounds of tiles (crops batched per forward).
+template <int MT, int TSLOTS>
 __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int TH = 2 * a.nslots, HR = TH + 2, NPIX = HR * CL_HW;
   const int AINS = (NPIX * 4 + 63) >> 6;         // LDS-DMA wave-instructions (1 KB each) per chunk of activations
-  constexpr int ACT_BYTES = CL_ACT_BYTES;        // (the layout is the same for every tile height: compile-time offsets)
+  constexpr int ACT_BYTES = cl_act_bytes(TSLOTS);   // (the layout is the same for every tile height up to TSLOTS: compile-time offsets)
   constexpr int WINS = 18 * MT;                  // ... and of weights
   constexpr int W_BYTES = WINS * 1024;
   // (byte offsets into smem, not pointers: a pointer picked from an array by a run-time index loses its LDS address space
@@ -95,7 +100,9 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   // -- sixteen consecutive pixels then cover the sixteen slots of the 256-byte bank row whatever the part: the fragment
   // reads below stay conflict-free without padding; the permutation is applied on the SOURCE side (lane -> part), the
   // destination stays linear.  Out-of-plane pixels are fetched from a zero block. ----
-  constexpr int ASTEPS = (30 + 7) / 8;           // AINS <= ceil(26 * 18 * 4 / 64) = 30 instructions over eight wavefronts
+  // (a bound that depends on TSLOTS -- (ACT_BYTES / 1024 + 7) / 8 -- makes hipcc drop the host stub of every instantiation
+  // without a diagnostic: the arrays below are captured by the generic lambdas)
+  constexpr int ASTEPS = (cl_act_bytes(CL_MAXSLOTS) / 1024 + 7) / 8;   // AINS <= 30 instructions over eight wavefronts
   constexpr int WSTEPS = (WINS + 7) / 8;
   const __bf16* asrc[ASTEPS];
   const __bf16* zsrc = reinterpret_cast<const __bf16*>(a.zeros);
@@ -576,16 +583,16 @@ void launch_cl_to_nchw(const float* res, float* y, long ysn, int N, int plane, h
 }
 
 // patches (of 2 rows) per tile: the plane in as few rounds of <= n_cus workgroups as possible, then the least work per SIMD
-static int cl16_choose_slots(int N, int H, int W, int n_cus) {
+static int cl16_choose_slots(int N, int H, int W, int n_cus, int maxs = CL_MAXSLOTS, int per_cu = 1) {
   static const int forced = getenv("DBM_CL16_SLOTS") ? atoi(getenv("DBM_CL16_SLOTS")) : 0;
-  if (forced >= 1 && forced <= CL_MAXSLOTS) return forced;
+  if (forced >= 1 && forced <= maxs) return forced;
   const int tilesX = (W + CL_TW - 1) / CL_TW;
   int best = 8;
   double best_cost = 1e30;
-  for (int ns = 2; ns <= CL_MAXSLOTS; ++ns) {
+  for (int ns = 2; ns <= maxs; ++ns) {
     const int tilesY = (H + 2 * ns - 1) / (2 * ns);
     const long wgs = (long)N * tilesX * tilesY;
-    const long rounds = (wgs + n_cus - 1) / n_cus;
+    const long rounds = (wgs + (long)n_cus * per_cu - 1) / ((long)n_cus * per_cu);
     int load = 0;  // patches on the busiest SIMD: waves s and s + 4 share one, wave w owns patches w and w + 8
     for (int sd = 0; sd < 4; ++sd) {
       int l = 0;
@@ -612,17 +619,31 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   a.y16 = (__bf16*)L.y16; a.yc = L.yc; a.y0 = L.y0; a.y32 = L.y32;
   a.r1 = L.r1; a.s1 = L.s1; a.r2 = L.r2; a.s2 = L.s2; a.act = L.act; a.slope = L.slope;
   a.N = L.N; a.H = L.H; a.W = L.W;
-  a.nslots = cl16_choose_slots(L.N, L.H, L.W, n_cus);
-  a.tilesX = (L.W + CL_TW - 1) / CL_TW;
-  a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
   const int MT = L.Cout / 32;
-  const size_t lds = 2 * (size_t)CL_ACT_BYTES + 2 * (size_t)18 * MT * 1024;
+  a.tilesX = (L.W + CL_TW - 1) / CL_TW;
+  // Layers with one output-channel tile in launches of several rounds (crops batched per forward): tiles of at most eight
+  // patches, 78 KB of LDS, TWO workgroups per CU (DBM_CL16_SMALL: 0 never -- the default --, 1 whenever the layer has one tile,
+  // 2 from three workgroups per CU on).  MEASURED (288 x 288 crops, 1 / 2 / 4 / 8 per forward): 5.95 / 5.87 / 5.81 / 5.44 ms per crop
+  // with one workgroup per CU, 6.04 / 6.31 / 5.80 / 5.52 with mode 2: a second resident workgroup buys nothing -- the LDS fragment
+  // reads of the CU, not one workgroup's latencies, are what the layer waits for.
+  static const int small_mode = getenv("DBM_CL16_SMALL") ? atoi(getenv("DBM_CL16_SMALL")) : 0;
+  bool small = false;
+  if (MT == 1 && small_mode) {
+    const int ns8 = cl16_choose_slots(L.N, L.H, L.W, n_cus, 8, 2);
+    const long wgs8 = (long)L.N * a.tilesX * ((L.H + 2 * ns8 - 1) / (2 * ns8));
+    small = small_mode == 1 || wgs8 >= 3L * n_cus;
+    if (small) a.nslots = ns8;
+  }
+  if (!small) a.nslots = cl16_choose_slots(L.N, L.H, L.W, n_cus);
+  a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
+  const size_t lds = 2 * (size_t)cl_act_bytes(small ? 8 : CL_MAXSLOTS) + 2 * (size_t)18 * MT * 1024;
   a.zeros = L.zeros;
   DBM_CHECK(L.zeros != nullptr, "cl16 conv: a device zero block is required");
   static bool attr = false;
   if (!attr) {
-    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1, CL_MAXSLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<2, CL_MAXSLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
   const unsigned grid = (unsigned)((long)L.N * a.tilesX * a.tilesY);
@@ -636,10 +657,12 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
     snprintf(tag, sizeof(tag), "cl16_c%d>%d_%dx%d_n%d", L.Cin, L.Cout, L.H, L.W, L.N);
     g_profiler.begin(s, 0, 2.0 * px * L.Cout * L.Cin * 9, bytes, tag, grid);
   }
-  if (MT == 1)
-    hipLaunchKernelGGL(conv_cl16_kernel<1>, dim3(grid), dim3(CL_NT), lds, s, a);
+  if (small)
+    hipLaunchKernelGGL((conv_cl16_kernel<1, 8>), dim3(grid), dim3(CL_NT), lds, s, a);
+  else if (MT == 1)
+    hipLaunchKernelGGL((conv_cl16_kernel<1, CL_MAXSLOTS>), dim3(grid), dim3(CL_NT), lds, s, a);
   else
-    hipLaunchKernelGGL(conv_cl16_kernel<2>, dim3(grid), dim3(CL_NT), lds, s, a);
+    hipLaunchKernelGGL((conv_cl16_kernel<2, CL_MAXSLOTS>), dim3(grid), dim3(CL_NT), lds, s, a);
   if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
 }

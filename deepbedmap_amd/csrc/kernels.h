@@ -139,6 +139,7 @@ struct TrunkFusedBwdLaunch {
 };
 size_t trunk_fused_xcc_offset(int nimg_alloc);  // granules in front of the XCC_ID table at the end of an inbox buffer
 int trunk_local_stores();                       // DBM_TRUNK_LOCAL_ST (default 1): same-XCD exchange stores stay in the L2
+extern bool g_trunk_local_off;                  // ... until a persistent kernel has timed out once in this process
 size_t trunk_fused_bwd_stream_floats(int nrdb);
 void launch_pack_trunk_fused_bwd(const float* const* d_wsrc, float* wstream, int nrdb, hipStream_t s);
 void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s);

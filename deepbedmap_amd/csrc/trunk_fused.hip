@@ -730,9 +730,10 @@ size_t trunk_fused_inbox_bytes(int nimg) {
 }
 // granules in front of the XCC_ID table [image][4] at the end of an inbox buffer sized for `nimg_alloc` images
 size_t trunk_fused_xcc_offset(int nimg_alloc) { return trunk_fused_inbox_bytes(nimg_alloc) / sizeof(unsigned long long) - (size_t)4 * nimg_alloc; }
+bool g_trunk_local_off = false;  // set by the first time-out event of the process: from then on agent-scope exchange stores only
 int trunk_local_stores() {
   static const int v = getenv("DBM_TRUNK_LOCAL_ST") ? atoi(getenv("DBM_TRUNK_LOCAL_ST")) : 1;
-  return v;
+  return v && !g_trunk_local_off;
 }
 
 void launch_pack_trunk_fused(const float* const* d_wsrc, const float* const* d_bsrc, float* wstream, float* bstream, int nrdb,
