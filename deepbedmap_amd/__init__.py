@@ -16,5 +16,5 @@ from .training import (  # noqa: F401
 )
 from .parallel import DataParallel, shard_batch, shard_slice  # noqa: F401
 from .geotiff import canvas_to_int16, read_geotiff, save_array_to_grid  # noqa: F401
-from .inference import (Shape, clip_inputs, crop_bounds, merge_ranks, predict_tiled, predict_tiled_resident,  # noqa: F401
-                        tile_steps)
+from .inference import (Shape, clip_inputs, crop_bounds, group_tiles_by_crop_shape, merge_ranks, predict_tiled,  # noqa: F401
+                        predict_tiled_resident, tile_steps)

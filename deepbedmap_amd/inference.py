@@ -53,6 +53,19 @@ def crop_bounds(step: Shape, final_shape: Shape, ary_shape: Shape, xtrapad: Shap
     return y0, y1, x0, x1
 
 
+def group_tiles_by_crop_shape(final_shape: Shape, ary_shape: Shape, stride: Shape, xtrapad: Shape, rank=0, world=1):
+    """The rank's tiles (dealt round-robin in the reference's loop order, :700-703) as {(crop height, crop width): [(y0, y1, x0, x1), ...]}:
+    what predict_tiled_resident batches.  The continent (18000 x 22000, 1000-pixel tiles, xtrapad 18): 396 tiles, 320 of them
+    288 x 288 low-resolution pixels, 40 + 32 along two edges (269 x 288 / 288 x 269) and 4 corner crops of 269 x 269."""
+    groups = {}
+    for i, step in enumerate(tile_steps(final_shape, stride)):
+        if i % world != rank:
+            continue
+        y0, y1, x0, x1 = crop_bounds(step, final_shape, ary_shape, xtrapad)
+        groups.setdefault((y1 - y0, x1 - x0), []).append((y0, y1, x0, x1))
+    return groups
+
+
 def predict_tiled(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape=Shape(y=18000, x=22000),
                   ary_shape=Shape(y=1000, x=1000), stride=Shape(y=1000, x=1000), xtrapad=Shape(y=18, x=18), rank=0,
                   world=1, dtype="float32"):
@@ -102,12 +115,7 @@ def predict_tiled_resident(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape
 
     # the rank's tiles grouped by crop shape (320 of the continent's 396 crops are 288 x 288), each group in batches of
     # `crops_per_batch` crops per generator forward: same arithmetic per crop, fewer and fuller launches
-    groups = {}
-    for i, step in enumerate(tile_steps(final_shape, stride)):
-        if i % world != rank:
-            continue
-        y0, y1, x0, x1 = crop_bounds(step, final_shape, ary_shape, xtrapad)
-        groups.setdefault((y1 - y0, x1 - x0), []).append((y0, y1, x0, x1))
+    groups = group_tiles_by_crop_shape(final_shape, ary_shape, stride, xtrapad, rank, world)
     B = max(1, int(crops_per_batch))
     for (h, w), tiles in groups.items():
         nb_max = min(B, len(tiles))

@@ -92,3 +92,19 @@ def test_get_train_dev_iterators_split_semantics():
     np.testing.assert_array_equal(dev_iter.next()[:2], [0, 1])
     with pytest.raises(ValueError):
         tr.split_dataset_random(ds, first_size=n + 1, seed=0)
+
+
+def test_continent_tiles_grouped_by_crop_shape():
+    """deepbedmap.py:689-741 at the continent's size: 396 tiles; the resident sweep batches crops of equal shape -- 320 interior
+    crops of 288 x 288 low-resolution pixels, 40 + 32 edge crops, 4 corners; two ranks split every group without overlap."""
+    from deepbedmap_amd.inference import Shape, group_tiles_by_crop_shape
+
+    final, ary, pad = Shape(y=18000, x=22000), Shape(y=1000, x=1000), Shape(y=18, x=18)
+    g = group_tiles_by_crop_shape(final, ary, ary, pad)
+    assert {k: len(v) for k, v in g.items()} == {(288, 288): 320, (269, 288): 40, (288, 269): 32, (269, 269): 4}
+    for (h, w), tiles in g.items():
+        assert all(y1 - y0 == h and x1 - x0 == w for y0, y1, x0, x1 in tiles)
+    parts = [group_tiles_by_crop_shape(final, ary, ary, pad, rank=r, world=2) for r in range(2)]
+    both = [t for p in parts for tiles in p.values() for t in tiles]
+    assert len(both) == 396 and len(set(both)) == 396
+    assert sorted(both) == sorted(t for tiles in g.values() for t in tiles)
