@@ -55,6 +55,7 @@ struct ClConvArgs {
   int act; float slope;
   int N, H, W, nslots, tilesX, tilesY;
   const void* zeros;                 // >= 16 bytes of device zeros (out-of-plane pixels of the halo block)
+  int abl;                           // measurement aid (DBM_CL16_ABL; results wrong): 1 no MFMA loop, 2 no epilogue, 4 no staging after chunk 0
 };
 
 // half-lane h (0..31) -> (row 0/1, column 0..15) of the wavefront's 2 x 16 patch: each 16-lane group of a ds_read_b128
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   // in the epilogue.
   auto compute = [&](auto BUF) {
     constexpr int buf = decltype(BUF)::value;
-    if (!has0) return;
+    if (!has0 || (a.abl & 1)) return;
     const unsigned char* ab = smem + buf * ACT_BYTES;
     const unsigned char* wb = smem + WGT0 + buf * W_BYTES + lane * 16;
     bf16x8 fa[3][MT], fb0[3], fb1[3];
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   __syncthreads();
   // chunk c is computed from buffer c & 1 while chunk c + 1 lands in the other one (two chunks per trip: the buffer
   // offsets are compile-time constants, so that hipcc can tell the DMA's destination from the fragment reads' source)
-  for (int c = 0; c < nchunk; c += 2) {
+  for (int c = 0; c < ((a.abl & 4) ? 1 : nchunk); c += 2) {
     if (c + 1 < nchunk) stage(c + 1, B1{});
     compute(B0{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c + 1 has landed (this wavefront's pieces; the barrier covers the rest)
@@ -226,50 +227,67 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane = (pixel, 4 * (lane >> 5) + 8 * (reg >> 2) + (reg & 3) inside each 32-channel tile) ----
+  // ---- epilogue ----
+  // The accumulators hold (pixel = lane & 31, channels 4 (lane >> 5) + 8 (reg >> 2) + (reg & 3)): stored from there, a wave
+  // instruction touches 32 pixels x 16 bytes -- thirty-two 16-byte pieces 384 / 256 bytes apart; measured (DBM_CL16_ABL) the
+  // epilogue was 4.4 of the 14 us of a 64 -> 32 layer and 7+ of conv_layer5's.  So every patch goes through LDS once (the staging
+  // buffers are free: all wavefronts have passed the last chunk's barrier; a wavefront only reads back what it wrote itself) and
+  // leaves with the lanes of a pixel side by side: 8 MT lanes x 16 bytes = a pixel's whole 128 / 256-byte run per residual load
+  // and fp32 store, its 64 / 128 bytes of bf16 per store, four or eight neighbouring pixels per instruction.
+  if (a.abl & 2) return;
   if (has0 && !has1) {  // (one patch: even steps went to acc[0], odd steps to acc[1])
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][m][r] += acc[1][m][r];
   }
+  constexpr int TROW = 32 * MT + 4;                 // floats per pixel row of the transpose tile (+ 16 bytes: conflict-free columns)
+  constexpr int QPP = 8 * MT;                       // channel quads per pixel
+  float* tbase = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    if (!(s == 0 ? has0 : has1)) continue;
-    const int prow = s == 0 ? prow0 : prow1;
-    const int gy = ty * TH + prow, gx = tx * CL_TW + i;
-    if (gy >= a.H || gx >= a.W) continue;
-    const long pix = img + (long)gy * a.W + gx;
+    if (!(s == 0 ? has0 : has1)) continue;          // (wave-uniform)
+    float* T = tbase + (size_t)(s == 0 ? wave : wave + 8) * 32 * TROW;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int co = 32 * m + 8 * rg + 4 * (lane >> 5);
-        const f4v bv = (f4v){a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
-        f4v v;
+      for (int rg = 0; rg < 4; ++rg)
+        *reinterpret_cast<f4v*>(T + (lane & 31) * TROW + 32 * m + 8 * rg + 4 * (lane >> 5)) =
+            (f4v){acc[s][m][4 * rg], acc[s][m][4 * rg + 1], acc[s][m][4 * rg + 2], acc[s][m][4 * rg + 3]};
+    const int prow_base = 2 * (s == 0 ? wave : wave + 8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[s][m][4 * rg + e] + bv[e];
-        if (a.r1) {
-          const f4v r = *reinterpret_cast<const f4v*>(a.r1 + pix * 64 + co);
+    for (int it = 0; it < 32 * QPP / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int h = idx / QPP, co = 4 * (idx - h * QPP);
+      int pg, pi;
+      patch_of(h, pg, pi);
+      const int gy = ty * TH + prow_base + pg, gx = tx * CL_TW + pi;
+      f4v v = *reinterpret_cast<const f4v*>(T + h * TROW + co);
+      if (gy >= a.H || gx >= a.W) continue;
+      const long pix = img + (long)gy * a.W + gx;
+      const f4v bv = (f4v){a.bias[co], a.bias[co + 1], a.bias[co + 2], a.bias[co + 3]};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = a.s1 * v[e] + r[e];
-        }
-        if (a.r2) {
-          const f4v r = *reinterpret_cast<const f4v*>(a.r2 + pix * 64 + co);
+      for (int e = 0; e < 4; ++e) v[e] += bv[e];
+      if (a.r1) {
+        const f4v r = *reinterpret_cast<const f4v*>(a.r1 + pix * 64 + co);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = a.s2 * v[e] + r[e];
-        }
-        if (a.act) {
+        for (int e = 0; e < 4; ++e) v[e] = a.s1 * v[e] + r[e];
+      }
+      if (a.r2) {
+        const f4v r = *reinterpret_cast<const f4v*>(a.r2 + pix * 64 + co);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : a.slope * v[e];
-        }
-        if (a.y32) *reinterpret_cast<f4v*>(a.y32 + pix * 64 + co) = v;
-        if (a.y16) {
-          bf16x4 o;
+        for (int e = 0; e < 4; ++e) v[e] = a.s2 * v[e] + r[e];
+      }
+      if (a.act) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-          *reinterpret_cast<bf16x4*>(a.y16 + pix * a.yc + a.y0 + co) = o;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : a.slope * v[e];
+      }
+      if (a.y32) *reinterpret_cast<f4v*>(a.y32 + pix * 64 + co) = v;
+      if (a.y16) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+        *reinterpret_cast<bf16x4*>(a.y16 + pix * a.yc + a.y0 + co) = o;
       }
     }
   }
@@ -638,6 +656,8 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
   const size_t lds = 2 * (size_t)cl_act_bytes(small ? 8 : CL_MAXSLOTS) + 2 * (size_t)18 * MT * 1024;
   a.zeros = L.zeros;
+  static const int abl = getenv("DBM_CL16_ABL") ? atoi(getenv("DBM_CL16_ABL")) : 0;
+  a.abl = abl;
   DBM_CHECK(L.zeros != nullptr, "cl16 conv: a device zero block is required");
   static bool attr = false;
   if (!attr) {
