@@ -266,6 +266,12 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   // chunk c is computed from buffer c & 1 while chunk c + 1 lands in the other one (two chunks per trip: the buffer
   // offsets are compile-time constants, so that hipcc can tell the DMA's destination from the fragment reads' source)
   for (int c = 0; c < ((a.abl & 4) ? 1 : nchunk); c += 2) {
+    // Dense-block mode: only the NEWEST chunk is staged past the L2 (sc1).  A 128-byte line of the concat buffer is one pixel's
+    // 64 channels = the outputs of two layers (c1 | c2, c3 | c4), written by the pixel's owner in two steps; a reader's first
+    // access to the line is the sc1 load of its first half, its second the sc1 load of the second half -- a coherent load
+    // re-fetches the line -- and only then plain loads (as an old chunk) may hit it.  Staging ALL in-launch channels with sc1 was
+    // measured too: 54 instead of 48-50 us per launch, i.e. no faster than four launches.  (Bitwise equality with the
+    // per-layer form is tested on a whole 288 x 288 crop, 234 tiles over all eight XCDs: tests/test_gpu_fullsize.py.)
     if (c + 1 < nchunk) {
       if (DENSE && c + 1 == newest) { wait_neighbours(a.flag_base + layer); stage(c + 1, B1{}, NEW{}); }
       else stage(c + 1, B1{}, OLD{});
@@ -726,11 +732,14 @@ static int cl16_n_cus() {
 // one tile per CU at most: every workgroup of a dense-block launch has to be resident (they wait for each other)
 bool g_cl16_dense_off = false;   // set by the first persistent-kernel time-out of the process (dbm_handle_persistent_timeout)
 bool cl16_dense_block_ok(int N, int H, int W) {
-  const int enabled = getenv("DBM_CL16_DENSE") ? atoi(getenv("DBM_CL16_DENSE")) : 1;   // (read per call, like DBM_CL16: tests toggle it)
+  // OFF by default (read per call, like DBM_CL16: tests toggle it).  Same-box A/B of a 288 x 288 crop, three runs each: 5.78 / 5.64-5.59 ms
+  // without / with on one box (the launch 48-50 us against 59.6 for four), 5.77-5.80 / 5.87-5.89 on another (55 us): not a
+  // robust gain -- what a layer costs inside the launch is its chain of latencies.
+  const int enabled = getenv("DBM_CL16_DENSE") ? atoi(getenv("DBM_CL16_DENSE")) : 0;
   if (!enabled || g_cl16_dense_off) return false;
   const int ns = cl16_choose_slots(1, H, W, cl16_n_cus());
   const long tiles = (long)((W + CL_TW - 1) / CL_TW) * ((H + 2 * ns - 1) / (2 * ns));
-  // 1 (default): only when the whole batch is resident at once -- a single crop of the sweep; 2: also larger batches, whose
+  // 1: only when the whole batch is resident at once -- a single crop of the sweep; 2: also larger batches, whose
   // images the workgroups then walk one after the other (measured at eight 288 x 288 crops per forward: 5.73 ms per crop against
   // 5.59 with one launch per layer -- a batch has enough tiles to hide a launch's fixed cost by itself)
   return enabled >= 2 ? tiles <= cl16_n_cus() : (long)N * tiles <= cl16_n_cus();
