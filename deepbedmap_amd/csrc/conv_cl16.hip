@@ -767,7 +767,7 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   // 2 from three workgroups per CU on).  MEASURED (288 x 288 crops, 1 / 2 / 4 / 8 per forward): 5.95 / 5.87 / 5.81 / 5.44 ms per crop
   // with one workgroup per CU, 6.04 / 6.31 / 5.80 / 5.52 with mode 2: a second resident workgroup buys nothing -- the LDS fragment
   // reads of the CU, not one workgroup's latencies, are what the layer waits for.
-  static const int small_mode = getenv("DBM_CL16_SMALL") ? atoi(getenv("DBM_CL16_SMALL")) : 0;
+  const int small_mode = getenv("DBM_CL16_SMALL") ? atoi(getenv("DBM_CL16_SMALL")) : 0;   // (read per call: tests toggle it)
   bool small = false;
   if (MT == 1 && small_mode && L.nlayers <= 1) {
     const int ns8 = cl16_choose_slots(L.N, L.H, L.W, n_cus, 8, 2);
