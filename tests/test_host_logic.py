@@ -108,3 +108,23 @@ def test_continent_tiles_grouped_by_crop_shape():
     both = [t for p in parts for tiles in p.values() for t in tiles]
     assert len(both) == 396 and len(set(both)) == 396
     assert sorted(both) == sorted(t for tiles in g.values() for t in tiles)
+
+
+def test_bench_shape_table_aggregates_profiler_records():
+    """bench.py's per-shape roofline table: records of an in-step and of a serialised step (Context.profile_records()) grouped by
+    (family, tag, flops, bytes); standalone TFLOP/s, fraction of the fp32 MFMA roof and the HBM rate the algorithmic bytes imply."""
+    import bench
+
+    rec = lambda fam, tag, fl, by, ms, wgs: {"family": fam, "tag": tag, "flops": fl, "bytes": by, "ms": ms, "wgs": wgs}
+    in_step = [rec(0, "c64>64_k9_36x36", 6.1e9, 4.0e7, 0.12, 2592), rec(0, "c64>64_k9_36x36", 6.1e9, 4.0e7, 0.10, 2592),
+               rec(2, "trunk_fwd_36rdb_n64_keep", 8.94e10, 1.8e8, 1.3, 192)]
+    serial = [rec(0, "c64>64_k9_36x36", 6.1e9, 4.0e7, 0.08, 2592), rec(0, "c64>64_k9_36x36", 6.1e9, 4.0e7, 0.09, 2592),
+              rec(2, "trunk_fwd_36rdb_n64_keep", 8.94e10, 1.8e8, 1.25, 192)]
+    rows = bench.shape_table(in_step, serial, ["igemm_conv_kernel", "wgrad_kernel", "trunk_fused_kernel"])
+    assert [r["shape"] for r in rows] == ["trunk_fwd_36rdb_n64_keep", "c64>64_k9_36x36"]  # sorted by standalone time
+    conv = rows[1]
+    assert conv["launches"] == 2 and conv["workgroups"] == 2592 and abs(conv["ms"] - 0.22) < 1e-9 and abs(conv["ms_standalone"] - 0.17) < 1e-9
+    assert abs(conv["tflops_standalone"] - 2 * 6.1 / 0.17) < 1e-2
+    assert abs(conv["frac_mfma_standalone"] - conv["tflops_standalone"] / bench.PEAK_FP32_MFMA_TFLOPS) < 1e-3
+    assert abs(conv["algorithmic_gbps_standalone"] - 2 * 4.0e7 / 0.17e-3 / 1e9) < 1.0
+    assert rows[0]["kernel"] == "trunk_fused_kernel"
