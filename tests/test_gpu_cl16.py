@@ -167,3 +167,57 @@ def test_split_bf16_conv_is_fp32_class(dbm, N, H, W, O, ups, lrelu, planar):
         _lib.check(_lib.lib().dbm_op_conv2d_cl16(ctx.handle, dx.ptr, dw.ptr, db.ptr, None, 1.0, y1.ptr, N, 64, H, W, O, lrelu), ctx.handle)
         err1 = np.abs(y1.get() - ref).max() / np.abs(ref).max()
         assert err1 > 30 * err, (err1, err)
+
+
+def _random_cases(seed, n, make):
+    rs = np.random.RandomState(seed)
+    return [make(rs) for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", _random_cases(101, 10, lambda r: (int(r.randint(1, 4)), 32 * int(r.randint(1, 9)), int(r.randint(1, 75)),
+                                                                   int(r.randint(1, 75)), int(r.choice([32, 64])), int(r.randint(0, 2)))))
+def test_cl16_conv_random_shapes(dbm, case):
+    """Randomised geometry for conv_cl16_kernel: planes from a single pixel up to a few tiles, 32..256 input channels, one to three
+    images; conv_layer5's residual epilogue whenever the layer has 64 outputs."""
+    d, _lib, ctx = dbm
+    N, Cc, H, W, O, lrelu = case
+    rs = np.random.RandomState(sum(case))
+    x = rs.normal(size=(N, Cc, H, W)).astype(np.float32)
+    w = (rs.normal(size=(O, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(np.float32)
+    b = rs.normal(size=(O,)).astype(np.float32)
+    resid = O == 64
+    r1 = rs.normal(size=(N, 64, H, W)).astype(np.float32) if resid else None
+    s1 = 0.1 if resid else 1.0
+    ref = ops.conv2d(bf16_round(x).astype(np.float64), bf16_round(w).astype(np.float64), b.astype(np.float64), 1, 1)
+    if resid:
+        ref = s1 * ref + r1
+    if lrelu:
+        ref = np.where(ref >= 0, ref, 0.2 * ref)
+    y = d.DeviceArray((N, O, H, W))
+    dx, dw, db = d.to_device(x), d.to_device(w), d.to_device(b)   # (held: a temporary's memory is freed with the temporary)
+    dr = d.to_device(r1) if resid else None
+    _lib.check(_lib.lib().dbm_op_conv2d_cl16(ctx.handle, dx.ptr, dw.ptr, db.ptr, dr.ptr if resid else None, s1, y.ptr, N, Cc, H, W, O, lrelu),
+               ctx.handle)
+    assert np.abs(y.get() - ref).max() / max(np.abs(ref).max(), 1e-30) < 2e-5
+
+
+@pytest.mark.parametrize("case", _random_cases(202, 10, lambda r: (int(r.randint(1, 3)), int(r.randint(1, 40)), int(r.randint(1, 40)),
+                                                                   int(r.randint(1, 65)), int(r.randint(0, 2)), int(r.randint(0, 2)), int(r.randint(0, 2)))))
+def test_split_bf16_conv_random_shapes(dbm, case):
+    """Randomised geometry for conv_cl16x3_kernel: any output-channel count 1..64, with and without the folded nearest x2
+    resize (even output planes then), NHWC-to-NCHW and channel-plane epilogues."""
+    d, _lib, ctx = dbm
+    N, Hs, Ws, O, ups, lrelu, planar = case
+    H, W = Hs << ups, Ws << ups
+    rs = np.random.RandomState(sum(case) + 7)
+    x = (rs.normal(size=(N, 64, Hs, Ws)) * 100.0 + 50.0).astype(np.float32)
+    w = (rs.normal(size=(O, 64, 3, 3)) / np.sqrt(9 * 64)).astype(np.float32)
+    b = rs.normal(size=(O,)).astype(np.float32)
+    xu = ops.upsample_nearest2(x) if ups else x
+    ref = ops.conv2d(xu.astype(np.float64), w.astype(np.float64), b.astype(np.float64), 1, 1)
+    if lrelu:
+        ref = np.where(ref >= 0, ref, 0.2 * ref)
+    y = d.DeviceArray((N, O, H, W))
+    dx, dw, db = d.to_device(x), d.to_device(w), d.to_device(b)
+    _lib.check(_lib.lib().dbm_op_conv2d_cl16x3(ctx.handle, dx.ptr, dw.ptr, db.ptr, y.ptr, N, H, W, O, ups, lrelu, planar), ctx.handle)
+    assert np.abs(y.get() - ref).max() / max(np.abs(ref).max(), 1e-30) < 3e-5

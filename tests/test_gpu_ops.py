@@ -262,3 +262,31 @@ def test_lds_staged_conv_form(dbm, shape):
     finally:
         os.environ.pop("DBM_IGEMM_LDS", None)
         os.environ.pop("DBM_IGEMM_LDS_MINPOS", None)
+
+
+def _random_deform_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    return [(int(rs.randint(1, 4)), int(rs.randint(1, 30)), int(rs.randint(1, 30)), int(rs.choice([1, 2, 5, 16, 64])), float(rs.choice([0.2, 1.5, 6.0])))
+            for _ in range(10)]
+
+
+@pytest.mark.parametrize("case", _random_deform_cases(303, 10))
+def test_deform_conv_forms_random_shapes(dbm, case):
+    """Randomised geometry for the generator's forward forms of the deformable layers (premultiplied few-channel form for
+    O <= 16, split-bf16 form for O = 64): planes from a single pixel on, offsets from a fraction of a pixel to far outside the
+    image, against the oracle AND against the sampler-then-GEMM kernel of the same library."""
+    d, _lib, ctx = dbm
+    N, H, W, O, scale = case
+    rs = np.random.RandomState(int(scale * 10) + N + H + W + O)
+    x = rs.normal(size=(N, 64, H, W)).astype(np.float32)
+    off = rs.normal(scale=scale, size=(N, 18, H, W)).astype(np.float32)
+    w = (rs.normal(size=(O, 64, 3, 3)) / np.sqrt(64 * 9)).astype(np.float32)
+    b = rs.normal(size=(O,)).astype(np.float32)
+    ref = ops.deform_conv2d(x, off, w, b)
+    l = _lib.lib()
+    dx, doff, dw, db = dev(d, x), dev(d, off), dev(d, w), dev(d, b)
+    y0, y1 = d.DeviceArray(ref.shape), d.DeviceArray(ref.shape)
+    _lib.check(l.dbm_op_deform_conv2d(ctx.handle, dx.ptr, doff.ptr, dw.ptr, db.ptr, y0.ptr, N, 64, H, W, O), ctx.handle)
+    _lib.check(l.dbm_op_deform_conv2d_form(ctx.handle, dx.ptr, doff.ptr, dw.ptr, db.ptr, y1.ptr, N, H, W, O, 1 if O <= 16 else 2, 0), ctx.handle)
+    assert rel(y0.get(), ref) < TOL
+    assert rel(y1.get(), ref) < (TOL if O <= 16 else 1e-4)
