@@ -77,6 +77,30 @@ CONV_CASES = [
 ]
 
 
+def _random_conv_cases(seed, n):
+    """Randomised geometry on top of the hand-picked cases: every layer kind of the models (3x3 pad 1 with and without the folded
+    nearest x2 resize, 4x4 stride 2 pad 1, 1x1) on planes from one pixel up, one to six images, 32..256 input channels."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        kind = int(rs.randint(0, 4))
+        N, C = int(rs.randint(1, 7)), 32 * int(rs.randint(1, 9))
+        O = int(rs.choice([32, 64, 96, 128]))
+        H, W = int(rs.randint(1, 41)), int(rs.randint(1, 41))
+        if kind == 0:
+            out.append((N, C, H, W, O, 3, 1, 1, 0, int(rs.randint(0, 2))))
+        elif kind == 1:
+            out.append((N, C, max(1, H // 2), max(1, W // 2), O, 3, 1, 1, 1, int(rs.randint(0, 2))))
+        elif kind == 2:
+            out.append((N, C, max(2, H), max(2, W), O, 4, 2, 1, 0, 0))
+        else:
+            out.append((N, C, H, W, O, 1, 1, 0, 0, int(rs.randint(0, 2))))
+    return out
+
+
+CONV_CASES += _random_conv_cases(404, 14)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_forward(dbm, case):
     d, _lib, ctx = dbm
