@@ -169,6 +169,32 @@ def test_generator_backward_parity(dbm, scale):
     assert worst[0] < 5e-4, worst  # gradients: sums over 3*81..3*1296 positions in a different order than BLAS
 
 
+def _random_generator_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    return [(int(rs.randint(1, 4)), int(rs.randint(1, 5)), int(rs.randint(3, 16)), int(rs.randint(3, 16)), float(rs.choice([1.0, 3.0])))
+            for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", _random_generator_cases(505, 6))
+def test_generator_forward_backward_random_shapes(dbm, case):
+    """Randomised tile geometry (the model is fully convolutional, deepbedmap.py:700-741): 1-3 dense-block groups, 1-4 tiles of
+    3 x 3 ... 15 x 15 low-resolution pixels -- trunk planes from a single pixel on, i.e. the layer-by-layer trunk path beside the
+    persistent kernels' 9 x 9 -- forward and every gradient against the oracle."""
+    n_blocks, n, h, w, scale = case
+    og = scaled_oracle_generator(n_blocks, scale, rs=0.3)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=n_blocks, residual_scaling=0.3, initialize=False), og.params)
+    ins = tile_inputs(n, 31 + h + w, h=h, w=w)
+    ref = og.forward(*ins, keep=True)
+    y = g.forward(*ins)
+    assert y.array.shape == ref.shape and rel(y.array, ref) < TOL
+    gy = np.random.RandomState(h * w).normal(size=ref.shape).astype(np.float32)
+    G = og.backward(gy)
+    g.cleargrads()
+    g.backward(gy)
+    worst = grad_errors(g, G)[0]
+    assert worst[0] < 5e-4, worst
+
+
 def test_config2_generator_only_l1_16_rrdb(dbm):
     """BASELINE.json config 2: generator-only fwd+bwd, 16 RRDB, pixel-L1 loss only.  Parity of loss and gradients
     at batch 2 against the oracle; at the full batch of 32 the size-independent properties: a repeated pass gives
