@@ -1494,7 +1494,10 @@ size_t wgrad_plan(const WgradDesc& d, WgradPlan& p, int level, int wave_task, in
   const int chx = p.G * 32;
   const int tail_ci = d.Cin - (p.groups - 1) * chx, tail_co = d.Cout - (p.coutTiles - 1) * 32;
   auto mult4 = [](long v) { return (v % 4) == 0; };
-  p.fast = p.nbr == 1 && d.ups == 0 && d.xsc == plane && d.dysc == oplane && mult4(d.xsn) && mult4(d.dysn) &&
+  // (d.Win > 1: the multiply-high constants ceil(2^32 / dv) do not exist for dv = 1 -- a plane one pixel wide, e.g. the 1x1
+  // view of the input block's k6 s2 branch on 3 x 3 tiles, got every sample of a run decoded to channel 0; found by the
+  // randomised-geometry tests of round 3)
+  p.fast = d.Win > 1 && p.nbr == 1 && d.ups == 0 && d.xsc == plane && d.dysc == oplane && mult4(d.xsn) && mult4(d.dysn) &&
            ((uintptr_t)d.x % 16) == 0 && ((uintptr_t)d.dy % 16) == 0 && mult4(32L * oplane) && mult4((long)chx * plane) &&
            mult4((long)std::min(32, tail_co) * oplane) && mult4((long)std::min(chx, tail_ci) * plane) &&
            (long)chx * plane < (1L << 20) && 32L * oplane < (1L << 20) && plane < 4096 && oplane < 4096;

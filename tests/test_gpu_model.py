@@ -175,7 +175,7 @@ def _random_generator_cases(seed, n):
             for _ in range(n)]
 
 
-@pytest.mark.parametrize("case", _random_generator_cases(505, 6))
+@pytest.mark.parametrize("case", _random_generator_cases(505, 6) + [(1, 1, 3, 3, 1.0), (2, 2, 3, 12, 3.0), (1, 3, 4, 3, 3.0)])
 def test_generator_forward_backward_random_shapes(dbm, case):
     """Randomised tile geometry (the model is fully convolutional, deepbedmap.py:700-741): 1-3 dense-block groups, 1-4 tiles of
     3 x 3 ... 15 x 15 low-resolution pixels -- trunk planes from a single pixel on, i.e. the layer-by-layer trunk path beside the

@@ -74,6 +74,11 @@ CONV_CASES = [
     (64, 128, 9, 9, 256, 4, 2, 1, 0, 0),   # D conv_layer5 at the full batch: 1024 positions -> 8 K slices (pair buffers)
     (37, 256, 4, 4, 512, 4, 2, 1, 0, 0),   # D conv_layer7
     (64, 96, 2, 2, 160, 4, 2, 1, 0, 0),    # conv_layer9-shaped: 12 of 16 taps never inside the image; 3 x 5 tiles
+    # planes ONE pixel wide (the 1x1 view of the input block's branches on 3 x 3 tiles): the weight gradient's contiguous staging
+    # decoded positions with ceil(2^32 / width), which does not exist for width 1 (fixed in round 3)
+    (1, 96, 1, 1, 32, 1, 1, 0, 0, 0),
+    (3, 96, 2, 1, 32, 1, 1, 0, 0, 0),
+    (2, 64, 5, 1, 64, 3, 1, 1, 0, 1),
 ]
 
 
