@@ -137,6 +137,8 @@ def predict_tiled_resident(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape
             ins = bufs if nb == nb_max else [DeviceArray((nb,) + b.shape[1:], ctx, ptr=b.ptr, owner=b) for b in bufs]
             with using_config(name="enable_backprop", value=False), using_config(name="dtype", value=dtype):
                 Y_pred = model.forward(x=ins[0], w1=ins[1], w2=ins[2], w3=ins[3])
+            if rows <= 0 or cols <= 0:   # (a crop clamped by the area's border down to its halo: nothing left to paste)
+                continue
             for j, (y0, y1, x0, x1) in enumerate(batch):
                 ys, xs = (y0 + xtrapad.y + 1) * 4, (x0 + xtrapad.x + 1) * 4
                 copy2d(canvas.ptr + 4 * (ys * final_shape.x + xs), final_shape.x,

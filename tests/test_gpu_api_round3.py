@@ -214,3 +214,26 @@ def test_clip_of_resident_grids_on_the_device(dbm):
     ref = dbm.predict_tiled_resident(g, X, *dbm.clip_inputs(W1, W2, W3), **kw)
     got = dbm.predict_tiled_resident(g, X, W1, W2, W3, clip=True, **kw)
     assert np.array_equal(np.nan_to_num(got, nan=-7.0), np.nan_to_num(ref, nan=-7.0))
+
+
+def _random_ssim_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        h, w = int(rs.randint(1, 60)), int(rs.randint(1, 60))
+        ws = int(rs.randint(1, min(h, w, 17) + 1))
+        out.append((ws, int(rs.randint(1, 6)), (int(rs.randint(1, 4)), int(rs.randint(1, 3)), h, w), str(rs.choice(["gaussian", "uniform"]))))
+    return out
+
+
+@pytest.mark.parametrize("ws,stride,shape,window", _random_ssim_cases(606, 12))
+def test_ssim_random_geometry(dbm, ws, stride, shape, window):
+    """ssim_loss_func(window_size, stride) on randomised planes (one pixel on), windows from 1 x 1 to the whole plane, strides 1..5,
+    one or two channels -- against the float64 oracle."""
+    rs = np.random.RandomState(ws * 131 + stride + shape[2])
+    y = rs.rand(*shape).astype(np.float32)
+    t = (0.5 * y + 0.5 * rs.rand(*shape)).astype(np.float32)
+    with dbm.using_config("ssim_window", window):
+        got = float(dbm.ssim_loss_func(dbm.Variable(y), t, window_size=ws, stride=stride))
+    ref = float(ops.ssim(y.astype(np.float64), t.astype(np.float64), ws, stride, window))
+    assert abs(got - ref) < 2e-5, (got, ref)

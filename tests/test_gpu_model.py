@@ -535,6 +535,41 @@ def test_tiled_area_inference_matches_oracle_loop(dbm):
     assert rel(Yb[m], Y[m]) < 1e-5
 
 
+def _random_tiling_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        pad = int(rs.randint(1, 4))
+        ty, tx = 4 * int(rs.randint(2 * pad + 3, 12)), 4 * int(rs.randint(2 * pad + 3, 12))   # output tile: wider than its halo
+        ny, nx = int(rs.randint(2, 4)), int(rs.randint(2, 4))                   # tiles per side
+        out.append((ty, tx, ny, nx, pad, int(rs.randint(1, 5)), str(rs.choice(["float32", "bfloat16"]))))
+    return out
+
+
+@pytest.mark.parametrize("ty,tx,ny,nx,pad,cpb,dtype", _random_tiling_cases(707, 5))
+def test_tiled_inference_random_geometry(dbm, ty, tx, ny, nx, pad, cpb, dtype):
+    """deepbedmap.py:689-741 with randomised tile sizes, tile counts, halo widths and crops per forward: the HBM-resident sweep
+    (pitched device-to-device crops and pastes, equal-shape crops batched) against the per-tile-upload loop of the same library,
+    which test_tiled_area_inference_matches_oracle_loop pins to the oracle -- same NaN frame, same values (to the summation order
+    of launches whose split depends on the batch size)."""
+    og = scaled_oracle_generator(1, 5.0)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=1, initialize=False), og.params)
+    S = dbm.Shape
+    final, ary, xp = S(y=ty * ny, x=tx * nx), S(y=ty, x=tx), S(y=pad, x=pad)
+    H, W = final.y // 4, final.x // 4
+    r = np.random.RandomState(ty + tx + ny)
+    X = r.rand(1, 1, H, W).astype(np.float32)
+    W1 = r.rand(1, 1, 10 * H, 10 * W).astype(np.float32)
+    W2 = r.rand(1, 2, 2 * H, 2 * W).astype(np.float32)
+    W3 = r.rand(1, 1, H, W).astype(np.float32)
+    Y = dbm.predict_tiled(g, X, W1, W2, W3, final, ary, ary, xp, dtype=dtype)
+    Yr = dbm.predict_tiled_resident(g, X, W1, W2, W3, final, ary, ary, xp, dtype=dtype, crops_per_batch=cpb)
+    assert np.array_equal(np.isnan(Y), np.isnan(Yr))
+    m = ~np.isnan(Y)
+    if m.any():
+        assert rel(Yr[m], Y[m]) < (1e-5 if dtype == "float32" else 1e-3)
+
+
 def test_trainer_epoch_no_nan(dbm):
     """features/srgan_train.feature:11-19: 1-RRDB model (residual_scaling 0.3, lr 5e-4), one `trainer` epoch with
     batch 1, no metric is NaN -- on synthetic tiles instead of the Quilt download."""
