@@ -1070,6 +1070,38 @@ def test_fused_iteration_equals_the_two_step_calls(dbm):
         assert np.array_equal(v, runs[1][2][k]), k
 
 
+@pytest.mark.parametrize("n,n_blocks", [(1, 1), (2, 3), (5, 1), (7, 2), (9, 12), (3, 4)])
+def test_fused_iteration_random_batch_sizes(dbm, n, n_blocks):
+    """The single-call iteration against the two step calls for batch sizes 1..9 and 1..12 dense-block groups (odd image
+    counts: ragged tiles in every position-major kernel, partially filled persistent launches): metrics and every
+    parameter bitwise after two iterations; and one D-step + G-step against the oracle's float64 metrics."""
+    host = fixture_arrays(n=n)
+    arrays = dbm.device_batch(host)
+    runs = []
+    for fused in (False, True):
+        og = scaled_oracle_generator(n_blocks, 3.0)
+        od = omodel.DiscriminatorModel(seed=5)
+        g = copy_params(dbm.GeneratorModel(num_residual_blocks=n_blocks, initialize=False), og.params)
+        d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
+        g_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(g)
+        d_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(d)
+        out = [dbm.train_minibatch(arrays, g, g_opt, d, d_opt, fused=fused) for _ in range(2)]
+        runs.append((out, g.serialize_dict(), d.serialize_dict()))
+    assert runs[0][0] == runs[1][0]
+    for k, v in runs[0][1].items():
+        assert np.array_equal(v, runs[1][1][k]), k
+    for k, v in runs[0][2].items():
+        assert np.array_equal(v, runs[1][2][k]), k
+    if n_blocks <= 4:   # (the oracle's iteration at 12 groups takes minutes)
+        og = scaled_oracle_generator(n_blocks, 3.0)
+        od = omodel.DiscriminatorModel(seed=5)
+        ref_d = otrain.train_eval_discriminator(host, og, od, otrain.Adam(od.params, alpha=1e-3, eps=1e-7))
+        ref_g = otrain.train_eval_generator(host, og, od, otrain.Adam(og.params, alpha=1e-3, eps=1e-7))
+        got = runs[1][0][0]
+        assert np.isclose(got[0], ref_d[0], rtol=2e-4, atol=1e-5), (got, ref_d)
+        assert np.allclose(got[2:], ref_g, rtol=2e-4, atol=1e-5), (got, ref_g)
+
+
 def test_profiler_brackets_in_step_and_standalone(dbm):
     """bench.py's roofline leg: hipEvent brackets around the launches of the MFMA kernel families, in the running step
     (dbm_profile_begin) and with the device synchronised around every launch (dbm_profile_begin_serial: standalone
