@@ -1070,9 +1070,10 @@ def test_fused_iteration_equals_the_two_step_calls(dbm):
         assert np.array_equal(v, runs[1][2][k]), k
 
 
-@pytest.mark.parametrize("n,n_blocks", [(1, 1), (2, 3), (5, 1), (7, 2), (9, 12), (3, 4)])
+@pytest.mark.parametrize("n,n_blocks", [(1, 1), (2, 3), (5, 1), (7, 2), (9, 12), (3, 4), (70, 2), (129, 1)])
 def test_fused_iteration_random_batch_sizes(dbm, n, n_blocks):
-    """The single-call iteration against the two step calls for batch sizes 1..9 and 1..12 dense-block groups (odd image
+    """The single-call iteration against the two step calls for batch sizes 1..9, 70 and 129 (more than one persistent launch per pass,
+    the last one partly filled) and 1..12 dense-block groups (odd image
     counts: ragged tiles in every position-major kernel, partially filled persistent launches): metrics and every
     parameter bitwise after two iterations; and one D-step + G-step against the oracle's float64 metrics."""
     host = fixture_arrays(n=n)
