@@ -126,3 +126,26 @@ def test_last_strip_holds_only_the_rows_that_exist(tmp_path, compression):
     PIL = pytest.importorskip("PIL.Image")
     with PIL.open(path) as im:
         assert np.array_equal(np.array(im).astype(np.int16), dem[0].astype(np.int16))
+
+
+def _random_grid_cases(seed, n):
+    rs = np.random.RandomState(seed)
+    return [(int(rs.randint(1, 700)), int(rs.randint(1, 700)), bool(rs.randint(0, 2)), str(rs.choice(["lzw", "none"])), bool(rs.randint(0, 2)))
+            for _ in range(n)]
+
+
+@pytest.mark.parametrize("h,w,tiled,compression,bigtiff", _random_grid_cases(808, 10) + [(1, 1, True, "lzw", False), (257, 1, False, "lzw", True)])
+def test_geotiff_random_geometry(tmp_path, h, w, tiled, compression, bigtiff):
+    """Randomised raster sizes (one pixel on: ragged last tiles / strips in both directions), tiled and stripped, LZW and raw,
+    classic and BigTIFF: the int16 DEM decodes back bit for bit with its georeferencing."""
+    r = np.random.RandomState(h * 7 + w)
+    z = (np.cumsum(r.normal(size=(h, w)), axis=1) * 30.0).astype(np.float32)[None]
+    z[0, r.randint(0, h), r.randint(0, w)] = np.nan
+    window = (-1000.0, -2000.0, -1000.0 + 250.0 * w, -2000.0 + 250.0 * h)
+    path = geotiff.save_array_to_grid(str(tmp_path / "g"), window, z, dtype=np.int16, tiled=tiled, compression=compression, bigtiff=bigtiff)
+    got, info = geotiff.read_geotiff(path)
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(got, z.astype(np.int16))
+    assert info["bigtiff"] == bigtiff and info["compression"] == (5 if compression == "lzw" else 1)
+    assert info["tile"][1] == (256 if tiled else w)
+    assert np.allclose(info["tiepoint"][3:5], (window[0], window[3])) and np.allclose(info["pixel_scale"][:2], (250.0, 250.0))
