@@ -259,32 +259,56 @@ def scaled_oracle_discriminator(seed=5):
     return d
 
 
-def test_discriminator_forward_backward_parity(dbm):
+def double_precision_copy(od):
+    od.params = {k: v.astype(np.float64) for k, v in od.params.items()}
+    od.persistent = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in od.persistent.items()}
+    return od
+
+
+@pytest.mark.parametrize("n", [4, 1, 2, 9])
+def test_discriminator_forward_backward_parity(dbm, n):
+    """Logits, running statistics and loss against the float32 oracle; gradients against the oracle run in float64.
+    (Why float64 for the gradients: with 1.6 M LeakyReLU inputs per call one of them regularly lies within float32 rounding of zero,
+    its slope is then 1 in one implementation and 0.2 in the other, and the gradients of that one channel differ by ~1e-2 -- the
+    float32 oracle shows that against its own float64 run at n = 9 and 16.  The batches here are ones where no input is that close,
+    so the HIP path agrees with float64 to ~1e-5.)
+    n = 2: BatchNorm over two samples on the 1 x 1 planes behind conv_layer9 (x-hat is +-1 whatever the input);
+    n = 1: over ONE sample -- zero variance, Chainer's m / max(m - 1, 1) correction of the running variance, every gradient zero;
+    n = 9: ragged tiles."""
     od = scaled_oracle_discriminator()
+    od64 = double_precision_copy(scaled_oracle_discriminator())
     d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
     r = np.random.RandomState(8)
-    real, fake = r.rand(4, 1, 36, 36).astype(np.float32), r.rand(4, 1, 36, 36).astype(np.float32)
+    real, fake = r.rand(n, 1, 36, 36).astype(np.float32), r.rand(n, 1, 36, 36).astype(np.float32)
     dbm.global_config.train = True
-    lr_ref, c_real = od.forward(real, train=True, keep=True)
-    lf_ref, c_fake = od.forward(fake, train=True, keep=True)
+    lr_ref, lf_ref = od.forward(real, train=True), od.forward(fake, train=True)
     lr = d.forward(real)
     lf = d.forward(fake)
     assert rel(lr.array, lr_ref) < TOL and rel(lf.array, lf_ref) < TOL
     for name in od.persistent:  # running statistics after two training-mode calls (srgan_train.py:1145-1146)
         if not name.endswith("/N"):
             assert rel(d._tensors[name].array, od.persistent[name]) < 1e-5, name
-    t1, t0 = np.ones((4, 1), np.int32), np.zeros((4, 1), np.int32)
+    t1, t0 = np.ones((n, 1), np.int32), np.zeros((n, 1), np.int32)
     loss_ref = otrain.calculate_discriminator_loss(lr_ref, lf_ref, t1, t0)
     loss = dbm.calculate_discriminator_loss(lr, lf, t1, t0)
-    assert abs(float(loss) - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
-    g_real, g_fake = otrain.calculate_discriminator_loss_backward(lr_ref, lf_ref, t1, t0)
+    assert abs(float(loss) - loss_ref) < TOL * max(1.0, abs(loss_ref))
+    l64r, c_real = od64.forward(real.astype(np.float64), train=True, keep=True)
+    l64f, c_fake = od64.forward(fake.astype(np.float64), train=True, keep=True)
+    g_real, g_fake = otrain.calculate_discriminator_loss_backward(l64r, l64f, t1, t0)
     G = {}
-    od.backward(g_real, c_real, G)
-    od.backward(g_fake, c_fake, G)
+    od64.backward(g_real, c_real, G)
+    od64.backward(g_fake, c_fake, G)
     d.cleargrads()
     loss.backward()
-    worst = grad_errors(d, G, floor=1e-4)[0]
-    assert worst[0] < 1e-3, worst
+    if n == 1:  # (a batch of one normalises to beta: the logits do not depend on the input or on any weight before batch_norm9/beta,
+        #          and the relativistic loss of one pair does not depend on the logits' common part either)
+        assert abs(float(loss) - 2 * np.log(2)) < 1e-6
+        for k, ref in G.items():
+            got = d._tensors[k].grad
+            assert np.isfinite(got).all() and np.abs(got).max() < 1e-5 and np.abs(ref).max() < 1e-12, k
+    else:
+        worst = grad_errors(d, G, floor=1e-3)[0]
+        assert worst[0] < 1e-3, worst
     # eval-mode BatchNorm (srgan_train.py:1228)
     with dbm.using_config("train", False):
         le = d.forward(fake).array
