@@ -88,6 +88,8 @@ struct ConvDesc {
   // (the planes differ by one row / column when the gradient's dims are odd).  nphase <= 1: a single-phase launch.
   int nosplit;         // set by the launcher: every wavefront owns a position tile over the whole K (blockIdx.x counts groups
                        // of WAVES tiles), no cross-wavefront reduction
+  int pm_groups;       // set by the launcher: > 0 = position-major tiles (igemm_pm_kernel): 32-image groups per output position
+  int pm_gshift;       // ... log2(sets of four channel pairs per live tap and wavefront)
   int nphase;
   const float* phwp[4];
   short phOH[4], phOW[4];

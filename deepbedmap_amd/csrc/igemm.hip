@@ -501,6 +501,119 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
 
 KernelProfiler g_profiler;
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Position-major form for the deep discriminator layers (planes of <= 4 x 4 pixels: conv_layer6 .. 9 and the data gradients
+// of the 3x3 ones; round 3, VERDICT next #4a).  On such planes most taps of most output positions fall into the padding --
+// 3x3 on 2 x 2: 4 of 9 taps are inside the image for every position, 4x4 stride 2 on 4 x 4 -> 2 x 2: 9 of 16, 2 x 2 -> 1 x 1:
+// 4 of 16, 3x3 on 4 x 4: 6.25 of 9 on average -- but WHICH taps differs from position to position, so the (n, a, b)-flattened
+// tiles of the general form (eight images x four positions per tile) need every tap.  Here a tile is ONE output position x 32
+// images (lane j = image): the set of live taps is the same for the whole tile, is found once (ballot over the taps, a compact
+// {input offset, weight offset} list in LDS) and the K loop runs over live taps only -- loads and MFMAs of the padding are not
+// issued at all.  Every step is one live tap x four channel pairs x two output-channel tiles (12 loads, 8 MFMAs), two register
+// sets in ping-pong; offsets of a step are wavefront-uniform (SGPRs), so a lane holds no per-tap state.  Split-K across the four
+// wavefronts and across workgroups, partial tiles and the epilogue exactly as in the general form (igemm_epilogue).
+// ----------------------------------------------------------------------------------------------------------------------
+template <int T, bool MT2>
+__global__ __launch_bounds__(256) void igemm_pm_kernel(const ConvDesc d) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // 4 x 1024 floats
+  constexpr int WAVES = 4, U = 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int j = lane & 31;
+  const int kh = lane >> 5;
+  const int ks = d.ksplit > 1 ? d.ksplit : 1;
+  const int kz = (int)blockIdx.z;
+  const int pos = (int)blockIdx.x / d.pm_groups;
+  const int grp = (int)blockIdx.x - pos * d.pm_groups;
+  const int a = pos / d.OWl, b = pos - a * d.OWl;
+  const int n = grp * 32 + j;
+  const bool pv = n < d.N;
+  const int cout0 = blockIdx.y * (MT2 ? 64 : 32);
+  const unsigned tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const int cpw = d.Cin / ks / WAVES;                               // input channels per wavefront: a multiple of 8
+  // buffer loads: descriptor (kernel-uniform) + loop-invariant 32-bit lane offset + a wavefront-uniform SGPR offset per load --
+  // the K loop has no VGPR address arithmetic (with 64-bit flat addresses hipcc recycles the loaded registers of one set as
+  // address temporaries of the other and then waits for the loads in flight before every address it forms)
+  const int cw = kz * (d.Cin / ks) + __builtin_amdgcn_readfirstlane(wave) * cpw;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.wp), 0, 0x7fffffff, 0x00020000);
+  const int xl = 4 * ((pv ? n : 0) * (int)d.xsn + kh * d.xsc);  // (lanes past the batch read image 0: their columns are dropped)
+  const int wl = 4 * (kh * d.CoutP + j);
+  const int xu = 4 * cw * d.xsc;                   // uniform byte offsets of the wavefront's first channel
+  const int wu = 4 * (cw * d.CoutP + cout0);
+  const int wtap = 4 * d.Cin * d.CoutP;            // bytes between taps / channel pairs
+  const int wstep = 8 * d.CoutP;
+  const int xstep = 8 * d.xsc;
+  // the live taps of this output position: tap t's input offset and weight offset are computed by lane t and pushed to lane
+  // rank(t) (ds_permute: a compact list across the lanes of a register); step s of the K loop fetches the offsets of live tap
+  // s >> gshift with v_readlane -- wavefront-uniform SGPRs, no LDS, no per-lane tap state, no branch in the loop
+  bool ok = false;
+  int xo = 0;
+  if (lane < T) {
+    const int iy = a * d.sin + d.dy[lane], ix = b * d.sin + d.dx[lane];
+    ok = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+    xo = iy * d.Win + ix;
+  }
+  const unsigned live = (unsigned)__ballot(ok);
+  const int dst = (ok ? __popc(live & ((1u << (lane & 31)) - 1u)) : 32 + j) << 2;   // (dead lanes push into the unused upper half)
+  const int xs = __builtin_amdgcn_ds_permute(dst, 4 * xo);       // (bytes)
+  const int ws = __builtin_amdgcn_ds_permute(dst, lane * wtap);   // (bytes)
+  const int S = __popc(live) << d.pm_gshift;                         // steps: live taps x sets of U channel pairs
+  const int gmask = (1 << d.pm_gshift) - 1;
+
+  f32x16 acc, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+  float a0[U], w0[U], b0[U], a1[U], w1[U], b1[U];
+  auto load_set = [&](int s, float (&av)[U], float (&wv)[U], float (&bv)[U]) {
+    const int i = s >> d.pm_gshift;
+    const int q = (s & gmask) * U;
+    const int wc = wu + __builtin_amdgcn_readlane(ws, i) + q * wstep;
+    const int xc = xu + __builtin_amdgcn_readlane(xs, i) + q * xstep;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      av[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wl, wc + u * wstep, 0));
+      if constexpr (MT2) wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wl, wc + u * wstep + 128, 0));
+      bv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xl, xc + u * xstep, 0));
+    }
+  };
+  auto mfma_set = [&](const float (&av)[U], const float (&wv)[U], const float (&bv)[U]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+      if constexpr (MT2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u], bv[u], acc2, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (S > 0) {
+    load_set(0, a0, w0, b0);
+    // (both exits leave the loop directly: with a shared latch hipcc's wait-count pass has to assume that the other set's loads
+    // are still in flight at the loop head and waits for this set's before it may reuse an address register)
+    for (int s = 0;;) {
+      load_set(s + 1 < S ? s + 1 : s, a1, w1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_set(a0, w0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 >= S) break;
+      load_set(s + 2 < S ? s + 2 : s + 1, a0, w0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_set(a1, w1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      s += 2;
+      if (s >= S) break;
+    }
+  }
+  if constexpr (MT2) {
+    igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, 2 * tile, d.oy0, d.ox0);
+    __syncthreads();
+    igemm_epilogue<WAVES>(d, red, acc2, tid, wave, j, kh, pv, n, a, b, cout0 + 32, ks, kz, 2 * tile + 1, d.oy0, d.ox0);
+  } else {
+    igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, tile, d.oy0, d.ox0);
+  }
+}
+
 void KernelProfiler::begin(hipStream_t s, int family, double flops, double bytes, const char* tag, long wgs) {
   if (serial) DBM_HIP(hipDeviceSynchronize());  // standalone durations: nothing else is running when the bracket opens
   Rec r;
@@ -1012,6 +1125,54 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
       return;
     }
   }
+  {  // the deep discriminator layers (planes of <= 4 x 4): position-major tiles, live taps only (igemm_pm_kernel)
+    const int pm_enable = getenv("DBM_IGEMM_PM") ? atoi(getenv("DBM_IGEMM_PM")) : 1;          // (read per call: A/B in one process)
+    const int pm_target = getenv("DBM_IGEMM_PM_KSTARGET") ? atoi(getenv("DBM_IGEMM_PM_KSTARGET")) : 512;
+    const int pm_min_n = getenv("DBM_IGEMM_PM_MIN_N") ? atoi(getenv("DBM_IGEMM_PM_MIN_N")) : 16;
+    if (pm_enable && !d.wp16 && d.ups == 0 && nph == 1 && (d.T == 9 || d.T == 16) && d.Hin * d.Win <= 16 && d.OHl * d.OWl <= 16 &&
+        d.N >= pm_min_n && d.Cin % 32 == 0 && 4L * d.T * d.Cin * d.CoutP < (1L << 31) && 4L * (d.N + 32) * d.xsn < (1L << 31)) {  // (32-bit byte offsets)
+      d.pm_groups = (d.N + 31) / 32;
+      const bool mt2 = d.CoutP % 64 == 0 && d.Cout > 32;
+      dim3 grid((unsigned)(d.OHl * d.OWl * d.pm_groups), (unsigned)((d.Cout + (mt2 ? 63 : 31)) / (mt2 ? 64 : 32)), 1u);
+      const long tiles = (long)grid.x * grid.y;
+      int ks = 1;  // input channels per workgroup stay a multiple of 32 (eight per wavefront)
+      while (ks < 32 && tiles * ks * 2 <= pm_target && (d.Cin / (ks * 2)) % 32 == 0) ks *= 2;
+      const size_t slots = (size_t)tiles * (mt2 ? 2 : 1);
+      if (ks > 1 && !(slots * ks * 1024 <= KS_PART_FLOATS && slots <= KS_COUNTERS)) ks = 1;
+      if (ks > 1) {
+        KsWorkspace& w = ks_workspace(s);
+        d.ksplit = ks;
+        d.ks_part = w.part;
+        d.ks_cnt = w.cnt;
+        grid.z = (unsigned)ks;
+      }
+      const int sets = d.Cin / ks / 4 / 8;  // sets of four channel pairs per live tap and wavefront: a power of two?
+      int sh = 0;
+      while ((1 << sh) < sets) ++sh;
+      if ((1 << sh) == sets && sets >= 1 && (d.Cin / ks) % 32 == 0) {
+        d.pm_gshift = sh;
+        if (g_profiler.enabled) {
+          const double bytes = 4.0 * ((double)d.N * d.Cin * d.Hin * d.Win + flop_positions * d.Cout + (double)d.T * d.Cin * d.CoutP) +
+                               (d.accumulate ? 4.0 * flop_positions * d.Cout : 0.0) + (d.mask ? 4.0 * flop_positions * (d.Cout - d.mask_c0) : 0.0);
+          char tag[40];
+          snprintf(tag, sizeof(tag), "c%d>%d_k%d_%dx%d_pm", d.Cin, d.Cout, d.T, d.Hin, d.Win);
+          g_profiler.begin(s, 0, 2.0 * flop_positions * d.Cout * d.Cin * d.T, bytes, tag, (long)grid.x * grid.y * grid.z);
+        }
+        const size_t lds = 4 * 4096;
+        if (d.T == 9) {
+          if (mt2) hipLaunchKernelGGL((igemm_pm_kernel<9, true>), grid, dim3(256), lds, s, d);
+          else hipLaunchKernelGGL((igemm_pm_kernel<9, false>), grid, dim3(256), lds, s, d);
+        } else {
+          if (mt2) hipLaunchKernelGGL((igemm_pm_kernel<16, true>), grid, dim3(256), lds, s, d);
+          else hipLaunchKernelGGL((igemm_pm_kernel<16, false>), grid, dim3(256), lds, s, d);
+        }
+        if (g_profiler.enabled) g_profiler.end(s);
+        DBM_HIP(hipGetLastError());
+        return;
+      }
+      d.ksplit = 1; d.ks_part = nullptr; d.ks_cnt = nullptr; d.pm_groups = 0;  // (odd channel counts: the general form)
+    }
+  }
   dim3 grid((unsigned)((total + 31) / 32), (unsigned)((d.Cout + 31) / 32), (unsigned)nph);
   long tiles = (long)grid.x * grid.y * nph;
   // Two output-channel tiles per wavefront (the gathered B operand feeds two MFMA chains): layers with >= 64 output
@@ -1019,7 +1180,10 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   // with a long K (DBM_IGEMM_MT2: 0 never, 1 large grids only, 2 also with split-K).
   static const int mt2_mode = getenv("DBM_IGEMM_MT2") ? atoi(getenv("DBM_IGEMM_MT2")) : 2;
   static const int ks_enable = getenv("DBM_IGEMM_KSPLIT") ? atoi(getenv("DBM_IGEMM_KSPLIT")) : 1;
-  static const int ks_target = getenv("DBM_IGEMM_KSTARGET") ? atoi(getenv("DBM_IGEMM_KSTARGET")) : 1024;
+  static const int ks_target = getenv("DBM_IGEMM_KSTARGET") ? atoi(getenv("DBM_IGEMM_KSTARGET")) : 256;
+  // (round 3: 1024 -> 256 workgroups per split launch, 512 for the position-major form: inside the step these launches live on
+  // the 64 CUs a persistent trunk launch leaves, where the number of workgroups, not the length of a K slice, is what they
+  // pay for -- 8.22-8.30 ms per step with 1024 / the general form only, 8.13-8.16 with 256 / 512 and the position-major form)
   // (2048: conv_layer2 of the discriminator -- 1296 two-tile workgroups = 5.06 per CU, a sixth round on sixteen CUs -- stays
   // on one tile per wavefront, the 36 x 36 generator layers (2592) take two: 8.56 -> 8.47 ms per step against 1024)
   static const int mt2_tiles = getenv("DBM_IGEMM_MT2_TILES") ? atoi(getenv("DBM_IGEMM_MT2_TILES")) : 2048;

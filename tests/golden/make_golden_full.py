@@ -270,7 +270,13 @@ def digest_dict(prefix, tensors):
             prefix + "offsets": np.array(offs, np.int64)}
 
 
-def digest_errors(gold, prefix, tensors, floor=1e-6):
+# linear_2/b of the discriminator: the two batches' loss gradients cancel EXACTLY in theory (symmetric relativistic loss); what a
+# float32 run leaves is the rounding of 128 terms of +-1/128, a few 1e-8, which changes with the last bit of any logit, i.e. with
+# the summation order of any convolution.  It is held to this fraction of the largest gradient instead of the common floor.
+ZERO_GRAD_FLOORS = {"linear_2/b": 4e-3}
+
+
+def digest_errors(gold, prefix, tensors, floor=1e-6, floors=None):
     """name -> (sample error, projection error) of a dict of arrays against a stored digest_dict: the sample error is
     max-norm relative to the tensor's largest magnitude, the projection error (incl. the l2 norm itself) relative to
     its l2 norm = the relative rms error.  Neither scale is finer than `floor` x the largest magnitude of the whole
@@ -284,19 +290,20 @@ def digest_errors(gold, prefix, tensors, floor=1e-6):
         s, st = digest(prefix + k, tensors[k])
         ref_s = samples[offs[i]:offs[i + 1]]
         assert s.shape == ref_s.shape, k
-        scale = max(float(stats[i, 1]), floor * gmax)
+        fl = max(floor, floors.get(k, 0.0)) if floors else floor
+        scale = max(float(stats[i, 1]), fl * gmax)
         e_s = float(np.abs(s.astype(np.float64) - ref_s).max()) / scale
-        l2 = max(float(stats[i, 0]), floor * gmax * np.sqrt(np.asarray(tensors[k]).size))
+        l2 = max(float(stats[i, 0]), fl * gmax * np.sqrt(np.asarray(tensors[k]).size))
         e_p = max(float(np.abs(st[2:] - stats[i, 2:]).max()), abs(st[0] - stats[i, 0])) / l2
         out[k] = (e_s, e_p)
     return out
 
 
-def check_digest_dict(gold, prefix, tensors, tol_sample, tol_proj, floor=1e-6, dev_factor=0.0):
+def check_digest_dict(gold, prefix, tensors, tol_sample, tol_proj, floor=1e-6, dev_factor=0.0, floors=None):
     """Compares a dict of arrays with a stored digest_dict.  Returns the worst (error / tolerance, name, what).
     dev_factor > 0: a tensor's tolerance is max(tol, dev_factor x the float32 oracle's own deviation from this float64
     reference), stored as `prefix + "dev"` (see the module docstring, Conditioning)."""
-    errs = digest_errors(gold, prefix, tensors, floor)
+    errs = digest_errors(gold, prefix, tensors, floor, floors)
     dev = gold[prefix + "dev"] if dev_factor > 0 else None
     worst = (0.0, "", "")
     for i, k in enumerate(sorted(tensors)):

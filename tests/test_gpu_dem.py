@@ -123,7 +123,7 @@ def test_dem_full_iteration_matches_oracle_fixture(dbm, gold):
     assert _close(got_d[0], gold["dem/d_step"][0], gold["dem/d_step_f32"][0], 2e-4), (got_d, gold["dem/d_step"])
     assert abs(got_d[1] - gold["dem/d_step"][1]) <= 2.0 / 128 + 1e-6
     # the discriminator of this fixture is in the linear regime (make_golden_full.models_dem): every gradient at 5e-4
-    worst = mgf.check_digest_dict(gold, "dem/gradD/", grads_of(d), TOL_GRAD, TOL_GRAD, floor=mgf.DLIN_FLOOR, dev_factor=DEV)
+    worst = mgf.check_digest_dict(gold, "dem/gradD/", grads_of(d), TOL_GRAD, TOL_GRAD, floor=mgf.DLIN_FLOOR, dev_factor=DEV, floors=mgf.ZERO_GRAD_FLOORS)
     assert worst[0] < 1.0, worst
     pers = {k: t.array for k, t in d._tensors.items() if t.kind == 1 and not k.endswith("/N")}
     worst = mgf.check_digest_dict(gold, "dem/persD/", pers, 1e-4, 1e-4, floor=mgf.G_FLOOR, dev_factor=DEV)
@@ -208,14 +208,15 @@ def test_dlin_discriminator_step_tight(dbm, gold, deterministic, path):
         pers = {k: t.array for k, t in d._tensors.items() if t.kind == 1 and not k.endswith("/N")}
     ref = gold["dlin/d_step"]
     assert abs(got[0] - ref[0]) <= 1e-4 * abs(ref[0]) and got[1] == ref[1], (got, ref)
-    worst = mgf.check_digest_dict(gold, "dlin/gradD/", grads, TOL_GRAD, TOL_GRAD, floor=mgf.DLIN_FLOOR)
+    zero = mgf.ZERO_GRAD_FLOORS  # (linear_2/b: zero in theory, rounding noise in practice)
+    worst = mgf.check_digest_dict(gold, "dlin/gradD/", grads, TOL_GRAD, TOL_GRAD, floor=mgf.DLIN_FLOOR, floors=zero)
     assert worst[0] < 1.0, worst
     worst_p = mgf.check_digest_dict(gold, "dlin/persD/", pers, 1e-4, 1e-4)
     assert worst_p[0] < 1.0, worst_p
     gmax = max(float(np.abs(gold["dlin/full/" + k]).max()) for k in mgf.DLIN_FULL)
     for k in mgf.DLIN_FULL:  # element by element
         r = gold["dlin/full/" + k].astype(np.float64)
-        scale = max(float(np.abs(r).max()), mgf.DLIN_FLOOR * gmax)
+        scale = max(float(np.abs(r).max()), max(mgf.DLIN_FLOOR, zero.get(k, 0.0)) * gmax)
         e = float(np.abs(grads[k].astype(np.float64) - r).max()) / scale
         assert e < TOL_GRAD, (k, e)
     _note(f"dlin_{path}_{int(deterministic)}", worst_digest=worst[0] * TOL_GRAD, worst_pers=worst_p[0] * 1e-4)

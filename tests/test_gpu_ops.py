@@ -73,6 +73,15 @@ CONV_CASES = [
     # 4x4 stride-2 layers on tiny planes (workgroup form, several K slices through the pair buffers), odd channel tiles
     (64, 128, 9, 9, 256, 4, 2, 1, 0, 0),   # D conv_layer5 at the full batch: 1024 positions -> 8 K slices (pair buffers)
     (37, 256, 4, 4, 512, 4, 2, 1, 0, 0),   # D conv_layer7
+    # position-major tiles with live taps only (igemm_pm_kernel: planes <= 4 x 4, >= 16 images): whole and ragged 32-image
+    # groups, every cross-workgroup K split the launcher picks (1 .. 16), one and two output tiles per wavefront, a 1 x 1 output
+    (64, 512, 2, 2, 512, 3, 1, 1, 0, 0),   # D conv_layer8 at the full batch (4 of 9 taps live at every position)
+    (64, 512, 2, 2, 512, 4, 2, 1, 0, 0),   # D conv_layer9 (4 of 16)
+    (64, 256, 4, 4, 512, 4, 2, 1, 0, 1),   # D conv_layer7 (9 of 16)
+    (16, 256, 4, 4, 256, 3, 1, 1, 0, 1),   # half a group
+    (40, 64, 3, 2, 64, 3, 1, 1, 0, 0),     # non-square plane, one two-tile output group, no K split possible below 32 channels
+    (33, 96, 4, 3, 32, 3, 1, 1, 0, 0),     # one output tile per wavefront; 96 channels: 24 per wavefront (three sets)... the general form
+    (48, 128, 1, 1, 96, 3, 1, 1, 0, 0),    # a 1 x 1 plane under a 3x3 kernel: only the centre tap is live
     (64, 96, 2, 2, 160, 4, 2, 1, 0, 0),    # conv_layer9-shaped: 12 of 16 taps never inside the image; 3 x 5 tiles
     # planes ONE pixel wide (the 1x1 view of the input block's branches on 3 x 3 tiles): the weight gradient's contiguous staging
     # decoded positions with ceil(2^32 / width), which does not exist for width 1 (fixed in round 3)
