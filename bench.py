@@ -469,6 +469,33 @@ def main():
         except Exception as e:  # pragma: no cover
             sweep = {"error": repr(e)}
 
+    # ---- the same iteration with ONE generator forward (outside the timed region, single GPU; never the headline) ----
+    shared = None
+    if rank == 0 and world == 1 and not args.share_generator_forward and not args.no_sweep:
+        try:
+            log_s = dbm.MetricsLog(ctx, rows=64)
+
+            def step_shared():
+                return dbm.train_minibatch(batch, g, g_opt, d, d_opt, share_generator_forward=True, prefetch_generator_forward=False,
+                                           log=log_s, fused=not args.no_fused_iteration)
+            for _ in range(5):
+                step_shared()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            n_shared = 40
+            for _ in range(n_shared):
+                step_shared()
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - ts) / n_shared
+            shared = {"ms_per_step": 1e3 * dts, "tiles_per_s": args.batch / dts, "steps": n_shared,
+                      "note": "opt-in share_generator_forward=True: the G-step reuses the D-step's generator forward (same weights, "
+                              "same inputs: bitwise the two-forward results, tests/test_gpu_model.py::"
+                              "test_shared_generator_forward_is_equivalent); 3 G_f + 7 D_f = 450 GFLOP per iteration instead of 539.5. "
+                              "Not the reference's call sequence (srgan_train.py:1131 and :1222 both run the generator), so `value` is "
+                              "the two-forward iteration."}
+        except Exception as e:  # pragma: no cover
+            shared = {"error": repr(e)}
+
     if rank == 0:
         tiles = args.batch * world * args.steps
         out = {
@@ -538,6 +565,8 @@ def main():
             out["config"]["gradient_exchange"] = comm_stats
         if sweep is not None:
             out["extras"] = {"sweep": sweep}
+        if shared is not None:
+            out.setdefault("extras", {})["one_generator_forward"] = shared
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

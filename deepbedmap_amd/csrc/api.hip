@@ -1303,7 +1303,10 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   DBM_HIP(hipEventRecord(c->ev_iter[0], pf));
   DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), pf));  // cleargrads (:1255)
   t->grads_cleared = true;
-  t->use_aux = false;  // (chain[0] carries the discriminator's fake-batch pass and the gradient exchange)
+  // (chain[0] carries the discriminator's fake-batch pass and the gradient exchange.  DBM_ITER_AUX=1, single GPU only: the offset-
+  // gradient kernel of final_conv_layer2 goes there all the same, next to the input-gradient gather)
+  static const int iter_aux = getenv("DBM_ITER_AUX") ? atoi(getenv("DBM_ITER_AUX")) : 0;
+  t->use_aux = iter_aux && !dp;
   t->backward(t->g_y.p);
   t->grads_cleared = false;
   t->use_aux = true;
