@@ -489,7 +489,7 @@ def main():
             dts = (time.perf_counter() - ts) / n_shared
             shared = {"ms_per_step": 1e3 * dts, "tiles_per_s": args.batch / dts, "steps": n_shared,
                       "note": "opt-in share_generator_forward=True: the G-step reuses the D-step's generator forward (same weights, "
-                              "same inputs: bitwise the two-forward results, tests/test_gpu_model.py::"
+                              "same inputs: the two-forward results up to fp32 rounding, tests/test_gpu_model.py::"
                               "test_shared_generator_forward_is_equivalent); 3 G_f + 7 D_f = 450 GFLOP per iteration instead of 539.5. "
                               "Not the reference's call sequence (srgan_train.py:1131 and :1222 both run the generator), so `value` is "
                               "the two-forward iteration."}

@@ -1185,7 +1185,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   DBM_CHECK(!c->sync_stats(), "dbm_train_iteration: sync_batch_stats runs use the two step calls (their statistics collectives "
                               "are enqueued on the main stream between the layers)");
   DBM_CHECK(ssim_window == 0 || ssim_window == 1, "ssim_window must be 0 (gaussian) or 1 (uniform)");
-  (void)flags;
+  const bool one_fwd = (flags & DBM_ONE_GEN_FORWARD) != 0;  // the retained forward also supplies the D-step's fakes
   hipStream_t s = c->stream;
   hipStream_t pf = c->chain[1];
   const int H4 = 4 * (H - 2), W4 = 4 * (W - 2);
@@ -1246,19 +1246,19 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   // forward's tail and the whole D(fake) pass still have to run on the other 64, and the discriminator chain (forward, backward,
   // weight gradients, update) is what the iteration's tail waits for.  Default 0.
   static const int twin_early = getenv("DBM_TWIN_EARLY") ? atoi(getenv("DBM_TWIN_EARLY")) : 0;
-  if (twin_early) {
+  if (twin_early || one_fwd) {
     g->ensure_packed();
     c->fork(s, pf, 6);
   }
   // ---- fakes under enable_backprop=False (:1131-1137) ----
-  g->forward(N, H, W, X, W1, W2, W3, g->yout.p, false);
+  if (!one_fwd) g->forward(N, H, W, X, W1, W2, W3, g->yout.p, false);
   DBM_MARK(s, "D:generator_forward");
   // ---- the G-step's own forward (:1222-1227), retained graph, second workspace, on chain[1] ----
   Generator* t = g->get_twin();
   scope.t = t;
   t->ensure_ws(N, H, W, true);
   t->max_split = 1;
-  if (!twin_early) c->fork(s, pf, 6);
+  if (!twin_early && !one_fwd) c->fork(s, pf, 6);
   if (prev_tail) DBM_HIP(hipStreamWaitEvent(pf, c->ev_tail, 0));  // (the tail reads the twin's fakes and the loss scratch)
   c->stream = pf;
   t->forward(N, H, W, X, W1, W2, W3, t->yout.p, true);
@@ -1269,7 +1269,8 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   c->join_side();
   if (prev_tail) DBM_HIP(hipStreamWaitEvent(s, c->ev_tail, 0));  // (the tail's pass used the slot-1 activation buffers)
   c->tail_pending = false;
-  d->forward(N, H4, W4, g->yout.p, lf, true, true, 1);
+  if (one_fwd) DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));  // (the fakes are the retained forward's, written on chain[1])
+  d->forward(N, H4, W4, one_fwd ? t->yout.p : g->yout.p, lf, true, true, 1);
   launch_ragan_loss(lr, lf, N, 1, 0, metrics, gr, gf, s);
   DBM_MARK(s, "D:disc_forward_fake+loss");
   DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));

@@ -298,11 +298,14 @@ class MetricsLog:
 
 
 @_repeat_after_timeout
-def train_iteration(train_arrays, g_model, g_optimizer, d_model, d_optimizer, metrics=None):
+def train_iteration(train_arrays, g_model, g_optimizer, d_model, d_optimizer, metrics=None, share_generator_forward=False):
     """dbm_train_iteration: D-step, discriminator update, G-step, generator update of one minibatch of DEVICE arrays as one
     library call.  Returns the device metrics buffer [d_loss, d_accu, g_loss, g_psnr, g_ssim, ...] (no host
     synchronisation).  On a context with a communicator (DataParallel.attach: "rccl", or "gloo" on a GPU) the call is one
-    data-parallel iteration: both gradient arenas are summed over ranks inside it and both updates take 1 / world."""
+    data-parallel iteration: both gradient arenas are summed over ranks inside it and both updates take 1 / world.
+    share_generator_forward=True (opt-in, DBM_ONE_GEN_FORWARD): the generator runs once, its retained forward also supplies the
+    D-step's fakes (both forwards of srgan_train.py:1131 / :1222 see the same weights and inputs) -- bit for bit the two step
+    calls with share_generator_forward=True, the default iteration up to fp32 rounding."""
     global_config.train = True
     assert d_optimizer is not None and g_optimizer is not None  # Optimizer required for neural network training
     n, h, w = _check_batch(train_arrays)
@@ -312,7 +315,7 @@ def train_iteration(train_arrays, g_model, g_optimizer, d_model, d_optimizer, me
     _apply_config(g_model.ctx)
     _prefetch_tokens.pop(id(g_model), None)
     _lib.check(_lib.lib().dbm_train_iteration(g_model._h, d_model._h, n, h, w, *[_dev_ptr(train_arrays[k]) for k in _KEYS], wts,
-                                              win, 0, m.ptr), g_model.ctx.handle)
+                                              win, 16 if share_generator_forward else 0, m.ptr), g_model.ctx.handle)
     d_optimizer.t += 1
     g_optimizer.t += 1
     return m
@@ -332,11 +335,12 @@ def train_minibatch(train_arrays, g_model, g_optimizer, d_model, d_optimizer, co
     # torch's own all-reduce ("nccl") and sync_batch_stats need the two step calls)
     comm_ok = comm is None or (hasattr(comm, "exchanges_in_step") and comm.exchanges_in_step(g_model.ctx)
                                and not getattr(comm, "sync_batch_stats", False))
-    if (fused and prefetch and comm_ok and g_optimizer is not None and d_optimizer is not None
+    if (fused and (prefetch or share_generator_forward) and comm_ok and g_optimizer is not None and d_optimizer is not None
             and all(_is_device(train_arrays[k]) for k in _KEYS)):
         # ONE library call for the whole minibatch (dbm_train_iteration): the same numbers as the two calls below, bit for
         # bit, with the generator's backward pass scheduled underneath the discriminator's
-        m = train_iteration(train_arrays, g_model, g_optimizer, d_model, d_optimizer, metrics=row)
+        m = train_iteration(train_arrays, g_model, g_optimizer, d_model, d_optimizer, metrics=row,
+                            share_generator_forward=share_generator_forward)
     else:
         train_eval_discriminator(train_arrays, g_model, d_model, d_optimizer, comm=comm, sync=False,
                                  share_generator_forward=share_generator_forward, prefetch_generator_forward=prefetch,

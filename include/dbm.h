@@ -38,8 +38,13 @@ enum {
   DBM_KEEP_GRAPH = 2,  /* retain activations for a following backward (Chainer: enable_backprop=True) */
   DBM_BF16 = 8,        /* dbm_gen_forward without DBM_KEEP_GRAPH: the convolutions multiply in bf16 (operands rounded to
                           nearest-even, fp32 accumulation, fp32 storage): the area-inference mode of BASELINE config 5 */
-  DBM_BN_TRAIN = 4     /* discriminator BatchNorm uses batch statistics and updates running stats
+  DBM_BN_TRAIN = 4,    /* discriminator BatchNorm uses batch statistics and updates running stats
                           (chainer.config.train=True, srgan_train.py:1125) */
+  DBM_ONE_GEN_FORWARD = 16 /* dbm_train_iteration (opt-in, not the reference's call sequence): the generator runs ONCE per
+                          minibatch -- the G-step's retained forward also supplies the D-step's fakes (same weights, same
+                          inputs: srgan_train.py:1131-1137 and :1222-1227 compute the same images); bit for bit the two step calls
+                          with their share flag, and the default iteration up to fp32 rounding (the unretained pass sums
+                          conv_layer5 of the trunk in another order) */
 };
 enum { DBM_KIND_PARAM = 0, DBM_KIND_PERSISTENT = 1 };
 
@@ -283,7 +288,8 @@ int dbm_lzw_decode(const void* src, size_t nbytes, void* dst, size_t cap, size_t
  * floats) receives [d_loss, d_accu, g_loss, psnr, ssim].  With a communicator on the context (dbm_comm_init /
  * dbm_comm_set_hook) the call is one data-parallel iteration: both models' gradient buckets are summed over ranks inside
  * it (on library stream chain[0], underneath the generator's backward pass) and both updates take 1 / world -- the same
- * collectives in the same order as the two step calls.  Refused with sync_batch_stats (use the two step calls). */
+ * collectives in the same order as the two step calls.  Refused with sync_batch_stats (use the two step calls).
+ * flags: 0 or DBM_ONE_GEN_FORWARD. */
 int dbm_train_iteration(dbm_model* g, dbm_model* d, int N, int H, int W, const float* X, const float* W1, const float* W2,
                         const float* W3, const float* Y, const float weights[4], int ssim_window, int flags,
                         float* metrics_dev);

@@ -1072,10 +1072,13 @@ def test_device_canvas_to_int16_geotiff(dbm, tmp_path):
     assert np.array_equal(got, ref) and info["nodata"] == "-2000" and info["bigtiff"]
 
 
-def test_fused_iteration_equals_the_two_step_calls(dbm):
+@pytest.mark.parametrize("share", [False, True])
+def test_fused_iteration_equals_the_two_step_calls(dbm, share):
     """dbm_train_iteration (what trainer / train_minibatch use on one GPU) schedules the generator's backward pass
     underneath the discriminator's; nothing changes numerically: metrics, parameters, Adam state (through a third
-    iteration) and BatchNorm running statistics are bitwise those of train_eval_discriminator + train_eval_generator."""
+    iteration) and BatchNorm running statistics are bitwise those of train_eval_discriminator + train_eval_generator.
+    share: the same for the opt-in one-forward iteration (DBM_ONE_GEN_FORWARD) against the two step calls with
+    share_generator_forward=True."""
     arrays = dbm.device_batch(fixture_arrays(n=6))
     runs = []
     for fused in (False, True):
@@ -1085,7 +1088,7 @@ def test_fused_iteration_equals_the_two_step_calls(dbm):
         d = copy_params(dbm.DiscriminatorModel(initialize=False), od.params, od.persistent)
         g_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(g)
         d_opt = dbm.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(d)
-        out = [dbm.train_minibatch(arrays, g, g_opt, d, d_opt, fused=fused) for _ in range(3)]
+        out = [dbm.train_minibatch(arrays, g, g_opt, d, d_opt, fused=fused, share_generator_forward=share) for _ in range(3)]
         runs.append((out, g.serialize_dict(), d.serialize_dict()))
     assert runs[0][0] == runs[1][0]
     for k, v in runs[0][1].items():
