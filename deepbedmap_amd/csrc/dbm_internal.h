@@ -209,7 +209,7 @@ struct WgradBatch {
   double abytes[NCAT] = {};      // algorithmic bytes of a category's launch: every layer's x, dy and gW once
   // 4x4 stride-2 layers on tiny planes (wgrad_s2tiny_kernel): their own plan table, outside the categories
   void* d_tiny = nullptr;
-  int n_tiny = 0, tiny_wgs = 0;
+  int n_tiny = 0, tiny_wgs = 0, tiny_rowlen = 4;
   double tiny_flops = 0.0, tiny_bytes = 0.0;
   std::vector<int> tiny_owner;
   void add(const WgradDesc& d) { if (!built) descs.push_back(d); }

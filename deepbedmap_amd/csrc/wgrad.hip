@@ -1177,6 +1177,7 @@ struct TinyPlan {
   int N, Cin, Cout, Hin, Win, OH, OW;
   float scale;
   int wg_start, ctiles;  // workgroups of this layer: (Cout / 16) * ctiles, ctiles = Cin / 16
+  int K;                 // 4: 4x4 stride 2 pad 1;  3: 3x3 stride 1 pad 1 (round 3: conv_layer6 / 8 of the discriminator)
 };
 
 struct __attribute__((packed, aligned(4))) f32x4u4 { float v[4]; };
@@ -1184,28 +1185,20 @@ constexpr int TINY_MAXK = 2048;  // K entries (images x valid output positions) 
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void wgrad_s2tiny_kernel(const TinyPlan* __restrict__ plans, int nplans) {
-  int lo = 0, hi = nplans - 1;
-  const int wg = blockIdx.x;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (plans[mid].wg_start <= wg) lo = mid; else hi = mid - 1;
-  }
-  const TinyPlan& p = plans[__builtin_amdgcn_readfirstlane(lo)];  // (uniform: the plan's fields become scalar loads)
-  const int local = wg - p.wg_start;
+// KS x KS taps, stride ST, pad 1; wavefront ky < KS owns kernel row ky (a 3x3 layer leaves the workgroup's fourth wavefront idle)
+template <int KS, int ST>
+__device__ __forceinline__ void tiny_body(const TinyPlan& p, int local, int2* tb, int ky, int lane) {
   const int ot = local / p.ctiles, ctile = local - ot * p.ctiles;   // 16 x 16 tiles of (out, in) channels
-  const int lane = threadIdx.x & 63, ky = threadIdx.x >> 6;
   const int j = lane & 15, k4 = lane >> 4;
   const int OH = p.OH, OW = p.OW, Hin = p.Hin, Win = p.Win;
-  // output rows a whose input row 2 a + ky - 1 lies inside the image
+  // output rows a whose input row ST a + ky - 1 lies inside the image
   const int a_lo = ky == 0 ? 1 : 0;
-  int a_hi = Hin - ky < 0 ? -1 : (Hin - ky) >> 1;  // 2 a + ky - 1 <= Hin - 1
+  int a_hi = Hin - ky < 0 ? -1 : (Hin - ky) / ST;  // ST a + ky - 1 <= Hin - 1
   if (a_hi > OH - 1) a_hi = OH - 1;
   const int OHv = a_hi - a_lo + 1;
-  f32x4 acc[4];
+  f32x4 acc[KS];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __shared__ int2 tbl[4][TINY_MAXK];  // per kernel row: K entry -> {x offset, dy offset | column mask << 27 | valid << 31}
+  for (int t = 0; t < KS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (OHv > 0) {
     const int per_img = OHv * OW;
     const int E = p.N * per_img;               // K entries of this kernel row
@@ -1214,7 +1207,6 @@ __global__ __launch_bounds__(256) void wgrad_s2tiny_kernel(const TinyPlan* __res
     // The (image, a, b) decode of every K entry -- divisions, 64-bit products -- is done ONCE per wavefront into an LDS
     // table (the first version decoded per fetch: 2000 VALU instructions per 64 MFMAs, five times the MFMA time);
     // both graphs use it.  Entries past the end read offset 0 with an all-zero mask.
-    int2* tb = tbl[ky];
     for (int e = lane; e < 4 * steps; e += 64) {
       int2 v = make_int2(0, 0);
       if (e < E) {
@@ -1222,10 +1214,10 @@ __global__ __launch_bounds__(256) void wgrad_s2tiny_kernel(const TinyPlan* __res
         const int rem = e - n * per_img;
         const int ai = rem / OW, b = rem - ai * OW;
         const int a = a_lo + ai;
-        const int row = 2 * a + ky - 1, col0 = 2 * b - 1;
+        const int row = ST * a + ky - 1, col0 = ST * b - 1;
         unsigned cm = 0;
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx) cm |= ((unsigned)(col0 + kx) < (unsigned)Win) ? (1u << kx) : 0u;
+        for (int kx = 0; kx < KS; ++kx) cm |= ((unsigned)(col0 + kx) < (unsigned)Win) ? (1u << kx) : 0u;
         v.x = (int)((long)n * p.xsn + row * Win + col0);
         v.y = (int)((unsigned)((long)n * p.dysn + a * OW + b) | (cm << 27) | (1u << 31));
       }
@@ -1237,10 +1229,10 @@ __global__ __launch_bounds__(256) void wgrad_s2tiny_kernel(const TinyPlan* __res
       const int2 t = tb[4 * s + k4];
       cm = (unsigned)t.y >> 27;  // bit 4: valid entry
       av = dyl[(unsigned)t.y & 0x7ffffffu];
-      bv = *reinterpret_cast<const f32x4u4*>(xl + t.x);
+      bv = *reinterpret_cast<const f32x4u4*>(xl + t.x);  // (3x3: the fourth word is not used -- guard bytes at the very end of a tensor)
     };
     // Chunks of eight K steps in ping-pong: the sixteen loads of chunk q + 1 (scattered: every lane reads its own plane)
-    // are in flight underneath the 32 MFMAs of chunk q.
+    // are in flight underneath the 8 KS MFMAs of chunk q.
     constexpr int CH = 8;
     struct Chunk { float a[CH]; f32x4u4 b[CH]; unsigned m[CH]; };
     auto fetch_chunk = [&](const float* xl, const float* dyl, int s0, Chunk& c) {
@@ -1253,7 +1245,7 @@ __global__ __launch_bounds__(256) void wgrad_s2tiny_kernel(const TinyPlan* __res
         // (steps past the end re-read the last one, entries past the end read element 0: their A value is zeroed)
         const float av = (s0 + u < steps && (c.m[u] & 16u)) ? c.a[u] : 0.f;
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx)
+        for (int kx = 0; kx < KS; ++kx)
           acc[kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ((c.m[u] >> kx) & 1u) ? c.b[u].v[kx] : 0.f, acc[kx], 0, 0, 0);
       }
     };
@@ -1277,23 +1269,52 @@ __global__ __launch_bounds__(256) void wgrad_s2tiny_kernel(const TinyPlan* __res
       }
     }
   }
-  // gW[o][c][ky][0..3] += scale * acc: 16 bytes per (o, c), this workgroup is their only writer.
+  // gW[o][c][ky][0..KS) += scale * acc: KS words per (o, c), this workgroup is their only writer.
   // D layout of v_mfma_f32_16x16x4_f32: register r of lane (j, k4) is row 4 k4 + r (out channel), column j (in channel)
-  float* gbase = p.gW + ((long)(ot * 16) * p.Cin + ctile * 16 + j) * 16 + ky * 4;
+  float* gbase = p.gW + ((long)(ot * 16) * p.Cin + ctile * 16 + j) * (KS * KS) + ky * KS;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int o = 4 * k4 + r;
-    f32x4u4* dst = reinterpret_cast<f32x4u4*>(gbase + (long)o * p.Cin * 16);  // (4-byte alignment is all the arena guarantees)
-    f32x4u4 v = *dst;
+    float* dst = gbase + (long)o * p.Cin * (KS * KS);  // (4-byte alignment is all the arena guarantees)
+    if constexpr (KS == 4) {
+      f32x4u4 v = *reinterpret_cast<f32x4u4*>(dst);
 #pragma unroll
-    for (int kx = 0; kx < 4; ++kx) v.v[kx] += p.scale * acc[kx][r];
-    *dst = v;
+      for (int kx = 0; kx < 4; ++kx) v.v[kx] += p.scale * acc[kx][r];
+      *reinterpret_cast<f32x4u4*>(dst) = v;
+    } else {
+      float v[KS];
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) v[kx] = dst[kx];
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) dst[kx] = v[kx] + p.scale * acc[kx][r];
+    }
   }
 }
 
+__global__ __launch_bounds__(256) void wgrad_s2tiny_kernel(const TinyPlan* __restrict__ plans, int nplans, int rowlen) {
+  int lo = 0, hi = nplans - 1;
+  const int wg = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (plans[mid].wg_start <= wg) lo = mid; else hi = mid - 1;
+  }
+  const TinyPlan& p = plans[__builtin_amdgcn_readfirstlane(lo)];  // (uniform: the plan's fields become scalar loads)
+  const int local = wg - p.wg_start;
+  const int lane = threadIdx.x & 63, ky = threadIdx.x >> 6;
+  // per kernel row: K entry -> {x offset, dy offset | column mask << 27 | valid << 31}; `rowlen` entries per row = the longest
+  // row of the launch's layers (round 3: it was a static 4 x 2048 table, 64 KB -- two workgroups per CU; the step's layers need
+  // 1028 entries, 32 KB: five)
+  extern __shared__ int2 tbl[];
+  if (p.K == 4) tiny_body<4, 2>(p, local, tbl + ky * rowlen, ky, lane);
+  else if (ky < 3) tiny_body<3, 1>(p, local, tbl + ky * rowlen, ky, lane);
+}
+
 static bool s2tiny_eligible(const WgradDesc& d) {
-  static const int on = getenv("DBM_WGRAD_TINY") ? atoi(getenv("DBM_WGRAD_TINY")) : 1;
-  return on && d.KH == 4 && d.KW == 4 && d.stride == 2 && d.pad == 1 && d.ups == 0 && d.OW <= 4 && d.OH <= 4 && d.gb == nullptr &&
+  static const int on = getenv("DBM_WGRAD_TINY") ? atoi(getenv("DBM_WGRAD_TINY")) : 1;   // bit 0: 4x4 stride 2, bit 1: 3x3 stride 1
+  const bool k4 = (on & 1) && d.KH == 4 && d.KW == 4 && d.stride == 2;
+  static const int on3 = getenv("DBM_WGRAD_TINY3") ? atoi(getenv("DBM_WGRAD_TINY3")) : 1;
+  const bool k3 = on3 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.Hin == d.OH && d.Win == d.OW;
+  return (k4 || k3) && d.pad == 1 && d.ups == 0 && d.OW <= 4 && d.OH <= 4 && d.gb == nullptr &&
          d.Cin % 32 == 0 && d.Cout % 32 == 0 && d.xsc == d.Hin * d.Win && d.dysc == d.OH * d.OW && d.Win >= 2 &&
          (long)d.N * d.OH * d.OW + 4 <= TINY_MAXK && (long)d.N * d.xsn < (1L << 31) && (long)d.N * d.dysn < (1L << 27);
 }
@@ -1600,7 +1621,7 @@ void WgradBatch::build() {
         if (descs[k].gW != d.gW) continue;
         const WgradDesc& f = descs[k];
         grp.push_back(k);
-        ok = ok && s2tiny_eligible(f) && f.N == d.N && f.Cin == d.Cin && f.Cout == d.Cout && f.Hin == d.Hin && f.Win == d.Win &&
+        ok = ok && s2tiny_eligible(f) && f.KH == d.KH && f.N == d.N && f.Cin == d.Cin && f.Cout == d.Cout && f.Hin == d.Hin && f.Win == d.Win &&
              f.OH == d.OH && f.OW == d.OW && f.xsn == d.xsn && f.dysn == d.dysn && f.scale == d.scale;
       }
       if (!ok || grp.size() > 2 || grp[0] != i) continue;
@@ -1609,13 +1630,15 @@ void WgradBatch::build() {
       for (size_t u = 0; u < grp.size(); ++u) { q.x[u] = descs[grp[u]].x; q.dy[u] = descs[grp[u]].dy; owner[grp[u]] = (int)tp.size(); }
       q.gW = d.gW; q.xsn = d.xsn; q.dysn = d.dysn;
       q.N = d.N; q.Cin = d.Cin; q.Cout = d.Cout; q.Hin = d.Hin; q.Win = d.Win; q.OH = d.OH; q.OW = d.OW; q.scale = d.scale;
-      q.ctiles = d.Cin / 16; q.wg_start = wgs;
+      q.ctiles = d.Cin / 16; q.wg_start = wgs; q.K = d.KH;
       wgs += (d.Cout / 16) * q.ctiles;
       tp.push_back(q);
-      fl += 2.0 * (double)grp.size() * d.N * d.OH * d.OW * d.Cout * d.Cin * 16;
-      tiny_bytes_acc += 4.0 * ((double)grp.size() * d.N * ((double)d.Cin * d.Hin * d.Win + (double)d.Cout * d.OH * d.OW) + (double)d.Cout * d.Cin * 16);
+      fl += 2.0 * (double)grp.size() * d.N * d.OH * d.OW * d.Cout * d.Cin * (d.KH * d.KW);
+      tiny_bytes_acc += 4.0 * ((double)grp.size() * d.N * ((double)d.Cin * d.Hin * d.Win + (double)d.Cout * d.OH * d.OW) + (double)d.Cout * d.Cin * (d.KH * d.KW));
     }
     n_tiny = (int)tp.size(); tiny_wgs = wgs; tiny_flops = fl; tiny_bytes = tiny_bytes_acc;
+    tiny_rowlen = 4;
+    for (const TinyPlan& q : tp) tiny_rowlen = std::max(tiny_rowlen, ((q.N * q.OH * q.OW + 3) / 4) * 4);
     tiny_owner = owner;
     if (d_tiny) { (void)hipFree(d_tiny); d_tiny = nullptr; }
     if (n_tiny) {
@@ -1810,7 +1833,8 @@ void WgradBatch::launch(hipStream_t s) {
   if (!built) build();
   if (n_tiny) {
     if (g_profiler.enabled) g_profiler.begin(s, 1, tiny_flops, tiny_bytes, "wgrad_s2tiny", tiny_wgs);
-    hipLaunchKernelGGL(wgrad_s2tiny_kernel, dim3(tiny_wgs), dim3(256), 0, s, (const TinyPlan*)d_tiny, n_tiny);
+    hipLaunchKernelGGL(wgrad_s2tiny_kernel, dim3(tiny_wgs), dim3(256), 4 * (size_t)tiny_rowlen * sizeof(int2), s, (const TinyPlan*)d_tiny, n_tiny,
+                       tiny_rowlen);
     DBM_HIP(hipGetLastError());
     if (g_profiler.enabled) g_profiler.end(s);
   }
