@@ -20,6 +20,8 @@
 //   wgrad_band_dma_kernel   3x3 / 4x4, any stride / folded resize, on large planes: row bands, dword LDS-DMA
 //   wgrad_kernel            general form (1x1 layers, 4x4 layers on tiny planes): four / eight wavefronts,
 //                           register-staged
+// (later: wgrad_direct_kernel / wgrad_1x1_kernel for large planes, wgrad_s2tiny_kernel for the deep discriminator layers --
+// 4x4 stride 2 AND, round 3, 3x3 stride 1 on planes of <= 4 x 4 -- each described where it is defined)
 #include "dbm_internal.h"
 #include <algorithm>
 #include <cstdlib>
@@ -1157,7 +1159,10 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const WgradPlan* __rest
 
 // ---------------------------------------------------------------------------------------------------------------
 // 4x4 / stride 2 / pad 1 layers on tiny output planes (OW <= 4: the discriminator's conv_layer5 / 7 / 9, 9x9 -> 4x4,
-// 4x4 -> 2x2, 2x2 -> 1x1).  GEMM view per tap: M = out channels, N = in channels, K = (image, output position) -- a few
+// 4x4 -> 2x2, 2x2 -> 1x1) and, round 3, 3x3 / stride 1 / pad 1 layers on such planes (conv_layer6 / 8: they used to go
+// through the trunk's LDS-DMA form, whose whole-image bands pay for all nine taps of every position; here output rows whose
+// input row is padding are never enumerated: 267 -> 164 us for the tail's weight gradients, with the LDS table sized by the
+// launch instead of a static 64 KB).  GEMM view per tap: M = out channels, N = in channels, K = (image, output position) -- a few
 // hundred at batch 64, against 16 taps x (Cout / 32) x (Cin / 32) output tiles: output-bound.  No LDS staging and no K
 // split: a workgroup owns one 16 (out) x 16 (in) tile (v_mfma_f32_16x16x4_f32: four times the workgroups of 32 x 32
 // tiles, which these layers need -- conv_layer5 has 64 of those) for ALL sixteen taps, wavefront w the kernel row ky = w
