@@ -16,6 +16,7 @@ DEVICE_PTRS = 1
 KEEP_GRAPH = 2
 BN_TRAIN = 4
 BF16 = 8
+ONE_GEN_FORWARD = 16  # dbm_train_iteration: one generator forward per minibatch (opt-in)
 
 c_float_p = C.POINTER(C.c_float)
 c_void_pp = C.POINTER(C.c_void_p)

@@ -315,7 +315,7 @@ def train_iteration(train_arrays, g_model, g_optimizer, d_model, d_optimizer, me
     _apply_config(g_model.ctx)
     _prefetch_tokens.pop(id(g_model), None)
     _lib.check(_lib.lib().dbm_train_iteration(g_model._h, d_model._h, n, h, w, *[_dev_ptr(train_arrays[k]) for k in _KEYS], wts,
-                                              win, 16 if share_generator_forward else 0, m.ptr), g_model.ctx.handle)
+                                              win, _lib.ONE_GEN_FORWARD if share_generator_forward else 0, m.ptr), g_model.ctx.handle)
     d_optimizer.t += 1
     g_optimizer.t += 1
     return m

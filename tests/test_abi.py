@@ -35,6 +35,15 @@ def test_header_symbols_are_exported_and_bound(built):
     assert set(syms) == bound, set(syms) ^ bound
 
 
+def test_flag_values_of_the_header_and_the_bindings_agree(built):
+    text = open(os.path.join(ROOT, "include", "dbm.h")).read()
+    flags = {k: int(v) for k, v in re.findall(r"\b(DBM_[A-Z0-9_]+)\s*=\s*(\d+)", text)}
+    for name in ("DEVICE_PTRS", "KEEP_GRAPH", "BN_TRAIN", "BF16", "ONE_GEN_FORWARD"):
+        assert flags["DBM_" + name] == getattr(built, name), name
+    used = [flags["DBM_" + n] for n in ("DEVICE_PTRS", "KEEP_GRAPH", "BN_TRAIN", "BF16", "ONE_GEN_FORWARD")]
+    assert len(set(used)) == len(used) and all(v & (v - 1) == 0 for v in used)  # distinct single bits
+
+
 def test_every_entry_point_cites_the_reference():
     text = open(os.path.join(ROOT, "include", "dbm.h")).read()
     for name in ("dbm_gen_create", "dbm_disc_create", "dbm_gen_forward", "dbm_disc_forward", "dbm_generator_loss",
