@@ -115,6 +115,28 @@ def _random_conv_cases(seed, n):
 CONV_CASES += _random_conv_cases(404, 14)
 
 
+def _random_tail_cases(seed, n):
+    """The deep-discriminator forms at random geometry (igemm_pm_kernel: position-major tiles, live taps only; wgrad_s2tiny_kernel
+    for 3x3 and 4x4 stride-2 layers): 16..80 images (whole, ragged and half-empty 32-image groups), planes of 1 x 1 .. 4 x 4 pixels,
+    square or not, 64..512 input channels (every K split the launchers pick), 32..256 output channels (one / two tiles per
+    wavefront, ragged last tile)."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        N = int(rs.randint(16, 81))
+        C = int(rs.choice([64, 128, 192, 256, 512]))
+        O = int(rs.choice([32, 64, 96, 128, 256]))
+        H, W = int(rs.randint(1, 5)), int(rs.randint(1, 5))
+        if rs.randint(0, 2):
+            out.append((N, C, H, W, O, 3, 1, 1, 0, int(rs.randint(0, 2))))
+        else:
+            out.append((N, C, max(2, H), max(2, W), O, 4, 2, 1, 0, int(rs.randint(0, 2))))
+    return out
+
+
+CONV_CASES += _random_tail_cases(77, 12)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_forward(dbm, case):
     d, _lib, ctx = dbm

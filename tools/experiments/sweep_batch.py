@@ -8,7 +8,7 @@ np.random.seed(1)
 g = dbm.GeneratorModel(num_residual_blocks=12)
 lib = dbm._lib.lib()
 h = w = 288
-for nb in (1, 2, 4, 8):
+for nb in (1, 2, 3, 4, 6, 8, 12, 16):
     r = np.random.RandomState(7)
     ins = [dbm.to_device(r.rand(nb, c, m * h, m * w).astype(np.float32), ctx) for c, m in ((1, 1), (1, 10), (2, 2), (1, 1))]
     y = dbm.DeviceArray((nb, 1, 4 * (h - 2), 4 * (w - 2)), ctx)
