@@ -1700,7 +1700,11 @@ void WgradBatch::build() {
         units += (long)p.groups * p.coutTiles;
       }
       static const int slots_env = getenv("DBM_WGRAD_SLOTS") ? atoi(getenv("DBM_WGRAD_SLOTS")) : 0;
-      const int slots = slots_env ? slots_env : (need > 40 * 1024 ? 512 : 1024);
+      // (few-layer launches -- the discriminator's conv_layer4: 16 units -- take a coarser K split: 256 workgroups of four images
+      // instead of 1024 of one, a quarter of the partial tiles to write and fold: 116 -> 90 us standalone, round 3)
+      static const int slots_small = getenv("DBM_WGRAD_SLOTS_SMALL") ? atoi(getenv("DBM_WGRAD_SLOTS_SMALL")) : 256;
+      int slots = slots_env ? slots_env : (need > 40 * 1024 ? 512 : 1024);
+      if (slots_small && units > 0 && units < 128) slots = std::min(slots, slots_small);
       if (units > 0) S_fixed = (int)std::max(1L, slots / units);
     }
     // workgroup forms: a launch should offer about two workgroups per CU; small batches split their position axis finer
