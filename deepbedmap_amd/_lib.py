@@ -6,6 +6,7 @@ context raises -- there is no CPU fallback.
 """
 import ctypes as C
 import os
+import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -123,16 +124,23 @@ class DbmError(RuntimeError):
     code = None
 
 
-def build(verbose=False):
-    """Compile libdbm.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+def build(verbose=False, fresh=False):
+    """Compile libdbm.so in-tree for gfx950 (hipcc cross-compiles without a GPU).  fresh=True: every translation unit is
+    compiled from scratch (`make -B`, ~20 s on eight cores) -- what `__graft_entry__.build()` does, so that "it builds" never
+    depends on objects that happened to lie in the tree.  Returns the library's path; `build.compiled` = the sources compiled
+    by this call."""
     jobs = str(min(8, os.cpu_count() or 1))
-    res = subprocess.run(["make", "-C", CSRC, "-j", jobs], capture_output=True, text=True)
+    res = subprocess.run(["make", "-C", CSRC, "-j", jobs] + (["-B"] if fresh else []), capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:])
         print(res.stderr[-4000:])
     if res.returncode != 0:
         raise DbmError("building libdbm.so failed")
+    build.compiled = sorted(set(re.findall(r"-c (\S+\.hip)", res.stdout)))
     return LIB_PATH
+
+
+build.compiled = []
 
 
 def lib():
