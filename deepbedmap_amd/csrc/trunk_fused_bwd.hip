@@ -62,7 +62,7 @@ struct Args {
   float rs, slope;
   unsigned off_xcc;  // XCC_ID table of the handshake (granule offset inside inbox)
   int local_st;
-  int abl;  // measurement aid (DBM_TFB_ABL): 1 = no halo exchange, 2 = no epilogue (results are then wrong)
+  int abl;  // measurement aid (DBM_TFB_ABL): 1 = no halo exchange, 2 = no epilogue, 4 = every weight unit re-reads the same (cache-hot) address (results are then wrong)
 };
 
 struct Wave {
@@ -232,7 +232,7 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
       }
     }
     issue_unit(nxt, W.wp, lane);
-    W.wp += BUNIT;
+    if (!(a.abl & 4)) W.wp += BUNIT;  // (abl 4: every unit re-reads the same weights -- always cache-hot; results wrong)
     __builtin_amdgcn_sched_barrier(0);
     mma_unit(cur, breg + u * QU * 4 * CS, u + 1 < NU ? breg + (u + 1) * QU * 4 * CS : -1, bq0, acc);
     __builtin_amdgcn_sched_barrier(0);
