@@ -1,13 +1,15 @@
 """End-to-end epoch throughput: `trainer` over a device-resident synthetic dataset of the reference's size
 (3826 training / 202 development tiles, batch 128: paper/tc-2020-74.tex:629-631, srgan_train.py:132-166, 1267-1329), i.e.
 what the reference's "150 epochs in about 30 min on a V100" (≈319 tiles/s) measures minus its plotting / uploads.
-usage (GPU box): PYTHONPATH=. python tools/epoch_bench.py [epochs]"""
+usage (GPU box): python tools/epoch_bench.py [epochs]"""
+import os
 import sys
 import time
 
 import numpy as np
 
-import deepbedmap_amd as dbm
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deepbedmap_amd as dbm  # noqa: E402
 
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 n = 4028
