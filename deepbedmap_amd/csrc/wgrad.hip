@@ -1704,7 +1704,8 @@ void WgradBatch::build() {
       // instead of 1024 of one, a quarter of the partial tiles to write and fold: 116 -> 90 us standalone, round 3)
       static const int slots_small = getenv("DBM_WGRAD_SLOTS_SMALL") ? atoi(getenv("DBM_WGRAD_SLOTS_SMALL")) : 256;
       int slots = slots_env ? slots_env : (need > 40 * 1024 ? 512 : 1024);
-      if (g == 3 && slots_small && units > 0 && units < 128) slots = std::min(slots, slots_small);  // (the row-band forms lose: 164 -> 204 us)
+      // (<= 32 units: in data-parallel runs the trunk's launches are cut into four groups of 126 units each -- those keep the fine split)
+      if (g == 3 && slots_small && units > 0 && units <= 32) slots = std::min(slots, slots_small);  // (the row-band forms lose: 164 -> 204 us)
       if (units > 0) S_fixed = (int)std::max(1L, slots / units);
     }
     // workgroup forms: a launch should offer about two workgroups per CU; small batches split their position axis finer
