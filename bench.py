@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 def _traffic_json():  # tools/pmc_traffic.sh (separate --pmc passes); the newest round's file
-    for r in ("r3", "r2", "r1"):
+    for r in ("r4", "r3", "r2", "r1"):
         p = os.path.join(ROOT, "profiles", r, "traffic_pmc.json")
         if os.path.exists(p):
             return p
@@ -35,6 +35,13 @@ TRAFFIC_JSON = _traffic_json()
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (the sweep's arithmetic, BASELINE config 5)
 PEAK_HBM_GBS = 8000.0
+# split-bf16 kernels (conv_cl16x3, deform_conv64_x3: hi*hi + hi*lo + lo*hi) issue THREE bf16 MFMAs per algorithmic product
+PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
+MAX_LINE_BYTES = 4096   # the driver keeps an 8 KB tail of stdout: the result line stays far below it (tests/test_host_logic.py)
+TABLES_PATH = os.path.join(ROOT, "bench_tables.json")   # the per-shape tables of the run (also echoed on stderr)
+# environment switches of libdbm_measure.so (built by tools/build_measure.sh with -DDBM_MEASURE) that SKIP work: a run with
+# one of them set is not a measurement of the iteration and bench.py refuses it
+WORK_SKIPPING_ENV = ("DBM_ABL_SKIP", "DBM_NO_WGRAD", "DBM_TFB_ABL", "DBM_CL16_ABL", "DBM_ABL_NOPACK", "DBM_LIB")
 G_FWD_MAC_PER_TILE = 845360064  # generator forward, 12 RRDB, one 11x11 -> 36x36 tile (81 trunk pixels)
 BATCH_PER_GPU = 64
 N_RRDB = 12
@@ -67,13 +74,13 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(threads=None, batch=BATCH_PER_GPU):
-    """The oracle (NumPy restatement of the Chainer CPU path: im2col + BLAS sgemm) on this box's host cores: ONE MEASURED
-    full iteration (D-step + G-step: forward, backward, Adam; 12 RRDB) at the benchmark's own batch 64 -- `value` is that
-    measurement, not a model -- after a warm-up iteration at batch 8, whose time is reported beside it (BASELINE.md section 3
-    asks for more repetitions; one batch-64 iteration of the port takes minutes on most hosts, so the sample is bounded to
-    one).  Beside it the same iteration in torch-CPU fp32 (oneDNN convolutions, autograd) at the same batch 64, a strong-CPU
-    yardstick.  BLAS / torch threads are pinned and reported."""
+def cpu_baseline(threads=None, batch=16):
+    """The oracle (NumPy restatement of the Chainer CPU path: im2col + BLAS sgemm) on this box's host cores, on a BOUNDED
+    sample of the benchmark's workload: full iterations (D-step + G-step: forward, backward, Adam; 12 RRDB) at batch 16 --
+    a quarter of the benchmark's 64 tiles, the same per-tile arithmetic -- after a warm-up iteration at batch 4; `value` is the
+    median of the measured iterations (two, or one when the first takes more than 20 s), about 10-30 s of CPU work.  Beside it
+    the same iteration in torch-CPU fp32 (oneDNN convolutions, autograd) at the benchmark's batch 64, a strong-CPU yardstick.
+    BLAS / torch threads are pinned and reported."""
     import statistics
 
     from oracle import model as omodel
@@ -99,15 +106,17 @@ def cpu_baseline(threads=None, batch=BATCH_PER_GPU):
         return time.perf_counter() - t0
 
     t_all = time.perf_counter()
-    port_step(8)  # warm-up: BLAS thread pool, page faults of the im2col buffers
-    t8 = port_step(8)
-    tN = port_step(batch)
+    tw = port_step(4)  # warm-up: BLAS thread pool, page faults of the im2col buffers
+    ts = [port_step(batch)]
+    if ts[0] < 20.0:
+        ts.append(port_step(batch))
+    tN = statistics.median(ts)
     out = {"value": batch / tN, "unit": "tiles/s", "cores": threads, "kind": "port",
            "host_cpus": ncpu, "cpu_model": _cpu_model(), "blas_threads": threads,
-           "measured": {f"batch{batch}_s": tN, "batch8_s": t8, "tiles_per_s_at_batch8": 8.0 / t8},
-           "sample": f"ONE measured full iteration (D-step + G-step, fwd+bwd+Adam, 12 RRDB) of the NumPy/BLAS oracle at batch {batch} "
-                     f"({tN:.1f} s) after a batch-8 warm-up; batch 8 beside it: {t8:.1f} s"}
-    try:  # torch-CPU (oneDNN) fp32, the same iteration at the same batch
+           "measured_s": [round(t, 3) for t in ts], "warmup_batch4_s": round(tw, 3),
+           "sample": f"{len(ts)} full iteration(s) (D+G step, fwd+bwd+Adam, 12 RRDB) of the NumPy/BLAS oracle at batch {batch} "
+                     f"(median {tN:.1f} s) after a batch-4 warm-up"}
+    try:  # torch-CPU (oneDNN) fp32, the same iteration at the benchmark's batch
         import torch
 
         from oracle import torch_ref as tr
@@ -117,7 +126,8 @@ def cpu_baseline(threads=None, batch=BATCH_PER_GPU):
         od = omodel.DiscriminatorModel(seed=2)
         Pg, Pd = tr.tp(og.params, torch.float32), tr.tp(od.params, torch.float32)
         Sd = {k: torch.tensor(np.asarray(v, np.float32)) for k, v in od.persistent.items() if not k.endswith("/N")}
-        arrays = {k: torch.tensor(v) for k, v in synthetic_batch(batch, 42).items()}
+        nb = BATCH_PER_GPU
+        arrays = {k: torch.tensor(v) for k, v in synthetic_batch(nb, 42).items()}
 
         def torch_step():
             t0 = time.perf_counter()
@@ -126,14 +136,13 @@ def cpu_baseline(threads=None, batch=BATCH_PER_GPU):
 
         torch_step()
         tt = statistics.median(torch_step() for _ in range(3))
-        out["torch_cpu"] = {"value": batch / tt, "unit": "tiles/s", "threads": threads,
-                            "sample": f"same iteration, torch {torch.__version__} CPU fp32 (oneDNN, autograd), batch {batch}, "
-                                      f"1 warm-up + median of 3 ({tt:.2f} s)"}
+        out["torch_cpu"] = {"value": nb / tt, "unit": "tiles/s", "threads": threads,
+                            "sample": f"torch {torch.__version__} CPU fp32 (oneDNN, autograd), batch {nb}, 1 warm-up + median of 3 ({tt:.2f} s)"}
     except Exception as e:  # pragma: no cover
-        out["torch_cpu"] = {"error": repr(e)}
+        out["torch_cpu"] = {"error": repr(e)[:200]}
     if limit is not None:
         limit.restore_original_limits() if hasattr(limit, "restore_original_limits") else None
-    out["wall_s"] = time.perf_counter() - t_all
+    out["wall_s"] = round(time.perf_counter() - t_all, 1)
     return out
 
 
@@ -160,6 +169,18 @@ def shape_table(recs, recs_s, keys):
         row["flop_per_byte"] = row["gflop_per_launch"] * 1e9 / max(row["algorithmic_bytes_per_launch"], 1.0)
         out.append({k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items()})
     return sorted(out, key=lambda r: -r["ms_standalone"])
+
+
+def sweep_roof(mode, tag):
+    """The MFMA roof a bracketed launch of the sweep is priced against.  fp32 mode: the fp32 MFMA peak.  bf16 mode: the bf16
+    peak for the bf16 trunk layers (`cl16_...` = conv_cl16_kernel); a THIRD of it for the split-bf16 launches (`x3_...` =
+    conv_cl16x3_kernel, `deform64x3_...` = deform_conv64_x3_kernel: hi*hi + hi*lo + lo*hi, three bf16 MFMAs per algorithmic
+    product); the fp32 peak for whatever still multiplies in fp32 (input block, the 64 -> 1 deformable layer)."""
+    if mode == "bf16" and tag.startswith("cl16_"):
+        return "bf16_mfma", PEAK_BF16_MFMA_TFLOPS
+    if mode == "bf16" and tag.startswith(("x3_", "deform64x3")):
+        return "bf16_mfma/3", PEAK_SPLIT_BF16_TFLOPS
+    return "fp32_mfma", PEAK_FP32_MFMA_TFLOPS
 
 
 def sweep_leg(dbm, ctx, g, crops=5):
@@ -205,7 +226,6 @@ def sweep_leg(dbm, ctx, g, crops=5):
         dbm._lib.check(lib.dbm_profile_begin_serial(ctx.handle), ctx.handle)
         fwd(flags)
         recs = ctx.profile_records()
-        peak = PEAK_BF16_MFMA_TFLOPS if name == "bf16" else PEAK_FP32_MFMA_TFLOPS
         shapes = {}
         for r_ in recs:
             row = shapes.setdefault((r_["tag"], r_["flops"], r_["bytes"]), {"shape": r_["tag"], "workgroups": r_["wgs"], "launches": 0, "ms": 0.0, "gflop_per_launch": r_["flops"] / 1e9,
@@ -216,8 +236,8 @@ def sweep_leg(dbm, ctx, g, crops=5):
         for row in sorted(shapes.values(), key=lambda q: -q["ms"]):
             row["avg_us"] = 1e3 * row["ms"] / row["launches"]
             row["tflops"] = row["gflop_per_launch"] * row["launches"] / row["ms"] if row["ms"] > 0 else 0.0
-            row["frac_of_fp32_mfma_peak" if (name == "fp32" or row["shape"].startswith(("deform", "x3_"))) else "frac_of_bf16_mfma_peak"] = \
-                row["tflops"] / (PEAK_FP32_MFMA_TFLOPS if (name == "fp32" or row["shape"].startswith(("deform", "x3_"))) else peak)
+            row["roof"], row["roof_tflops"] = sweep_roof(name, row["shape"])
+            row["frac_of_roof"] = row["tflops"] / row["roof_tflops"]
             row["algorithmic_gbps"] = row["algorithmic_bytes_per_launch"] * row["launches"] / (row["ms"] * 1e-3) / 1e9 if row["ms"] > 0 else 0.0
             rows.append({k: (round(v, 4) if isinstance(v, float) else v) for k, v in row.items()})
         res[name]["bracketed_ms"] = sum(r_["ms"] for r_ in recs)
@@ -246,6 +266,194 @@ def sweep_leg(dbm, ctx, g, crops=5):
     return res
 
 
+def resident_grid(dbm, ctx, r, c, h, w, lo, hi, band=100):
+    """A (1, c, h, w) float32 grid in HBM without a host copy of it: `band` rows of U[lo, hi) are drawn on the host, uploaded once
+    and replicated down the plane with device-to-device copies (the sweep's cost does not depend on the values; distinct rows
+    within a band keep the crops from being constant)."""
+    lib = dbm._lib.lib()
+    band = min(band, h)
+    src = dbm.to_device(r.uniform(lo, hi, (1, c, band, w)).astype(np.float32), ctx)
+    grid = dbm.DeviceArray((1, c, h, w), ctx)
+    for ch in range(c):
+        for y in range(0, h, band):
+            rows = min(band, h - y)
+            dbm._lib.check(lib.dbm_memcpy2d_d2d(ctx.handle, C.c_void_p(grid.ptr + 4 * ((ch * h + y) * w)), 4 * w,
+                                                C.c_void_p(src.ptr + 4 * (ch * band * w)), 4 * w, 4 * w, rows), ctx.handle)
+    ctx.synchronize()
+    return grid
+
+
+def continent_leg(dbm, ctx, args, rank, world, comm):
+    """BASELINE config 5: the whole-continent sweep of deepbedmap.py:689-741 -- 18000 x 22000 output pixels, 396 tiles of
+    1000 x 1000 (320 interior 288 x 288 crops, 72 edge, 4 corner) dealt round-robin to the ranks (predict_tiled_resident(rank,
+    world): every rank keeps the four grids resident, 10.7 GB, and writes its own tiles of its own canvas; no collective on the
+    data path), generator forward in bf16, eight equal-shape crops per forward.  One warm-up sweep, then `--steps` timed sweeps
+    (default 1 here) between barriers; the line's value is seconds per continent, max over ranks."""
+    import torch
+
+    S = dbm.Shape
+    k = max(1, args.sweep_scale)
+    H, W = 4500 // k, 5500 // k
+    final = S(y=4 * H, x=4 * W)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dem_model import dem_generator
+
+    g = dem_generator(dbm, seed=909)  # activations at the data's magnitude (metres), like a trained model's
+    r = np.random.RandomState(1 + rank)
+    grids = [resident_grid(dbm, ctx, r, 1, H, W, -2000, 2000), resident_grid(dbm, ctx, r, 1, 10 * H, 10 * W, -100, 4000, band=1000),
+             resident_grid(dbm, ctx, r, 2, 2 * H, 2 * W, -10, 1000, band=200), resident_grid(dbm, ctx, r, 1, H, W, 0, 500)]
+    n_tiles = len(dbm.tile_steps(final, S(y=1000, x=1000)))
+    mine = sum(len(v) for v in dbm.group_tiles_by_crop_shape(final, S(y=1000, x=1000), S(y=1000, x=1000), S(y=18, x=18), rank, world).values())
+    kw = dict(final_shape=final, dtype="bfloat16", download=False, crops_per_batch=8, rank=rank, world=world)
+    for i in range(max(1, args.warmup)):  # warm-up sweeps (the first also does the one-time >= 0 clip, deepbedmap.py:663-665)
+        canvas = dbm.predict_tiled_resident(g, *grids, clip=(i == 0), **kw)
+        del canvas
+    sweeps = max(1, args.steps)
+    if comm is not None:
+        comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(sweeps):
+        canvas = dbm.predict_tiled_resident(g, *grids, **kw)
+    torch.cuda.synchronize()
+    if comm is not None:
+        comm.barrier()
+    dt = (time.perf_counter() - t0) / sweeps
+    if comm is not None:
+        dt = comm.max_over_ranks(dt)
+    ok = True
+    if k > 1 or rank == 0:   # the rank's own tiles are finite, nothing else was written (checked on a corner block of the canvas)
+        blk = dbm.DeviceArray((1, min(final.y, 2152), min(final.x, 2152)), ctx)
+        dbm._lib.check(dbm._lib.lib().dbm_memcpy2d_d2d(ctx.handle, C.c_void_p(blk.ptr), 4 * blk.shape[2], C.c_void_p(canvas.ptr), 4 * final.x,
+                                                      4 * blk.shape[2], blk.shape[1]), ctx.handle)
+        a = blk.get()[0]
+        ok = bool(np.isnan(a[:76]).all() and np.isnan(a[:, :76]).all() and (np.isfinite(a[76:1076, 76:1076]).all() if rank == 0 else True))
+    if rank != 0:
+        return None
+    flop = 2.0 * G_FWD_MAC_PER_TILE / 81.0 * sum((h - 2) * (w - 2) * len(t) for (h, w), t in
+                                                  dbm.group_tiles_by_crop_shape(final, S(y=1000, x=1000), S(y=1000, x=1000), S(y=18, x=18)).items())
+    return {"metric": "whole-continent tiled inference sweep, seconds (bf16 generator forward, tiles resident in HBM)", "value": _r(dt),
+            "unit": "s", "n_gpus": world, "steps": sweeps, "warmup": max(1, args.warmup), "ms_per_step": _r(1e3 * dt), "higher_is_better": False, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"continent sweep {final.y} x {final.x} px, {n_tiles} tiles of 1000 x 1000, 12 RRDB, bf16 (BASELINE config 5)",
+                       "crops_per_forward": 8, "tiles_rank0": mine, "resident_gb_per_rank": _r(sum(4.0 * a.size for a in grids) / 1e9 + 4.0 * final.y * final.x / 1e9, 2),
+                       "parallelism": f"tiles round-robin over {world} ranks, no collective", "env": dbm_env()},
+            "s_per_continent": _r(dt), "ranks": world, "tiles_per_s": _r(n_tiles / dt, 2), "algorithmic_tflop": _r(flop / 1e12, 1),
+            "roofline": {"bound": "mfma", "achieved": _r(flop / dt / 1e12, 2), "peak": PEAK_BF16_MFMA_TFLOPS * world, "unit": "TFLOP/s",
+                         "frac": _r(flop / dt / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world)), "traffic": None},
+            "canvas_check_ok": ok}
+
+
+def dbm_env(environ=None):
+    """Every DBM_* variable of the environment (they select kernel variants / schedules; recorded in the line's config.env)."""
+    environ = os.environ if environ is None else environ
+    return {k: environ[k] for k in sorted(environ) if k.startswith("DBM_")}
+
+
+def refuse_work_skipping_env(environ=None):
+    """A measurement switch that skips work (libdbm_measure.so's ablations, or a library override) makes the timed region
+    something other than the training iteration: bench.py does not run with one set."""
+    bad = [k for k in dbm_env(environ) if k in WORK_SKIPPING_ENV]
+    if bad:
+        raise SystemExit(f"bench.py: refusing to run with work-skipping / library-override switches set: {bad}")
+
+
+def _r(v, n=4):
+    return round(v, n) if isinstance(v, float) else v
+
+
+def compose_line(*, tiles, dt, steps, warmup, world, batch, ev_ms, config, fam, traffic=None, comm_stats=None, sweep=None, shared=None,
+                 cpu=None, continent=None, tables_path=None, env=None):
+    """The ONE JSON line rank 0 prints, as a dict: scalars only (the per-shape tables of the run go to bench_tables.json and to
+    stderr).  `fam`: one dict per kernel family of the roofline leg (key, ms_per_step, launches_per_step, flop, bytes per step,
+    standalone_ms_per_step).  json.dumps of the result stays below MAX_LINE_BYTES (fit_line enforces it)."""
+    def tf(flop, ms):
+        return flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+    dom = max(fam, key=lambda f: f["ms_per_step"])  # the dominant kernel = most summed launch time in one step
+    n = max(dom["launches_per_step"], 1)
+    ach, ach_s = tf(dom["flop"], dom["ms_per_step"]), tf(dom["flop"], dom["standalone_ms_per_step"])
+    roof = {"bound": "mfma", "kernel": dom["key"], "achieved": _r(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": _r(ach / PEAK_FP32_MFMA_TFLOPS), "traffic": None,
+            "frac_standalone": _r(ach_s / PEAK_FP32_MFMA_TFLOPS), "achieved_standalone": _r(ach_s, 3),
+            "frac_step": _r(GFLOP_PER_TILE * batch * world / (dt / steps) / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world)),
+            "launches_per_step": dom["launches_per_step"], "avg_launch_us": _r(1e3 * dom["ms_per_step"] / n, 2),
+            "standalone_avg_launch_us": _r(1e3 * dom["standalone_ms_per_step"] / n, 2),
+            "algorithmic_gflop_per_launch": _r(dom["flop"] / n / 1e9), "algorithmic_bytes_per_launch": _r(dom["bytes"] / n, 0)}
+    if traffic is not None:
+        roof["traffic"] = traffic.get("hbm_bytes_per_launch")
+        if roof["traffic"]:
+            roof["traffic_over_algorithmic_bytes"] = _r(roof["traffic"] / max(dom["bytes"] / n, 1.0), 3)
+        roof["traffic_source"] = traffic.get("source")
+    roof["other_kernels"] = [{"kernel": f["key"], "ms": _r(f["ms_per_step"], 3), "ms_standalone": _r(f["standalone_ms_per_step"], 3),
+                              "launches": f["launches_per_step"], "frac": _r(tf(f["flop"], f["ms_per_step"]) / PEAK_FP32_MFMA_TFLOPS),
+                              "frac_standalone": _r(tf(f["flop"], f["standalone_ms_per_step"]) / PEAK_FP32_MFMA_TFLOPS)}
+                             for f in fam if f is not dom and f["launches_per_step"] > 0]
+    fwd = next((f for f in fam if f["key"] == "trunk_fused_kernel<helper>" and f["launches_per_step"] > 0), None) or \
+        next((f for f in fam if f["key"] == "trunk_fused_kernel<retained>" and f["launches_per_step"] > 0), None)
+    if fwd is not None:  # SURVEY 8d's second figure: the RRDB trunk forward of one 64-tile batch against the fp32 MFMA roof
+        k = max(fwd["launches_per_step"], 1)
+        roof["rrdb_forward"] = {"form": fwd["key"], "ms_per_batch": _r(fwd["standalone_ms_per_step"] / k),
+                                "frac_standalone": _r(tf(fwd["flop"], fwd["standalone_ms_per_step"]) / PEAK_FP32_MFMA_TFLOPS)}
+    out = {"metric": baseline_metric(), "value": _r(tiles / dt, 2), "unit": "tiles/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": _r(1e3 * dt / steps), "ms_per_step_hip_events": _r(ev_ms / steps), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": dict(config, env=dbm_env() if env is None else env), "roofline": roof}
+    if comm_stats is not None:
+        out["rccl_ranks"] = comm_stats.get("world")
+        out["config"]["gradient_exchange"] = comm_stats
+    if cpu is not None:
+        c = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample", "host_cpus", "cpu_model", "wall_s") if k in cpu}
+        c["value"] = _r(c["value"], 3)
+        if "torch_cpu" in cpu:
+            t = cpu["torch_cpu"]
+            c["torch_cpu"] = {"value": _r(t["value"], 2), "threads": t.get("threads"), "sample": t.get("sample")} if "value" in t else t
+        out["cpu_baseline"] = c
+    extras = {}
+    if sweep is not None:
+        if "error" in sweep:
+            extras["sweep"] = {"error": sweep["error"][:200]}
+        else:
+            sw = {"crop": sweep["crop"], "algorithmic_tflop_per_crop": _r(sweep["algorithmic_tflop_per_crop"])}
+            for name in ("fp32", "bf16"):
+                if name in sweep:
+                    sw[name] = {k: _r(sweep[name][k]) for k in ("ms_per_crop", "tflops", "frac_of_mfma_peak", "s_per_continent_one_gpu")}
+            if "batch8" in sweep.get("bf16", {}):
+                sw["bf16"]["batch8_ms_per_crop"] = _r(sweep["bf16"]["batch8"]["ms_per_crop"])
+            extras["sweep"] = sw
+    if continent is not None:
+        extras["continent"] = continent
+    if shared is not None:
+        extras["one_generator_forward"] = ({k: _r(shared[k]) for k in ("ms_per_step", "tiles_per_s")} if "error" not in shared
+                                           else {"error": shared["error"][:200]})
+    if extras:
+        out["extras"] = extras
+    if tables_path:
+        out["tables"] = os.path.relpath(tables_path, ROOT)
+    return out
+
+
+def fit_line(out, limit=MAX_LINE_BYTES):
+    """json.dumps(out), guaranteed below `limit` bytes: optional detail is dropped (least important first) until it fits."""
+    droppable = [("roofline", "traffic_source"), ("cpu_baseline", "sample"), ("cpu_baseline", "cpu_model"), ("extras", "one_generator_forward"),
+                 ("roofline", "other_kernels"), ("config", "env"), ("extras", "sweep"), ("extras", "continent"), ("config", "gradient_exchange")]
+    line = json.dumps(out, separators=(",", ":"))
+    dropped = []
+    for a, b in droppable:
+        if len(line.encode()) < limit:
+            break
+        if isinstance(out.get(a), dict) and b in out[a]:
+            if (a, b) == ("config", "env"):   # never silently: the NAMES of the switches stay
+                out[a][b] = sorted(out[a][b])
+            else:
+                del out[a][b]
+            dropped.append(f"{a}.{b}")
+            out["dropped_for_length"] = dropped
+            line = json.dumps(out, separators=(",", ":"))
+    assert len(line.encode()) < limit, len(line)
+    return line
+
+
 def spawn_ranks(n_gpus):
     """`python bench.py --gpus N` without a launcher: this process has not touched the GPU (torch is not even imported
     yet), so it starts N fresh children -- one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
@@ -264,7 +472,14 @@ def spawn_ranks(n_gpus):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    # a rank that dies leaves the others waiting in a collective or the rendezvous: end them (these exact children only)
+    # rank 0's pipe is drained by a thread WHILE the ranks run (a full pipe would block its write() and, behind it, every
+    # rank's final barrier); a rank that dies leaves the others waiting in a collective or the rendezvous: end them (these
+    # exact children only)
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     while True:
         codes = [p.poll() for p in procs]
         if all(c is not None for c in codes):
@@ -275,9 +490,9 @@ def spawn_ranks(n_gpus):
                     p.terminate()
             break
         time.sleep(0.1)
-    out, _ = procs[0].communicate()  # (rank 0 writes one JSON line: far below the pipe's capacity)
     codes = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    reader.join(timeout=30)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -316,8 +531,8 @@ def launcher_selftest(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200; 1 sweep with --sweep-continent)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 10; 1 sweep with --sweep-continent)")
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="tiles per GPU (BASELINE: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the inference leg (extras.sweep: ms per 288x288 crop, fp32 and bf16)")
@@ -346,7 +561,16 @@ def main():
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="no GPU work: the ranks only rendezvous over gloo on the CPU and rank 0 prints a JSON line "
                          "(tests/test_parallel_gloo.py drives the self-spawn path with it)")
+    ap.add_argument("--sweep-continent", action="store_true",
+                    help="BASELINE config 5 instead of the training iteration: the whole 18000 x 22000 sweep (396 tiles dealt round-robin "
+                         "to the ranks, grids resident in HBM, bf16), one compact line with s_per_continent")
+    ap.add_argument("--sweep-scale", type=int, default=1, help="--sweep-continent on a 1/k-scale area (tests)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 1 if args.sweep_continent else 200
+    if args.warmup is None:
+        args.warmup = 1 if args.sweep_continent else 10
+    refuse_work_skipping_env()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -379,8 +603,16 @@ def main():
     dbm._lib._default_ctx = ctx
     # multi-GPU: libdbm enqueues on the stream torch issues its RCCL collectives on (stream-ordered, no host waits);
     # single GPU: the context's own stream (torch.cuda.synchronize() below is device-wide)
-    if comm is not None:
+    if comm is not None and not args.sweep_continent:   # (the sweep has no collective: the group only carries barriers)
         comm.attach(ctx)
+
+    if args.sweep_continent:
+        line = continent_leg(dbm, ctx, args, rank, world, comm)
+        if rank == 0:
+            os.write(result_fd, (fit_line(line) + "\n").encode())
+        if comm is not None:
+            comm.barrier()
+        return
 
     np.random.seed(1234)  # identical initial weights on every rank (and broadcast below for good measure)
     g, g_opt, d, d_opt = dbm.compile_srgan_model(num_residual_blocks=N_RRDB, residual_scaling=0.1,
@@ -438,28 +670,20 @@ def main():
     dbm._lib.check(lib.dbm_profile_begin_serial(ctx.handle), ctx.handle)
     step()
     recs_s = ctx.profile_records()
-    FAMILIES = [
-        ("igemm_conv_kernel + the fused deformable-convolution GEMMs (per-layer conv forward + data gradient, v_mfma_f32_32x32x2_f32)", "igemm_conv_kernel"),
-        ("weight gradients (wgrad_wave_dma_kernel, wgrad_band_dma_kernel, wgrad_kernel)", "wgrad_kernel"),
-        ("trunk_fused_kernel (RRDB trunk forward of a retained pass, one persistent launch on 192 CUs, v_mfma_f32_32x32x2_f32)",
-         "trunk_fused_kernel"),
-        ("trunk_fused_bwd_kernel (RRDB trunk data-gradient chain, persistent, v_mfma_f32_16x16x4_f32)", "trunk_fused_bwd_kernel"),
-        ("trunk_fused_kernel, helper form (RRDB trunk forward of a pass that keeps nothing -- the D-step's fakes, inference: a fourth "
-         "workgroup per image takes half of conv_layer5, 256 CUs)", "trunk_fused_kernel"),
+    FAMILIES = [   # (key in the line, what it is) -- family index = KernelProfiler family (csrc/dbm_internal.h)
+        ("igemm_conv_kernel", "igemm_conv_kernel / igemm_pm_kernel + the fused deformable-convolution GEMMs: per-layer conv forward + data gradient, v_mfma_f32_32x32x2_f32"),
+        ("wgrad_kernel", "weight gradients: wgrad_wave_dma_kernel, wgrad_band_dma_kernel, wgrad_direct_kernel, wgrad_kernel"),
+        ("trunk_fused_kernel<retained>", "RRDB trunk forward of a retained pass, one persistent launch"),
+        ("trunk_fused_bwd_kernel", "RRDB trunk data-gradient chain, persistent"),
+        ("trunk_fused_kernel<helper>", "RRDB trunk forward of a pass that keeps nothing (the D-step's fakes, inference): a helper workgroup per image"),
     ]
     fam = []
-    for i, (label, key) in enumerate(FAMILIES):
+    for i, (key, label) in enumerate(FAMILIES):
         mine, mine_s = [r for r in recs if r["family"] == i], [r for r in recs_s if r["family"] == i]
-        ms, flop, byt, n = (sum(r["ms"] for r in mine), sum(r["flops"] for r in mine), sum(r["bytes"] for r in mine), len(mine))
-        ms_s = sum(r["ms"] for r in mine_s)
-        fam.append({"kernel": label, "key": key, "ms_per_step": ms, "launches_per_step": int(n),
-                    "avg_launch_us": 1e3 * ms / max(n, 1), "algorithmic_gflop_per_launch": flop / max(n, 1) / 1e9,
-                    "algorithmic_bytes_per_launch": byt / max(n, 1),
-                    "achieved": (flop / (ms * 1e-3) / 1e12) if ms > 0 else 0.0,
-                    "standalone_ms_per_step": ms_s, "standalone_avg_launch_us": 1e3 * ms_s / max(n, 1),
-                    "achieved_standalone": (flop / (ms_s * 1e-3) / 1e12) if ms_s > 0 else 0.0})
-    per_shape = shape_table(recs, recs_s, [k for _, k in FAMILIES])
-    dom = max(fam, key=lambda f: f["ms_per_step"])  # the dominant kernel = most summed launch time in one step
+        fam.append({"key": key, "label": label, "ms_per_step": sum(r["ms"] for r in mine), "launches_per_step": len(mine),
+                    "flop": sum(r["flops"] for r in mine), "bytes": sum(r["bytes"] for r in mine),
+                    "standalone_ms_per_step": sum(r["ms"] for r in mine_s)})
+    per_shape = shape_table(recs, recs_s, [k for k, _ in FAMILIES])
 
     # ---- inference leg (outside the timed region, rank 0 of a single-GPU run): BASELINE config 5's unit of work ----
     sweep = None
@@ -497,79 +721,38 @@ def main():
             shared = {"error": repr(e)}
 
     if rank == 0:
-        tiles = args.batch * world * args.steps
-        out = {
-            "metric": baseline_metric(),
-            "value": tiles / dt,
-            "unit": "tiles/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
-            "ms_per_step_hip_events": ev_ms.value / args.steps,  # start .. stop events on the main stream (rank 0)
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "full ESRGAN training iteration (D-step + G-step, fwd+bwd+Adam), 12 RRDB, "
-                                   "11x11 -> 36x36 tiles, fp32",
-                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}",
-                       "generator_forwards_per_iteration": 1 if args.share_generator_forward else 2,
-                       "g_step_forward_prefetched_under_d_step": bool(prefetch),
-                       "cudnn_deterministic": bool(dbm.global_config.cudnn_deterministic),
-                       "fused_iteration_call": bool(not args.no_fused_iteration and prefetch and
-                                                    (comm is None or (comm.exchanges_in_step(ctx) and not args.sync_batch_stats))),
-                       "metrics_read_back": "every minibatch" if args.sync_metrics else "once per run (device-resident log)",
-                       "sync_batch_stats": bool(args.sync_batch_stats and world > 1)},
-            "roofline": {
-                "bound": "mfma", "kernel": dom["kernel"],
-                "achieved": dom["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": dom["achieved"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                # the whole step against the same roof: SURVEY 8d's 8.43 GFLOP per tile (4 G_f + 7 D_f at 12 RRDB)
-                "step_algorithmic_gflop": GFLOP_PER_TILE * args.batch,
-                "frac_step": GFLOP_PER_TILE * args.batch * world / (dt / args.steps) / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world),
-                # the same launches with the device synchronised around each of them (nothing shares the chip): what
-                # `rocprofv3 --pmc`'s serialised kernel statistics under profiles/ show; `achieved` / `frac` above are the
-                # in-step figures (up to four streams overlap inside a bracket) and err low
-                "achieved_standalone": dom["achieved_standalone"],
-                "frac_standalone": dom["achieved_standalone"] / PEAK_FP32_MFMA_TFLOPS,
-                "standalone_avg_launch_us": dom["standalone_avg_launch_us"],
-                "launches_per_step": dom["launches_per_step"], "avg_launch_us": dom["avg_launch_us"],
-                "algorithmic_gflop_per_launch": dom["algorithmic_gflop_per_launch"],
-                "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                # every distinct launch shape of the step (tag = layer geometry): launches, standalone time, fraction of the fp32
-                # MFMA roof, algorithmic bytes and the HBM rate they imply -- sorted by standalone time
-                "per_shape": per_shape,
-                "other_kernels": [{k: f[k] for k in ("kernel", "achieved", "achieved_standalone", "ms_per_step", "standalone_ms_per_step",
-                                                     "launches_per_step", "avg_launch_us")}
-                                  for f in fam if f is not dom and f["launches_per_step"] > 0],
-                # SURVEY 8d's second figure: the RRDB trunk forward of one 64-tile batch against the fp32 MFMA roof (target
-                # >= 0.50 = 1.14 ms), standalone, in the form a forward-only pass runs
-                "rrdb_forward": (lambda f: {"ms_per_batch": f["standalone_ms_per_step"] / max(f["launches_per_step"], 1),
-                                            "achieved_standalone": f["achieved_standalone"],
-                                            "frac_standalone": f["achieved_standalone"] / PEAK_FP32_MFMA_TFLOPS,
-                                            "form": f["kernel"]})(fam[4] if fam[4]["launches_per_step"] > 0 else fam[2]),
-            },
-        }
+        config = {"workload": "full ESRGAN training iteration (D-step + G-step, fwd+bwd+Adam), 12 RRDB, 11x11 -> 36x36 tiles, fp32",
+                  "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                  "generator_forwards_per_iteration": 1 if args.share_generator_forward else 2,
+                  "g_step_forward_prefetched_under_d_step": bool(prefetch),
+                  "cudnn_deterministic": bool(dbm.global_config.cudnn_deterministic),
+                  "fused_iteration_call": bool(not args.no_fused_iteration and prefetch and
+                                               (comm is None or (comm.exchanges_in_step(ctx) and not args.sync_batch_stats))),
+                  "metrics_read_back": "every minibatch" if args.sync_metrics else "once per run",
+                  "sync_batch_stats": bool(args.sync_batch_stats and world > 1)}
+        dom_key = max(fam, key=lambda f: f["ms_per_step"])["key"]
+        traffic = None
         try:  # HBM bytes per launch of the dominant kernel: PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, from the committed pass
             with open(TRAFFIC_JSON) as f:
-                out["roofline"]["traffic"] = json.load(f)[dom["key"]]["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_over_algorithmic_bytes"] = out["roofline"]["traffic"] / max(dom["algorithmic_bytes_per_launch"], 1.0)
-                out["roofline"]["traffic_source"] = ("static: " + os.path.relpath(TRAFFIC_JSON, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / "
-                                                     "WRITE_SIZE in separate passes of this command; not measured in this run)")
+                traffic = {"hbm_bytes_per_launch": json.load(f)[dom_key.split("<")[0]]["hbm_bytes_per_launch"],
+                           "source": "static: " + os.path.relpath(TRAFFIC_JSON, ROOT) + " (rocprofv3 --pmc, separate passes; not this run)"}
         except Exception:
             pass
-        if comm_stats is not None:
-            out["config"]["gradient_exchange"] = comm_stats
-        if sweep is not None:
-            out["extras"] = {"sweep": sweep}
-        if shared is not None:
-            out.setdefault("extras", {})["one_generator_forward"] = shared
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        cpu = cpu_baseline() if (not args.no_cpu_baseline and world == 1) else None
+        tables = {"families": fam, "per_shape": per_shape, "sweep": sweep, "one_generator_forward": shared, "cpu_baseline": cpu,
+                  "note": "per_shape: every distinct launch shape of the step (tag = layer geometry), sorted by standalone time"}
+        tables_path = None
+        try:
+            with open(TABLES_PATH, "w") as f:
+                json.dump(tables, f, indent=1)
+            tables_path = TABLES_PATH
+        except OSError:
+            pass
+        print("bench tables: " + json.dumps(tables), file=sys.stderr, flush=True)
+        out = compose_line(tiles=args.batch * world * args.steps, dt=dt, steps=args.steps, warmup=args.warmup, world=world, batch=args.batch,
+                           ev_ms=ev_ms.value, config=config, fam=fam, traffic=traffic, comm_stats=comm_stats, sweep=sweep, shared=shared,
+                           cpu=cpu, tables_path=tables_path)
+        os.write(result_fd, (fit_line(out) + "\n").encode())
     if comm is not None:
         comm.barrier()
 

@@ -11,6 +11,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdbm.so")
+# Measurement tools only (tools/README.md): DBM_LIB=<path>/libdbm_measure.so loads the -DDBM_MEASURE build, whose work-skipping
+# ablation switches the product library does not contain.  bench.py refuses to run with DBM_LIB set.
+MEASURE_LIB_PATH = os.path.join(_HERE, "libdbm_measure.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 DEVICE_PTRS = 1
@@ -147,12 +150,19 @@ def lib():
     """The loaded library with argtypes set.  Raises if libdbm.so has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATH
+        override = os.environ.get("DBM_LIB")
+        if override:
+            if os.path.basename(override) != "libdbm_measure.so" or not os.path.exists(override):
+                raise DbmError(f"DBM_LIB={override}: only an existing libdbm_measure.so (tools/build_measure.sh) may replace libdbm.so")
+            path = override
+        if not os.path.exists(path):
             raise DbmError(
-                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or make -C deepbedmap_amd/csrc).  deepbedmap_amd has no CPU fallback."
             )
-        l = C.CDLL(LIB_PATH)
+        l = C.CDLL(path)
+        l._dbm_path = path
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args

@@ -4,14 +4,10 @@
 
 static thread_local std::string g_last_error;
 
-// (every entry point first lets the context's stream wait for the tail of the last dbm_train_iteration -- the G-step's
-// detached discriminator pass and the metrics, which that call leaves running on chain[0]; dbm_train_iteration itself
-// orders its streams against the tail one by one and says so with g_in_train_iteration)
-static thread_local bool g_in_train_iteration = false;
 #define DBM_API_BEGIN(ctxptr) \
   dbm_ctx* _ectx = (ctxptr);  \
-  try {                       \
-    if (_ectx && _ectx->tail_pending && !g_in_train_iteration) _ectx->join_tail(_ectx->stream);
+  (void)_ectx;                \
+  try {
 // ---- a persistent trunk kernel that gives up (bounded spins: another process starving the GPU, a partitioned device) ----
 // It raises the context's error word (host-mapped) and a STICKY device flag.  While the flag is up, every kernel that commits
 // training state is a no-op: the optimizer launches (gated ONCE per launch by adam_gate_kernel, so an update is all or
@@ -166,15 +162,7 @@ int dbm_init(int hip_device, dbm_ctx** out) {
     DBM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     DBM_HIP(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least));
   }
-  {  // chain[1] carries the generator's own forward and backward pass in dbm_train_iteration -- the iteration's critical
-     // path: DBM_PF_PRIORITY=1 gives it the highest stream priority (measurement knob)
-    static const int pf_prio = getenv("DBM_PF_PRIORITY") ? atoi(getenv("DBM_PF_PRIORITY")) : 0;
-    int least = 0, greatest = 0;
-    DBM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    DBM_HIP(hipStreamCreateWithFlags(&c->chain[0], hipStreamNonBlocking));
-    if (pf_prio) DBM_HIP(hipStreamCreateWithPriority(&c->chain[1], hipStreamNonBlocking, greatest));
-    else DBM_HIP(hipStreamCreateWithFlags(&c->chain[1], hipStreamNonBlocking));
-  }
+  for (auto& st : c->chain) DBM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   for (auto& e : c->ev_fork) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   DBM_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   DBM_HIP(hipHostMalloc((void**)&c->dev_err, sizeof(int), hipHostMallocMapped));
@@ -211,8 +199,6 @@ int dbm_shutdown(dbm_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->ev_iter)
     if (e) (void)hipEventDestroy(e);
-  if (ctx->ev_tail) (void)hipEventDestroy(ctx->ev_tail);
-  if (ctx->ev_dadam) (void)hipEventDestroy(ctx->ev_dadam);
   if (ctx->ev_persist) (void)hipEventDestroy(ctx->ev_persist);
   if (ctx->ev_comm) (void)hipEventDestroy(ctx->ev_comm);
   if (ctx->ev_comm_done) (void)hipEventDestroy(ctx->ev_comm_done);
@@ -1202,51 +1188,27 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   float* lf_eval = gf + N;  // logits of the G-step's eval-mode pass (lf / gf are still being read by the backward passes)
   if (!c->ev_iter[0]) for (auto& e : c->ev_iter) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (!g->ev_prefetch) DBM_HIP(hipEventCreateWithFlags(&g->ev_prefetch, hipEventDisableTiming));
-  if (!c->ev_tail) {
-    DBM_HIP(hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming));
-    DBM_HIP(hipEventCreateWithFlags(&c->ev_dadam, hipEventDisableTiming));
-  }
-  // The iteration's TAIL -- the discriminator's weight repack, the G-step's detached eval-mode discriminator pass on the
-  // fakes (:1228-1237) and the metrics -- only feeds the metrics row: it goes to chain[0] behind the discriminator's update
-  // and the call returns with the main stream at the generator's update, so that the NEXT iteration's generator forward
-  // does not queue behind it (it used to run on the main stream, beside the trunk's weight gradients, in the last and
-  // most contended millisecond of the iteration).  What the next iteration shares with it -- BatchNorm's running
-  // averages and the discriminator's slot-1 activations, the twin's fakes, the loss scratch -- is ordered by ev_tail.
-  // MEASURED (round 3, same box, 100 iterations each): 8.37 / 8.37 ms with the tail on the main stream, 8.40 / 8.44 ms with the
-  // tail on chain[0], 8.44 / 8.46 with chain[1] at the highest stream priority on top (DBM_PF_PRIORITY=1; 8.36 / 8.39 with the
-  // priority alone): the iteration is bound by the chip's throughput, not by the order of its streams -- so the default stays
-  // DBM_ITER_TAIL=0 (the tail on the main stream, as in round 2) and this path remains as the measured alternative.
-  static const int tail_aside = getenv("DBM_ITER_TAIL") ? atoi(getenv("DBM_ITER_TAIL")) : 0;
-  const bool prev_tail = c->tail_pending;   // the previous iteration's tail may still be running
+  // (The iteration's tail -- the discriminator's weight repack, the G-step's detached eval-mode discriminator pass and the
+  // metrics -- runs on the main stream.  Moving it to chain[0], forking the twin's forward early and raising chain[1]'s stream
+  // priority were all measured in round 3 and lost: profiles/README.md, "schedule experiments".)
   struct Scope {  // every helper below enqueues on ctx->stream / reads the exchange switches: restore them whatever happens
     dbm_ctx* c; hipStream_t s; Discriminator* d; Generator* t = nullptr;
     ~Scope() {
       c->stream = s; c->comm_in_step = false; c->comm_defer = false; c->comm_stream = nullptr; c->comm_pending.clear();
       d->merge_slots = false;
-      g_in_train_iteration = false;
       if (t) { t->grads_cleared = false; t->use_aux = true; t->max_split = 2; }
     }
   } scope{c, s, d};
-  g_in_train_iteration = true;
   c->comm_in_step = dp;
   c->comm_stream = dp ? c->chain[0] : nullptr;
   DBM_MARK(s, "D:begin");
   // ---- D(real) forward on the side stream, underneath the generator forward (:1145) ----
   c->fork_to_side(0);
-  if (prev_tail) DBM_HIP(hipStreamWaitEvent(c->side, c->ev_tail, 0));  // (its eval-mode pass reads the running averages this one updates)
   c->stream = c->side;
   d->forward(N, H4, W4, Y, lr, true, true, 0);
   c->stream = s;
-  // The G-step's own forward (below, on chain[1]) depends on the generator's weights and the inputs only -- not on the fakes
-  // of the D-step's forward.  DBM_TWIN_EARLY=1: chain[1] is forked from the main stream HERE, behind the weight repack, instead of
-  // behind the whole first forward: its input block then runs as soon as the first forward's persistent trunk kernel lets go of
-  // the CUs, and its own trunk launch follows directly (persistent launches are serialised among themselves), instead of
-  // waiting for the first forward's upsampling and deformable layers.  MEASURED (round 3, 2 x 80 iterations each): 8.72 / 8.73 ms
-  // against 8.22 / 8.23 with the fork behind the first forward -- the second trunk launch then takes 192 CUs while the first
-  // forward's tail and the whole D(fake) pass still have to run on the other 64, and the discriminator chain (forward, backward,
-  // weight gradients, update) is what the iteration's tail waits for.  Default 0.
-  static const int twin_early = getenv("DBM_TWIN_EARLY") ? atoi(getenv("DBM_TWIN_EARLY")) : 0;
-  if (twin_early || one_fwd) {
+  // (The G-step's own forward goes to chain[1] behind the first forward; one_fwd: it is the only forward, forked here.)
+  if (one_fwd) {
     g->ensure_packed();
     c->fork(s, pf, 6);
   }
@@ -1258,8 +1220,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   scope.t = t;
   t->ensure_ws(N, H, W, true);
   t->max_split = 1;
-  if (!twin_early && !one_fwd) c->fork(s, pf, 6);
-  if (prev_tail) DBM_HIP(hipStreamWaitEvent(pf, c->ev_tail, 0));  // (the tail reads the twin's fakes and the loss scratch)
+  if (!one_fwd) c->fork(s, pf, 6);
   c->stream = pf;
   t->forward(N, H, W, X, W1, W2, W3, t->yout.p, true);
   DBM_HIP(hipEventRecord(g->ev_prefetch, pf));  // the twin's fakes are final (the G-step's eval-mode discriminator pass reads them)
@@ -1267,8 +1228,6 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   t->max_split = 2;
   // ---- D(fake) forward, RaGAN loss, cleargrads (:1146-1162) ----
   c->join_side();
-  if (prev_tail) DBM_HIP(hipStreamWaitEvent(s, c->ev_tail, 0));  // (the tail's pass used the slot-1 activation buffers)
-  c->tail_pending = false;
   if (one_fwd) DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));  // (the fakes are the retained forward's, written on chain[1])
   d->forward(N, H4, W4, one_fwd ? t->yout.p : g->yout.p, lf, true, true, 1);
   launch_ragan_loss(lr, lf, N, 1, 0, metrics, gr, gf, s);
@@ -1316,32 +1275,16 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   c->stream = s;
   // ---- discriminator update (:1164), then the G-step's detached eval-mode discriminator pass (:1228-1237) ----
   adam_update_impl(d, gscale);
-  hipStream_t tl = tail_aside ? c->chain[0] : s;
-  if (dp && tail_aside) {  // (chain[0] is also the exchange stream: the generator's last bucket is marked BEFORE the tail joins it)
-    c->comm_join(s);
-    DBM_MARK(s, "G:gradients_exchanged");
-  }
-  if (tail_aside) {
-    DBM_HIP(hipEventRecord(c->ev_dadam, s));
-    DBM_HIP(hipStreamWaitEvent(tl, c->ev_dadam, 0));  // (chain[0]: behind the fake-batch backward pass and the exchange)
-  }
-  DBM_HIP(hipStreamWaitEvent(tl, g->ev_prefetch, 0));  // the twin's fakes (written on chain[1]: nothing else orders this read)
-  c->stream = tl;
-  d->forward(N, H4, W4, t->yout.p, lf_eval, false, false, 1);  // (repacks the updated weights first, on `tl`)
-  DBM_HIP(hipStreamWaitEvent(tl, c->ev_iter[0], 0));  // the loss scratch was cleared on chain[1]
+  DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));  // the twin's fakes (written on chain[1]: nothing else orders this read)
+  d->forward(N, H4, W4, t->yout.p, lf_eval, false, false, 1);  // (repacks the updated weights first)
+  DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[0], 0));  // the loss scratch was cleared on chain[1]
   gen_loss_adv(c, nullptr, lf_eval, N, 0, 1);
-  if (tail_aside) {
-    gen_loss_finish(c, N, H4, W4, weights, metrics + 2);
-    DBM_HIP(hipEventRecord(c->ev_tail, tl));
-    c->tail_pending = true;
-  }
-  c->stream = s;
   DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[1], 0));  // generator backward (and its weight gradients) done
-  if (dp && !tail_aside) {
+  if (dp) {
     c->comm_join(s);  // ... and its last bucket summed over ranks
     DBM_MARK(s, "G:gradients_exchanged");
   }
-  if (!tail_aside) gen_loss_finish(c, N, H4, W4, weights, metrics + 2);
+  gen_loss_finish(c, N, H4, W4, weights, metrics + 2);
   DBM_MARK(s, "G:generator_backward_joined");
   adam_update_impl(g, gscale);  // (:1257)
   DBM_API_END

@@ -55,7 +55,9 @@ struct ClConvArgs {
   int act; float slope;
   int N, H, W, nslots, tilesX, tilesY;
   const void* zeros;                 // >= 16 bytes of device zeros (out-of-plane pixels of the halo block)
-  int abl;                           // measurement aid (DBM_CL16_ABL; results wrong): 1 no MFMA loop, 2 no epilogue, 4 no staging after chunk 0
+#ifdef DBM_MEASURE
+  int abl;                           // libdbm_measure.so only (results wrong): 1 no MFMA loop, 2 no epilogue, 4 no staging after chunk 0
+#endif
   // Dense-block mode (nlayers = 4: conv_layer1..4 of a ResidualDenseBlock in ONE launch, x == y16 == the block's concat
   // buffer): layer l reads channels [0, Cin + 32 l) and writes [Cin + 32 l, + 32); wl / bl = the layers' weights and biases.
   // Every workgroup must be resident (grid <= CUs): a tile waits for its eight neighbours' previous layer through `flags`
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   // in the epilogue.
   auto compute = [&](auto BUF) {
     constexpr int buf = decltype(BUF)::value;
-    if (!has0 || (a.abl & 1)) return;
+    if (!has0 || DBM_ABL_BIT(a, 1)) return;
     const unsigned char* ab = smem + buf * ACT_BYTES;
     const unsigned char* wb = smem + WGT0 + buf * W_BYTES + lane * 16;
     bf16x8 fa[3][MT], fb0[3], fb1[3];
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   }
   // chunk c is computed from buffer c & 1 while chunk c + 1 lands in the other one (two chunks per trip: the buffer
   // offsets are compile-time constants, so that hipcc can tell the DMA's destination from the fragment reads' source)
-  for (int c = 0; c < ((a.abl & 4) ? 1 : nchunk); c += 2) {
+  for (int c = 0; c < (DBM_ABL_BIT(a, 4) ? 1 : nchunk); c += 2) {
     // Dense-block mode: only the NEWEST chunk is staged past the L2 (sc1).  A 128-byte line of the concat buffer is one pixel's
     // 64 channels = the outputs of two layers (c1 | c2, c3 | c4), written by the pixel's owner in two steps; a reader's first
     // access to the line is the sc1 load of its first half, its second the sc1 load of the second half -- a coherent load
@@ -291,12 +293,12 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
 
   // ---- epilogue ----
   // The accumulators hold (pixel = lane & 31, channels 4 (lane >> 5) + 8 (reg >> 2) + (reg & 3)): stored from there, a wave
-  // instruction touches 32 pixels x 16 bytes -- thirty-two 16-byte pieces 384 / 256 bytes apart; measured (DBM_CL16_ABL) the
+  // instruction touches 32 pixels x 16 bytes -- thirty-two 16-byte pieces 384 / 256 bytes apart; measured (libdbm_measure.so) the
   // epilogue was 4.4 of the 14 us of a 64 -> 32 layer and 7+ of conv_layer5's.  So every patch goes through LDS once (the staging
   // buffers are free: all wavefronts have passed the last chunk's barrier; a wavefront only reads back what it wrote itself) and
   // leaves with the lanes of a pixel side by side: 8 MT lanes x 16 bytes = a pixel's whole 128 / 256-byte run per residual load
   // and fp32 store, its 64 / 128 bytes of bf16 per store, four or eight neighbouring pixels per instruction.
-  if (a.abl & 2) return;
+  if (DBM_ABL_BIT(a, 2)) return;
   if (has0 && !has1) {  // (one patch: even steps went to acc[0], odd steps to acc[1])
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -762,33 +764,24 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   a.N = L.N; a.H = L.H; a.W = L.W;
   const int MT = L.Cout / 32;
   a.tilesX = (L.W + CL_TW - 1) / CL_TW;
-  // Layers with one output-channel tile in launches of several rounds (crops batched per forward): tiles of at most eight
-  // patches, 78 KB of LDS, TWO workgroups per CU (DBM_CL16_SMALL: 0 never -- the default --, 1 whenever the layer has one tile,
-  // 2 from three workgroups per CU on).  MEASURED (288 x 288 crops, 1 / 2 / 4 / 8 per forward): 5.95 / 5.87 / 5.81 / 5.44 ms per crop
-  // with one workgroup per CU, 6.04 / 6.31 / 5.80 / 5.52 with mode 2: a second resident workgroup buys nothing -- the LDS fragment
-  // reads of the CU, not one workgroup's latencies, are what the layer waits for.
-  const int small_mode = getenv("DBM_CL16_SMALL") ? atoi(getenv("DBM_CL16_SMALL")) : 0;   // (read per call: tests toggle it)
-  bool small = false;
-  if (MT == 1 && small_mode && L.nlayers <= 1) {
-    const int ns8 = cl16_choose_slots(L.N, L.H, L.W, n_cus, 8, 2);
-    const long wgs8 = (long)L.N * a.tilesX * ((L.H + 2 * ns8 - 1) / (2 * ns8));
-    small = small_mode == 1 || wgs8 >= 3L * n_cus;
-    if (small) a.nslots = ns8;
-  }
-  if (!small) a.nslots = cl16_choose_slots(L.nlayers > 1 ? 1 : L.N, L.H, L.W, n_cus);   // (dense-block mode: one image's tiles fill the chip)
+  // (Tiles of at most eight patches with two workgroups per CU were measured in round 3 and bought nothing: the LDS fragment
+  //  reads of the CU, not one workgroup's latencies, are what a layer waits for.)
+  a.nslots = cl16_choose_slots(L.nlayers > 1 ? 1 : L.N, L.H, L.W, n_cus);   // (dense-block mode: one image's tiles fill the chip)
   a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
-  size_t lds = 2 * (size_t)cl_act_bytes(small ? 8 : CL_MAXSLOTS) + 2 * (size_t)18 * MT * 1024;
+  size_t lds = 2 * (size_t)cl_act_bytes(CL_MAXSLOTS) + 2 * (size_t)18 * MT * 1024;
   if (L.nlayers > 1) lds += (size_t)CL_MAXSLOTS * 32 * 36 * sizeof(float);   // the transpose tile's own region (dense-block mode)
   a.zeros = L.zeros;
-  static const int abl = getenv("DBM_CL16_ABL") ? atoi(getenv("DBM_CL16_ABL")) : 0;
+#ifdef DBM_MEASURE
+  static const int abl = DBM_MEASURE_ENV("CL16_ABL");
   a.abl = abl;
+#endif
   a.nlayers = L.nlayers > 1 ? L.nlayers : 1;
   for (int i = 0; i < 4; ++i) { a.wl[i] = (const bf16x8*)L.wl[i]; a.bl[i] = L.bl[i]; }
   a.flags = L.flags; a.flag_base = L.flag_base; a.err = L.err; a.err_dev = L.err_dev;
   a.ngroup = 1;
   if (L.nlayers > 1) {
     const long tiles = (long)a.tilesX * a.tilesY;
-    DBM_CHECK(L.nlayers == 4 && MT == 1 && !small && L.x == L.y16 && L.y0 == L.Cin && L.flags && L.err && L.err_dev && tiles <= n_cus,
+    DBM_CHECK(L.nlayers == 4 && MT == 1 && L.x == L.y16 && L.y0 == L.Cin && L.flags && L.err && L.err_dev && tiles <= n_cus,
               "cl16 dense-block mode: four 32-channel layers on one concat buffer, every workgroup resident");
     a.ngroup = (int)std::min<long>(L.N, std::max<long>(1, n_cus / tiles));   // images in flight; the others follow in the same workgroups
   }
@@ -797,7 +790,6 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   if (!attr) {
     DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1, CL_MAXSLOTS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<2, CL_MAXSLOTS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1, CL_MAXSLOTS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
@@ -814,8 +806,6 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   }
   if (a.nlayers > 1)
     hipLaunchKernelGGL((conv_cl16_kernel<1, CL_MAXSLOTS, true>), dim3(grid), dim3(CL_NT), lds, s, a);
-  else if (small)
-    hipLaunchKernelGGL((conv_cl16_kernel<1, 8, false>), dim3(grid), dim3(CL_NT), lds, s, a);
   else if (MT == 1)
     hipLaunchKernelGGL((conv_cl16_kernel<1, CL_MAXSLOTS, false>), dim3(grid), dim3(CL_NT), lds, s, a);
   else

@@ -1,5 +1,22 @@
 // Internal declarations shared by the HIP translation units of libdbm.so (gfx950 only).
 #pragma once
+// Measurement switches that SKIP work (results are then wrong) exist only in libdbm_measure.so (make MEASURE=1, built by
+// tools/build_measure.sh with -DDBM_MEASURE): in the product library the queries below are the constant 0, the branches behind
+// them are compiled out and the switch names do not occur in the binary.
+//   dbm_abl_skip(): bit mask of kernel classes that are NOT launched (1 BatchNorm, 4 Adam, 8 pair folds, 32 linear layers,
+//                   128 few-channel convs, 256 im2col, 512 per-layer implicit GEMMs): what a class costs INSIDE the step
+//   DBM_MEASURE_ENV(name): atoi of an environment switch (weight gradients off, chain / cl16 kernel ablations, no repack)
+#include <cstdlib>
+#ifdef DBM_MEASURE
+inline int dbm_measure_env(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
+#define DBM_MEASURE_ENV(name) dbm_measure_env("DBM_" name)
+#define DBM_ABL_BIT(a, m) ((a).abl & (m))
+#else
+#define DBM_MEASURE_ENV(name) 0
+#define DBM_ABL_BIT(a, m) false
+#endif
+inline int dbm_abl_skip() { static const int v = DBM_MEASURE_ENV("ABL_SKIP"); return v; }
+
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

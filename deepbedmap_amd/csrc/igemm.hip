@@ -697,273 +697,6 @@ static bool igemm_tap_skip(const ConvDesc& d) {
 constexpr int IGEMM_NPB = 6;  // channel pairs a wavefront may hold entirely in registers (T = 9 -> 54 VGPRs)
 
 
-// ----------------------------------------------------------------------------------------------------------------------
-// LDS-staged form for 3x3, unit-stride, pad-1 layers on planes of >= 9 columns (forward and data gradient; the nearest x2
-// resize folded into the staging): round 3.  The form above takes both operands straight from L2 / L1 and stops at ~0.5 of
-// the MFMA rate inside its K loop (measured with Cin swept at fixed grids: 36 x 36, 64 -> 64: 25 us fixed + 1.10 us per
-// input channel = 87 TFLOP/s in the loop) and re-reads the activations once per output-channel tile.  Here a workgroup of NT
-// wavefronts owns 32 NT consecutive output positions (flattened over images and rows) x 32 MT output channels:
-//   * the input rows of a chunk of KC = 8 channels are staged ONCE into zero-framed LDS planes [channel][row][W + 2] (the
-//     rows of the tile in order, one zero row between two images, a halo row above and below), so that the B operand of a
-//     tap is ONE ds_read_b32 with an immediate column offset from one of three per-lane row bases -- no border logic, no
-//     per-tap gather;
-//   * the chunk's weights [tap][channel][32 MT] are staged once per workgroup and read by all its wavefronts;
-//   * a wavefront owns one position tile x MT output-channel tiles over the WHOLE K: no split-K, no reduction, the
-//     accumulators leave through igemm_epilogue_ns (bias, residuals, mask, accumulate, LeakyReLU as above);
-//   * chunks are double buffered: the global loads of chunk c + 1 are issued before the MFMAs of chunk c and written to
-//     the other buffer after them; one barrier per chunk.
-// FLIP: the data gradient's tap order (tap t reads (a + 1 - t / 3, b + 1 - t % 3)) -- not instantiated: forward layers only.
-// ----------------------------------------------------------------------------------------------------------------------
-typedef float il_f4 __attribute__((ext_vector_type(4)));
-constexpr int IL_MAXCPT = 3;        // staged plane cells per thread and channel (launcher: ncells <= IL_MAXCPT * threads)
-
-struct IgLdsGeo {
-  int NT, rows_total, ncells, lrows;   // wavefronts (= position tiles of 32) per workgroup, N * OH, cells per LDS plane, its rows
-  long total;                          // output positions N * OH * OW
-};
-
-template <int MT, bool FLIP, int KC>
-__global__ __launch_bounds__(512) void igemm_lds_kernel(const ConvDesc d, const IgLdsGeo g) {
-  extern __shared__ __attribute__((aligned(16))) float il_smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, kh = lane >> 5;
-  const int nthreads = g.NT * 64;
-  const int OH = d.OHl, OW = d.OWl, PW = OW + 2;
-  const int Bsz = KC * g.ncells;                     // floats of one activation buffer
-  constexpr int Asz = 9 * KC * 32 * MT;              // ... of one weight buffer
-  float* Bbuf = il_smem;                             // [2][Bsz]
-  float* Abuf = il_smem + 2 * Bsz;                   // [2][Asz]
-  // the tile: 32 NT consecutive output positions (n, a, b) flattened; g0 / glast = its first / last output row (n * OH + a)
-  const long P0 = (long)blockIdx.x * 32 * g.NT;
-  const long P1 = (P0 + 32 * g.NT < g.total ? P0 + 32 * g.NT : g.total) - 1;
-  const int g0 = (int)(P0 / OW), glast = (int)(P1 / OW);
-  const int n0 = g0 / OH;
-  const int cout0 = blockIdx.y * 32 * MT;
-  auto lrow_of = [&](int gr) { return (gr - g0) + (gr / OH - n0) + 1; };   // LDS row of global row gr (gr >= 0)
-
-  // ---- staging plan of this thread: cells tid + k * nthreads of a plane -> element offset of the pixel inside channel 0 of
-  // its image (+ image offset), or -1 (frame column, zero row between two images, halo row outside the image) ----
-  long coff[IL_MAXCPT];
-  {
-    const int a0 = g0 - n0 * OH, rem0 = OH - a0;     // rows of image n0 from the tile's first row on
-#pragma unroll
-    for (int k = 0; k < IL_MAXCPT; ++k) {
-      coff[k] = -1;
-      const int cell = tid + k * nthreads;
-      if (cell < g.ncells) {
-        const int lr = cell / PW, bcol = cell - lr * PW - 1;
-        // LDS row lr -> global row: rows of image n0 first (lr - 1 = offset from g0; -1 = the halo row above), then per
-        // further image one zero row followed by its OH rows
-        int gr = -1;
-        const int e = lr - 1;
-        if (e < rem0) gr = (e >= 0 || a0 > 0) ? g0 + e : -1;
-        else {
-          const int f = e - rem0;                      // 0 = the zero row behind image n0
-          if (f >= 1) {
-            const int img = (f - 1) / (OH + 1), r = (f - 1) - img * (OH + 1);
-            if (r < OH) gr = (n0 + 1 + img) * OH + r;
-          }
-        }
-        // (a halo row belongs to the plane only if it lies in the image of the adjacent tile row)
-        const bool ok = gr >= 0 && gr < g.rows_total && bcol >= 0 && bcol < OW &&
-                        ((gr >= g0 - 1 && gr <= glast) || (gr == glast + 1 && gr / OH == glast / OH));
-        if (ok) {
-          const int n = gr / OH, a = gr - n * OH;
-          coff[k] = (long)n * d.xsn + (long)(a >> d.ups) * d.Win + (bcol >> d.ups);
-        }
-      }
-    }
-  }
-  // weights: float4 pieces e = tid + k * nthreads of the chunk's [9][KC][32 MT] block (rows of 32 MT consecutive output channels)
-  constexpr int APIECES = 9 * KC * 8 * MT;
-  constexpr int AG_MAX = (APIECES + 127) / 128;      // (at least two wavefronts per workgroup)
-  const long wtap = (long)d.Cin * d.CoutP;
-
-  // Every load of the staging is UNCONDITIONAL (cells outside the image read a zero word with stride 0, surplus weight
-  // pieces re-read the last one): conditional loads cut the body into basic blocks at whose joins hipcc waits with vmcnt(0)
-  // -- one exposed memory round trip per pair of loads in the first version.
-  const float* bsrc[IL_MAXCPT];
-  long bstride[IL_MAXCPT];
-#pragma unroll
-  for (int k = 0; k < IL_MAXCPT; ++k) {
-    bsrc[k] = coff[k] >= 0 ? d.x + coff[k] : d.zeros;
-    bstride[k] = coff[k] >= 0 ? (long)d.xsc : 0L;
-  }
-  const float* asrc[AG_MAX];
-#pragma unroll
-  for (int k = 0; k < AG_MAX; ++k) {
-    int e = tid + k * nthreads;
-    e = e < APIECES ? e : APIECES - 1;
-    const int row = e / (8 * MT), q4 = e - row * (8 * MT);     // row = t * KC + kc
-    const int t = row / KC, kc = row - t * KC;
-    asrc[k] = d.wp + t * wtap + (long)kc * d.CoutP + cout0 + 4 * q4;
-  }
-  float bst[IL_MAXCPT][KC];
-  il_f4 ast[AG_MAX];
-  auto issue = [&](int c0) {
-#pragma unroll
-    for (int k = 0; k < IL_MAXCPT; ++k) {
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) bst[k][kc] = bsrc[k][(long)(c0 + kc) * bstride[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < AG_MAX; ++k) ast[k] = *reinterpret_cast<const il_f4*>(asrc[k] + (long)c0 * d.CoutP);
-  };
-  auto commit = [&](int buf) {
-    float* B = Bbuf + buf * Bsz;
-    float* A = Abuf + buf * Asz;
-#pragma unroll
-    for (int k = 0; k < IL_MAXCPT; ++k) {
-      const int cell = tid + k * nthreads;
-      if (cell < g.ncells) {
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc) B[kc * g.ncells + cell] = bst[k][kc];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < AG_MAX; ++k) {
-      const int e = tid + k * nthreads;
-      if (e < APIECES) *reinterpret_cast<il_f4*>(A + 4 * e) = ast[k];
-    }
-  };
-
-  // ---- this lane's output position ----
-  const long P = P0 + 32 * wave + j;
-  const bool pv = P <= P1;
-  const int gr = pv ? (int)(P / OW) : g0;
-  const int b = pv ? (int)(P - (long)gr * OW) : 0;
-  const int n = gr / OH, a = gr - n * OH;
-  const int lr = lrow_of(gr);
-  // B operand: cell (lr - 1 + ky) * PW + b + kx of plane kh (+ 2 kp planes)
-  int rowbase[3];
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky) rowbase[ky] = kh * g.ncells + (lr - 1 + ky) * PW + b;
-  const int abase = kh * 32 * MT + j;     // A operand: [(t * KC + 2 kp + kh)][32 mt + j]
-
-  f32x16 acc[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
-  const int nchunk = d.Cin / KC;
-  issue(0);
-  commit(0);
-  __syncthreads();
-  constexpr int NS = 9 * (KC / 2);   // steps of a chunk: (channel pair kp, tap t)
-  for (int c = 0; c < nchunk; ++c) {
-    const int buf = c & 1;
-    if (c + 1 < nchunk) issue((c + 1) * KC);
-    __builtin_amdgcn_sched_barrier(0);
-    const float* B = Bbuf + buf * Bsz;
-    const float* A = Abuf + buf * Asz + abase;
-    // operands of step s + 2 are requested before the MFMAs of step s (ring of three register sets, compile-time slots):
-    // hipcc otherwise puts every ds_read right in front of its MFMA behind an lgkmcnt(0)
-    float rb[3], ra[3][MT];
-    auto ld = [&](int st, int slot) {
-      const int kp = st / 9, t = st - 9 * kp;
-      const int ky = FLIP ? 2 - t / 3 : t / 3, kx = FLIP ? 2 - t % 3 : t % 3;
-      rb[slot] = B[rowbase[ky] + kp * 2 * g.ncells + kx];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) ra[slot][m] = A[((t * KC + 2 * kp) * 32 * MT) + 32 * m];
-    };
-    ld(0, 0);
-    ld(1, 1);
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
-      if (st + 2 < NS) ld(st + 2, (st + 2) % 3);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[st % 3][m], rb[st % 3], acc[m], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (c + 1 < nchunk) commit(buf ^ 1);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-    if (cout0 + 32 * m < d.Cout) igemm_epilogue_ns(d, acc[m], kh, pv, n, a, b, cout0 + 32 * m, d.oy0, d.ox0);
-}
-
-// Tile choice: NT position tiles (= wavefronts) per workgroup and the chunk depth KC, by the work on the busiest CU
-// (workgroups are dealt round-robin) x a penalty for fewer than three wavefronts per SIMD.  Returns false if the layer does
-// not qualify.
-static bool igemm_lds_plan(const ConvDesc& d, IgLdsGeo& g, int& MT, bool& flip, int& KC, size_t& lds) {
-  // OFF by default: measured (round 3, batch 64, standalone, best NT x KC per shape against the form above) 36 x 36 64 -> 64:
-  // 89.7 vs 92.9 us; 18 x 18 64 -> 128: 63.1 vs 50.5; 18 x 18 128 -> 64: 71.1 vs 53.2; 9 x 9 128 -> 128: 66.3 vs 34.9 -- the K loop
-  // does run at the MFMA rate (ISA: exact lgkmcnt counts, two reads per two MFMAs), but a workgroup must hold 26-61 KB of LDS, so
-  // 2-3 wavefronts share a SIMD, the chunk barrier drains them together, and 330-1300 workgroups quantise badly over 256 CUs;
-  // the direct form's 2592 small workgroups at four per SIMD balance better.  Kept as DBM_IGEMM_LDS=1 (parity-green).
-  const int enabled = getenv("DBM_IGEMM_LDS") ? atoi(getenv("DBM_IGEMM_LDS")) : 0;   // (read per call: tests toggle it)
-  if (!enabled || d.wp16 || d.T != 9 || d.sin != 1 || d.so != 1 || d.nphase > 1 || d.Cin % 8 != 0) return false;
-  if (d.OHl != (d.Hin << d.ups) || d.OWl != (d.Win << d.ups) || d.OWl < 9 || d.OWp != d.OWl) return false;
-  bool fwd = true, rev = true;
-  for (int t = 0; t < 9; ++t) {
-    fwd = fwd && d.dy[t] == t / 3 - 1 && d.dx[t] == t % 3 - 1;
-    rev = rev && d.dy[t] == 1 - t / 3 && d.dx[t] == 1 - t % 3;
-  }
-  // (forward layers only: the data-gradient tap order -- FLIP -- was not brought to parity before the form was shelved)
-  (void)rev;
-  if (!fwd) return false;
-  flip = false;
-  const long rows_total = (long)d.N * d.OHl;
-  const long positions = rows_total * d.OWl;
-  const long min_pos = getenv("DBM_IGEMM_LDS_MINPOS") ? atol(getenv("DBM_IGEMM_LDS_MINPOS")) : 4096;
-  if (positions < min_pos || rows_total >= (1L << 30)) return false;
-  static const int force_nt = getenv("DBM_IGEMM_LDS_NT") ? atoi(getenv("DBM_IGEMM_LDS_NT")) : 0;
-  static const int force_kc = getenv("DBM_IGEMM_LDS_KC") ? atoi(getenv("DBM_IGEMM_LDS_KC")) : 0;
-  MT = (d.CoutP % 64 == 0 && d.Cout > 32) ? 2 : 1;
-  const int cgroups = (d.Cout + 32 * MT - 1) / (32 * MT);
-  const int PW = d.OWl + 2;
-  double best = 1e300;
-  int bestNT = 0, bestKC = 0;
-  for (int NT = 2; NT <= 8; ++NT) {
-    if (force_nt && NT != force_nt) continue;
-    const int rmax = (32 * NT + d.OWl - 2) / d.OWl + 1;          // output rows a tile can touch
-    const int lrows = rmax + 2 + (rmax - 1) / d.OHl + 1;
-    const int ncells = lrows * PW;
-    if (ncells > IL_MAXCPT * NT * 64) continue;
-    for (int kc = 4; kc <= 8; kc += 4) {
-      if (force_kc && kc != force_kc) continue;
-      const size_t bytes = 2 * ((size_t)kc * ncells + 9 * kc * 32 * MT) * sizeof(float);
-      if (bytes > 64 * 1024) continue;
-      int per_cu = (int)std::min<size_t>(160 * 1024 / bytes, (size_t)(2048 / (64 * NT)));
-      if (per_cu > 8) per_cu = 8;
-      const long wgs = (positions + 32 * NT - 1) / (32 * NT) * cgroups;
-      const long on_cu = (wgs + 255) / 256;                       // workgroups of the busiest CU over the whole launch
-      const double resident = (double)std::min<long>(per_cu, on_cu) * NT / 4.0;   // wavefronts per SIMD while it is busy
-      const double occ_pen = resident >= 3.0 ? 1.0 : (resident >= 2.0 ? 1.15 : 1.5);
-      const double chunk_pen = kc == 4 ? 1.05 : 1.0;              // (twice the barriers and staging rounds)
-      const double cost = ((double)on_cu * NT * MT) * occ_pen * chunk_pen + 0.5 * ((on_cu + per_cu - 1) / per_cu);
-      if (cost < best - 1e-12) { best = cost; bestNT = NT; bestKC = kc; }
-    }
-  }
-  if (!bestNT) return false;
-  const int rmax = (32 * bestNT + d.OWl - 2) / d.OWl + 1;
-  g.NT = bestNT;
-  g.rows_total = (int)rows_total;
-  g.total = positions;
-  g.lrows = rmax + 2 + (rmax - 1) / d.OHl + 1;
-  g.ncells = g.lrows * PW;
-  KC = bestKC;
-  lds = 2 * ((size_t)KC * g.ncells + 9 * KC * 32 * MT) * sizeof(float);
-  return true;
-}
-
-template <int MT, bool FLIP>
-static void launch_igemm_lds_kc(const ConvDesc& d, const IgLdsGeo& g, int KC, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
-  if (KC == 4) hipLaunchKernelGGL((igemm_lds_kernel<MT, FLIP, 4>), grid, block, lds, s, d, g);
-  else hipLaunchKernelGGL((igemm_lds_kernel<MT, FLIP, 8>), grid, block, lds, s, d, g);
-}
-static long igemm_lds_wgs(const ConvDesc& d, const IgLdsGeo& g, int MT) {
-  return (g.total + 32 * g.NT - 1) / (32 * g.NT) * ((d.Cout + 32 * MT - 1) / (32 * MT));
-}
-static void launch_igemm_lds(const ConvDesc& d, const IgLdsGeo& g, int MT, bool flip, int KC, size_t lds, hipStream_t s) {
-  const dim3 grid((unsigned)((g.total + 32 * g.NT - 1) / (32 * g.NT)), (unsigned)((d.Cout + 32 * MT - 1) / (32 * MT)));
-  const dim3 block(64 * g.NT);
-  (void)flip;
-  if (MT == 2) launch_igemm_lds_kc<2, false>(d, g, KC, grid, block, lds, s);
-  else launch_igemm_lds_kc<1, false>(d, g, KC, grid, block, lds, s);
-}
 
 template <int T, int WAVES, bool ROW>
 static void launch_twr(const ConvDesc& d, dim3 grid, hipStream_t s, bool mt2) {
@@ -1079,7 +812,7 @@ static const std::map<IgemmKey, IgemmForce>& igemm_overrides() {
 }
 
 void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
-  { static const bool abl = getenv("DBM_ABL_SKIP") && (atoi(getenv("DBM_ABL_SKIP")) & 512); if (abl) return; }  // measurement aid
+  if (dbm_abl_skip() & 512) return;  // (libdbm_measure.so only)
   ConvDesc d = d_in;
   d.ksplit = 1;
   const int nph = d.nphase > 1 ? d.nphase : 1;
@@ -1103,28 +836,6 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   DBM_CHECK(d.Cin % 32 == 0, "igemm: Cin must be a multiple of 32");
   DBM_CHECK(d.CoutP % 32 == 0 && d.Cout <= d.CoutP, "igemm: bad CoutP");
   DBM_CHECK(d.T == 1 || d.T == 4 || d.T == 9 || d.T == 16, "igemm: tap count must be 1, 4, 9 or 16");
-  {  // 3x3 unit-stride layers on planes of >= 9 columns: the LDS-staged form
-    IgLdsGeo lg;
-    int MT = 1, KC = 8;
-    bool flip = false;
-    size_t lds = 0;
-    if (igemm_lds_plan(d, lg, MT, flip, KC, lds)) {
-      if (g_profiler.enabled) {
-        double bytes = 4.0 * ((double)d.N * d.Cin * d.Hin * d.Win + flop_positions * d.Cout + (double)d.T * d.Cin * d.CoutP);
-        if (d.r1) bytes += 4.0 * flop_positions * d.r1_nch;
-        if (d.r2) bytes += 4.0 * flop_positions * d.Cout;
-        if (d.mask) bytes += 4.0 * flop_positions * (d.Cout - d.mask_c0);
-        if (d.accumulate) bytes += 4.0 * flop_positions * d.Cout;
-        char tag[40];
-        snprintf(tag, sizeof(tag), "c%d>%d_k9_%dx%d%s_lds", d.Cin, d.Cout, d.Hin, d.Win, d.ups ? "u" : "");
-        g_profiler.begin(s, 0, 2.0 * flop_positions * d.Cout * d.Cin * d.T, bytes, tag, igemm_lds_wgs(d, lg, MT));
-      }
-      launch_igemm_lds(d, lg, MT, flip, KC, lds, s);
-      if (g_profiler.enabled) g_profiler.end(s);
-      DBM_HIP(hipGetLastError());
-      return;
-    }
-  }
   {  // the deep discriminator layers (planes of <= 4 x 4): position-major tiles, live taps only (igemm_pm_kernel)
     const int pm_enable = getenv("DBM_IGEMM_PM") ? atoi(getenv("DBM_IGEMM_PM")) : 1;          // (read per call: A/B in one process)
     const int pm_target = getenv("DBM_IGEMM_PM_KSTARGET") ? atoi(getenv("DBM_IGEMM_PM_KSTARGET")) : 512;

@@ -1,9 +1,6 @@
 // Launchers of the non-GEMM kernels (misc.hip, norm_loss.hip).
 #pragma once
 #include <cstdlib>
-// measurement aid: DBM_ABL_SKIP bit mask of kernel classes that are NOT launched (1 BatchNorm, 4 Adam, 8 pair folds, 32 linear
-// layers, 128 few-channel convs, 256 im2col): what a class costs INSIDE the step.  Results are then wrong.
-inline int dbm_abl_skip() { static const int v = getenv("DBM_ABL_SKIP") ? atoi(getenv("DBM_ABL_SKIP")) : 0; return v; }
 #include "dbm_internal.h"
 
 struct SmallConvDesc {

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void smallcin_conv_fwd_kernel(const SmallConvD
 }
 
 void launch_smallcin_conv_fwd(const SmallConvDesc& d, hipStream_t s) {
-  if (dbm_abl_skip() & 128) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
+  if (dbm_abl_skip() & 128) return;  // (libdbm_measure.so only)
   DBM_CHECK(d.Cout % 8 == 0, "smallcin conv: Cout must be a multiple of 8");
   const long total = (long)d.N * d.OH * d.OW;
   dim3 grid((unsigned)((total + 63) / 64), (unsigned)((d.Cout + 31) / 32));
@@ -199,7 +199,7 @@ size_t smallcin_wgrad_scratch_floats(int Cout) { return (size_t)SCW_SLICES * Cou
 
 void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dysn, float* gW, float* gb,
                                 hipStream_t s, float* scratch) {
-  if (dbm_abl_skip() & 128) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
+  if (dbm_abl_skip() & 128) return;  // (libdbm_measure.so only)
   const int K = d.Cin * d.KH * d.KW;
   if (scratch && K <= 9 && (long)d.N * d.OH * d.OW >= 16384) {
     if (d.Cin == 1 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Cout % SCW_OG == 0)
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
 
 void launch_im2col(const float* x, float* col, int N, int Cin, int Hin, int Win, int KH, int KW, int stride, int OH, int OW,
                    int KP, hipStream_t s) {
-  if (dbm_abl_skip() & 256) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
+  if (dbm_abl_skip() & 256) return;  // (libdbm_measure.so only)
   const long total = (long)N * KP * OH * OW;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;

@@ -49,16 +49,6 @@ struct dbm_ctx {
   hipEvent_t ev_comm = nullptr, ev_comm_done = nullptr;
   hipEvent_t ev_timer[2] = {nullptr, nullptr};  // dbm_timer
   hipEvent_t ev_iter[2] = {nullptr, nullptr};   // dbm_train_iteration: loss scratch cleared / generator backward done
-  // dbm_train_iteration leaves its tail -- the discriminator's weight repack, the G-step's detached eval-mode discriminator
-  // pass and the metrics -- on chain[0] and returns with the main stream at the generator's update: ev_tail fires when the
-  // tail is done.  Everybody who touches what it reads or writes waits for it first (join_tail; DBM_API_BEGIN does it for
-  // every other entry point).
-  hipEvent_t ev_tail = nullptr, ev_dadam = nullptr;
-  bool tail_pending = false;
-  void join_tail(hipStream_t s) {
-    if (tail_pending && ev_tail) (void)hipStreamWaitEvent(s, ev_tail, 0);
-    if (s == stream) tail_pending = false;
-  }
   // The persistent trunk kernels need every workgroup of a launch resident at once: two of them on different streams, each
   // holding part of the chip, would wait for each other's compute units until their spin limits.  Every persistent launch
   // therefore waits for the previous one (whatever its stream) and leaves its own completion here.

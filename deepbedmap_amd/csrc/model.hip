@@ -218,7 +218,7 @@ static void build_pack_table(const dbm_model& m, bool want_lazy, PackJob** d_job
 
 void dbm_model::ensure_packed(hipStream_t on) {
   if (!packed_dirty) return;
-  static const int abl_nopack = getenv("DBM_ABL_NOPACK") ? atoi(getenv("DBM_ABL_NOPACK")) : 0;  // measurement aid (results wrong)
+  static const int abl_nopack = DBM_MEASURE_ENV("ABL_NOPACK");  // (libdbm_measure.so only; results wrong)
   if (pack_tables_built && type == 1 && (abl_nopack & 1)) { packed_dirty = false; return; }
   if (pack_tables_built && type == 0 && (abl_nopack & 6)) {
     hipStream_t s2 = on ? on : ctx->stream;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NT) void bn_train_fwd_kernel(const float* __restric
 void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* inv_std,
                          float* avg_mean, float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
                          hipStream_t s, const int* hold) {
-  if (dbm_abl_skip() & 1) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
+  if (dbm_abl_skip() & 1) return;  // (libdbm_measure.so only)
   if (plane >= 64 && C <= 256)
     hipLaunchKernelGGL(bn_train_fwd_kernel<1024>, dim3(C), dim3(1024), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean,
                        avg_var, N, C, plane, eps, decay, slope, hold);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void bn_eval_fwd_kernel(const float* __restric
 
 void launch_bn_eval_fwd(const float* z, float* y, const float* gamma, const float* beta, const float* avg_mean,
                         const float* avg_var, int N, int C, int plane, float eps, float slope, hipStream_t s) {
-  if (dbm_abl_skip() & 1) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
+  if (dbm_abl_skip() & 1) return;  // (libdbm_measure.so only)
   const long total = (long)N * C * plane;
   hipLaunchKernelGGL(bn_eval_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, y, gamma, beta,
                      avg_mean, avg_var, total, C, plane, eps, slope);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT) void bn_train_bwd_kernel(const float* __restric
 void launch_bn_train_bwd(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
                          const float* inv_std, float* gz, float* ggamma, float* gbeta, float* scratch, int N, int C,
                          int plane, float slope, hipStream_t s) {
-  if (dbm_abl_skip() & 1) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
+  if (dbm_abl_skip() & 1) return;  // (libdbm_measure.so only)
   (void)scratch;
   if (plane >= 64 && C <= 256)
     hipLaunchKernelGGL(bn_train_bwd_kernel<1024>, dim3(C), dim3(1024), 0, s, z, gh, gamma, beta, mean, inv_std, gz, ggamma,
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 
 void launch_linear_fwd(const float* x, const float* W, const float* b, float* y, int N, int K, int O, int act,
                        float slope, hipStream_t s) {
-  if (dbm_abl_skip() & 32) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
+  if (dbm_abl_skip() & 32) return;  // (libdbm_measure.so only)
   hipLaunchKernelGGL(linear_fwd_kernel, dim3((N * O + 3) / 4), dim3(256), 0, s, x, W, b, y, N, K, O, act, slope);
   DBM_HIP(hipGetLastError());
 }
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict
 
 void launch_linear_bwd(const float* x, const float* W, const float* gy, const float* y_act, float* gx, float* gW,
                        float* gb, int N, int K, int O, float slope, hipStream_t s) {
-  if (dbm_abl_skip() & 32) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
+  if (dbm_abl_skip() & 32) return;  // (libdbm_measure.so only)
   const int total = N * K + O * K + O;
   hipLaunchKernelGGL(linear_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, s, x, W, gy, y_act, gx, gW, gb, N, K, O,
                      slope);
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 void launch_adam(float* p, const float* g, float* m, float* v, long n, float alpha_t, float one_minus_beta1,
                  float one_minus_beta2, float eps, float gscale, hipStream_t s, const int* skip, int* skipped) {
-  if (dbm_abl_skip() & 4) return;  // measurement aid DBM_ABL_SKIP (results then wrong)
+  if (dbm_abl_skip() & 4) return;  // (libdbm_measure.so only)
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   const int* gate = nullptr;

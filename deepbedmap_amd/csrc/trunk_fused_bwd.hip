@@ -62,7 +62,9 @@ struct Args {
   float rs, slope;
   unsigned off_xcc;  // XCC_ID table of the handshake (granule offset inside inbox)
   int local_st;
-  int abl;  // measurement aid (DBM_TFB_ABL): 1 = no halo exchange, 2 = no epilogue, 4 = every weight unit re-reads the same (cache-hot) address (results are then wrong)
+#ifdef DBM_MEASURE
+  int abl;  // libdbm_measure.so only: 1 = no halo exchange, 2 = no epilogue, 4 = every weight unit re-reads the same (cache-hot) address (results are then wrong)
+#endif
 };
 
 struct Wave {
@@ -232,14 +234,14 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
       }
     }
     issue_unit(nxt, W.wp, lane);
-    if (!(a.abl & 4)) W.wp += BUNIT;  // (abl 4: every unit re-reads the same weights -- always cache-hot; results wrong)
+    if (!DBM_ABL_BIT(a, 4)) W.wp += BUNIT;  // (abl 4: every unit re-reads the same weights -- always cache-hot; results wrong)
     __builtin_amdgcn_sched_barrier(0);
     mma_unit(cur, breg + u * QU * 4 * CS, u + 1 < NU ? breg + (u + 1) * QU * 4 * CS : -1, bq0, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- epilogue: this lane's four cells ----
-  if (a.abl & 2) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); return; }
+  if (DBM_ABL_BIT(a, 2)) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); return; }
   const float sc = third ? a.rs * a.rs : a.rs;
   const float r1s = third ? a.rs : 1.f;
   const unsigned tag_out = ((unsigned)a.epoch << 12) | (unsigned)(serial + 1);
@@ -287,7 +289,7 @@ template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[AU], float (
   // the block that becomes final in this layer feeds the next one: its sub-tiles (the highest channels) go first
   constexpr int NCH = KL == 0 ? 64 : 32;
   const int plane0 = KL == 0 ? dlow_region : Q0 + 32 * (KL - 1) * CS;
-  const bool fetch = !(KL == 0 && j == a.j0) && !(a.abl & 1);
+  const bool fetch = !(KL == 0 && j == a.j0) && !DBM_ABL_BIT(a, 1);
   HaloReq<NCH> hq;
   // the first quad's nine B operands are the same for all of this wavefront's sub-tiles of the layer: requested once
   float bfirst[9];
@@ -465,8 +467,10 @@ void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s) {
   }
   a.nrdb = L.nrdb; a.j0 = L.j0; a.j1 = L.j1; a.nimg = L.nimg; a.img0 = L.img0; a.epoch = L.epoch & 0xFFFFF;
   a.rs = L.rs; a.slope = L.slope;
-  static const int abl = getenv("DBM_TFB_ABL") ? atoi(getenv("DBM_TFB_ABL")) : 0;
+#ifdef DBM_MEASURE
+  static const int abl = DBM_MEASURE_ENV("TFB_ABL");
   a.abl = abl;
+#endif
   a.off_xcc = (unsigned)trunk_fused_xcc_offset(64);
   a.local_st = trunk_local_stores();
   const int grid = ((L.nimg + 7) / 8) * 24;

@@ -1832,8 +1832,8 @@ static void launch_dma(K kernel, const WgradPlan* plans, const int* starts, int 
 }
 
 void WgradBatch::launch(hipStream_t s) {
-  // measurement aid (tools/phases.py): DBM_NO_WGRAD=1 times the data-gradient chains alone (gradients are then wrong)
-  static const bool skip_all = getenv("DBM_NO_WGRAD") && atoi(getenv("DBM_NO_WGRAD")) != 0;
+  // libdbm_measure.so only (tools/phases.py): the data-gradient chains alone (gradients are then wrong)
+  static const bool skip_all = DBM_MEASURE_ENV("NO_WGRAD") != 0;
   if (skip_all) return;
   if (built && (built_deterministic != g_wgrad_deterministic || built_cleared != cleared_target)) {  // mode switched: re-plan (keeps the descriptors)
     std::vector<WgradDesc> keep = descs;
@@ -1868,7 +1868,7 @@ void WgradBatch::launch(hipStream_t s) {
     else if (g == 8) launch_dma(wgrad_direct_kernel<2>, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
     else launch_dma(wgrad_1x1_kernel, d_plans[g], d_starts[g], nplans[g], total_wg[g], lds[g], s, 256);
     if (fold_wgs[g]) {
-      static const bool abl_fold = getenv("DBM_ABL_SKIP") && (atoi(getenv("DBM_ABL_SKIP")) & 8);  // measurement aid
+      static const bool abl_fold = (dbm_abl_skip() & 8) != 0;  // (libdbm_measure.so only)
       if (pair_mode[g]) {
         if (!abl_fold)
           hipLaunchKernelGGL(wgrad_pair_fold_kernel, dim3(fold_wgs[g]), dim3(256), 0, s, d_plans[g], d_starts[g] + nplans[g] + 1, nplans[g]);

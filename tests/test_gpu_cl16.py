@@ -68,29 +68,6 @@ def test_cl16_conv_matches_oracle_on_rounded_operands(dbm, N, Cc, H, W, O, lrelu
     assert err < 2e-5, err
 
 
-def test_cl16_two_workgroups_per_cu_variant_is_bitwise_the_default(dbm):
-    """DBM_CL16_SMALL=1: tiles of at most eight patches, 78 KB of LDS, two workgroups per CU (conv_cl16_kernel<1, 8>) -- a measured,
-    switched-off alternative; the same arithmetic per output pixel, so bit for bit the default's result."""
-    d, _lib, ctx = dbm
-    rs = np.random.RandomState(5)
-    N, Cc, H, W, O = 3, 96, 70, 53, 32
-    x = rs.normal(size=(N, Cc, H, W)).astype(np.float32)
-    w = (rs.normal(size=(O, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(np.float32)
-    b = rs.normal(size=(O,)).astype(np.float32)
-    dx, dw, db = d.to_device(x), d.to_device(w), d.to_device(b)
-    out = []
-    for mode in (None, "1"):
-        if mode:
-            os.environ["DBM_CL16_SMALL"] = mode
-        try:
-            y = d.DeviceArray((N, O, H, W))
-            _lib.check(_lib.lib().dbm_op_conv2d_cl16(ctx.handle, dx.ptr, dw.ptr, db.ptr, None, 1.0, y.ptr, N, Cc, H, W, O, 1), ctx.handle)
-            out.append(y.get())
-        finally:
-            os.environ.pop("DBM_CL16_SMALL", None)
-    assert np.array_equal(out[0], out[1])
-
-
 def test_cl16_trunk_equals_the_per_layer_bf16_path(dbm):
     """GeneratorModel.forward in the bf16 sweep mode with the trunk on conv_cl16 (default) against the same mode on the
     per-layer implicit GEMM (DBM_CL16=0): both round the same operands at the same places (the dense block's activations

@@ -296,34 +296,6 @@ def test_deform_conv_premultiplied_form_at_dem_range(dbm, O):
     assert rel(y.get(), ref) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(3, 64, 36, 36, 64, 0), (2, 64, 18, 18, 128, 0), (5, 128, 9, 9, 32, 0), (2, 64, 18, 18, 64, 1), (1, 32, 40, 37, 18, 0)])
-def test_lds_staged_conv_form(dbm, shape):
-    """DBM_IGEMM_LDS=1: the LDS-staged form of the 3x3 unit-stride convolution (igemm_lds_kernel: flattened position tiles,
-    zero-framed planes with a zero row between images, weights staged per workgroup, no split-K) -- measured against the direct
-    form and left switched off; the forward pass against the oracle, incl. the folded nearest x2 resize,
-    tiles that straddle images and an output-channel count that is not a multiple of 32."""
-    import os
-
-    d, _lib, ctx = dbm
-    N, Cc, H, W, O, ups = shape
-    rs = np.random.RandomState(sum(shape))
-    x = rs.normal(size=(N, Cc, H, W)).astype(np.float32)
-    w = (rs.normal(size=(O, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(np.float32)
-    b = rs.normal(size=(O,)).astype(np.float32)
-    xu = ops.upsample_nearest2(x) if ups else x
-    ref = ops.conv2d(xu, w, b, 1, 1)
-    os.environ["DBM_IGEMM_LDS"] = "1"
-    os.environ["DBM_IGEMM_LDS_MINPOS"] = "1"
-    try:
-        y = d.DeviceArray(ref.shape)
-        dx, dw, db = dev(d, x), dev(d, w), dev(d, b)
-        _lib.check(_lib.lib().dbm_op_conv2d(ctx.handle, dx.ptr, dw.ptr, db.ptr, y.ptr, N, Cc, H, W, O, 3, 1, 1, ups, 0), ctx.handle)
-        assert rel(y.get(), ref) < TOL
-    finally:
-        os.environ.pop("DBM_IGEMM_LDS", None)
-        os.environ.pop("DBM_IGEMM_LDS_MINPOS", None)
-
-
 def _random_deform_cases(seed, n):
     rs = np.random.RandomState(seed)
     return [(int(rs.randint(1, 4)), int(rs.randint(1, 30)), int(rs.randint(1, 30)), int(rs.choice([1, 2, 5, 16, 64])), float(rs.choice([0.2, 1.5, 6.0])))

@@ -128,3 +128,99 @@ def test_bench_shape_table_aggregates_profiler_records():
     assert abs(conv["frac_mfma_standalone"] - conv["tflops_standalone"] / bench.PEAK_FP32_MFMA_TFLOPS) < 1e-3
     assert abs(conv["algorithmic_gbps_standalone"] - 2 * 4.0e7 / 0.17e-3 / 1e9) < 1.0
     assert rows[0]["kernel"] == "trunk_fused_kernel"
+
+
+def _canned_bench_inputs():
+    fam = [{"key": "igemm_conv_kernel", "label": "x" * 150, "ms_per_step": 5.61234567, "launches_per_step": 72, "flop": 134.8e9, "bytes": 1.55e9,
+            "standalone_ms_per_step": 2.94123},
+           {"key": "wgrad_kernel", "label": "y" * 90, "ms_per_step": 3.9, "launches_per_step": 13, "flop": 138.3e9, "bytes": 0.9e9, "standalone_ms_per_step": 2.26},
+           {"key": "trunk_fused_kernel<retained>", "label": "", "ms_per_step": 1.286, "launches_per_step": 1, "flop": 89.44e9, "bytes": 1.8e8,
+            "standalone_ms_per_step": 1.257},
+           {"key": "trunk_fused_bwd_kernel", "label": "", "ms_per_step": 1.551, "launches_per_step": 1, "flop": 89.44e9, "bytes": 2.0e8,
+            "standalone_ms_per_step": 1.536},
+           {"key": "trunk_fused_kernel<helper>", "label": "", "ms_per_step": 1.019, "launches_per_step": 1, "flop": 89.44e9, "bytes": 1.8e8,
+            "standalone_ms_per_step": 1.047}]
+    mode = lambda ms: {"ms_per_crop": ms, "tflops": 1707.0 / ms, "frac_of_mfma_peak": 0.1191, "mfma_peak_tflops": 2500.0, "compulsory_gbs": 12.3,
+                       "s_per_continent_one_gpu": 0.396 * ms, "bracketed_ms": ms * 1.1, "per_shape_standalone": [{"shape": "cl16_c64>32_286x286_n1"}] * 40}
+    sweep = {"crop": [288, 288], "output": [1144, 1144], "algorithmic_tflop_per_crop": 1.7071, "compulsory_bytes_per_crop": 5.7e7, "crops_timed": 5,
+             "fp32": mode(19.9), "bf16": dict(mode(5.73), batch8={"ms_per_crop": 5.36, "tflops": 318.0, "frac_of_mfma_peak": 0.127,
+                                                                 "s_per_continent_one_gpu": 2.12})}
+    cpu = {"value": 1.0412345, "unit": "tiles/s", "cores": 64, "kind": "port", "host_cpus": 256, "cpu_model": "AMD EPYC 9575F 64-Core Processor",
+           "blas_threads": 64, "measured_s": [15.4, 15.2], "sample": "2 full iteration(s) ..." + "z" * 120, "wall_s": 61.0,
+           "torch_cpu": {"value": 13.6, "unit": "tiles/s", "threads": 64, "sample": "torch 2.10 CPU fp32 ..." + "w" * 80}}
+    config = {"workload": "full ESRGAN training iteration (D-step + G-step, fwd+bwd+Adam), 12 RRDB, 11x11 -> 36x36 tiles, fp32",
+              "batch_per_gpu": 64, "global_batch": 64, "parallelism": "dp1", "generator_forwards_per_iteration": 2,
+              "g_step_forward_prefetched_under_d_step": True, "cudnn_deterministic": True, "fused_iteration_call": True,
+              "metrics_read_back": "once per run", "sync_batch_stats": False}
+    return dict(tiles=64 * 200, dt=1.6288, steps=200, warmup=10, world=1, batch=64, ev_ms=1628.1, config=config, fam=fam,
+                traffic={"hbm_bytes_per_launch": 57.0e6, "source": "static: profiles/r4/traffic_pmc.json (rocprofv3 --pmc, separate passes; not this run)"},
+                sweep=sweep, shared={"ms_per_step": 7.46, "tiles_per_s": 8579.1, "steps": 40, "note": "n" * 500}, cpu=cpu,
+                tables_path="/root/repo/bench_tables.json")
+
+
+def test_bench_line_is_short_and_complete():
+    """The driver keeps an 8 KB tail of stdout: the ONE JSON line must stay below 4 KB and still carry everything the contract
+    names (round 3's 30 KB line was unreadable to it).  Built from canned measurements -- no GPU."""
+    import json
+
+    import bench
+
+    out = bench.compose_line(env={"DBM_IGEMM_WAVES": "8"}, **_canned_bench_inputs())
+    line = bench.fit_line(out)
+    assert len(line.encode()) < bench.MAX_LINE_BYTES == 4096, len(line)
+    assert "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert "dropped_for_length" not in d
+    assert d["config"]["workload"] and d["config"]["env"] == {"DBM_IGEMM_WAVES": "8"}
+    assert abs(d["value"] - 64 * 200 / 1.6288) < 0.01 and abs(d["ms_per_step"] - 8.144) < 1e-3
+    rf = d["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_standalone", "frac_step", "traffic", "traffic_over_algorithmic_bytes",
+              "rrdb_forward", "other_kernels"):
+        assert k in rf, k
+    assert rf["kernel"] == "igemm_conv_kernel" and rf["bound"] == "mfma" and rf["peak"] == bench.PEAK_FP32_MFMA_TFLOPS
+    assert abs(rf["achieved"] - 134.8 / 5.61234567) < 1e-2 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert abs(rf["frac_standalone"] - 134.8 / 2.94123 / 157.3) < 1e-3
+    assert abs(rf["frac_step"] - 8.43 * 64 / 8.144 / 157.3) < 1e-3
+    assert rf["rrdb_forward"]["form"] == "trunk_fused_kernel<helper>" and abs(rf["rrdb_forward"]["frac_standalone"] - 89.44 / 1.047 / 157.3) < 1e-3
+    assert {o["kernel"] for o in rf["other_kernels"]} == {"wgrad_kernel", "trunk_fused_kernel<retained>", "trunk_fused_bwd_kernel", "trunk_fused_kernel<helper>"}
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 64 and cb["torch_cpu"]["value"] == 13.6 and "sample" in cb
+    assert d["extras"]["sweep"]["bf16"]["ms_per_crop"] == 5.73 and d["extras"]["sweep"]["fp32"]["ms_per_crop"] == 19.9
+    assert d["extras"]["sweep"]["bf16"]["batch8_ms_per_crop"] == 5.36
+    assert d["tables"] == "bench_tables.json"
+    # no table rides in the line
+    assert "per_shape" not in line and "per_shape_standalone" not in line
+
+
+def test_bench_line_sheds_detail_rather_than_grow():
+    import json
+
+    import bench
+
+    kw = _canned_bench_inputs()
+    out = bench.compose_line(env={f"DBM_SWITCH_{i}": "v" * 200 for i in range(40)}, **kw)
+    line = bench.fit_line(out)
+    d = json.loads(line)
+    assert len(line.encode()) < 4096 and "config.env" in d["dropped_for_length"]
+    assert sorted(d["config"]["env"]) == sorted(f"DBM_SWITCH_{i}" for i in range(40))  # the names survive
+    for k in ("value", "ms_per_step", "roofline", "cpu_baseline"):
+        assert k in d
+
+
+def test_bench_refuses_work_skipping_switches_and_prices_split_bf16_correctly():
+    import bench
+
+    bench.refuse_work_skipping_env({"DBM_IGEMM_WAVES": "8", "PATH": "/bin"})
+    for name in ("DBM_ABL_SKIP", "DBM_NO_WGRAD", "DBM_TFB_ABL", "DBM_CL16_ABL", "DBM_ABL_NOPACK"):
+        with pytest.raises(SystemExit):
+            bench.refuse_work_skipping_env({name: "1"})
+    assert bench.dbm_env({"DBM_B": "2", "DBM_A": "1", "HOME": "/"}) == {"DBM_A": "1", "DBM_B": "2"}
+    # three bf16 MFMAs per product in the split-bf16 kernels: a third of the bf16 roof (round 3 divided them by the fp32 peak: 2.13)
+    assert bench.sweep_roof("bf16", "x3_c64>64_1144x1144_n1u") == ("bf16_mfma/3", 2500.0 / 3)
+    assert bench.sweep_roof("bf16", "deform64x3_1144x1144_n1")[1] == 2500.0 / 3
+    assert bench.sweep_roof("bf16", "cl16_c64>32_286x286_n1")[1] == 2500.0
+    assert bench.sweep_roof("bf16", "deform1_1144x1144_n1")[1] == bench.PEAK_FP32_MFMA_TFLOPS
+    assert bench.sweep_roof("fp32", "x3_c64>64_1144x1144_n1u")[1] == bench.PEAK_FP32_MFMA_TFLOPS
