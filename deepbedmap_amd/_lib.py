@@ -123,7 +123,8 @@ _lib = None
 class DbmError(RuntimeError):
     # libdbm status.  7: a persistent kernel timed out; the call that reports it enqueued nothing (re-issue it), the
     # optimizer updates queued since the event were skipped (`Context.timeout_info()`).  8: the same in a data-parallel
-    # run -- fatal, the replicas have diverged.
+    # run -- fatal, the replicas have diverged.  9 (dbm_adam_update only): the gradients about to be applied come from a
+    # void pass; nothing was applied -- repeat forward + backward, then update.
     code = None
 
 

@@ -127,8 +127,22 @@ static void finish_out(dbm_ctx* c, int slot, float* host, size_t n, int flags) {
   if ((flags & DBM_DEVICE_PTRS) || !host) return;
   DBM_HIP(hipMemcpyAsync(host, c->stage[slot].p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 }
+// End of a host-synchronising entry point (host pointers: the results are about to be read by the caller).  The stream is
+// drained; if a persistent kernel gave up meanwhile, the results of THIS call are void as well: the condition is handled
+// here (like at a step entry) and the call returns status 7 / 8 -- re-issue it, it then runs on the layer-by-layer kernels.
+// Calls on device pointers only enqueue: their callers observe the condition with dbm_check_timeout after synchronising.
 static void finish_sync(dbm_ctx* c, int flags) {
-  if (!(flags & DBM_DEVICE_PTRS)) DBM_HIP(hipStreamSynchronize(c->stream));
+  if (flags & DBM_DEVICE_PTRS) return;
+  DBM_HIP(hipStreamSynchronize(c->stream));
+  if (c->dev_err && *(volatile int*)c->dev_err) {
+    const bool dp = c->comm_active();
+    dbm_handle_persistent_timeout(c);
+    if (dp)
+      throw DbmError(8, "a persistent kernel gave up waiting for a neighbouring workgroup in a data-parallel run: the replicas are "
+                        "no longer identical; abort the job");
+    throw DbmError(7, "a persistent kernel gave up waiting for a neighbouring workgroup: the results of this call are void -- "
+                      "re-issue it (the layer-by-layer trunk path is active for a while)");
+  }
 }
 
 extern "C" {
@@ -897,7 +911,16 @@ static void adam_update_impl(dbm_model* m, double grad_scale) {
 
 int dbm_adam_update(dbm_model* m, double grad_scale) {
   DBM_API_BEGIN(m->ctx)
-  dbm_step_entry(m->ctx, false);
+  try {
+    dbm_step_entry(m->ctx, false);
+  } catch (const DbmError& e) {
+    // The event lies BEFORE this update: the gradients in the arena come from a void pass, and the handler has just cleared
+    // the sticky flag -- an update re-issued now would apply them.  Status 9: nothing was applied; redo forward + backward.
+    if (e.code == 7)
+      throw DbmError(9, "dbm_adam_update: a persistent kernel gave up during the pass that produced these gradients -- they are "
+                        "void and NOTHING was applied; repeat the forward and backward pass (or the step call), then update");
+    throw;
+  }
   adam_update_impl(m, grad_scale);
   DBM_API_END
 }

@@ -755,6 +755,11 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
     hipLaunchKernelGGL(deform_conv64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, bias, y, yt, colout, N, H, W, offsn, act, slope);
   else if (z) {
     const int nz = 9 * O;
+    static bool attr = false;   // (O >= 15: 2 * 9 * O * 64 floats exceed the 64 KB default of dynamic LDS)
+    if (!attr) {
+      DBM_HIP(hipFuncSetAttribute((const void*)deform1_premul_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 9 * 16 * 64 * (int)sizeof(float)));
+      attr = true;
+    }
     hipLaunchKernelGGL(deform1_premul_kernel, dim3(blocks), dim3(256), (size_t)2 * nz * 64 * sizeof(float), s, xt, w, z, total, H * W, nz);
     hipLaunchKernelGGL(deform1_sample_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)O), dim3(256), 0, s, z, off, bias, y, total, H, W,
                        offsn, O);

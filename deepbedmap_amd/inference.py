@@ -54,7 +54,9 @@ def crop_bounds(step: Shape, final_shape: Shape, ary_shape: Shape, xtrapad: Shap
 
 
 def group_tiles_by_crop_shape(final_shape: Shape, ary_shape: Shape, stride: Shape, xtrapad: Shape, rank=0, world=1):
-    """The rank's tiles (dealt round-robin in the reference's loop order, :700-703) as {(crop height, crop width): [(y0, y1, x0, x1), ...]}:
+    """The rank's tiles (dealt round-robin in the reference's loop order, :700-703) as {(crop height, crop width): [(y0, y1, x0, x1), ...]}
+    (tiles of one shape keep the loop's order; the groups are pasted one after the other, which equals the reference's paste order
+    whenever pasted regions do not overlap, i.e. stride >= ary_shape -- predict_tiled_resident checks it):
     what predict_tiled_resident batches.  The continent (18000 x 22000, 1000-pixel tiles, xtrapad 18): 396 tiles, 320 of them
     288 x 288 low-resolution pixels, 40 + 32 along two edges (269 x 288 / 288 x 269) and 4 corner crops of 269 x 269."""
     groups = {}
@@ -98,11 +100,16 @@ def predict_tiled_resident(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape
                            world=1, download=True, dtype="float32", clip=False, crops_per_batch=1):
     """predict_tiled with the grids resident in HBM.  Inputs are NumPy arrays (uploaded once) or DeviceArrays of the
     same shapes as for predict_tiled.  Returns Y_hat as a NumPy array (download=True) or as the device canvas.
-    clip=True: W1, W2, W3 are clipped to >= 0 (deepbedmap.py:663-665) on the device, after the upload (DeviceArrays: in place).
+    clip=True: W1, W2, W3 are clipped to >= 0 (deepbedmap.py:663-665) on the device, after the upload.  NOTE: DeviceArrays passed in
+    are clipped IN PLACE (np.clip in the reference returns new arrays) -- a caller that reuses its resident W1 / W2 / W3 grids sees
+    the clipped values afterwards; pass copies if the raw grids are still needed.
     crops_per_batch > 1: crops of equal shape go through the generator that many at a time (the reference's loop, :704-741, is one
     crop per forward; per crop the arithmetic is the same, so is the canvas) -- 6.5 -> 5.9 ms per 288 x 288 bf16 crop at 8."""
     ctx = model.ctx
     lib = _lib.lib()
+    if stride.y < ary_shape.y or stride.x < ary_shape.x:
+        # overlapping pastes: the reference's loop order decides which tile's pixels survive; grouping by crop shape would change it
+        raise ValueError("predict_tiled_resident needs stride >= ary_shape (non-overlapping pasted regions); use predict_tiled")
     grids = [a if isinstance(a, DeviceArray) else to_device(a, ctx) for a in (X_tile, W1_tile, W2_tile, W3_tile)]
     if clip:
         grids[1:] = clip_inputs(*grids[1:])

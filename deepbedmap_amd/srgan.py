@@ -375,8 +375,8 @@ class GeneratorModel(_Link):
         else:
             xs = [_f32(a) for a in (x, w1, w2, w3)]
             out = np.empty(oshape, dtype=np.float32)
-            _lib.check(l.dbm_gen_forward(self._h, n, h, w, _hp(xs[0]), _hp(xs[1]), _hp(xs[2]), _hp(xs[3]), _hp(out),
-                                         flags), self.ctx.handle)
+            _reissue_once(lambda: l.dbm_gen_forward(self._h, n, h, w, _hp(xs[0]), _hp(xs[1]), _hp(xs[2]), _hp(xs[3]), _hp(out), flags),
+                          self.ctx)
         self._graph_shape = oshape if keep else None
         v = Variable(out, creator=None)
         v._gen = self if keep else None
@@ -432,7 +432,10 @@ class DiscriminatorModel(_Link):
         else:
             xs = _f32(x)
             out = np.empty((n, 1), dtype=np.float32)
-            _lib.check(l.dbm_disc_forward(self._h, n, h, w, _hp(xs), _hp(out), flags, slot), self.ctx.handle)
+            if train:   # (a training-mode pass updates the running averages: not re-issued blindly -- status 7 goes to the caller)
+                _lib.check(l.dbm_disc_forward(self._h, n, h, w, _hp(xs), _hp(out), flags, slot), self.ctx.handle)
+            else:
+                _reissue_once(lambda: l.dbm_disc_forward(self._h, n, h, w, _hp(xs), _hp(out), flags, slot), self.ctx)
         v = Variable(out)
         v._disc = (self, slot) if keep else None
         return v
@@ -446,6 +449,19 @@ class DiscriminatorModel(_Link):
         else:
             g = _f32(glogits)
             _lib.check(_lib.lib().dbm_disc_backward(self._h, slot, _hp(g), 0), self.ctx.handle)
+
+
+def _reissue_once(call, ctx):
+    """A host-synchronising forward that reports status 7 (a persistent kernel gave up: include/dbm.h) has produced void
+    results and changed nothing: it is issued again, once -- the library has switched to the layer-by-layer kernels."""
+    rc = call()
+    if rc == 7:
+        import warnings
+
+        warnings.warn("libdbm: a persistent kernel timed out during a forward pass; repeating it on the layer-by-layer kernels",
+                      RuntimeWarning, stacklevel=3)
+        rc = call()
+    _lib.check(rc, ctx.handle)
 
 
 # --------------------------------------------------------------------------------------
@@ -466,8 +482,10 @@ class Adam:
         return self
 
     def update(self, grad_scale=1.0):
-        self.t += 1
+        """optimizer.update() (srgan_train.py:1164, 1257).  DbmError code 9: a persistent kernel timed out during the pass that
+        produced the gradients -- nothing was applied (and `t` is unchanged): repeat forward + backward, then update."""
         _lib.check(_lib.lib().dbm_adam_update(self.target._h, float(grad_scale)), self.target.ctx.handle)
+        self.t += 1
 
 
 class optimizers:  # namespace parity with chainer.optimizers

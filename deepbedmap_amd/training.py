@@ -366,6 +366,9 @@ def trainer(i: int, columns: list, train_iter, dev_iter, g_model, g_optimizer, d
         if lost:  # a timeout was observed by the previous call: the rows of the minibatches whose updates were skipped
             log.invalidate_last(lost, keep_last=1)  # (the last row is the re-issued, valid, minibatch)
         train_minibatch(train_arrays, g_model, g_optimizer, d_model, d_optimizer, comm=comm, log=log)
+    lost = pop_dropped_updates(g_model.ctx)  # (a timeout observed by the epoch's LAST minibatch call: same bookkeeping, this epoch's log)
+    if lost:
+        log.invalidate_last(lost, keep_last=1)
     rows = log.fetch()
     try:  # the epoch's last iterations have no following step call that would notice a timeout
         g_model.ctx.check_timeout()

@@ -12,8 +12,12 @@
  *     (dbm_train_iteration, dbm_discriminator_step, dbm_generator_step, dbm_adam_update) and by dbm_check_timeout: the call
  *     drains the device, gives the skipped launches' step counts back, switches to the layer-by-layer trunk kernels for a
  *     while (re-armed after DBM_TRUNK_REARM = 64 iterations, doubling) and returns 7 WITHOUT having enqueued anything --
- *     re-issue it; dbm_timeout_info says how many queued updates were dropped.  Status 8: the same in a data-parallel run,
- *     where a local retry cannot keep the replicas identical -- fatal, abort the job;
+ *     re-issue it; dbm_timeout_info says how many queued updates were dropped.  Entry points that take HOST pointers and
+ *     therefore end with a stream synchronisation (dbm_gen_forward, dbm_disc_forward, the dbm_op_* and loss calls without
+ *     DBM_DEVICE_PTRS) observe the condition after that synchronisation as well: their results are void, status 7, re-issue.
+ *     dbm_adam_update is the exception to "re-issue": an event observed at its entry means the gradients it was about to apply
+ *     are void -- it returns status 9, applies nothing, and the caller repeats forward + backward before updating.  Status 8:
+ *     the same in a data-parallel run, where a local retry cannot keep the replicas identical -- fatal, abort the job;
  *   - tensors are NCHW float32, C-contiguous; weights OIHW, exactly the arrays stored by
  *     chainer.serializers.save_npz (key layout: SURVEY.md Appendix B);
  *   - pointers are HOST pointers unless flags contains DBM_DEVICE_PTRS, in which case they are

@@ -237,3 +237,77 @@ def test_ssim_random_geometry(dbm, ws, stride, shape, window):
         got = float(dbm.ssim_loss_func(dbm.Variable(y), t, window_size=ws, stride=stride))
     ref = float(ops.ssim(y.astype(np.float64), t.astype(np.float64), ws, stride, window))
     assert abs(got - ref) < 2e-5, (got, ref)
+
+
+_FWD_TIMEOUT_SCRIPT = r"""
+import sys, warnings, ctypes as C, numpy as np
+sys.path.insert(0, sys.argv[1])
+import deepbedmap_amd as d
+from deepbedmap_amd import _lib
+np.random.seed(3)
+g = d.GeneratorModel(num_residual_blocks=2)
+lib = _lib.lib()
+rs = np.random.RandomState(1)
+n = 8
+xs = [rs.rand(n, c, m * 11, m * 11).astype(np.float32) for c, m in ((1, 1), (1, 10), (2, 2), (1, 1))]
+hp = lambda a: a.ctypes.data_as(C.c_void_p)
+with d.using_config("enable_backprop", False):
+    ref = g.forward(*xs).array.copy()
+    # (1) the C ABI: a forward on host pointers that ends while the condition is up returns status 7 (its results are void) ...
+    out = np.zeros_like(ref)
+    _lib.check(lib.dbm_debug_inject_timeout_async(g.ctx.handle), g.ctx.handle)
+    rc = lib.dbm_gen_forward(g._h, n, 11, 11, hp(xs[0]), hp(xs[1]), hp(xs[2]), hp(xs[3]), hp(out), 0)
+    assert rc == 7, rc
+    assert g.ctx.timeout_info()[0] == 1
+    # ... and the re-issued call is valid (layer-by-layer trunk kernels now)
+    rc = lib.dbm_gen_forward(g._h, n, 11, 11, hp(xs[0]), hp(xs[1]), hp(xs[2]), hp(xs[3]), hp(out), 0)
+    assert rc == 0, rc
+    assert np.abs(out - ref).max() <= 2e-5 * np.abs(ref).max()
+    # (2) the Python mirror re-issues by itself, with a warning
+    _lib.check(lib.dbm_debug_inject_timeout_async(g.ctx.handle), g.ctx.handle)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y = g.forward(*xs).array
+    assert any("timed out" in str(x.message) for x in w)
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()
+# (3) dbm_adam_update behind an event: status 9, NOTHING applied, step counter unchanged; after a fresh backward the update goes through
+opt = d.optimizers.Adam(alpha=1e-3, eps=1e-7).setup(g)
+before = {k: v.copy() for k, v in g.serialize_dict().items()}
+y = g.forward(*xs)
+g.cleargrads()
+g.backward(np.ones(y.shape, np.float32))
+_lib.check(lib.dbm_debug_inject_timeout_async(g.ctx.handle), g.ctx.handle)
+try:
+    opt.update()
+    raise SystemExit("update() did not report the void gradients")
+except _lib.DbmError as e:
+    assert e.code == 9, e.code
+assert opt.t == 0
+after = g.serialize_dict()
+assert all(np.array_equal(before[k], after[k]) for k in before)
+try:  # a blind re-issue would have applied the void pass's gradients: the arena is what it is, but the CONTRACT is "redo the pass"
+    y = g.forward(*xs)
+    g.cleargrads()
+    g.backward(np.ones(y.shape, np.float32))
+    opt.update()
+except _lib.DbmError as e:
+    raise SystemExit(f"valid pass refused: {e}")
+assert opt.t == 1
+moved = g.serialize_dict()
+assert any(not np.array_equal(before[k], moved[k]) for k in before)
+print("ok")
+"""
+
+
+def test_timeouts_are_observed_by_host_synchronising_forwards_and_by_adam_update(dbm, tmp_path):
+    """a persistent kernel that gives up during a forward-only call must not hand garbage to the host with status 0
+    (dbm_gen_forward on host pointers now observes the condition after its final synchronisation: status 7, re-issue), and
+    dbm_adam_update must not be re-issuable onto the gradients of a void pass (status 9, nothing applied)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fwd_timeout.py"
+    script.write_text(_FWD_TIMEOUT_SCRIPT)
+    res = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-3000:] + res.stdout[-500:]

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(HERE, "golden"))
 import make_golden_full as mgf  # noqa: E402
 
@@ -246,3 +247,55 @@ def test_config3_other_forms_of_the_trunk_forward_match_the_fixture(form):
                           "config3_full_iteration or config3_generator_step_reference_init"],
                          env=env, cwd=os.path.dirname(os.path.dirname(here)), capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "2 passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("cpb", [1, 8])
+def test_reduced_continent_every_crop_kind_bf16(dbm, cpb):
+    """Config 5 on a 3 x 3-tile continent (3000 x 3000 output pixels at the reference's stride 1000 and 18-pixel halo,
+    deepbedmap.py:689-741): ONE interior crop of 288 x 288, FOUR edge crops (269 x 288 / 288 x 269) and FOUR corner crops
+    (269 x 269) -- every crop kind of the real sweep -- bf16, grids resident in HBM, one and eight crops per forward, against the
+    per-tile loop (predict_tiled: host crops, one forward each, the reference's own loop form)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from dem_model import dem_generator
+
+    g = dem_generator(dbm, seed=909)   # activations at the data's magnitude (metres)
+    H = W = 750
+    r = np.random.RandomState(11)
+    X = r.uniform(-2000, 2000, (1, 1, H, W)).astype(np.float32)
+    W1 = r.uniform(-100, 4000, (1, 1, 10 * H, 10 * W)).astype(np.float32)
+    W2 = r.uniform(-10, 1000, (1, 2, 2 * H, 2 * W)).astype(np.float32)
+    W3 = r.uniform(0, 500, (1, 1, H, W)).astype(np.float32)
+    S = dbm.Shape
+    final = S(y=4 * H, x=4 * W)
+    kw = dict(final_shape=final, ary_shape=S(y=1000, x=1000), stride=S(y=1000, x=1000), xtrapad=S(y=18, x=18))
+    groups = dbm.group_tiles_by_crop_shape(final, kw["ary_shape"], kw["stride"], kw["xtrapad"])
+    assert {k: len(v) for k, v in groups.items()} == {(269, 269): 4, (269, 288): 2, (288, 269): 2, (288, 288): 1}
+    W1c, W2c, W3c = dbm.clip_inputs(W1, W2, W3)   # deepbedmap.py:663-665 (host arrays: new arrays)
+    ref = dbm.predict_tiled(g, X, W1c, W2c, W3c, dtype="bfloat16", **kw)
+    got = dbm.predict_tiled_resident(g, X, W1, W2, W3, dtype="bfloat16", clip=True, crops_per_batch=cpb, **kw)
+    m = ~np.isnan(ref)
+    frame = (18 + 1) * 4
+    assert np.array_equal(np.isnan(got), ~m) and m[:, frame:-frame, frame:-frame].all() and not m[:, :frame].any()
+    scale = float(np.abs(ref[m]).max())
+    assert scale > 100.0   # metres, not U[0, 1)
+    if cpb == 1:
+        assert np.array_equal(got[m], ref[m])   # the same launches per crop: bit for bit
+    else:   # eight crops per forward: launch splits depend on the batch size (summation order)
+        assert np.abs(got[m] - ref[m]).max() / scale < 1e-4
+
+
+def test_bench_sweep_continent_entry_on_a_reduced_area(dbm):
+    """`bench.py --sweep-continent` (the config-5 entry a SCALE run uses), on a 1/6-scale area so that it takes seconds: one JSON
+    line below 4 KB with s_per_continent, ranks and a canvas check."""
+    import json
+    import subprocess
+
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sweep-continent", "--sweep-scale", "6"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["ranks"] == 1 and d["n_gpus"] == 1 and d["dtype"] == "bf16" and d["higher_is_better"] is False
+    assert d["s_per_continent"] == d["value"] > 0 and d["canvas_check_ok"] is True
+    assert "750 x 916" not in d["config"]["workload"] and "3000 x 3664" in d["config"]["workload"]
