@@ -749,7 +749,8 @@ def main():
             tables_path = TABLES_PATH
         except OSError:
             pass
-        print("bench tables: " + json.dumps(tables), file=sys.stderr, flush=True)
+        if tables_path is None:   # (no writable directory: the tables go to stderr instead)
+            print("bench tables: " + json.dumps(tables), file=sys.stderr, flush=True)
         out = compose_line(tiles=args.batch * world * args.steps, dt=dt, steps=args.steps, warmup=args.warmup, world=world, batch=args.batch,
                            ev_ms=ev_ms.value, config=config, fam=fam, traffic=traffic, comm_stats=comm_stats, sweep=sweep, shared=shared,
                            cpu=cpu, tables_path=tables_path)

@@ -637,7 +637,7 @@ int dbm_gen_forward(dbm_model* gm, int N, int H, int W, const float* x, const fl
     DBM_HIP(hipMemcpyAsync(g->in_w3.p, w3, n * hw * 4, hipMemcpyHostToDevice, s));
     g->forward(N, H, W, g->in_x.p, g->in_w1.p, g->in_w2.p, g->in_w3.p, g->yout.p, keep);
     DBM_HIP(hipMemcpyAsync(y, g->yout.p, n * P4 * 4, hipMemcpyDeviceToHost, s));
-    DBM_HIP(hipStreamSynchronize(s));
+    finish_sync(g->ctx, flags);   // (observes a persistent-kernel time-out: status 7, the results are void)
   }
   DBM_API_END
 }
@@ -653,7 +653,7 @@ int dbm_gen_backward(dbm_model* gm, const float* gy, int flags) {
     const size_t cnt = (size_t)g->wsN * 16 * (g->wsH - 2) * (g->wsW - 2);
     DBM_HIP(hipMemcpyAsync(g->g_y.p, gy, cnt * 4, hipMemcpyHostToDevice, g->ctx->stream));
     g->backward(g->g_y.p);
-    DBM_HIP(hipStreamSynchronize(g->ctx->stream));
+    finish_sync(g->ctx, flags);
   }
   DBM_API_END
 }

@@ -17,7 +17,14 @@
 
 namespace {
 
-constexpr int CS = 56;
+// LDS channel-plane stride.  A plane is 5 rows (own three + a halo row either side) x 10 cells (9 + a shared zero column) + frame
+// = 56 floats; the stride is 80 = 16 (mod 32) so that the B operand of v_mfma_f32_16x16x4_f32 -- lanes 0..15 read channel k,
+// lanes 16..31 channel k + 1 at the same sixteen positions, one ds_read_b32 bank group (bank = dword address mod 32) -- meets
+// no bank conflict: the position halves are cut 14 + 13 (cells 0..14 / 15..28 of the own rows: each spans < 16 banks), so the
+// two channels of a group occupy disjoint halves of the 32 banks.  (Round 3: stride 56 and halves of 16 + 11 positions -- nine
+// of sixteen lanes collided, every B read took four LDS cycles instead of two.)
+constexpr int CS = 80;
+constexpr int NPOS0 = 14;            // positions of the first half (the second holds 27 - 14 = 13)
 #ifndef TFB_NWAVE
 #define TFB_NWAVE 8
 #endif
@@ -325,15 +332,17 @@ __global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
                                         (W.band > 0 ? 1u << (W.band - 1) : 0u) | (W.band < 2 ? 1u << (W.band + 1) : 0u),
                                         ((unsigned)a.epoch << 12) | 0xFFFu, W.lane);
   W.nh = W.w & 1;
-  W.pos = W.nh * 16 + (W.lane & 15);
   {
-    const int n = W.pos;
-    const int po = n < 27 ? (n / 9) * 10 + n % 9 : (n == 27 ? 9 : n == 28 ? 19 : 29 + (n - 29));
+    const int l15 = W.lane & 15;
+    W.st_ok = W.nh == 0 ? l15 < NPOS0 : l15 < 27 - NPOS0;
+    // padding lanes compute on their half's first position (a broadcast read); their results go nowhere
+    const int n = W.nh * NPOS0 + (W.st_ok ? l15 : 0);
+    W.pos = n;
+    const int po = (n / 9) * 10 + n % 9;
     W.bofs = (W.lane >> 4) * CS + po;
     W.pofs = 11 + po;
-    W.st_ok = n < 27;
-    W.up_ok = n < 9 && W.band > 0;
-    W.dn_ok = n >= 18 && n < 27 && W.band < 2;
+    W.up_ok = W.st_ok && n < 9 && W.band > 0;
+    W.dn_ok = W.st_ok && n >= 18 && W.band < 2;
   }
   {
     const int nblk = a.nrdb - a.j1;  // dense blocks already done by earlier launches

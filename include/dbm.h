@@ -13,8 +13,8 @@
  *     drains the device, gives the skipped launches' step counts back, switches to the layer-by-layer trunk kernels for a
  *     while (re-armed after DBM_TRUNK_REARM = 64 iterations, doubling) and returns 7 WITHOUT having enqueued anything --
  *     re-issue it; dbm_timeout_info says how many queued updates were dropped.  Entry points that take HOST pointers and
- *     therefore end with a stream synchronisation (dbm_gen_forward, dbm_disc_forward, the dbm_op_* and loss calls without
- *     DBM_DEVICE_PTRS) observe the condition after that synchronisation as well: their results are void, status 7, re-issue.
+ *     therefore end with a stream synchronisation (dbm_gen_forward / dbm_gen_backward -- the calls that launch persistent kernels --
+ *     dbm_disc_forward and the loss calls, without DBM_DEVICE_PTRS) observe the condition after that synchronisation as well: their results are void, status 7, re-issue.
  *     dbm_adam_update is the exception to "re-issue": an event observed at its entry means the gradients it was about to apply
  *     are void -- it returns status 9, applies nothing, and the caller repeats forward + backward before updating.  Status 8:
  *     the same in a data-parallel run, where a local retry cannot keep the replicas identical -- fatal, abort the job;

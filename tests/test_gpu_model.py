@@ -851,7 +851,7 @@ batch = d.device_batch({"X": rs.rand(4, 1, 11, 11), "W1": rs.rand(4, 1, 110, 110
 inject = sys.argv[3] == "1"
 if inject:
     # a retained generator gradient that is NOT zero, then the condition: the optimizer entry point observes it, returns
-    # status 7 and has done nothing
+    # status 9 (the gradients are void: redo the pass -- round 4; it was the re-issuable status 7 before) and has done nothing
     with d.using_config("enable_backprop", True):
         y = g.forward(batch["X"], batch["W1"], batch["W2"], batch["W3"])
     g.cleargrads()
@@ -864,9 +864,9 @@ if inject:
     _ = d.to_device(np.zeros(4, np.float32)).get()
     try:
         g_opt.update()
-        raise SystemExit("status 7 expected")
+        raise SystemExit("status 9 expected")
     except _lib.DbmError as e:
-        assert e.code == 7, e
+        assert e.code == 9, e
     assert all(np.array_equal(before[k], v) for k, v in g.serialize_dict().items())
     assert g.ctx.timeout_info()[0] == 1 and g.ctx.timeout_info()[3]
     g.cleargrads()
