@@ -51,7 +51,12 @@ constexpr size_t LDS_BYTES = (size_t)256 * CS * sizeof(float);
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f2v __attribute__((ext_vector_type(2)));
-constexpr int NACC = 2;  // independent accumulator chains of a sub-tile (summed in the epilogue)
+#ifndef TFB_NACC
+#define TFB_NACC 2
+#endif
+constexpr int NACC = TFB_NACC;  // independent accumulator chains of a sub-tile (summed in the epilogue).  Round 4 measured 1, 2, 3, 4 and the
+                                // same loop with in-place inline-asm MFMAs: 1255-1266 us for the K loops alone in every case (in-place: slower)
+                                // -- the loop is bound neither by MFMA dependencies nor by the order of its LDS reads (profiles/README.md)
 
 extern __shared__ float lds[];
 
@@ -69,6 +74,9 @@ struct Args {
   float rs, slope;
   unsigned off_xcc;  // XCC_ID table of the handshake (granule offset inside inbox)
   int local_st;
+#ifdef TFB_TIMING
+  long long* tstamp;   // [block][wave][8] cycle sums (measurement build): 0 sub-tile bodies, 1 barrier waits, 2 layer prologues, 3 halo finish, 7 total
+#endif
 #ifdef DBM_MEASURE
   int abl;  // libdbm_measure.so only: 1 = no halo exchange, 2 = no epilogue, 4 = every weight unit re-reads the same (cache-hot) address (results are then wrong)
 #endif
@@ -85,10 +93,20 @@ struct Wave {
   bool local;       // the neighbouring bands run on this XCD: exchange stores stay in its L2
   unsigned me;      // inbox slot of this workgroup
   const float* wp;
+#ifdef TFB_TIMING
+  long long tsum[8];
+#endif
   float skipv[4];   // gradient of the RRDB output at this thread's conv_layer1 outputs (the `x` skip of :402)
 };
 
 #define DI __device__ __forceinline__
+#ifdef TFB_TIMING
+#define TFB_T0() const long long _t0 = (long long)__builtin_amdgcn_s_memtime()
+#define TFB_ACC(slot) W.tsum[slot] += (long long)__builtin_amdgcn_s_memtime() - _t0
+#else
+#define TFB_T0()
+#define TFB_ACC(slot)
+#endif
 
 DI void issue_unit(float (&A)[AU], const float* p, int lane) {
 #pragma unroll
@@ -122,14 +140,17 @@ DI void mma_unit(const float (&A)[AU], int b, int b_next, float (&bq0)[9], f4v (
     // (round 2) the nine reads above are dealt out BETWEEN the nine MFMAs below -- one MFMA, one DS read, ... -- instead
     // of standing in front of them: their issue slots disappear in the matrix pipe's shadow
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < 9; ++tap) {
       acc[(q * 9 + tap) % NACC] =
           __builtin_amdgcn_mfma_f32_16x16x4f32(A[q * 9 + tap], bq[q & 1][tap], acc[(q * 9 + tap) % NACC], 0, 0, 0);
+    }
+#ifndef TFB_NO_INTERLEAVE
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -248,7 +269,11 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
   }
 
   // ---- epilogue: this lane's four cells ----
-  if (DBM_ABL_BIT(a, 2)) { asm volatile("" ::"v"(acc[0]), "v"(acc[1])); return; }
+  if (DBM_ABL_BIT(a, 2)) {
+#pragma unroll
+    for (int c = 0; c < NACC; ++c) asm volatile("" ::"v"(acc[c]));
+    return;
+  }
   const float sc = third ? a.rs * a.rs : a.rs;
   const float r1s = third ? a.rs : 1.f;
   const unsigned tag_out = ((unsigned)a.epoch << 12) | (unsigned)(serial + 1);
@@ -260,7 +285,9 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
     for (int r = 0; r < 4; ++r) {
       const int ch = ch0 + r;
       const int cell = (ch < 64 ? dlow_region + ch * CS : Q0 + (ch - 64) * CS) + W.pofs;
-      float v = acc[0][r] + acc[1][r];
+      float v = acc[0][r];
+#pragma unroll
+      for (int c = 1; c < NACC; ++c) v += acc[c][r];
       if (KL == 4) {
         v *= sc;
         if (ch < 64) v += r1s * lds[gin_region + ch * CS + W.pofs];  // d out / d a0  (:358, :402)
@@ -301,9 +328,15 @@ template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[AU], float (
   // the first quad's nine B operands are the same for all of this wavefront's sub-tiles of the layer: requested once
   float bfirst[9];
   {
+    TFB_T0();
     const int b0 = (KL == 4 ? gin_region : Q0 + 32 * KL * CS) + W.bofs;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) bfirst[tap] = lds[b0 + (tap / 3) * 10 + tap % 3];
+#ifdef TFB_TIMING
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) asm volatile("" ::"v"(bfirst[tap]));
+#endif
+    TFB_ACC(2);
   }
 #pragma unroll
   for (int s = SMAX - 1; s >= 0; --s) {
@@ -311,10 +344,22 @@ template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[AU], float (
       halo_issue<NCH>(a, W, serial & 1, hq);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (W.w + NWAVE * s < S) sub_tile<KL>(a, W, A0, A1, s, j, gin_region, dlow_region, serial, bfirst);
+    if (W.w + NWAVE * s < S) {
+      TFB_T0();
+      sub_tile<KL>(a, W, A0, A1, s, j, gin_region, dlow_region, serial, bfirst);
+      TFB_ACC(0);
+    }
   }
-  if (fetch) halo_finish<NCH>(a, W, plane0, serial & 1, ((unsigned)a.epoch << 12) | (unsigned)(serial + 1), hq);
-  __syncthreads();
+  if (fetch) {
+    TFB_T0();
+    halo_finish<NCH>(a, W, plane0, serial & 1, ((unsigned)a.epoch << 12) | (unsigned)(serial + 1), hq);
+    TFB_ACC(3);
+  }
+  {
+    TFB_T0();
+    __syncthreads();
+    TFB_ACC(1);
+  }
 }
 
 }  // namespace
@@ -369,6 +414,10 @@ __global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
   }
   __syncthreads();
 
+#ifdef TFB_TIMING
+  for (int i = 0; i < 8; ++i) W.tsum[i] = 0;
+  const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
+#endif
   float A0[AU], A1[AU];
   issue_unit(A0, W.wp, W.lane);
   W.wp += BUNIT;
@@ -384,6 +433,11 @@ __global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
     serial += 5;
     par ^= 1;
   }
+#ifdef TFB_TIMING
+  W.tsum[7] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+  if (W.lane == 0 && a.tstamp)
+    for (int i = 0; i < 8; ++i) a.tstamp[((size_t)blockIdx.x * NWAVE + W.w) * 8 + i] = W.tsum[i];
+#endif
 }
 
 // dst-driven gather of the transposed, tap-flipped trunk weights into the per-wavefront streams
@@ -492,7 +546,27 @@ void launch_trunk_fused_bwd(const TrunkFusedBwdLaunch& L, hipStream_t s) {
     snprintf(tag, sizeof(tag), "trunk_bwd_%d..%d_n%d", L.j0, L.j1, L.nimg);
     g_profiler.begin(s, 3, 2.0 * 19408896.0 * (L.j1 - L.j0) * L.nimg, bytes, tag, grid);
   }
+#ifdef TFB_TIMING
+  static long long* d_ts = nullptr;
+  if (!d_ts) DBM_HIP(hipMalloc((void**)&d_ts, sizeof(long long) * 256 * NWAVE * 8));
+  a.tstamp = d_ts;
+#endif
   hipLaunchKernelGGL(trunk_fused_bwd_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, s, a);
   if (g_profiler.enabled) g_profiler.end(s);
+#ifdef TFB_TIMING
+  if (g_profiler.enabled && g_profiler.serial) {   // (the serialised profile pass of tools/experiments/step_shapes.py)
+    std::vector<long long> h((size_t)grid * NWAVE * 8);
+    DBM_HIP(hipDeviceSynchronize());
+    DBM_HIP(hipMemcpy(h.data(), d_ts, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int b : {0, 1, 100}) {
+      if (b >= grid) continue;
+      for (int w = 0; w < NWAVE; ++w) {
+        const long long* t = &h[((size_t)b * NWAVE + w) * 8];
+        fprintf(stderr, "chain timing block %3d wave %d: subtiles %9lld  barrier %9lld  prologue %8lld  halo %8lld  total %9lld cycles (s_memtime)\n", b, w,
+                t[0], t[1], t[2], t[3], t[7]);
+      }
+    }
+  }
+#endif
   DBM_HIP(hipGetLastError());
 }
