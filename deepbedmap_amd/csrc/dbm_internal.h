@@ -91,6 +91,9 @@ struct ConvDesc {
   const float* mask;
   long masksn;
   int mask_c0;
+  const float* ch_scale;  // per-output-channel multiplier applied BEFORE the bias (null: 1): v = acc * ch_scale[c] + bias[c] -- an
+                          // eval-mode BatchNorm folded into the convolution (ch_scale = gamma / sqrt(avg_var + eps), bias = beta -
+                          // avg_mean * ch_scale; discriminator.hip)
   const float* zeros;  // >= 4 bytes of device zeros
   unsigned planeM, owM; // set by the launcher: floor(2^32 / (OHl*OWl)), floor(2^32 / OWl) (division-free position decode)
   const void* wp16;    // bf16 forward image [T][Cin/16][2][CoutP][8] (null: fp32 MFMA path)

@@ -71,28 +71,51 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
     d.KH = d.KW = 3; d.stride = 1; d.pad = 1; d.N = N; d.act = 1; d.slope = SLOPE;
     launch_smallcin_conv_fwd(d, s);
   }
+  // Eval mode (chainer.config.train = False: the G-step's detached pass, :1228, and the dev-set evaluation): BatchNorm is a
+  // per-channel affine map of running statistics -- folded into the convolutions' epilogues with the LeakyReLU (one
+  // coefficient launch for the nine layers, no BatchNorm launch, no pre-normalisation planes).
+  BnEvalJobs ej;
+  memset(&ej, 0, sizeof(ej));
+  if (!bn_train) {
+    ej.n = 9;
+    for (int i = 1; i < 10; ++i) {
+      ej.start[i - 1] = ej.total;
+      ej.gamma[i - 1] = P(T_bn[i][0]); ej.beta[i - 1] = P(T_bn[i][1]);
+      ej.avg_mean[i - 1] = S(T_bn[i][2]); ej.avg_var[i - 1] = S(T_bn[i][3]);
+      ej.total += DC_O[i];
+    }
+    ej.start[9] = ej.total;
+    bn_coef.ensure(2 * (size_t)ej.total);
+    ej.scale = bn_coef.p; ej.shift = bn_coef.p + ej.total;
+    launch_bn_eval_coeffs(ej, 1e-5f, s);
+  }
   for (int i = 1; i < 10; ++i) {  // conv -> BatchNorm -> LeakyReLU  (:663-689)
     const IgLayer& L = layers[L_conv[i]];
     const int hin = hs[i], win = ws[i], ho = hs[i + 1], wo = ws[i + 1];
     const size_t cnt = n * DC_O[i] * ho * wo;
-    c.z[i].ensure(cnt);
     c.h[i].ensure(cnt);
+    if (!bn_train) {
+      ConvDesc d = fwd_desc(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, c.h[i].p, (long)DC_O[i] * ho * wo, N);
+      d.ch_scale = ej.scale + ej.start[i - 1];
+      d.bias = ej.shift + ej.start[i - 1];
+      d.act = 1; d.slope = SLOPE;
+      launch_igemm_conv(d, s);
+      continue;
+    }
+    c.z[i].ensure(cnt);
     c.mean[i].ensure(DC_O[i]);
     c.istd[i].ensure(DC_O[i]);
     ConvDesc d = fwd_desc(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, c.z[i].p, (long)DC_O[i] * ho * wo, N);
     launch_igemm_conv(d, s);
-    if (bn_train && ctx->sync_stats()) {  // statistics of the global batch: local sums -> all-reduce -> apply
+    if (ctx->sync_stats()) {  // statistics of the global batch: local sums -> all-reduce -> apply
       ctx->sync_buf.ensure(3 * 512 + 4);
       launch_bn_sync_stats(c.z[i].p, ctx->sync_buf.p, N, DC_O[i], ho * wo, s);
       ctx->allreduce(ctx->sync_buf.p, 3 * DC_O[i]);
       launch_bn_sync_fwd_apply(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), ctx->sync_buf.p, c.mean[i].p, c.istd[i].p,
                                S(T_bn[i][2]), S(T_bn[i][3]), N, DC_O[i], ho * wo, ctx->sync_world, 1e-5f, 0.9f, SLOPE, s, ctx->dev_err_flag);
-    } else if (bn_train)
+    } else
       launch_bn_train_fwd(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, S(T_bn[i][2]),
                           S(T_bn[i][3]), N, DC_O[i], ho * wo, 1e-5f, 0.9f, SLOPE, s, ctx->dev_err_flag);
-    else
-      launch_bn_eval_fwd(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), S(T_bn[i][2]), S(T_bn[i][3]), N, DC_O[i],
-                         ho * wo, 1e-5f, SLOPE, s);
   }
   if (c.N != N || c.H != H || c.W != W) {
     for (auto& b : wb[slot]) b.reset();

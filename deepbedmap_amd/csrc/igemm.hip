@@ -57,17 +57,18 @@ __device__ __forceinline__ bool igemm_epilogue(const ConvDesc& d, float* red, co
   // then the arithmetic and the stores.  (One pass at a time, the compiler cannot hoist the next
   // pass's loads above the previous pass's store -- y, r1, r2 and mask may alias -- and a short-K layer then spends
   // more time in PASSES serialised memory round trips than in its MFMAs.)
-  float e_r1[PASSES], e_r2[PASSES], e_y[PASSES], e_m[PASSES], e_b[PASSES];
+  float e_r1[PASSES], e_r2[PASSES], e_y[PASSES], e_m[PASSES], e_b[PASSES], e_s[PASSES];
   auto load_operands = [&]() {
 #pragma unroll
     for (int q = 0; q < PASSES; ++q) {
       const int i = irow + ROWS_PER_PASS * q;
       const int c = cout0 + i;
       e_r1[q] = e_r2[q] = e_y[q] = e_b[q] = 0.f;
-      e_m[q] = 1.f;
+      e_m[q] = e_s[q] = 1.f;
       if (!pv || c >= d.Cout) continue;
       const long co = (long)c * d.ysc + pix;
       if (d.bias) e_b[q] = d.bias[c];
+      if (d.ch_scale) e_s[q] = d.ch_scale[c];
       if (d.r1 && c < d.r1_nch) e_r1[q] = d.r1[(long)n * d.r1sn + co];
       if (d.r2) e_r2[q] = d.r2[(long)n * d.r2sn + co];
       if (d.accumulate) e_y[q] = d.y[(long)n * d.ysn + co];
@@ -132,7 +133,7 @@ __device__ __forceinline__ bool igemm_epilogue(const ConvDesc& d, float* red, co
     if (!pv || c >= d.Cout) continue;
     const long co = (long)c * d.ysc + pix;
     float* yp = d.y + (long)n * d.ysn + co;
-    float v = (vs[q] + e_b[q]) * d.s1 + d.r1s * e_r1[q];
+    float v = (vs[q] * e_s[q] + e_b[q]) * d.s1 + d.r1s * e_r1[q];
     if (d.r2) v = d.s2 * v + e_r2[q];
     v += e_y[q];
     if (d.act) v = v >= 0.f ? v : d.slope * v;
@@ -150,15 +151,16 @@ __device__ __forceinline__ void igemm_epilogue_ns(const ConvDesc& d, const f32x1
   const long pix = (long)(a * d.so + oy0) * d.OWp + (b * d.so + ox0);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {  // four channels at a time: their global reads first (they overlap), then arithmetic and stores
-    float e_r1[4], e_r2[4], e_y[4], e_m[4], e_b[4];
+    float e_r1[4], e_r2[4], e_y[4], e_m[4], e_b[4], e_s[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int c = cout0 + rr + 8 * q + 4 * kh;
       e_r1[rr] = e_r2[rr] = e_y[rr] = e_b[rr] = 0.f;
-      e_m[rr] = 1.f;
+      e_m[rr] = e_s[rr] = 1.f;
       if (c >= d.Cout) continue;
       const long co = (long)c * d.ysc + pix;
       if (d.bias) e_b[rr] = d.bias[c];
+      if (d.ch_scale) e_s[rr] = d.ch_scale[c];
       if (d.r1 && c < d.r1_nch) e_r1[rr] = d.r1[(long)n * d.r1sn + co];
       if (d.r2) e_r2[rr] = d.r2[(long)n * d.r2sn + co];
       if (d.accumulate) e_y[rr] = d.y[(long)n * d.ysn + co];
@@ -168,7 +170,7 @@ __device__ __forceinline__ void igemm_epilogue_ns(const ConvDesc& d, const f32x1
     for (int rr = 0; rr < 4; ++rr) {
       const int c = cout0 + rr + 8 * q + 4 * kh;
       if (c >= d.Cout) continue;
-      float v = (acc[4 * q + rr] + e_b[rr]) * d.s1 + d.r1s * e_r1[rr];
+      float v = (acc[4 * q + rr] * e_s[rr] + e_b[rr]) * d.s1 + d.r1s * e_r1[rr];
       if (d.r2) v = d.s2 * v + e_r2[rr];
       v += e_y[rr];
       if (d.act) v = v >= 0.f ? v : d.slope * v;

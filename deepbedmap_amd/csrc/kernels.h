@@ -55,8 +55,14 @@ void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int
 void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* inv_std,
                          float* avg_mean, float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
                          hipStream_t s, const int* hold = nullptr);  // hold: device word; non-zero = no running-average update
-void launch_bn_eval_fwd(const float* z, float* y, const float* gamma, const float* beta, const float* avg_mean,
-                        const float* avg_var, int N, int C, int plane, float eps, float slope, hipStream_t s);
+struct BnEvalJobs {   // every BatchNorm layer of a model: layer l covers elements [start[l], start[l + 1]) of scale / shift
+  static const int MAXL = 12;
+  int n, total;
+  int start[MAXL + 1];
+  const float* gamma[MAXL]; const float* beta[MAXL]; const float* avg_mean[MAXL]; const float* avg_var[MAXL];
+  float* scale; float* shift;
+};
+void launch_bn_eval_coeffs(const BnEvalJobs& jobs, float eps, hipStream_t s);
 // backward through lrelu + BN(train): gz = d loss/d z ; ggamma/gbeta accumulated (+=)
 void launch_bn_train_bwd(const float* z, const float* gh, const float* gamma, const float* beta, const float* mean,
                          const float* inv_std, float* gz, float* ggamma, float* gbeta, float* scratch, int N, int C,

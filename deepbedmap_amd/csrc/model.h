@@ -249,6 +249,7 @@ struct Discriminator : dbm_model {
     bool valid = false;
     DevBuf img, h[10], z[10], mean[10], istd[10], l1, out;
   } cache[2];
+  DevBuf bn_coef;   // eval-mode passes: [scale | shift] of all nine BatchNorm layers (launch_bn_eval_coeffs)
   DevBuf g_h[2][2], g_z[2][10], g_l1[2], g_out, c0_scratch[2];  // per retained graph: the two backward passes overlap
   static const int NWG = 4;
   WgradBatch wbm[NWG];     // the same for BOTH graphs in one launch per group (the fused D-step: twice the work per launch)

@@ -123,24 +123,23 @@ void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const flo
   DBM_HIP(hipGetLastError());
 }
 
-__global__ __launch_bounds__(256) void bn_eval_fwd_kernel(const float* __restrict__ z, float* __restrict__ y,
-                                                          const float* gamma, const float* beta, const float* avg_mean,
-                                                          const float* avg_var, long total, int C, int plane, float eps,
-                                                          float slope) {
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
-  const int c = (int)((e / plane) % C);
-  const float istd = 1.f / sqrtf(avg_var[c] + eps);
-  float v = gamma[c] * (z[e] - avg_mean[c]) * istd + beta[c];
-  y[e] = v >= 0.f ? v : slope * v;
+// Eval-mode BatchNorm (chainer.config.train = False, srgan_train.py:1228) as a per-channel affine map of the convolution's
+// output: scale = gamma / sqrt(avg_var + eps), shift = beta - avg_mean * scale, for ALL layers of the discriminator in one launch;
+// the convolutions then apply them in their epilogues (ConvDesc::ch_scale / bias) together with the LeakyReLU: an eval-mode
+// pass has no BatchNorm launches of its own and never writes the pre-normalisation planes.
+__global__ __launch_bounds__(256) void bn_eval_coeffs_kernel(BnEvalJobs jobs, float eps) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= jobs.total) return;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < BnEvalJobs::MAXL; ++k) l += (k < jobs.n && e >= jobs.start[k]) ? 1 : 0;
+  const int c = e - jobs.start[l];
+  const float sc = jobs.gamma[l][c] / sqrtf(jobs.avg_var[l][c] + eps);
+  jobs.scale[e] = sc;
+  jobs.shift[e] = jobs.beta[l][c] - jobs.avg_mean[l][c] * sc;
 }
-
-void launch_bn_eval_fwd(const float* z, float* y, const float* gamma, const float* beta, const float* avg_mean,
-                        const float* avg_var, int N, int C, int plane, float eps, float slope, hipStream_t s) {
-  if (dbm_abl_skip() & 1) return;  // (libdbm_measure.so only)
-  const long total = (long)N * C * plane;
-  hipLaunchKernelGGL(bn_eval_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, y, gamma, beta,
-                     avg_mean, avg_var, total, C, plane, eps, slope);
+void launch_bn_eval_coeffs(const BnEvalJobs& jobs, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((unsigned)((jobs.total + 255) / 256)), dim3(256), 0, s, jobs, eps);
   DBM_HIP(hipGetLastError());
 }
 
