@@ -778,6 +778,10 @@ void Generator::backward(const float* gy) {
     }
   }
   DBM_MARK(s, "G:backward_input_block");
+  // (Round 4, measured on one box: launching the trunk's weight gradients on the side stream right behind the chain -- before
+  //  the pre-residual data gradient above instead of after it -- costs 0.7-1.0 ms per iteration, 8.05 -> 8.73 / 9.04 ms: the
+  //  1008 long workgroups then hold every CU while the eight short dependent launches of this tail and the discriminator's
+  //  eval-mode pass each wait for a free slot.  The order below stays.)
   ctx->fork_to_side(6);
   if (prev_grp >= 0) wbs[prev_grp].launch(ctx->side);
   wbs[6].launch(ctx->side);
