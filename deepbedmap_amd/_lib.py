@@ -147,16 +147,21 @@ def build(verbose=False, fresh=False):
 build.compiled = []
 
 
+def library_path(environ=None):
+    """libdbm.so, unless DBM_LIB names an existing libdbm_measure.so (measurement tools only; anything else is refused)."""
+    override = (os.environ if environ is None else environ).get("DBM_LIB")
+    if not override:
+        return LIB_PATH
+    if os.path.basename(override) != "libdbm_measure.so" or not os.path.exists(override):
+        raise DbmError(f"DBM_LIB={override}: only an existing libdbm_measure.so (tools/build_measure.sh) may replace libdbm.so")
+    return override
+
+
 def lib():
     """The loaded library with argtypes set.  Raises if libdbm.so has not been built."""
     global _lib
     if _lib is None:
-        path = LIB_PATH
-        override = os.environ.get("DBM_LIB")
-        if override:
-            if os.path.basename(override) != "libdbm_measure.so" or not os.path.exists(override):
-                raise DbmError(f"DBM_LIB={override}: only an existing libdbm_measure.so (tools/build_measure.sh) may replace libdbm.so")
-            path = override
+        path = library_path()
         if not os.path.exists(path):
             raise DbmError(
                 f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

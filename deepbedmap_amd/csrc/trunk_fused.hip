@@ -66,6 +66,10 @@ struct Args {
   int ntiles, tpx;         // tiles of this launch; tiles per XCD (block b = tile (b % 8) * tpx + b / 8)
   unsigned off_xcc;        // granule offset of the XCC_ID table [image][4] (xcd_handshake)
   int local_st;            // exchange stores may stay in the XCD's L2 when the reader is on the same XCD (DBM_TRUNK_LOCAL_ST)
+#ifdef TF_TIMING
+  long long* tstamp;       // [block][wave][8] cycle sums (measurement build): 0 K loops, 1 first barrier, 2 reduction + epilogue, 3 last barrier,
+                           // 4 layer prologue (weights wait + granule requests), 7 total
+#endif
   unsigned off_hb, off_bh; // helper mode: granule offsets of the helpers' inboxes [image][2][5][32][81] and of the boxes the
                            // helpers fill for their bands [image][2][32][81]
   float rs, slope;
@@ -93,7 +97,16 @@ struct Wave {
   unsigned ep_h;
   bool st_ok, up_ok, dn_ok;
   bool local;              // every workgroup that reads this one's granules runs on this XCD
+#ifdef TF_TIMING
+  long long tsum[8];
+#endif
 };
+#ifdef TF_TIMING
+#define TF_NOW() ((long long)__builtin_amdgcn_s_memtime())
+#define TF_LAP(slot) do { const long long _n = TF_NOW(); W.tsum[slot] += _n - _tl; _tl = _n; } while (0)
+#else
+#define TF_LAP(slot)
+#endif
 
 #define DI __device__ __forceinline__
 
@@ -183,6 +196,9 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
   constexpr int U = 2 + K;
   constexpr int base = K == 0 ? 0 : K == 1 ? 2 : K == 2 ? 5 : K == 3 ? 9 : 14;
   const int lane = W.lane, w = W.w;
+#ifdef TF_TIMING
+  long long _tl = TF_NOW();
+#endif
   const int serial = j * 5 + K;                      // layer serial inside the trunk
   const unsigned tag_in = ((unsigned)a.epoch << 12) | (unsigned)serial;  // what the producer (layer serial - 1) wrote
   const int par_in = (serial - 1) & 1;
@@ -241,6 +257,7 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
   f16v acc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+  TF_LAP(4);
 
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -329,6 +346,20 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifndef TF_NO_EARLY_WAIT
+  {
+    // The NEXT layer's first weights (requested a unit ago) are awaited HERE, before the epilogue's global and granule stores:
+    // vmcnt counts stores as well, the stores sit in divergent branches, and behind a branch hipcc can only wait with vmcnt(0) --
+    // the wait at the next layer's start then covered the full write latency of this layer's stores, 1 900 cycles per layer
+    // (TF_TIMING: 11 % of the launch).  Here nothing younger than the weights is in flight yet.
+    constexpr bool lastpar = ((base + U - 1) & 1) != 0;
+    float (&pend)[36] = lastpar ? A0 : A1;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) asm volatile("" ::"v"(pend[i]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
+  TF_LAP(0);
   // ---- split-K reduction over the eight wavefronts + epilogue, one 32-channel tile at a time ----
   const unsigned tag_out = ((unsigned)a.epoch << 12) | (unsigned)(serial + 1);
   const int par_out = serial & 1;
@@ -345,7 +376,9 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
     if (mt) __syncthreads();  // the previous tile's sums have been read
 #pragma unroll
     for (int r = 0; r < 16; ++r) lds[RED0 + (w * 16 + r) * 64 + lane] = acc[mt][r];
+    TF_LAP(2);
     __syncthreads();
+    TF_LAP(1);
     float v[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -387,7 +420,9 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
       }
     }
   }
+  TF_LAP(2);
   __syncthreads();  // planes written: the next layer may read them
+  TF_LAP(3);
 }
 
 
@@ -669,6 +704,14 @@ __global__ __launch_bounds__(512) void trunk_fused_kernel(Args a) {
   }
   __syncthreads();
 
+#ifdef TF_TIMING
+  for (int i = 0; i < 8; ++i) W.tsum[i] = 0;
+  const long long t_begin = TF_NOW();
+#endif
+#ifdef TF_PRIO
+  // the second wavefront of every SIMD (dispatched later = the loser of every issue arbitration by age) gets a static priority
+  if (W.w >= NWAVE / 2) __builtin_amdgcn_s_setprio(TF_PRIO);
+#endif
   float A0[36], A1[36];
   issue_loads<1>(A0, W.wp, W.lane);
   W.wp += UNIT;
@@ -680,6 +723,11 @@ __global__ __launch_bounds__(512) void trunk_fused_kernel(Args a) {
     dense_layer<TP, 3, HM>(a, W, A0, A1, j, last);
     dense_layer<TP, 4, HM>(a, W, A0, A1, j, last);
   }
+#ifdef TF_TIMING
+  W.tsum[7] = TF_NOW() - t_begin;
+  if (W.lane == 0 && a.tstamp)
+    for (int i = 0; i < 8; ++i) a.tstamp[((size_t)blockIdx.x * NWAVE + W.w) * 8 + i] = W.tsum[i];
+#endif
 }
 
 // The trunk's weights into the per-wavefront streams (one launch per optimizer step).  One wavefront per (unit, tile) block:
@@ -794,6 +842,12 @@ void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
     snprintf(tag, sizeof(tag), "trunk_fwd_%drdb_n%d%s%s", L.nrdb, L.nimg, L.cat ? "_keep" : "", helper ? "_helper" : "");
     g_profiler.begin(s, helper ? 4 : 2, flop, wbytes + abytes, tag, helper ? 32 * ((L.nimg + 7) / 8) : 8 * a.tpx);
   }
+#ifdef TF_TIMING
+  static long long* d_ts = nullptr;
+  if (!d_ts) DBM_HIP(hipMalloc((void**)&d_ts, sizeof(long long) * 512 * NWAVE * 8));
+  DBM_HIP(hipMemsetAsync(d_ts, 0, sizeof(long long) * 512 * NWAVE * 8, s));
+  a.tstamp = d_ts;
+#endif
   if (helper)
     hipLaunchKernelGGL((trunk_fused_kernel<27, true>), dim3(32 * ((L.nimg + 7) / 8)), dim3(NTHREADS), LDS_HELPER, s, a);
   else if (TP == 27)
@@ -801,5 +855,19 @@ void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
   else
     hipLaunchKernelGGL((trunk_fused_kernel<32, false>), dim3(8 * a.tpx), dim3(NTHREADS), Geo<32>::LDS_BYTES, s, a);
   if (g_profiler.enabled) g_profiler.end(s);
+#ifdef TF_TIMING
+  if (g_profiler.enabled && g_profiler.serial) {   // (the serialised profile pass of tools/experiments/step_shapes.py)
+    std::vector<long long> h((size_t)512 * NWAVE * 8);
+    DBM_HIP(hipDeviceSynchronize());
+    DBM_HIP(hipMemcpy(h.data(), d_ts, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int b : {0, 8, 16}) {   // (helper form: blocks 0, 8, 16 are the three bands of image 0; block 24 its helper)
+      for (int w = 0; w < NWAVE; ++w) {
+        const long long* t = &h[((size_t)b * NWAVE + w) * 8];
+        fprintf(stderr, "trunk fwd timing (%s) block %3d wave %d: K loops %9lld  barrier1 %8lld  reduce+epilogue %8lld  barrier2 %8lld  prologue %8lld  total %9lld\n",
+                helper ? "helper" : "retained", b, w, t[0], t[1], t[2], t[3], t[4], t[7]);
+      }
+    }
+  }
+#endif
   DBM_HIP(hipGetLastError());
 }

@@ -268,6 +268,16 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
     __builtin_amdgcn_sched_barrier(0);
   }
 
+#ifndef TFB_NO_EARLY_WAIT
+  {
+    // The next sub-tile's first weights (requested during the last unit above) are awaited HERE, before the epilogue's global
+    // and granule stores: see trunk_fused.hip (vmcnt counts the stores too, and behind their branches hipcc waits with vmcnt(0)).
+    float (&pend)[AU] = ((NU - 1) & 1) ? A0 : A1;
+#pragma unroll
+    for (int i = 0; i < AU; ++i) asm volatile("" ::"v"(pend[i]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
   // ---- epilogue: this lane's four cells ----
   if (DBM_ABL_BIT(a, 2)) {
 #pragma unroll
@@ -417,6 +427,10 @@ __global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
 #ifdef TFB_TIMING
   for (int i = 0; i < 8; ++i) W.tsum[i] = 0;
   const long long t_begin = (long long)__builtin_amdgcn_s_memtime();
+#endif
+#ifdef TF_PRIO
+  // the second wavefront of every SIMD (dispatched later = the loser of every issue arbitration by age) gets a static priority
+  if (W.w >= NWAVE / 2) __builtin_amdgcn_s_setprio(TF_PRIO);
 #endif
   float A0[AU], A1[AU];
   issue_unit(A0, W.wp, W.lane);

@@ -73,3 +73,26 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_product_library_has_no_work_skipping_switches(built):
+    """switches that skip work (results then wrong) must not ship.  They are compiled only with -DDBM_MEASURE
+    into libdbm_measure.so (tools/build_measure.sh); the product library does not even contain their names, the package loads another
+    library only when DBM_LIB points at a libdbm_measure.so, and bench.py refuses to run with DBM_LIB or one of the switches set."""
+    from deepbedmap_amd import _lib
+
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"DBM_ABL_SKIP", b"DBM_NO_WGRAD", b"DBM_TFB_ABL", b"DBM_CL16_ABL", b"DBM_ABL_NOPACK", b"ABL_SKIP", b"NO_WGRAD", b"TFB_ABL",
+                 b"CL16_ABL", b"ABL_NOPACK"):
+        assert name not in blob, name
+    # switched-off variants that lost their A/B in round 3 are gone as well
+    for name in (b"DBM_TWIN_EARLY", b"DBM_ITER_TAIL", b"DBM_PF_PRIORITY", b"DBM_CL16_SMALL", b"DBM_IGEMM_LDS"):
+        assert name not in blob, name
+    import bench
+
+    assert set(("DBM_ABL_SKIP", "DBM_NO_WGRAD", "DBM_TFB_ABL", "DBM_CL16_ABL", "DBM_ABL_NOPACK", "DBM_LIB")) <= set(bench.WORK_SKIPPING_ENV)
+    assert _lib.library_path({}) == _lib.LIB_PATH
+    with pytest.raises(_lib.DbmError, match="libdbm_measure.so"):
+        _lib.library_path({"DBM_LIB": "/tmp/some_other_library.so"})
+    with pytest.raises(_lib.DbmError, match="libdbm_measure.so"):
+        _lib.library_path({"DBM_LIB": _lib.LIB_PATH})   # (not even the product library under that switch)

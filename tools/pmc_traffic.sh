@@ -11,6 +11,7 @@ mkdir -p "$OUT"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C -f csv -d "$OUT" -o $C -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/$C.log" 2>&1 || { echo "rocprofv3 failed; last lines of "$OUT/$C.log":" >&2; tail -n 30 "$OUT/$C.log" >&2; exit 1; }
 done
+cp bench_tables.json "$OUT/tables.json"   # (the per-shape tables of the last pass: bench.py keeps them out of its JSON line)
 python3 - "$OUT" <<'PY'
 import csv, json, sys, collections
 out = sys.argv[1]
@@ -47,8 +48,7 @@ def tag_class(tag):
 # these only -- the command's inference leg launches the same kernels on much larger grids
 train_keys = None
 try:
-    _line = [l for l in open(f"{out}/FETCH_SIZE.log") if l.startswith("{")][-1]
-    train_keys = {(tag_class(r["shape"]), r["workgroups"]) for r in json.loads(_line)["roofline"].get("per_shape", [])}
+    train_keys = {(tag_class(r["shape"]), r["workgroups"]) for r in json.load(open(f"{out}/tables.json"))["per_shape"]}
 except Exception:
     pass
 
@@ -78,11 +78,10 @@ for k, v in res.items():
 # ---- per launch shape, against the ALGORITHMIC bytes bench.py's brackets carry (same command: its JSON line is in the log) ----
 alg = collections.defaultdict(lambda: [0.0, 0, set()])  # (class, workgroups) -> [algorithmic bytes summed, launches, tags]
 try:
-    line = [l for l in open(f"{out}/FETCH_SIZE.log") if l.startswith("{")][-1]
-    bench = json.loads(line)
-    tables = [bench["roofline"].get("per_shape", [])]
+    bench = json.load(open(f"{out}/tables.json"))
+    tables = [bench.get("per_shape", [])]
     for leg in ("fp32", "bf16"):
-        tables.append(bench.get("extras", {}).get("sweep", {}).get(leg, {}).get("per_shape_standalone", []))
+        tables.append(((bench.get("sweep") or {}).get(leg) or {}).get("per_shape_standalone", []))
     for t in tables:
         for row in t:
             a = alg[(tag_class(row["shape"]), row["workgroups"])]
