@@ -185,6 +185,21 @@ DI bool xcd_handshake(unsigned long long* table, int base, int mine, unsigned ma
 
 }  // namespace
 
+#ifndef TF_LATE_LOADS
+#define TF_LATE_LOADS 1
+#endif
+// The request a layer's FIRST unit makes for its second unit's weights (layer KN = 0..4), factored out so that the previous
+// layer can issue it before its epilogue (TF_LATE_LOADS).  Same stream bookkeeping as in dense_layer's loop at u = 0.
+template <int KN, bool HM> DI void issue_second_unit(float (&buf)[36], Wave& W, int lane) {
+  if (!HM) {
+    if (KN == 4) { issue_loads<2>(buf, W.wp, lane); W.wp += 2 * UNIT; }
+    else { issue_loads<1>(buf, W.wp, lane); W.wp += UNIT; }
+  } else {
+    if (KN == 4) issue_loads<1>(buf, W.wp + 2 * C5U(1) * UNIT, lane);   // (conv_layer5 walks its units in the order C5U; W.wp stays)
+    else { issue_loads<1>(buf, W.wp, lane); W.wp += UNIT; }
+  }
+}
+
 // One layer of a dense block.  K = 0..4 (conv_layer1..5).  A0 / A1: the weight ping-pong (static parity per dense block).
 // HM (helper mode, TP = 27): a fourth workgroup per image computes output channels 32..63 of every conv_layer5 for the three
 // bands (helper_trunk below); a band computes channels 0..31, hands every output of every layer to the helper and takes the
@@ -217,10 +232,22 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
   // use) and the biases of this thread's epilogue outputs.  Every lane loads (lanes without a granule re-read slot 0).
   // granule slot s (0 .. 8 HS - 1) of a quad: channel e = s / (2 HS), side = (s / HS) & 1 (0: before, 1: after), position s % HS
   constexpr int NQ = (K == 0 && !HM) ? 2 : 1;        // newest quads of this wavefront whose halo comes from the neighbours
+#ifdef TF_TIMING
+  __builtin_amdgcn_sched_barrier(0);
+  TF_LAP(5);   // (slot 5: the layer's first VALU work, before any memory instruction)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   const unsigned long long* gp[NQ][2];
   unsigned long long gv[NQ][2];
   int gdst[NQ][2];
-  {
+  float bias[2 * NM];
+  // Round 4: the first memory instruction a wavefront issues behind the previous layer's epilogue stores (granule stores are
+  // write-through) stalls until those have drained -- 1 700 cycles per layer for every wavefront but the first to arrive
+  // (TF_TIMING: 11 % of the launch).  Layers whose halo is not needed at once (conv_layer2..5: the newest unit is their last)
+  // therefore issue NOTHING at their start: these requests follow the first unit's MFMAs, and the weights of the layer's second
+  // unit were requested before the previous layer's epilogue (below).
+  constexpr bool LATE = TF_LATE_LOADS && K > 0;
+  auto layer_requests = [&]() {
     const unsigned long long* inb = a.inbox + (par_in ? 2 * 64 * HS : 0);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -233,7 +260,13 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
         gv[q][r] = granule_load(gp[q][r]);
       }
     }
-  }
+#pragma unroll
+    for (int k = 0; k < 2 * NM; ++k) {
+      const int r = 2 * w + (k & 1);
+      bias[k] = a.bstream[j * 192 + (K < 4 ? 32 * K : 128) + (k >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+    }
+  };
+  if (!LATE) layer_requests();
   // helper mode, conv_layer1: channels 32 + 4 w .. of the block input come from the helper
   const bool from_helper = HM && K == 0 && j > 0;
   const unsigned long long* hp[3];
@@ -245,12 +278,6 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
       hp[r] = bh + W.hh_g[r];
       hv[r] = granule_load(hp[r]);
     }
-  }
-  float bias[2 * NM];
-#pragma unroll
-  for (int k = 0; k < 2 * NM; ++k) {
-    const int r = 2 * w + (k & 1);
-    bias[k] = a.bstream[j * 192 + (K < 4 ? 32 * K : 128) + (k >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
   }
   __builtin_amdgcn_sched_barrier(0);
 
@@ -271,7 +298,9 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
       for (int i = 0; i < 18 * NM; ++i) asm volatile("" ::"v"(cur[i]));
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!HM) {
+    if (TF_LATE_LOADS && u == 0) {
+      // (this unit's successor was requested before the previous layer's epilogue: issue_second_unit)
+    } else if (!HM) {
       if (next_is_c5) { issue_loads<2>(nxt, W.wp, lane); W.wp += 2 * UNIT; }
       else { issue_loads<1>(nxt, W.wp, lane); W.wp += UNIT; }
     } else {
@@ -345,6 +374,10 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
       mma_taps<TP, NM, 2>(cur, b, acc);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (LATE && u == 0) {
+      layer_requests();
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 #ifndef TF_NO_EARLY_WAIT
   {
@@ -357,6 +390,13 @@ __device__ __forceinline__ void dense_layer(const Args& a, Wave& W, float (&A0)[
 #pragma unroll
     for (int i = 0; i < 36; ++i) asm volatile("" ::"v"(pend[i]));
     __builtin_amdgcn_sched_barrier(0);
+    if (TF_LATE_LOADS) {
+      // ... and the NEXT layer's second unit is requested here, into the buffer the last unit has just finished with
+      // (what that layer's first unit used to request at its start, right behind the stores below)
+      float (&freebuf)[36] = lastpar ? A1 : A0;
+      issue_second_unit<(K + 1) % 5, HM>(freebuf, W, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 #endif
   TF_LAP(0);
@@ -715,6 +755,7 @@ __global__ __launch_bounds__(512) void trunk_fused_kernel(Args a) {
   float A0[36], A1[36];
   issue_loads<1>(A0, W.wp, W.lane);
   W.wp += UNIT;
+  if (TF_LATE_LOADS) issue_second_unit<0, HM>(A1, W, W.lane);
   for (int j = 0; j < a.nrdb; ++j) {
     const bool last = j == a.nrdb - 1;
     dense_layer<TP, 0, HM>(a, W, A0, A1, j, last);
@@ -770,7 +811,7 @@ __global__ __launch_bounds__(256) void pack_trunk_fused_kernel(const float* cons
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-size_t trunk_fused_stream_floats(int nrdb) { return (size_t)nrdb * NWAVE * WAVE_RDB + 4 * UNIT; }  // + read-ahead pad
+size_t trunk_fused_stream_floats(int nrdb) { return (size_t)nrdb * NWAVE * WAVE_RDB + 8 * UNIT; }  // + read-ahead pad
 // the neighbour boxes [tiles][2][2][64][HS] at three tiles per image, the helpers' inboxes and the boxes they fill (the
 // backward chain's boxes are smaller)
 size_t trunk_fused_inbox_bytes(int nimg) {
@@ -863,8 +904,8 @@ void launch_trunk_fused(const TrunkFusedLaunch& L, hipStream_t s) {
     for (int b : {0, 8, 16}) {   // (helper form: blocks 0, 8, 16 are the three bands of image 0; block 24 its helper)
       for (int w = 0; w < NWAVE; ++w) {
         const long long* t = &h[((size_t)b * NWAVE + w) * 8];
-        fprintf(stderr, "trunk fwd timing (%s) block %3d wave %d: K loops %9lld  barrier1 %8lld  reduce+epilogue %8lld  barrier2 %8lld  prologue %8lld  total %9lld\n",
-                helper ? "helper" : "retained", b, w, t[0], t[1], t[2], t[3], t[4], t[7]);
+        fprintf(stderr, "trunk fwd timing (%s) block %3d wave %d: K loops %9lld  barrier1 %8lld  reduce+epilogue %8lld  barrier2 %8lld  prologue: before the first load %8lld, loads %8lld  total %9lld\n",
+                helper ? "helper" : "retained", b, w, t[0], t[1], t[2], t[3], t[5], t[4], t[7]);
       }
     }
   }

@@ -224,9 +224,16 @@ template <int NCH> DI void halo_finish(const Args& a, const Wave& W, int plane0,
 
 // One sub-tile (16 output channels x 16 positions) of one layer's data gradient.
 //  KL: 4 = conv_layer5 (input Gout, 64 channels, NU = 4 units), 3..0 = conv_layer4..1 (32 input channels, NU = 2)
-template <int KL>
+#ifndef TFB_LATE_LOADS
+#define TFB_LATE_LOADS 0   // (measured: chain 1.52 ms with, 1.49-1.50 without -- the stall only moves into the K loop; kept for A/B)
+#endif
+// TFB_LATE_LOADS (round 4): the first memory instruction a wavefront issues behind a sub-tile's epilogue stores stalls until they
+// have drained (trunk_fused.hip, TF_TIMING).  A sub-tile therefore issues NOTHING before its first unit's MFMAs: the weights of
+// its second unit were requested before the previous sub-tile's epilogue (into the buffer that one's last unit had finished
+// with), and the epilogue's own global reads (LeakyReLU masks) and the layer's halo requests follow the first unit.
+template <int KL, int NCH>
 DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s, int j, int gin_region, int dlow_region,
-                 int serial, const float (&bfirst)[9]) {
+                 int serial, const float (&bfirst)[9], HaloReq<NCH>* hq) {
   constexpr int NU = (KL == 4 ? 16 : 8) / QU;
   constexpr int fin0 = KL == 4 ? 160 : KL == 3 ? 128 : KL == 2 ? 96 : KL == 1 ? 64 : 0;  // first channel that is final
   const int lane = W.lane;
@@ -254,18 +261,26 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
 #pragma unroll
     for (int i = 0; i < AU; ++i) asm volatile("" ::"v"(cur[i]));  // the wait for this unit's weights, BEFORE the next issue
     __builtin_amdgcn_sched_barrier(0);
-    if (u == 0 && W.st_ok) {  // what the epilogue reads from global memory: masks of final channels, the j == 0 extras
-      if (use_mask) {
+    auto epilogue_reads = [&]() {  // what the epilogue reads from global memory: masks of final channels
+      if (W.st_ok && use_mask) {
         const float* C = a.cat[j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) maskv[r] = C[gofs + r * 81];
       }
+    };
+    if (!TFB_LATE_LOADS && u == 0) epilogue_reads();
+    if (!(TFB_LATE_LOADS && u == 0)) {
+      issue_unit(nxt, W.wp, lane);
+      if (!DBM_ABL_BIT(a, 4)) W.wp += BUNIT;  // (abl 4: every unit re-reads the same weights -- always cache-hot; results wrong)
     }
-    issue_unit(nxt, W.wp, lane);
-    if (!DBM_ABL_BIT(a, 4)) W.wp += BUNIT;  // (abl 4: every unit re-reads the same weights -- always cache-hot; results wrong)
     __builtin_amdgcn_sched_barrier(0);
     mma_unit(cur, breg + u * QU * 4 * CS, u + 1 < NU ? breg + (u + 1) * QU * 4 * CS : -1, bq0, acc);
     __builtin_amdgcn_sched_barrier(0);
+    if (TFB_LATE_LOADS && u == 0) {
+      epilogue_reads();
+      if (hq) halo_issue<NCH>(a, W, serial & 1, *hq);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
 #ifndef TFB_NO_EARLY_WAIT
@@ -276,6 +291,12 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
 #pragma unroll
     for (int i = 0; i < AU; ++i) asm volatile("" ::"v"(pend[i]));
     __builtin_amdgcn_sched_barrier(0);
+    if (TFB_LATE_LOADS) {  // the next sub-tile's SECOND unit, into the buffer this sub-tile's last unit has finished with
+      static_assert(NU % 2 == 0, "every sub-tile starts on buffer A0");
+      issue_unit(A1, W.wp, lane);
+      if (!DBM_ABL_BIT(a, 4)) W.wp += BUNIT;
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 #endif
   // ---- epilogue: this lane's four cells ----
@@ -350,13 +371,16 @@ template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[AU], float (
   }
 #pragma unroll
   for (int s = SMAX - 1; s >= 0; --s) {
-    if (s == 0 && fetch) {
+    // (the halo requests go out before the wavefront's LAST sub-tile of the layer -- the final block is computed first, so the
+    //  neighbours have usually published by then; TFB_LATE_LOADS: behind that sub-tile's first unit)
+    const bool mine = W.w + NWAVE * s < S;
+    if (s == 0 && fetch && !(TFB_LATE_LOADS && mine)) {
       halo_issue<NCH>(a, W, serial & 1, hq);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (W.w + NWAVE * s < S) {
+    if (mine) {
       TFB_T0();
-      sub_tile<KL>(a, W, A0, A1, s, j, gin_region, dlow_region, serial, bfirst);
+      sub_tile<KL, NCH>(a, W, A0, A1, s, j, gin_region, dlow_region, serial, bfirst, (s == 0 && fetch) ? &hq : nullptr);
       TFB_ACC(0);
     }
   }
@@ -435,6 +459,10 @@ __global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
   float A0[AU], A1[AU];
   issue_unit(A0, W.wp, W.lane);
   W.wp += BUNIT;
+  if (TFB_LATE_LOADS) {
+    issue_unit(A1, W.wp, W.lane);
+    W.wp += BUNIT;
+  }
   int serial = 0;
   int par = 0;  // Gout bank
   for (int j = a.j1 - 1; j >= a.j0; --j) {
@@ -503,7 +531,7 @@ __global__ __launch_bounds__(256) void pack_trunk_fused_bwd_kernel(const float* 
 size_t trunk_fused_bwd_stream_floats(int nrdb) {
   size_t units = 0;
   for (int q = 0; q < NWAVE / 2; ++q) units += wave_units(2 * q);
-  return (size_t)nrdb * units * BUNIT + 4 * BUNIT;
+  return (size_t)nrdb * units * BUNIT + 8 * BUNIT;
 }
 
 void launch_pack_trunk_fused_bwd(const float* const* d_wsrc, float* wstream, int nrdb, hipStream_t s) {
