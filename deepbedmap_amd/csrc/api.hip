@@ -44,7 +44,6 @@ static void dbm_handle_persistent_timeout(dbm_ctx* c) {
   const long pause = trunk_rearm_after() <= 0 ? -1 : (long)trunk_rearm_after() << (c->timeout_events > 16 ? 16 : c->timeout_events - 1);
   g_trunk_fused_off = true;
   g_trunk_local_off = true;  // (whatever the cause was: the re-armed kernels exchange through agent-scope stores only)
-  g_cl16_dense_off = true;   // ... and the sweep's trunk goes back to one launch per layer
   g_trunk_rearm_at = pause < 0 ? -1 : g_step_serial + pause;
   fprintf(stderr, "libdbm: a persistent trunk kernel gave up waiting for a neighbouring workgroup (event %ld); %d discriminator / %d "
                   "generator optimizer updates were skipped; the layer-by-layer trunk path is used for the next %ld iterations\n",

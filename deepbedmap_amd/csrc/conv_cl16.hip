@@ -58,16 +58,6 @@ struct ClConvArgs {
 #ifdef DBM_MEASURE
   int abl;                           // libdbm_measure.so only (results wrong): 1 no MFMA loop, 2 no epilogue, 4 no staging after chunk 0
 #endif
-  // Dense-block mode (nlayers = 4: conv_layer1..4 of a ResidualDenseBlock in ONE launch, x == y16 == the block's concat
-  // buffer): layer l reads channels [0, Cin + 32 l) and writes [Cin + 32 l, + 32); wl / bl = the layers' weights and biases.
-  // Every workgroup must be resident (grid <= CUs): a tile waits for its eight neighbours' previous layer through `flags`
-  // (one word per tile: flag_base + layers finished) before it stages the newest 32 channels.
-  int nlayers;
-  const bf16x8* wl[4];
-  const float* bl[4];
-  unsigned* flags; unsigned flag_base;
-  int* err; int* err_dev;            // raised when a neighbour does not show up (bounded spin), as in the trunk kernels
-  int ngroup;                        // dense-block mode: images covered by the grid at a time; a workgroup walks n, n + ngroup, ...
 };
 
 // half-lane h (0..31) -> (row 0/1, column 0..15) of the wavefront's 2 x 16 patch: each 16-lane group of a ds_read_b128
@@ -88,7 +78,7 @@ __host__ __device__ constexpr int cl_act_bytes(int maxs) { return (((2 * maxs + 
 // TSLOTS: the largest tile height (in 2-row patches) the LDS layout is sized for.  12: one workgroup per CU (96 / 132 KB), what a
 // single crop wants (234 tiles of eleven patches on 256 CUs); 8: 78 KB with one output-channel tile -- two workgroups per CU, so
 // that one's staging and epilogue run under the other's MFMAs when a launch has several rounds of tiles (crops batched per forward).
-template <int MT, int TSLOTS, bool DENSE>
+template <int MT, int TSLOTS>
 __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -128,18 +118,14 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
     const bool inside = q < NPIX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     asrc[s] = inside ? a.x + (img + (long)gy * a.W + gx) * a.xc + 8 * part : nullptr;
   }
-  const int nlayers = DENSE ? a.nlayers : 1;        // (DENSE is an instantiation of its own: the single-layer form keeps its registers)
-  const bf16x8* wcur = DENSE ? a.wl[0] : a.w;
-  // FRESH: the chunk holds channels other workgroups of THIS launch have just written (dense-block mode): its loads bypass the
-  // L2 (sc1), like the stores that produced them
-  auto stage = [&](int c, auto BUF, auto FRESH) {
+  const bf16x8* wcur = a.w;
+  auto stage = [&](int c, auto BUF) {
     constexpr int buf = decltype(BUF)::value;
-    constexpr int aux = decltype(FRESH)::value ? 16 : 0;   // (cache-policy immediate: 16 = sc1 on gfx950)
 #pragma unroll
     for (int s = 0; s < ASTEPS; ++s) {
       const int k = wave + 8 * s;
       if (k < AINS)
-        __builtin_amdgcn_global_load_lds(asrc[s] ? asrc[s] + 32 * c : zsrc, (lds_ptr)(smem + buf * ACT_BYTES + k * 1024), 16, 0, aux);
+        __builtin_amdgcn_global_load_lds(asrc[s] ? asrc[s] + 32 * c : zsrc, (lds_ptr)(smem + buf * ACT_BYTES + k * 1024), 16, 0, 0);
     }
     const u4v* wsrc = reinterpret_cast<const u4v*>(wcur) + (long)c * (WINS * 64) + lane;
 #pragma unroll
@@ -148,8 +134,6 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
       if (k < WINS) __builtin_amdgcn_global_load_lds(wsrc + k * 64, (lds_ptr)(smem + WGT0 + buf * W_BYTES + k * 1024), 16, 0, 0);
     }
   };
-  using OLD = std::integral_constant<int, 0>;
-  using NEW = std::integral_constant<int, 1>;
 
   // ---- this lane's patches ----
   int g, i;
@@ -222,37 +206,17 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
 
-  // dense-block mode: the eight neighbouring tiles of this one (same image), polled by threads 0..7
-  const unsigned* nflag = nullptr;
-  long myflag = ((long)n * a.tilesY + ty) * a.tilesX + tx;
-  if (DENSE && tid < 8) {
-    const int k = tid < 4 ? tid : tid + 1;            // 0..8 without the centre
-    const int ny = ty + k / 3 - 1, nx = tx + k % 3 - 1;
-    if (ny >= 0 && ny < a.tilesY && nx >= 0 && nx < a.tilesX) nflag = a.flags + ((long)n * a.tilesY + ny) * a.tilesX + nx;
-  }
-  auto wait_neighbours = [&](unsigned target) {       // every neighbour has finished `target - flag_base` layers
-    if (nflag) {
-      int spins = 0;
-      while ((int)(__hip_atomic_load(nflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 22)) { *a.err = 1; *a.err_dev = 1; break; }
-      }
-    }
-    __syncthreads();
-  };
-
-  for (;;) {   // (dense-block mode: the images n, n + ngroup, ... of a batch, one after the other)
-#pragma nounroll
-  for (int layer = 0; layer < nlayers; ++layer) {
-  // (hipcc otherwise hoists every address of every chunk and tap out of the layer loop and spills: the lane constants are
-  // laundered through an empty asm per layer -- the same medicine as in the trunk kernels)
+  // (One layer per launch.  The four 32-channel layers of a dense block as ONE launch whose tiles wait for their neighbours'
+  //  previous layer through flag words -- `DBM_CL16_DENSE`, round 3 -- was bit for bit the same and not robustly faster (48-50 us
+  //  against 59.6 for four launches on one box, 55 on another): removed in round 4.)
+#ifndef CL16_NO_LAUNDER
+  // (the lane constants are laundered through an empty asm: hipcc otherwise rematerialises the addresses of every chunk and tap)
 #pragma unroll
   for (int s = 0; s < ASTEPS; ++s) asm volatile("" : "+v"(asrc[s]));
 #pragma unroll
   for (int t = 0; t < 9; ++t) { asm volatile("" : "+v"(bad0[t])); asm volatile("" : "+v"(bad1[t])); }
-  const int nchunk = (a.Cin >> 5) + layer;
-  const int newest = layer > 0 ? nchunk - 1 : -1;       // the chunk the previous layer of this launch produced
-  if (DENSE) wcur = a.wl[layer];
+#endif
+  const int nchunk = a.Cin >> 5;
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -260,32 +224,18 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[s][m][r] = 0.f;
 
-  if (!DENSE || layer == 0) {   // (dense-block mode: chunk 0 of the later layers was requested before the previous epilogue)
-    stage(0, B0{}, OLD{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
+  stage(0, B0{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   // chunk c is computed from buffer c & 1 while chunk c + 1 lands in the other one (two chunks per trip: the buffer
   // offsets are compile-time constants, so that hipcc can tell the DMA's destination from the fragment reads' source)
   for (int c = 0; c < (DBM_ABL_BIT(a, 4) ? 1 : nchunk); c += 2) {
-    // Dense-block mode: only the NEWEST chunk is staged past the L2 (sc1).  A 128-byte line of the concat buffer is one pixel's
-    // 64 channels = the outputs of two layers (c1 | c2, c3 | c4), written by the pixel's owner in two steps; a reader's first
-    // access to the line is the sc1 load of its first half, its second the sc1 load of the second half -- a coherent load
-    // re-fetches the line -- and only then plain loads (as an old chunk) may hit it.  Staging ALL in-launch channels with sc1 was
-    // measured too: 54 instead of 48-50 us per launch, i.e. no faster than four launches.  (Bitwise equality with the
-    // per-layer form is tested on a whole 288 x 288 crop, 234 tiles over all eight XCDs: tests/test_gpu_fullsize.py.)
-    if (c + 1 < nchunk) {
-      if (DENSE && c + 1 == newest) { wait_neighbours(a.flag_base + layer); stage(c + 1, B1{}, NEW{}); }
-      else stage(c + 1, B1{}, OLD{});
-    }
+    if (c + 1 < nchunk) stage(c + 1, B1{});
     compute(B0{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c + 1 has landed (this wavefront's pieces; the barrier covers the rest)
     __syncthreads();
     if (c + 1 >= nchunk) break;
-    if (c + 2 < nchunk) {
-      if (DENSE && c + 2 == newest) { wait_neighbours(a.flag_base + layer); stage(c + 2, B0{}, NEW{}); }
-      else stage(c + 2, B0{}, OLD{});
-    }
+    if (c + 2 < nchunk) stage(c + 2, B0{});
     compute(B1{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -307,15 +257,9 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   }
   constexpr int TROW = 32 * MT + 4;                 // floats per pixel row of the transpose tile (+ 16 bytes: conflict-free columns)
   constexpr int QPP = 8 * MT;                       // channel quads per pixel
-  // dense-block mode: the transpose tile has a region of its own behind the staging buffers, and chunk 0 of the NEXT layer
-  // (old channels: nothing to wait for) is requested now -- it lands under this epilogue and the flag round trip
-  float* tbase = reinterpret_cast<float*>(smem + (DENSE ? WGT0 + 2 * W_BYTES : 0));
-  if (DENSE && layer + 1 < nlayers) {
-    wcur = a.wl[layer + 1];
-    stage(0, B0{}, OLD{});
-  }
-  const float* bias = DENSE ? a.bl[layer] : a.bias;
-  const int y0 = a.y0 + 32 * layer;
+  float* tbase = reinterpret_cast<float*>(smem);
+  const float* bias = a.bias;
+  const int y0 = a.y0;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     if (!(s == 0 ? has0 : has1)) continue;          // (wave-uniform)
@@ -360,36 +304,10 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
         __bf16* dst = a.y16 + pix * a.yc + y0 + co;
-        if (DENSE)  // (read by other workgroups of this launch: written through to the fabric)
-          __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), __builtin_bit_cast(unsigned long long, o), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        else
-          *reinterpret_cast<bf16x4*>(dst) = o;
+        *reinterpret_cast<bf16x4*>(dst) = o;
       }
     }
   }
-  if (DENSE) {
-    // this layer's outputs are acknowledged by the memory system (every wavefront's stores), then the tile's word goes up;
-    // the barrier also frees the transpose tile for the next layer's staging
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-      __hip_atomic_store(a.flags + myflag, a.flag_base + layer + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  }  // layer
-  if (!DENSE) break;
-  n += a.ngroup;
-  if (n >= a.N) break;
-  {  // the next image of the batch: same tile, its pixels / flag words one group of images further
-    const long dpix = (long)a.ngroup * a.H * a.W;
-    img += dpix;
-#pragma unroll
-    for (int s = 0; s < ASTEPS; ++s) if (asrc[s]) asrc[s] += dpix * a.xc;
-    const long dflag = (long)a.ngroup * a.tilesY * a.tilesX;
-    myflag += dflag;
-    if (nflag) nflag += dflag;
-  }
-  }  // image
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -722,32 +640,6 @@ static int cl16_choose_slots(int N, int H, int W, int n_cus, int maxs = CL_MAXSL
   return best;
 }
 
-static int cl16_n_cus() {
-  static const int n = [] {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    return prop.multiProcessorCount;
-  }();
-  return n;
-}
-// one tile per CU at most: every workgroup of a dense-block launch has to be resident (they wait for each other)
-bool g_cl16_dense_off = false;   // set by the first persistent-kernel time-out of the process (dbm_handle_persistent_timeout)
-bool cl16_dense_block_ok(int N, int H, int W) {
-  // OFF by default (read per call, like DBM_CL16: tests toggle it).  Same-box A/B of a 288 x 288 crop, three runs each: 5.78 / 5.64-5.59 ms
-  // without / with on one box (the launch 48-50 us against 59.6 for four), 5.77-5.80 / 5.87-5.89 on another (55 us): not a
-  // robust gain -- what a layer costs inside the launch is its chain of latencies.
-  const int enabled = getenv("DBM_CL16_DENSE") ? atoi(getenv("DBM_CL16_DENSE")) : 0;
-  if (!enabled || g_cl16_dense_off) return false;
-  const int ns = cl16_choose_slots(1, H, W, cl16_n_cus());
-  const long tiles = (long)((W + CL_TW - 1) / CL_TW) * ((H + 2 * ns - 1) / (2 * ns));
-  // 1: only when the whole batch is resident at once -- a single crop of the sweep; 2: also larger batches, whose
-  // images the workgroups then walk one after the other (measured at eight 288 x 288 crops per forward: 5.73 ms per crop against
-  // 5.59 with one launch per layer -- a batch has enough tiles to hide a launch's fixed cost by itself)
-  return enabled >= 2 ? tiles <= cl16_n_cus() : (long)N * tiles <= cl16_n_cus();
-}
-size_t cl16_flag_words(int N, int H, int W) { return (size_t)N * ((W + CL_TW - 1) / CL_TW) * ((H + 3) / 4) + 64; }
-
 void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   DBM_CHECK(L.Cin % 32 == 0 && L.Cin >= 32 && (L.Cout == 32 || L.Cout == 64), "cl16 conv: Cin % 32 == 0, Cout 32 or 64");
   DBM_CHECK(L.xc % 8 == 0 && (!L.y16 || (L.yc % 4 == 0 && L.y0 % 4 == 0)), "cl16 conv: channel strides must keep 16- / 8-byte alignment");
@@ -766,34 +658,22 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   a.tilesX = (L.W + CL_TW - 1) / CL_TW;
   // (Tiles of at most eight patches with two workgroups per CU were measured in round 3 and bought nothing: the LDS fragment
   //  reads of the CU, not one workgroup's latencies, are what a layer waits for.)
-  a.nslots = cl16_choose_slots(L.nlayers > 1 ? 1 : L.N, L.H, L.W, n_cus);   // (dense-block mode: one image's tiles fill the chip)
+  a.nslots = cl16_choose_slots(L.N, L.H, L.W, n_cus);
   a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
   size_t lds = 2 * (size_t)cl_act_bytes(CL_MAXSLOTS) + 2 * (size_t)18 * MT * 1024;
-  if (L.nlayers > 1) lds += (size_t)CL_MAXSLOTS * 32 * 36 * sizeof(float);   // the transpose tile's own region (dense-block mode)
   a.zeros = L.zeros;
 #ifdef DBM_MEASURE
   static const int abl = DBM_MEASURE_ENV("CL16_ABL");
   a.abl = abl;
 #endif
-  a.nlayers = L.nlayers > 1 ? L.nlayers : 1;
-  for (int i = 0; i < 4; ++i) { a.wl[i] = (const bf16x8*)L.wl[i]; a.bl[i] = L.bl[i]; }
-  a.flags = L.flags; a.flag_base = L.flag_base; a.err = L.err; a.err_dev = L.err_dev;
-  a.ngroup = 1;
-  if (L.nlayers > 1) {
-    const long tiles = (long)a.tilesX * a.tilesY;
-    DBM_CHECK(L.nlayers == 4 && MT == 1 && L.x == L.y16 && L.y0 == L.Cin && L.flags && L.err && L.err_dev && tiles <= n_cus,
-              "cl16 dense-block mode: four 32-channel layers on one concat buffer, every workgroup resident");
-    a.ngroup = (int)std::min<long>(L.N, std::max<long>(1, n_cus / tiles));   // images in flight; the others follow in the same workgroups
-  }
   DBM_CHECK(L.zeros != nullptr, "cl16 conv: a device zero block is required");
   static bool attr = false;
   if (!attr) {
-    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1, CL_MAXSLOTS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<2, CL_MAXSLOTS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1, CL_MAXSLOTS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1, CL_MAXSLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<2, CL_MAXSLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  const unsigned grid = (unsigned)((long)(L.nlayers > 1 ? a.ngroup : L.N) * a.tilesX * a.tilesY);
+  const unsigned grid = (unsigned)((long)L.N * a.tilesX * a.tilesY);
   if (g_profiler.enabled) {
     // algorithmic bytes: Cin bf16 channels per pixel in, the packed weights, the outputs (bf16 and / or the 64-channel fp32
     // residual stream) and the fp32 residual operands
@@ -804,12 +684,10 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
     snprintf(tag, sizeof(tag), "cl16_c%d>%d_%dx%d_n%d", L.Cin, L.Cout, L.H, L.W, L.N);
     g_profiler.begin(s, 0, 2.0 * px * L.Cout * L.Cin * 9, bytes, tag, grid);
   }
-  if (a.nlayers > 1)
-    hipLaunchKernelGGL((conv_cl16_kernel<1, CL_MAXSLOTS, true>), dim3(grid), dim3(CL_NT), lds, s, a);
-  else if (MT == 1)
-    hipLaunchKernelGGL((conv_cl16_kernel<1, CL_MAXSLOTS, false>), dim3(grid), dim3(CL_NT), lds, s, a);
+  if (MT == 1)
+    hipLaunchKernelGGL((conv_cl16_kernel<1, CL_MAXSLOTS>), dim3(grid), dim3(CL_NT), lds, s, a);
   else
-    hipLaunchKernelGGL((conv_cl16_kernel<2, CL_MAXSLOTS, false>), dim3(grid), dim3(CL_NT), lds, s, a);
+    hipLaunchKernelGGL((conv_cl16_kernel<2, CL_MAXSLOTS>), dim3(grid), dim3(CL_NT), lds, s, a);
   if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
 }

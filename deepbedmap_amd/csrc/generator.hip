@@ -328,34 +328,12 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     for (auto& b : resb) b.ensure(n * 64 * hw);
     for (int c = 1; c < nsplit; ++c) ctx->fork(cstream(c), s, 4 + c);  // (the pre-residual conv's image ranges)
     launch_nchw_to_cl(cat[0].p, 192 * hw, resb[0].p, catb[0].p, 192, N, (int)hw, s);
-    // conv_layer1..4 of a dense block as ONE persistent launch when every tile of the plane gets a CU of its own (a single
-    // crop of the sweep: 234 tiles): the tiles exchange each layer's 32 new channels through the concat buffer itself
-    // (write-through stores, L2-bypassing loads) and one flag word per tile
-    const bool dense = cl16_dense_block_ok(N, h, w);
-    if (dense) {
-      const size_t words = cl16_flag_words(N, h, w);
-      if (words > cl16_flag_cap) {
-        cl16_flags.ensure(words);
-        DBM_HIP(hipMemsetAsync(cl16_flags.p, 0, words * sizeof(float), s));
-        cl16_flag_cap = words;
-        cl16_serial = 0;
-      }
-    }
     for (int j = 0; j < nrdb; ++j) {
       void* C16 = catb[j & 1].p;
       for (int k = 0; k < 5; ++k) {
         const IgLayer& L = layers[L_rdb[j * 5 + k]];
         ClConvLaunch q;
-        if (dense && k > 0 && k < 4) continue;       // (part of the k == 0 launch)
         memset(&q, 0, sizeof(q));
-        q.nlayers = 1;
-        if (dense && k == 0) {
-          q.nlayers = 4;
-          for (int l = 0; l < 4; ++l) { q.wl[l] = layers[L_rdb[j * 5 + l]].wcl16; q.bl[l] = P(layers[L_rdb[j * 5 + l]].bi); }
-          q.flags = reinterpret_cast<unsigned*>(cl16_flags.p);
-          q.flag_base = 8u * (++cl16_serial);
-          q.err = ctx->dev_err_d; q.err_dev = ctx->dev_err_flag;
-        }
         q.x = C16; q.xc = 192; q.Cin = 64 + 32 * k; q.Cout = k < 4 ? 32 : 64; q.w = L.wcl16; q.bias = P(L.bi);
         q.N = N; q.H = h; q.W = w; q.slope = SLOPE; q.s1 = 1.f; q.s2 = 1.f; q.zeros = ctx->zeros;
         if (k < 4) {

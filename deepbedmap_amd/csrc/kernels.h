@@ -177,19 +177,7 @@ struct ClConvLaunch {
   int act; float slope;
   int N, H, W;
   const void* zeros;         // >= 16 bytes of device zeros (dbm_ctx::zeros)
-  // dense-block mode (launch_conv_cl16 with nlayers = 4): conv_layer1..4 of a ResidualDenseBlock in ONE persistent launch on
-  // the block's concat buffer (x == y16, y0 == Cin == 64, Cout 32, LeakyReLU); wl / bl = the four layers' packed weights /
-  // biases; flags = cl16_flag_words(N, H, W) zero-initialised words, flag_base = 8 x a launch serial; err / err_dev as for the
-  // trunk kernels.  cl16_dense_block_ok(N, H, W) says whether the launch fits (every workgroup resident).
-  int nlayers = 1;
-  const void* wl[4] = {nullptr, nullptr, nullptr, nullptr};
-  const float* bl[4] = {nullptr, nullptr, nullptr, nullptr};
-  unsigned* flags = nullptr; unsigned flag_base = 0;
-  int* err = nullptr; int* err_dev = nullptr;
 };
-bool cl16_dense_block_ok(int N, int H, int W);
-extern bool g_cl16_dense_off;
-size_t cl16_flag_words(int N, int H, int W);
 size_t cl16_packed_elems(int Cin, int Cout);   // bf16 elements of a layer's packed image
 void launch_pack_cl16(const float* w_oihw, void* dst, int O, int C, hipStream_t s);
 void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s);

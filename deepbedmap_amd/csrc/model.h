@@ -204,9 +204,6 @@ struct Generator : dbm_model {
   // bf16 sweep mode on large planes (conv_cl16.hip): the dense block's concat as NHWC bf16 (two buffers in ping-pong, 192
   // channels per pixel) and the 64-channel residual stream as NHWC fp32 (block input, block output, RRDB input)
   DevBuf catb[2], resb[4];
-  DevBuf cl16_flags;          // dense-block launches of the sweep's trunk: one word per tile (cl16_flag_words), zeroed when (re)allocated
-  size_t cl16_flag_cap = 0;
-  unsigned cl16_serial = 0;   // launch serial: flag_base = 8 * serial
   DevBuf a3t, a41t;  // NHWC fp32 inputs of the two upsampling convolutions in the sweep's split-bf16 tail (conv_cl16x3_kernel)
   DevBuf g_a0, g_a3, g_u1, g_z41, g_u2, g_a42, goff1, goff2, gcol, g_a51, g_y;
   // A second workspace on the same parameters: the G-step's generator forward can be enqueued while the D-step's

@@ -150,8 +150,8 @@ def predict_tiled_resident(model, X_tile, W1_tile, W2_tile, W3_tile, final_shape
                 ys, xs = (y0 + xtrapad.y + 1) * 4, (x0 + xtrapad.x + 1) * 4
                 copy2d(canvas.ptr + 4 * (ys * final_shape.x + xs), final_shape.x,
                        Y_pred.array.ptr + 4 * (j * Ho * Wo + 4 * xtrapad.y * Wo + 4 * xtrapad.x), Wo, cols, rows)
-    # the sweep's trunk uses launches whose workgroups wait for each other (csrc/conv_cl16.hip, dense-block mode): a time-out
-    # (another process holding the GPU) is reported here instead of in a canvas with wrong tiles -- status 7: run the sweep again
+    # small crops (9 x 9 trunk planes) run the persistent trunk kernels, whose workgroups wait for each other: a time-out (another
+    # process holding the GPU) is reported here instead of in a canvas with wrong tiles -- status 7: run the sweep again
     ctx.synchronize()
     ctx.check_timeout()
     return canvas.get() if download else canvas

@@ -92,18 +92,12 @@ def test_cl16_trunk_equals_the_per_layer_bf16_path(dbm):
                 y_cl = g.forward(*ins).array.get()
                 os.environ["DBM_CL16"] = "0"
                 y_ig = g.forward(*ins).array.get()
-                os.environ["DBM_CL16"] = "1"
-                os.environ["DBM_CL16_DENSE"] = "1"   # conv_layer1..4 of a dense block as ONE launch instead of four
-                y_4l = g.forward(*ins).array.get()
     finally:
-        os.environ.pop("DBM_CL16_DENSE", None)
         if old is None:
             os.environ.pop("DBM_CL16", None)
         else:
             os.environ["DBM_CL16"] = old
     scale = np.abs(y32).max()
-    # the dense-block launch (DBM_CL16_DENSE=1: tiles waiting for their neighbours' previous layer) computes bit for bit what four launches do
-    assert np.array_equal(y_cl, y_4l)
     assert np.abs(y_cl - y_ig).max() / scale < 1e-4, np.abs(y_cl - y_ig).max() / scale
     e = np.abs(y_cl - y32).max() / scale
     assert 1e-7 < e < 3e-2, e  # really bf16 arithmetic, within the mode's tolerance of the fp32 forward
