@@ -98,8 +98,8 @@ def test_ssim_window_size_and_stride(dbm, window, ws, stride, shape):
         dbm.ssim_loss_func(dbm.Variable(y), t, window_size=max(shape[2:]) + 1)
 
 
-def test_generator_out_channels_forward_only(dbm):
-    oc = 3
+@pytest.mark.parametrize("oc", [3, 16])   # (16: the premultiplied 64 -> out_channels layer needs 72 KB of dynamic LDS -- ADVICE round 3)
+def test_generator_out_channels_forward_only(dbm, oc):
     og = omodel.GeneratorModel(num_residual_blocks=1, out_channels=oc, seed=21)
     for k in og.params:
         og.params[k] = (og.params[k] * np.float32(5.0) if k.endswith("/W") else
