@@ -729,7 +729,9 @@ void Generator::backward(const float* gy) {
   int small_i[4], nsmall = 0;
   {
     const IgLayer& L = layers[L_pre];
-    run_wgrad(L, a0.p, 128 * hw, h, w, 0, dA[0].p, 192 * hw, h, w, N, 1.f, &wbs[6]);
+    // (its inputs -- a0 and the chain's last output -- are final when the chain is: the pre-residual weight gradient rides in the
+    //  trunk's last launch (same kernel form) instead of being a 50-us launch + fold of its own in the serial tail behind it)
+    run_wgrad(L, a0.p, 128 * hw, h, w, 0, dA[0].p, 192 * hw, h, w, N, 1.f, &wbs[prev_grp >= 0 ? prev_grp : 6]);
     ConvDesc d;
     memset(&d, 0, sizeof(d));
     d.x = dA[0].p; d.xsn = 192 * hw; d.N = N;
