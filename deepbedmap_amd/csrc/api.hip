@@ -1229,7 +1229,9 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   c->stream = c->side;
   d->forward(N, H4, W4, Y, lr, true, true, 0);
   c->stream = s;
-  // (The G-step's own forward goes to chain[1] behind the first forward; one_fwd: it is the only forward, forked here.)
+  // (The G-step's own forward goes to chain[1] behind the first forward; one_fwd: it is the only forward, forked here.
+  //  Round 4 measured releasing only its INPUT BLOCK early -- beside the first forward's tail, the trunk launch still behind it:
+  //  8.073 against 8.027 ms, two alternations on one box: not kept.)
   if (one_fwd) {
     g->ensure_packed();
     c->fork(s, pf, 6);
