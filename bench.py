@@ -78,7 +78,7 @@ def cpu_baseline(threads=None, batch=16):
     """The oracle (NumPy restatement of the Chainer CPU path: im2col + BLAS sgemm) on this box's host cores, on a BOUNDED
     sample of the benchmark's workload: full iterations (D-step + G-step: forward, backward, Adam; 12 RRDB) at batch 16 --
     a quarter of the benchmark's 64 tiles, the same per-tile arithmetic -- after a warm-up iteration at batch 4; `value` is the
-    median of the measured iterations (as many of up to three as fit into ~45 s of CPU work; 21 s each on the round-4 box).  Beside it
+    median of the measured iterations (as many of up to three as fit into ~60 s of CPU work; 16-25 s each on the round-4 boxes).  Beside it
     the same iteration in torch-CPU fp32 (oneDNN convolutions, autograd) at the benchmark's batch 64, a strong-CPU yardstick.
     BLAS / torch threads are pinned and reported."""
     import statistics
@@ -108,7 +108,7 @@ def cpu_baseline(threads=None, batch=16):
     t_all = time.perf_counter()
     tw = port_step(4)  # warm-up: BLAS thread pool, page faults of the im2col buffers
     ts = [port_step(batch)]
-    while len(ts) < 3 and sum(ts) + ts[-1] < 45.0:   # (two or three samples within ~45 s of CPU work)
+    while len(ts) < 3 and sum(ts) + ts[-1] < 60.0:   # (two or three samples within ~60 s of CPU work: 16-25 s each)
         ts.append(port_step(batch))
     tN = statistics.median(ts)
     out = {"value": batch / tN, "unit": "tiles/s", "cores": threads, "kind": "port",
