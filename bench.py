@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 def _traffic_json():  # tools/pmc_traffic.sh (separate --pmc passes); the newest round's file
-    for r in ("r4", "r3", "r2", "r1"):
+    for r in ("r5", "r4", "r3", "r2", "r1"):
         p = os.path.join(ROOT, "profiles", r, "traffic_pmc.json")
         if os.path.exists(p):
             return p
@@ -41,7 +41,7 @@ MAX_LINE_BYTES = 4096   # the driver keeps an 8 KB tail of stdout: the result li
 TABLES_PATH = os.path.join(ROOT, "bench_tables.json")   # the per-shape tables of the run (also echoed on stderr)
 # environment switches of libdbm_measure.so (built by tools/build_measure.sh with -DDBM_MEASURE) that SKIP work: a run with
 # one of them set is not a measurement of the iteration and bench.py refuses it
-WORK_SKIPPING_ENV = ("DBM_ABL_SKIP", "DBM_NO_WGRAD", "DBM_TFB_ABL", "DBM_CL16_ABL", "DBM_ABL_NOPACK", "DBM_LIB")
+WORK_SKIPPING_ENV = ("DBM_ABL_SKIP", "DBM_NO_WGRAD", "DBM_TFB_ABL", "DBM_CL16_ABL", "DBM_ABL_NOPACK", "DBM_ITER_ABL", "DBM_LIB")
 G_FWD_MAC_PER_TILE = 845360064  # generator forward, 12 RRDB, one 11x11 -> 36x36 tile (81 trunk pixels)
 BATCH_PER_GPU = 64
 N_RRDB = 12
@@ -78,7 +78,8 @@ def cpu_baseline(threads=None, batch=16):
     """The oracle (NumPy restatement of the Chainer CPU path: im2col + BLAS sgemm) on this box's host cores, on a BOUNDED
     sample of the benchmark's workload: full iterations (D-step + G-step: forward, backward, Adam; 12 RRDB) at batch 16 --
     a quarter of the benchmark's 64 tiles, the same per-tile arithmetic -- after a warm-up iteration at batch 4; `value` is the
-    median of the measured iterations (as many of up to three as fit into ~60 s of CPU work; 16-25 s each on the round-4 boxes).  Beside it
+    median of THREE measured iterations (16-25 s each on the round-4 boxes), and the oracle's generator forward alone is timed at
+    N = 1 (BASELINE configs[0]) and N = 64 (`g_forward_n1_ms`, `g_forward_n64_ms`).  Beside it
     the same iteration in torch-CPU fp32 (oneDNN convolutions, autograd) at the benchmark's batch 64, a strong-CPU yardstick.
     BLAS / torch threads are pinned and reported."""
     import statistics
@@ -105,17 +106,29 @@ def cpu_baseline(threads=None, batch=16):
         otrain.train_eval_generator(arrays, og, od, g_opt)
         return time.perf_counter() - t0
 
+    def port_forward(n, reps):
+        """BASELINE configs[0] / BASELINE.md section 3 (a), (b): the generator forward alone (srgan_train.py:437-447, deepbedmap.py:420-421)."""
+        arrays = synthetic_batch(n, 42)
+        og = omodel.GeneratorModel(num_residual_blocks=N_RRDB, seed=1)
+        og.forward(arrays["X"], arrays["W1"], arrays["W2"], arrays["W3"])   # warm-up
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            og.forward(arrays["X"], arrays["W1"], arrays["W2"], arrays["W3"])
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
     t_all = time.perf_counter()
     tw = port_step(4)  # warm-up: BLAS thread pool, page faults of the im2col buffers
-    ts = [port_step(batch)]
-    while len(ts) < 3 and sum(ts) + ts[-1] < 60.0:   # (two or three samples within ~60 s of CPU work: 16-25 s each)
-        ts.append(port_step(batch))
+    ts = [port_step(batch) for _ in range(3)]   # (three samples, 16-25 s each on the round-4 boxes: the median is not one of two)
     tN = statistics.median(ts)
+    f1, f64 = port_forward(1, 10), port_forward(BATCH_PER_GPU, 3)
     out = {"value": batch / tN, "unit": "tiles/s", "cores": threads, "kind": "port",
            "host_cpus": ncpu, "cpu_model": _cpu_model(), "blas_threads": threads,
            "measured_s": [round(t, 3) for t in ts], "warmup_batch4_s": round(tw, 3),
-           "sample": f"{len(ts)} full iteration(s) (D+G step, fwd+bwd+Adam, 12 RRDB) of the NumPy/BLAS oracle at batch {batch} "
-                     f"(median {tN:.1f} s) after a batch-4 warm-up"}
+           "g_forward_n1_ms": round(1e3 * f1, 2), "g_forward_n64_ms": round(1e3 * f64, 1),
+           "sample": f"{len(ts)} full iterations (D+G step, fwd+bwd+Adam, 12 RRDB) of the NumPy/BLAS oracle at batch {batch} "
+                     f"(median {tN:.1f} s) after a batch-4 warm-up; g_forward_*: generator forward alone, N = 1 (median of 10) / 64 (of 3)"}
     try:  # torch-CPU (oneDNN) fp32, the same iteration at the benchmark's batch
         import torch
 
@@ -364,7 +377,7 @@ def _r(v, n=4):
 
 
 def compose_line(*, tiles, dt, steps, warmup, world, batch, ev_ms, config, fam, traffic=None, comm_stats=None, sweep=None, shared=None,
-                 cpu=None, continent=None, tables_path=None, env=None):
+                 cpu=None, continent=None, tables_path=None, env=None, sync_metrics_ms=None):
     """The ONE JSON line rank 0 prints, as a dict: scalars only (the per-shape tables of the run go to bench_tables.json and to
     stderr).  `fam`: one dict per kernel family of the roofline leg (key, ms_per_step, launches_per_step, flop, bytes per step,
     standalone_ms_per_step).  json.dumps of the result stays below MAX_LINE_BYTES (fit_line enforces it)."""
@@ -384,7 +397,10 @@ def compose_line(*, tiles, dt, steps, warmup, world, batch, ev_ms, config, fam, 
     if traffic is not None:
         roof["traffic"] = traffic.get("hbm_bytes_per_launch")
         if roof["traffic"]:
-            roof["traffic_over_algorithmic_bytes"] = _r(roof["traffic"] / max(dom["bytes"] / n, 1.0), 3)
+            # ONE denominator: the counter pass's own join of its launches to the brackets' algorithmic bytes (tools/pmc_traffic.sh:
+            # launch-weighted over the shapes it sampled) -- the ratio profiles/<round>/traffic_pmc.json states; this run's bracket
+            # average only when the file carries none
+            roof["traffic_over_algorithmic_bytes"] = _r(traffic.get("traffic_over_algorithmic") or roof["traffic"] / max(dom["bytes"] / n, 1.0), 3)
         roof["traffic_source"] = traffic.get("source")
     roof["other_kernels"] = [{"kernel": f["key"], "ms": _r(f["ms_per_step"], 3), "ms_standalone": _r(f["standalone_ms_per_step"], 3),
                               "launches": f["launches_per_step"], "frac": _r(tf(f["flop"], f["ms_per_step"]) / PEAK_FP32_MFMA_TFLOPS),
@@ -404,7 +420,8 @@ def compose_line(*, tiles, dt, steps, warmup, world, batch, ev_ms, config, fam, 
         out["rccl_ranks"] = comm_stats.get("world")
         out["config"]["gradient_exchange"] = comm_stats
     if cpu is not None:
-        c = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample", "host_cpus", "cpu_model", "wall_s") if k in cpu}
+        c = {k: cpu[k] for k in ("value", "unit", "cores", "kind", "sample", "host_cpus", "cpu_model", "wall_s", "g_forward_n1_ms", "g_forward_n64_ms")
+             if k in cpu}
         c["value"] = _r(c["value"], 3)
         if "torch_cpu" in cpu:
             t = cpu["torch_cpu"]
@@ -427,10 +444,12 @@ def compose_line(*, tiles, dt, steps, warmup, world, batch, ev_ms, config, fam, 
     if shared is not None:
         extras["one_generator_forward"] = ({k: _r(shared[k]) for k in ("ms_per_step", "tiles_per_s")} if "error" not in shared
                                            else {"error": shared["error"][:200]})
+    if sync_metrics_ms is not None:   # the reference's five float(...) per minibatch (srgan_train.py:1166, 1259-1263): one D2H read per step
+        extras["sync_metrics_ms_per_step"] = _r(sync_metrics_ms)
     if extras:
         out["extras"] = extras
     if tables_path:
-        out["tables"] = os.path.relpath(tables_path, ROOT)
+        out["tables"] = os.path.relpath(tables_path, ROOT) if os.path.abspath(tables_path).startswith(ROOT + os.sep) else tables_path
     return out
 
 
@@ -566,6 +585,10 @@ def main():
                     help="BASELINE config 5 instead of the training iteration: the whole 18000 x 22000 sweep (396 tiles dealt round-robin "
                          "to the ranks, grids resident in HBM, bf16), one compact line with s_per_continent")
     ap.add_argument("--sweep-scale", type=int, default=1, help="--sweep-continent on a 1/k-scale area (tests)")
+    ap.add_argument("--tables", default=TABLES_PATH,
+                    help="where the per-shape tables of THIS run go (default bench_tables.json; profiling passes give their own path so "
+                         "that they do not overwrite the tables of the unprofiled run)")
+    ap.add_argument("--no-continent", action="store_true", help="skip extras.continent (one full 18000 x 22000 bf16 sweep on this GPU)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 1 if args.sweep_continent else 200
@@ -721,6 +744,36 @@ def main():
         except Exception as e:  # pragma: no cover
             shared = {"error": repr(e)}
 
+    # ---- the same iteration with the reference's per-minibatch read-back (outside the timed region, single GPU) ----
+    sync_ms = None
+    if rank == 0 and world == 1 and not args.sync_metrics and not args.no_sweep:
+        try:
+            def step_sync():
+                return dbm.train_minibatch(batch, g, g_opt, d, d_opt, share_generator_forward=args.share_generator_forward,
+                                           prefetch_generator_forward=prefetch, log=None, fused=not args.no_fused_iteration)
+            for _ in range(3):
+                step_sync()
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            n_sync = max(1, min(args.steps, 50))
+            for _ in range(n_sync):
+                step_sync()
+            torch.cuda.synchronize()
+            sync_ms = 1e3 * (time.perf_counter() - ts) / n_sync
+        except Exception as e:  # pragma: no cover
+            print("sync-metrics leg failed: " + repr(e), file=sys.stderr)
+
+    # ---- BASELINE config 5 as far as one GPU reaches (outside the timed region): ONE full 18000 x 22000 sweep, bf16, resident ----
+    continent = None
+    if rank == 0 and world == 1 and not args.no_sweep and not args.no_continent:
+        try:
+            cl = continent_leg(dbm, ctx, argparse.Namespace(sweep_scale=1, warmup=1, steps=1), 0, 1, None)
+            continent = {k: cl[k] for k in ("s_per_continent", "tiles_per_s", "canvas_check_ok")}
+            continent["frac_of_bf16_mfma_peak"] = cl["roofline"]["frac"]
+            continent["area_px"] = [18000, 22000]
+        except Exception as e:  # pragma: no cover
+            continent = {"error": repr(e)[:200]}
+
     if rank == 0:
         config = {"workload": "full ESRGAN training iteration (D-step + G-step, fwd+bwd+Adam), 12 RRDB, 11x11 -> 36x36 tiles, fp32",
                   "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
@@ -735,25 +788,27 @@ def main():
         traffic = None
         try:  # HBM bytes per launch of the dominant kernel: PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, from the committed pass
             with open(TRAFFIC_JSON) as f:
-                traffic = {"hbm_bytes_per_launch": json.load(f)[dom_key.split("<")[0]]["hbm_bytes_per_launch"],
+                tj = json.load(f)[dom_key.split("<")[0]]
+                traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "traffic_over_algorithmic": tj.get("traffic_over_algorithmic"),
                            "source": "static: " + os.path.relpath(TRAFFIC_JSON, ROOT) + " (rocprofv3 --pmc, separate passes; not this run)"}
         except Exception:
             pass
         cpu = cpu_baseline() if (not args.no_cpu_baseline and world == 1) else None
         tables = {"families": fam, "per_shape": per_shape, "sweep": sweep, "one_generator_forward": shared, "cpu_baseline": cpu,
+                  "continent": continent, "sync_metrics_ms_per_step": sync_ms,
                   "note": "per_shape: every distinct launch shape of the step (tag = layer geometry), sorted by standalone time"}
         tables_path = None
         try:
-            with open(TABLES_PATH, "w") as f:
+            with open(args.tables, "w") as f:
                 json.dump(tables, f, indent=1)
-            tables_path = TABLES_PATH
+            tables_path = args.tables
         except OSError:
             pass
         if tables_path is None:   # (no writable directory: the tables go to stderr instead)
             print("bench tables: " + json.dumps(tables), file=sys.stderr, flush=True)
         out = compose_line(tiles=args.batch * world * args.steps, dt=dt, steps=args.steps, warmup=args.warmup, world=world, batch=args.batch,
                            ev_ms=ev_ms.value, config=config, fam=fam, traffic=traffic, comm_stats=comm_stats, sweep=sweep, shared=shared,
-                           cpu=cpu, tables_path=tables_path)
+                           cpu=cpu, tables_path=tables_path, continent=continent, sync_metrics_ms=sync_ms)
         os.write(result_fd, (fit_line(out) + "\n").encode())
     if comm is not None:
         comm.barrier()

@@ -31,6 +31,9 @@ static void dbm_handle_persistent_timeout(dbm_ctx* c) {
   for (dbm_model* m : c->models) {  // optimizer launches that found the condition up did nothing: take their step counts back
     int n = 0;
     if (m->type == 0) static_cast<Generator*>(m)->graph_version = -1;  // retained / prefetched passes are void
+    // ... and so is whatever a backward pass has summed into the gradient arenas since the event (the observing call may be a
+    // host-synchronising forward, long before the update that would apply them): marked until the next cleargrads
+    m->grads_void = true;
     if (m->is_view || !m->d_adam_skipped) continue;
     if (hipMemcpy(&n, m->d_adam_skipped, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && n > 0) {
       m->adam_t -= n;
@@ -48,6 +51,12 @@ static void dbm_handle_persistent_timeout(dbm_ctx* c) {
   fprintf(stderr, "libdbm: a persistent trunk kernel gave up waiting for a neighbouring workgroup (event %ld); %d discriminator / %d "
                   "generator optimizer updates were skipped; the layer-by-layer trunk path is used for the next %ld iterations\n",
           c->timeout_events, c->timeout_skipped[0], c->timeout_skipped[1], pause);
+}
+
+// the gradient arena of `m` (shared with its views) has just been cleared on the stream: whatever a void pass left there is gone
+static void mark_grads_cleared(dbm_model* m) {
+  for (dbm_model* o : m->ctx->models)
+    if (o->grads == m->grads) o->grads_void = false;
 }
 
 // entry of a step entry point: re-arm the persistent kernels when their pause is over, then observe the condition
@@ -586,6 +595,7 @@ int dbm_model_count_params(dbm_model* m, int64_t* n) {
 int dbm_model_cleargrads(dbm_model* m) {
   DBM_API_BEGIN(m->ctx)
   DBM_HIP(hipMemsetAsync(m->grads, 0, m->nparam * sizeof(float), m->ctx->stream));
+  mark_grads_cleared(m);  // (a view shares its owner's arena: both marks go)
   DBM_API_END
 }
 int dbm_model_param_arena(dbm_model* m, void** dptr, size_t* n) {
@@ -920,6 +930,11 @@ int dbm_adam_update(dbm_model* m, double grad_scale) {
                         "void and NOTHING was applied; repeat the forward and backward pass (or the step call), then update");
     throw;
   }
+  // ... or the event was observed EARLIER, by a host-synchronising call between the void backward pass and this update (an
+  // eval-mode forward that answered 7 and was repeated): the flag is clean again, the arena is not
+  if (m->grads_void)
+    throw DbmError(9, "dbm_adam_update: a persistent-kernel time-out was handled since this model's gradients were last cleared -- "
+                      "they may come from a void pass and NOTHING was applied; cleargrads, repeat forward and backward, then update");
   adam_update_impl(m, grad_scale);
   DBM_API_END
 }
@@ -1022,6 +1037,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
   DBM_MARK(s, "D:disc_forward_fake+loss");
   if (train) {
     DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));  // cleargrads (:1162)
+    mark_grads_cleared(d);
     // d_loss.backward() (:1163): the real- and the fake-batch graphs are independent (gradients are accumulated
     // with atomics), so the fake batch's pass runs on a second stream; both hand their weight gradients to the side stream
     // (while a prefetched generator forward owns chain[0] / chain[1], both passes stay on the main stream)
@@ -1146,6 +1162,7 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
     c->stream = s;
     DBM_MARK(s, "G:disc_forward+loss");
     DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), s));  // cleargrads (:1255)
+    mark_grads_cleared(g);
     gg->grads_cleared = true;  // (the memset above: two-slice weight gradients may fold with atomics, bit for bit)
     gg->backward(gg->g_y.p);                                             // g_loss.backward() (:1256)
     gg->grads_cleared = false;
@@ -1159,6 +1176,7 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
     DBM_MARK(s, "G:disc_forward+loss");
     if (train) {
       DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), s));  // cleargrads (:1255)
+      mark_grads_cleared(g);
       gg->grads_cleared = true;
       gg->backward(gg->g_y.p);                                             // g_loss.backward() (:1256)
       gg->grads_cleared = false;
@@ -1211,8 +1229,10 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   if (!c->ev_iter[0]) for (auto& e : c->ev_iter) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (!g->ev_prefetch) DBM_HIP(hipEventCreateWithFlags(&g->ev_prefetch, hipEventDisableTiming));
   // (The iteration's tail -- the discriminator's weight repack, the G-step's detached eval-mode discriminator pass and the
-  // metrics -- runs on the main stream.  Moving it to chain[0], forking the twin's forward early and raising chain[1]'s stream
-  // priority were all measured in round 3 and lost: profiles/README.md, "schedule experiments".)
+  // metrics -- runs on the main stream.  Round 3 tried three alternatives (profiles/design_history_r1-r3.md): raising chain[1]'s
+  // stream priority lost its A/B; moving the tail to chain[0] (DBM_ITER_TAIL) was NEVER validly measured -- DBM_API_BEGIN's
+  // join cleared tail_pending, so both arms ran the same schedule -- and the path was deleted without a re-measurement;
+  // forking the twin's forward early is measured again in round 5: DBM_ITER_EARLY_TWIN below.)
   struct Scope {  // every helper below enqueues on ctx->stream / reads the exchange switches: restore them whatever happens
     dbm_ctx* c; hipStream_t s; Discriminator* d; Generator* t = nullptr;
     ~Scope() {
@@ -1224,48 +1244,71 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   c->comm_in_step = dp;
   c->comm_stream = dp ? c->chain[0] : nullptr;
   DBM_MARK(s, "D:begin");
+  // (libdbm_measure.so only; results are then wrong -- what a part of the iteration costs INSIDE it: 1 = no discriminator work at all
+  //  (forwards, backward passes, weight gradients, update, repack, eval-mode pass), 2 = no trunk weight-gradient launch (generator.hip),
+  //  4 = no weight gradients of the generator's tail, 8 = no eval-mode discriminator pass)
+  static const int iter_abl = DBM_MEASURE_ENV("ITER_ABL");
+  const bool no_d = (iter_abl & 1) != 0;
   // ---- D(real) forward on the side stream, underneath the generator forward (:1145) ----
   c->fork_to_side(0);
   c->stream = c->side;
-  d->forward(N, H4, W4, Y, lr, true, true, 0);
+  if (!no_d) d->forward(N, H4, W4, Y, lr, true, true, 0);
   c->stream = s;
   // (The G-step's own forward goes to chain[1] behind the first forward; one_fwd: it is the only forward, forked here.
   //  Round 4 measured releasing only its INPUT BLOCK early -- beside the first forward's tail, the trunk launch still behind it:
   //  8.073 against 8.027 ms, two alternations on one box: not kept.)
-  if (one_fwd) {
+  // DBM_ITER_EARLY_TWIN (round 5; persistent trunk path, single GPU): where the G-step's own forward is released.
+  //   0: behind the WHOLE first forward (its full-resolution tail included);
+  //   1: behind the first forward's TRUNK launch -- the persistent launches are serialised anyway (persist_begin), and the first
+  //      forward's tail (a serial chain of seven short kernels) then runs beside the second trunk's 192 workgroups instead of alone;
+  //   2: FIRST -- the retained forward's trunk precedes the D-step's in the chain of persistent launches: the generator's own
+  //      forward -> loss -> backward -> update path is the iteration's critical path, the D-step has slack behind it.
+  // Nothing is skipped and no number changes: the two forwards read the same weights and inputs and write separate workspaces.
+  static const int early_env = getenv("DBM_ITER_EARLY_TWIN") ? atoi(getenv("DBM_ITER_EARLY_TWIN")) : 0;
+  const int early = (!one_fwd && !dp && g->trunk_fused_ok(H - 2, W - 2)) ? early_env : 0;
+  if (one_fwd || early == 2) {
     g->ensure_packed();
     c->fork(s, pf, 6);
   }
-  // ---- fakes under enable_backprop=False (:1131-1137) ----
-  if (!one_fwd) g->forward(N, H, W, X, W1, W2, W3, g->yout.p, false);
-  DBM_MARK(s, "D:generator_forward");
-  // ---- the G-step's own forward (:1222-1227), retained graph, second workspace, on chain[1] ----
   Generator* t = g->get_twin();
   scope.t = t;
   t->ensure_ws(N, H, W, true);
-  t->max_split = 1;
-  if (!one_fwd) c->fork(s, pf, 6);
-  c->stream = pf;
-  t->forward(N, H, W, X, W1, W2, W3, t->yout.p, true);
-  DBM_HIP(hipEventRecord(g->ev_prefetch, pf));  // the twin's fakes are final (the G-step's eval-mode discriminator pass reads them)
-  c->stream = s;
-  t->max_split = 2;
+  auto twin_forward = [&]() {  // the G-step's own forward (:1222-1227), retained graph, second workspace, on chain[1]
+    t->max_split = 1;
+    c->stream = pf;
+    t->forward(N, H, W, X, W1, W2, W3, t->yout.p, true);
+    DBM_HIP(hipEventRecord(g->ev_prefetch, pf));  // the twin's fakes are final (the G-step's eval-mode discriminator pass reads them)
+    c->stream = s;
+    t->max_split = 2;
+  };
+  if (early == 2) twin_forward();
+  // ---- fakes under enable_backprop=False (:1131-1137) ----
+  if (!one_fwd) {
+    g->mark_trunk = early == 1;
+    g->forward(N, H, W, X, W1, W2, W3, g->yout.p, false);
+    g->mark_trunk = false;
+  }
+  DBM_MARK(s, "D:generator_forward");
+  if (early == 1) DBM_HIP(hipStreamWaitEvent(pf, g->ev_trunk, 0));  // weights packed, inputs final, the first trunk launch enqueued
+  else if (!one_fwd && early == 0) c->fork(s, pf, 6);
+  if (early != 2) twin_forward();
   // ---- D(fake) forward, RaGAN loss, cleargrads (:1146-1162) ----
   c->join_side();
   if (one_fwd) DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));  // (the fakes are the retained forward's, written on chain[1])
-  d->forward(N, H4, W4, one_fwd ? t->yout.p : g->yout.p, lf, true, true, 1);
+  if (!no_d) d->forward(N, H4, W4, one_fwd ? t->yout.p : g->yout.p, lf, true, true, 1);
   launch_ragan_loss(lr, lf, N, 1, 0, metrics, gr, gf, s);
   DBM_MARK(s, "D:disc_forward_fake+loss");
   DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));
+  mark_grads_cleared(d);
   // ---- d_loss.backward() (:1163): real batch on the main stream, fake batch on chain[0], weight gradients on side ----
   c->fork(s, c->chain[0], 7);
   d->merge_slots = true;
   d->merge_launcher = 1;
   d->comm_sent_lo = d->comm_sent_hi = 0;
   c->comm_defer = dp;  // (chain[0] is the exchange stream AND carries the fake-batch pass: its bucket goes out behind the pass)
-  d->backward(0, gr, false);
+  if (!no_d) d->backward(0, gr, false);
   c->stream = c->chain[0];
-  d->backward(1, gf, false);
+  if (!no_d) d->backward(1, gf, false);
   c->stream = s;
   d->merge_slots = false;
   c->comm_defer = false;
@@ -1286,6 +1329,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   gen_loss_terms(c, t->yout.p, Y, X, N, H4, W4, weights, ssim_window, t->g_y.p);
   DBM_HIP(hipEventRecord(c->ev_iter[0], pf));
   DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), pf));  // cleargrads (:1255)
+  mark_grads_cleared(g);
   t->grads_cleared = true;
   // (chain[0] carries the discriminator's fake-batch pass and the gradient exchange.  DBM_ITER_AUX=1, single GPU only: the offset-
   // gradient kernel of final_conv_layer2 goes there all the same, next to the input-gradient gather)
@@ -1298,9 +1342,9 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   DBM_HIP(hipEventRecord(c->ev_iter[1], pf));
   c->stream = s;
   // ---- discriminator update (:1164), then the G-step's detached eval-mode discriminator pass (:1228-1237) ----
-  adam_update_impl(d, gscale);
+  if (!no_d) adam_update_impl(d, gscale);
   DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));  // the twin's fakes (written on chain[1]: nothing else orders this read)
-  d->forward(N, H4, W4, t->yout.p, lf_eval, false, false, 1);  // (repacks the updated weights first)
+  if (!no_d && !(iter_abl & 8)) d->forward(N, H4, W4, t->yout.p, lf_eval, false, false, 1);  // (repacks the updated weights first)
   DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[0], 0));  // the loss scratch was cleared on chain[1]
   gen_loss_adv(c, nullptr, lf_eval, N, 0, 1);
   DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[1], 0));  // generator backward (and its weight gradients) done

@@ -85,8 +85,9 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
       ej.total += DC_O[i];
     }
     ej.start[9] = ej.total;
-    bn_coef.ensure(2 * (size_t)ej.total);
-    ej.scale = bn_coef.p; ej.shift = bn_coef.p + ej.total;
+    DevBuf& coef = bn_coef[slot & 1];
+    coef.ensure(2 * (size_t)ej.total);
+    ej.scale = coef.p; ej.shift = coef.p + ej.total;
     launch_bn_eval_coeffs(ej, 1e-5f, s);
   }
   for (int i = 1; i < 10; ++i) {  // conv -> BatchNorm -> LeakyReLU  (:663-689)

@@ -72,6 +72,7 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
 Generator::~Generator() {
   if (twin) delete twin;
   if (ev_prefetch) (void)hipEventDestroy(ev_prefetch);
+  if (ev_trunk) (void)hipEventDestroy(ev_trunk);
   for (auto& e : ev_pack) if (e) (void)hipEventDestroy(e);
   if (!is_view) {
     (void)hipFree(tf_wstream); (void)hipFree(tf_bstream); (void)hipFree(tf_bwd_wstream); (void)hipFree((void*)tf_wsrc); (void)hipFree((void*)tf_bsrc);
@@ -316,6 +317,10 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       ctx->persist_begin(s);
       launch_trunk_fused(L, s);
       ctx->persist_end(s);
+    }
+    if (mark_trunk) {
+      if (!ev_trunk) DBM_HIP(hipEventCreateWithFlags(&ev_trunk, hipEventDisableTiming));
+      DBM_HIP(hipEventRecord(ev_trunk, s));
     }
   }
   // bf16 sweep mode on planes the persistent kernels do not serve: the trunk on channels-last bf16 activations
@@ -580,7 +585,8 @@ void Generator::backward(const float* gy) {
   // leaves most of the chip idle: the batches go to the side stream as soon as their inputs are final.
   DBM_MARK(s, "G:backward_tail_layers");
   ctx->fork_to_side(0);
-  wbs[0].launch(ctx->side);
+  static const int iter_abl = DBM_MEASURE_ENV("ITER_ABL");  // (libdbm_measure.so only: 2 = no trunk weight gradients, 4 = none of the tail's)
+  if (!(iter_abl & 4)) wbs[0].launch(ctx->side);
   // Data-parallel run: the gradient arena is in construction order (input block | pre | trunk | tail), and the backward
   // pass finishes it from the end: every group of weight gradients that has been enqueued on the side stream is a
   // contiguous range that can be summed over ranks (chain[1]) while the rest of the pass still runs.
@@ -594,9 +600,13 @@ void Generator::backward(const float* gy) {
   // (data-parallel: four groups, so that the last, exposed, gradient bucket is a quarter of the trunk instead of all of it)
   static const int ngroups_forced = getenv("DBM_BWD_GROUPS") ? atoi(getenv("DBM_BWD_GROUPS")) : -1;
   const int ngroups_env = ngroups_forced >= 0 ? ngroups_forced : (ctx->comm_in_step ? 4 : 1);
-  if (ngroups_env != wbs_groups) {
+  // (the batches' membership depends on the trunk PATH as well -- fused: one group per launch; layer-wise: the fixed five groups --
+  //  and WgradBatch::add is a no-op once a batch is built: a path change (persistent kernels paused after a time-out, re-armed later)
+  //  re-plans them, or the stale fused batch would be launched next to the layer-wise groups and count 11 of 12 RRDBs twice)
+  const int wbs_key = fused ? ngroups_env : -2;
+  if (wbs_key != wbs_groups) {
     for (int i = 1; i <= 5; ++i) wbs[i].reset();
-    wbs_groups = ngroups_env;
+    wbs_groups = wbs_key;
   }
   auto group_of = [&](int j) {
     // groups of residual-in-residual blocks, shrinking towards the end of the chain: what is still to do once the
@@ -763,7 +773,7 @@ void Generator::backward(const float* gy) {
   //  1008 long workgroups then hold every CU while the eight short dependent launches of this tail and the discriminator's
   //  eval-mode pass each wait for a free slot.  The order below stays.)
   ctx->fork_to_side(6);
-  if (prev_grp >= 0) wbs[prev_grp].launch(ctx->side);
+  if (prev_grp >= 0 && !(iter_abl & 2)) wbs[prev_grp].launch(ctx->side);
   wbs[6].launch(ctx->side);
   for (int k = 0; k < nsmall; ++k) {  // the two single-channel 3x3 branches of the input block
     const int i = small_i[k];

@@ -139,6 +139,10 @@ struct dbm_model {
   long adam_t = 0;
   int* d_adam_skipped = nullptr;  // device counter of optimizer launches that were no-ops (dbm_ctx::dev_err_flag was set)
   bool adam_ready = false;
+  // a persistent-kernel time-out was handled while this model's gradient arena held (or may have held) the sums of a void
+  // backward pass: dbm_adam_update answers status 9 until the arena has been cleared (dbm_model_cleargrads, or the cleargrads
+  // inside the step entry points) -- whichever call observed the event, and however many host-synchronising calls lie between
+  bool grads_void = false;
   bool packed_dirty = true;
   long param_version = 0;  // bumped by every write to the parameter arena
   long packed16_version = -1;  // param_version the bf16 forward images were built from
@@ -217,6 +221,8 @@ struct Generator : dbm_model {
   bool use_aux = true;  // backward(): the deformable layers' offset-gradient kernel may run on chain[chain_base]
   int max_split = 2;  // image ranges the 9x9 stage may be cut into (1: everything on the caller's stream)
   hipEvent_t ev_prefetch = nullptr;
+  hipEvent_t ev_trunk = nullptr;   // forward(): recorded behind the 9x9 stage's trunk launch when mark_trunk is set (dbm_train_iteration:
+  bool mark_trunk = false;         // the G-step's own forward may start there instead of behind this forward's full-resolution tail)
   hipEvent_t ev_pack[3] = {nullptr, nullptr, nullptr};  // pack_extra: main stream reached the repack / forward streams built / backward streams built
   // fused 9x9 trunk forward (trunk_fused.hip): per-wavefront weight streams (owner only), per-workspace hand-off granules
   float* tf_wstream = nullptr;
@@ -246,7 +252,8 @@ struct Discriminator : dbm_model {
     bool valid = false;
     DevBuf img, h[10], z[10], mean[10], istd[10], l1, out;
   } cache[2];
-  DevBuf bn_coef;   // eval-mode passes: [scale | shift] of all nine BatchNorm layers (launch_bn_eval_coeffs)
+  DevBuf bn_coef[2];  // eval-mode passes: [scale | shift] of all nine BatchNorm layers (launch_bn_eval_coeffs), one buffer per cache
+                      // slot: two eval-mode passes in flight on different streams never share coefficients
   DevBuf g_h[2][2], g_z[2][10], g_l1[2], g_out, c0_scratch[2];  // per retained graph: the two backward passes overlap
   static const int NWG = 4;
   WgradBatch wbm[NWG];     // the same for BOTH graphs in one launch per group (the fused D-step: twice the work per launch)

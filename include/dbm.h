@@ -14,9 +14,12 @@
  *     while (re-armed after DBM_TRUNK_REARM = 64 iterations, doubling) and returns 7 WITHOUT having enqueued anything --
  *     re-issue it; dbm_timeout_info says how many queued updates were dropped.  Entry points that take HOST pointers and
  *     therefore end with a stream synchronisation (dbm_gen_forward / dbm_gen_backward -- the calls that launch persistent kernels --
- *     dbm_disc_forward and the loss calls, without DBM_DEVICE_PTRS) observe the condition after that synchronisation as well: their results are void, status 7, re-issue.
- *     dbm_adam_update is the exception to "re-issue": an event observed at its entry means the gradients it was about to apply
- *     are void -- it returns status 9, applies nothing, and the caller repeats forward + backward before updating.  Status 8:
+ *     dbm_disc_forward and the loss calls, without DBM_DEVICE_PTRS) observe the condition after that synchronisation as well: their
+ *     results are void, status 7.  FORWARD and loss calls are simply re-issued.  dbm_gen_backward / dbm_disc_backward are NOT: gradients
+ *     accumulate, so after status 7 from a backward call: dbm_model_cleargrads, then repeat forward AND backward.
+ *     dbm_adam_update is the other exception: whenever an event has been handled (by any call) since the model's gradient arena
+ *     was last cleared, the arena may hold the sums of a void pass -- it returns status 9, applies nothing, and the caller clears
+ *     the gradients and repeats forward + backward before updating (the step entry points clear them themselves).  Status 8:
  *     the same in a data-parallel run, where a local retry cannot keep the replicas identical -- fatal, abort the job;
  *   - tensors are NCHW float32, C-contiguous; weights OIHW, exactly the arrays stored by
  *     chainer.serializers.save_npz (key layout: SURVEY.md Appendix B);

@@ -295,6 +295,30 @@ except _lib.DbmError as e:
 assert opt.t == 1
 moved = g.serialize_dict()
 assert any(not np.array_equal(before[k], moved[k]) for k in before)
+# (4) ADVICE round 4: the event is observed -- and the sticky flag cleared -- by a HOST-SYNCHRONISING call between the void backward
+# pass (device pointers: it only enqueues) and the update.  The update must still refuse (status 9) until the arena has been cleared.
+y = g.forward(*xs)
+g.cleargrads()
+_lib.check(lib.dbm_debug_inject_timeout_async(g.ctx.handle), g.ctx.handle)
+g.backward(d.to_device(np.ones(y.shape, np.float32)))          # enqueued under the raised flag: void
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    with d.using_config("enable_backprop", False):
+        _ = g.forward(*xs).array                                # status 7 inside, repeated by the mirror: flag clean again
+assert any("timed out" in str(x.message) for x in w)
+t0 = opt.t
+held = {k: v.copy() for k, v in g.serialize_dict().items()}
+try:
+    opt.update()
+    raise SystemExit("update() applied the gradients of a void pass after a host-synchronising call had cleared the flag")
+except _lib.DbmError as e:
+    assert e.code == 9, e.code
+assert opt.t == t0 and all(np.array_equal(held[k], v) for k, v in g.serialize_dict().items())
+y = g.forward(*xs)
+g.cleargrads()
+g.backward(np.ones(y.shape, np.float32))
+opt.update()
+assert opt.t == t0 + 1
 print("ok")
 """
 

@@ -1,0 +1,113 @@
+"""-m gpu: regressions of round 5.
+
+* eval-mode BatchNorm folded into the convolution epilogues (v = acc * scale + (beta - mean * scale)) at the reference's DATA RANGE:
+  images in metres (sigma 2000 m), running statistics from training-mode passes on such images, against the float64 oracle's
+  gamma * (z - mean) / sqrt(var + eps);
+* the batched weight gradients of the generator's trunk are re-planned when the trunk PATH changes (persistent kernels paused by a
+  time-out): the RAW gradients of the first layer-by-layer backward after the event equal those of a process that never used the
+  persistent kernels (a stale fused batch next to the layer-wise groups summed every RRDB but the first twice; Adam's m / sqrt(v)
+  hides a constant gradient scale, so the older tests that compare parameters after an update could not see it).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import model as omodel
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_RAW_GRADS_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import deepbedmap_amd as d
+from deepbedmap_amd import _lib
+np.random.seed(11)
+g = d.GeneratorModel(num_residual_blocks=3, residual_scaling=0.3)
+rs = np.random.RandomState(12)
+n = 8
+xs = [rs.rand(n, c, m * 11, m * 11).astype(np.float32) for c, m in ((1, 1), (1, 10), (2, 2), (1, 1))]
+gy = rs.normal(size=(n, 1, 36, 36)).astype(np.float32)
+if sys.argv[3] == "1":
+    # a backward pass on the persistent kernels first (plans the trunk's weight-gradient batch for the fused path) ...
+    y = g.forward(*xs)
+    g.cleargrads()
+    g.backward(gy)
+    # ... then the event: observed by dbm_check_timeout, the layer-by-layer trunk path takes over
+    _lib.check(_lib.lib().dbm_debug_inject_timeout(g.ctx.handle), g.ctx.handle)
+    try:
+        g.ctx.check_timeout()
+        raise SystemExit("status 7 expected")
+    except _lib.DbmError as e:
+        assert e.code == 7, e
+    assert g.ctx.timeout_info()[3]
+y = g.forward(*xs)
+g.cleargrads()
+g.backward(gy)
+np.savez(sys.argv[2], **{k.strip("/").replace("/", "|"): p.grad for k, p in g.namedparams()})
+"""
+
+
+def test_raw_gradients_after_a_timeout_equal_the_layerwise_path(tmp_path):
+    script = tmp_path / "raw_grads.py"
+    script.write_text(_RAW_GRADS_SCRIPT)
+    outs = []
+    for inject, fused in (("1", "1"), ("0", "0")):
+        out = str(tmp_path / f"g{inject}.npz")
+        res = subprocess.run([sys.executable, str(script), ROOT, out, inject], env=dict(os.environ, DBM_TRUNK_FUSED=fused),
+                             capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        outs.append(dict(np.load(out)))
+    assert set(outs[0]) == set(outs[1]) and len(outs[0]) > 100
+    for k in outs[0]:
+        a, b = outs[0][k].astype(np.float64), outs[1][k].astype(np.float64)
+        scale = max(np.abs(b).max(), 1e-30)
+        # same kernels on both sides once the persistent ones are paused: equal up to the summation order of the batched launches
+        assert np.abs(a - b).max() <= 1e-4 * scale, (k, np.abs(a - b).max() / scale)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("n", [4, 16])
+def test_discriminator_eval_mode_at_the_data_range(n):
+    """srgan_train.py:1228 (chainer.config.train = False) on DEM-like images: mean 800 m, sigma 2000 m.  The running statistics come
+    from two training-mode passes on such images (so |running mean| is large against the running std in the first layers), then the
+    eval-mode logits are held to 1e-4 of the float64 oracle -- the folded form must not lose the digits the un-folded one keeps."""
+    import deepbedmap_amd as dbm
+
+    od = omodel.DiscriminatorModel(seed=21)
+    r = np.random.RandomState(22)
+    for k in od.params:   # weights x10 as in the other parity tests (HeNormal(0.1) alone dies out), first layer / 2000: O(1) activations
+        if k.endswith("/W"):
+            od.params[k] = (od.params[k] * (10.0 / 2000.0 if k.startswith("conv_layer0/") else 10.0)).astype(np.float32)
+        elif k.endswith("gamma"):
+            od.params[k] = (od.params[k] + r.normal(0, 0.2, od.params[k].shape)).astype(np.float32)
+        else:
+            od.params[k] = (od.params[k] + r.normal(0, 0.1, od.params[k].shape)).astype(np.float32)
+    od.params["conv_layer0/b"] = (od.params["conv_layer0/b"] + 8.0).astype(np.float32)   # |mean| of conv_layer1's output >> its std
+    od64 = omodel.DiscriminatorModel(seed=21)
+    od64.params = {k: v.astype(np.float64) for k, v in od.params.items()}
+    od64.persistent = {k: (v.astype(np.float64) if v.dtype == np.float32 else v) for k, v in od.persistent.items()}
+    d = dbm.DiscriminatorModel(initialize=False)
+    for name, p in d._tensors.items():
+        if name in od.params:
+            p.array = od.params[name]
+        elif name in od.persistent:
+            p.array = np.asarray(od.persistent[name], dtype=np.float32)
+    imgs = [(800.0 + 2000.0 * r.standard_normal((n, 1, 36, 36))).astype(np.float32) for _ in range(3)]
+    with dbm.using_config("train", True):
+        for im in imgs[:2] * 8:   # sixteen passes: the running mean reaches 0.81 of the batch mean
+            d.forward(im)
+            od64.forward(im.astype(np.float64), train=True)
+    with dbm.using_config("train", False):
+        got = d.forward(imgs[2]).array
+    ref = od64.forward(imgs[2].astype(np.float64), train=False)
+    assert np.isfinite(got).all()
+    assert _rel(got, ref) < 1e-4, _rel(got, ref)

@@ -224,3 +224,33 @@ def test_bench_refuses_work_skipping_switches_and_prices_split_bf16_correctly():
     assert bench.sweep_roof("bf16", "cl16_c64>32_286x286_n1")[1] == 2500.0
     assert bench.sweep_roof("bf16", "deform1_1144x1144_n1")[1] == bench.PEAK_FP32_MFMA_TFLOPS
     assert bench.sweep_roof("fp32", "x3_c64>64_1144x1144_n1u")[1] == bench.PEAK_FP32_MFMA_TFLOPS
+
+
+def test_committed_bench_tables_belong_to_the_line_beside_them():
+    """`profiles/<round>/<prefix>_bench_tables.json` must be the tables OF the run whose line is
+    `<prefix>_bench.json` (round 4 committed tables a later --pmc pass had overwritten).  For every such pair from round 5 on:
+    every kernel family's standalone total in the tables equals standalone_avg_launch_us x launches (dominant family) /
+    ms_standalone (the others) of the line, within 5 %."""
+    import glob
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = []
+    for rnd in sorted(glob.glob(os.path.join(root, "profiles", "r[5-9]"))):
+        for tp in sorted(glob.glob(os.path.join(rnd, "*_bench_tables.json"))):
+            lp = tp[: -len("_tables.json")] + ".json"
+            if os.path.exists(lp):
+                pairs.append((tp, lp))
+    for tp, lp in pairs:
+        tables = json.load(open(tp))
+        line = json.loads(open(lp).read().strip().splitlines()[-1])
+        fam = {f["key"]: f for f in tables["families"]}
+        roof = line["roofline"]
+        want = {roof["kernel"]: 1e-3 * roof["standalone_avg_launch_us"] * roof["launches_per_step"]}
+        for o in roof.get("other_kernels", []):
+            want[o["kernel"]] = o["ms_standalone"]
+        assert want, lp
+        for k, ms in want.items():
+            got = fam[k]["standalone_ms_per_step"]
+            assert abs(got - ms) <= 0.05 * ms + 2e-3, (os.path.basename(tp), k, got, ms)

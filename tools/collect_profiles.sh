@@ -2,6 +2,7 @@
 # Runs on the GPU box: everything profiles/<round>/ holds for one state of the code, into gpurun_out/<tag>/ under the names the
 # round directory uses.  usage: tools/collect_profiles.sh <tag> <prefix>      (e.g. r3z z_round3_final)
 #   <prefix>_bench.json                     default `python bench.py` (unprofiled; cpu_baseline + extras.sweep included)
+#   <prefix>_bench_tables.json              the per-shape tables OF THAT RUN (bench.py --tables)
 #   <prefix>_bench_profiled.json            the line of the same command under rocprofv3 --kernel-trace --stats
 #   <prefix>_kernel_stats.csv               rocprofv3 --stats per-kernel summary (in-step: streams overlap)
 #   <prefix>_serialised_kernel_stats.csv    the same with --pmc GRBM_GUI_ACTIVE (dispatches serialised: standalone durations)
@@ -16,7 +17,9 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-python3 bench.py > "$OUT/${PFX}_bench.json" 2> "$OUT/bench.err" || { tail -n 20 "$OUT/bench.err" >&2; exit 1; }
+# (the per-shape tables of THIS unprofiled run are written straight to their final name: the profiled passes below write their own
+#  tables elsewhere -- round 4 copied bench_tables.json after the --pmc passes had overwritten it)
+python3 bench.py --tables "$OUT/${PFX}_bench_tables.json" > "$OUT/${PFX}_bench.json" 2> "$OUT/bench.err" || { tail -n 20 "$OUT/bench.err" >&2; exit 1; }
 bash tools/profile_bench.sh $TAG/prof > /dev/null
 cp "$OUT/prof/bench.json" "$OUT/${PFX}_bench_profiled.json"
 cp "$OUT/prof/trace_kernel_stats.csv" "$OUT/${PFX}_kernel_stats.csv"

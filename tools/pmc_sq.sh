@@ -7,7 +7,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd /tmp && export TMPDIR=/tmp && cd "${ROOT:?repository root not found}"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -f csv -d "$OUT" -o sq -- python3 ${SQ_CMD:-bench.py --no-cpu-baseline --no-sweep --steps 1 --warmup 1} > "$OUT/sq.log" 2>&1 || { echo "rocprofv3 failed; last lines of "$OUT/sq.log":" >&2; tail -n 30 "$OUT/sq.log" >&2; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -f csv -d "$OUT" -o sq -- python3 ${SQ_CMD:-bench.py --no-cpu-baseline --no-sweep --tables /tmp/sq_tables.json --steps 1 --warmup 1} > "$OUT/sq.log" 2>&1 || { echo "rocprofv3 failed; last lines of "$OUT/sq.log":" >&2; tail -n 30 "$OUT/sq.log" >&2; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, json, sys, collections, re
 out = sys.argv[1]

@@ -9,9 +9,9 @@ cd /tmp && export TMPDIR=/tmp && cd "${ROOT:?repository root not found}"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -f csv -d "$OUT" -o $C -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/$C.log" 2>&1 || { echo "rocprofv3 failed; last lines of "$OUT/$C.log":" >&2; tail -n 30 "$OUT/$C.log" >&2; exit 1; }
+  rocprofv3 --kernel-trace --pmc $C -f csv -d "$OUT" -o $C -- python3 bench.py --no-cpu-baseline --no-continent --tables "$OUT/tables.json" --steps 2 --warmup 1 > "$OUT/$C.log" 2>&1 || { echo "rocprofv3 failed; last lines of "$OUT/$C.log":" >&2; tail -n 30 "$OUT/$C.log" >&2; exit 1; }
 done
-cp bench_tables.json "$OUT/tables.json"   # (the per-shape tables of the last pass: bench.py keeps them out of its JSON line)
+# ("$OUT/tables.json": the per-shape tables of the last counter pass -- its own file, bench.py --tables)
 python3 - "$OUT" <<'PY'
 import csv, json, sys, collections
 out = sys.argv[1]

@@ -7,7 +7,7 @@ ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd /tmp && export TMPDIR=/tmp && cd "${ROOT:?repository root not found}"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT" -o trace -- python3 bench.py --no-cpu-baseline "$@" > "$OUT/bench.log" 2>&1 || { echo "rocprofv3 failed; last lines of "$OUT/bench.log":" >&2; tail -n 30 "$OUT/bench.log" >&2; exit 1; }
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT" -o trace -- python3 bench.py --no-cpu-baseline --no-continent --tables "$OUT/tables.json" "$@" > "$OUT/bench.log" 2>&1 || { echo "rocprofv3 failed; last lines of "$OUT/bench.log":" >&2; tail -n 30 "$OUT/bench.log" >&2; exit 1; }
 grep '^{' "$OUT/bench.log" > "$OUT/bench.json" || true
 # per-dispatch trace is large: keep only the last 2600 dispatches (about two training step) for inspection
 python3 - "$OUT" <<'PY'
