@@ -1238,7 +1238,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
     ~Scope() {
       c->stream = s; c->comm_in_step = false; c->comm_defer = false; c->comm_stream = nullptr; c->comm_pending.clear();
       d->merge_slots = false;
-      if (t) { t->grads_cleared = false; t->use_aux = true; t->max_split = 2; }
+      if (t) { t->grads_cleared = false; t->use_aux = true; t->max_split = 2; t->wgrad_inline = false; }
     }
   } scope{c, s, d};
   c->comm_in_step = dp;
@@ -1335,7 +1335,10 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   // gradient kernel of final_conv_layer2 goes there all the same, next to the input-gradient gather)
   static const int iter_aux = getenv("DBM_ITER_AUX") ? atoi(getenv("DBM_ITER_AUX")) : 0;
   t->use_aux = iter_aux && !dp;
+  static const int wg_inline = getenv("DBM_ITER_WGRAD_INLINE") ? atoi(getenv("DBM_ITER_WGRAD_INLINE")) : -1;
+  t->wgrad_inline = wg_inline >= 0 ? wg_inline != 0 : early == 2;
   t->backward(t->g_y.p);
+  t->wgrad_inline = false;
   t->grads_cleared = false;
   t->use_aux = true;
   t->graph_version = -1;

@@ -257,9 +257,31 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   }
   constexpr int TROW = 32 * MT + 4;                 // floats per pixel row of the transpose tile (+ 16 bytes: conflict-free columns)
   constexpr int QPP = 8 * MT;                       // channel quads per pixel
+  constexpr int NIT = 32 * QPP / 64;                // store iterations per patch (4 / 8)
   float* tbase = reinterpret_cast<float*>(smem);
-  const float* bias = a.bias;
   const int y0 = a.y0;
+  // Round 5: vmcnt counts stores as well as loads, in order -- a load issued behind a store cannot be awaited without draining
+  // that store (a write round trip).  The loop below used to load bias / r1 / r2 in EVERY iteration, behind the previous
+  // iteration's stores, each load under its own (uniform) branch and hence awaited with vmcnt(0): eight drains + up to 24
+  // serialised load round trips per wavefront (the "4.4 of 14 us" epilogue of round 4's ablation).  Now the bias quad is loaded
+  // once (its channel depends on the lane only: QPP divides 64), the residual operands of a WHOLE patch are requested before the
+  // patch's first store, and every access is a raw buffer access whose bounds check replaces the branches: offset -1 reads zero /
+  // drops the store (pixels outside the plane), a zero-length buffer stands for an absent operand.
+  auto rsrc = [](const void* ptr, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, ptr ? (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes) : 0, 0x00020000);
+  };
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  const long npix = (long)a.N * a.H * a.W;
+  const int co = 4 * (lane & (QPP - 1));            // this lane's channel quad, the same in every iteration
+  const f4v bv = *reinterpret_cast<const f4v*>(a.bias + co);
+  // (byte offsets relative to the IMAGE's first pixel: 32-bit for every plane the launcher accepts -- checked there)
+  const __amdgpu_buffer_rsrc_t r1r = rsrc(a.r1 ? a.r1 + img * 64 : nullptr, 256L * a.H * a.W);
+  const __amdgpu_buffer_rsrc_t r2r = rsrc(a.r2 ? a.r2 + img * 64 : nullptr, 256L * a.H * a.W);
+  const __amdgpu_buffer_rsrc_t y32r = rsrc(a.y32 ? a.y32 + img * 64 : nullptr, 256L * a.H * a.W);
+  const __amdgpu_buffer_rsrc_t y16r = rsrc(a.y16 ? a.y16 + img * a.yc : nullptr, 2L * a.yc * a.H * a.W);
+  (void)npix;
+  const bool resid = a.r1 != nullptr || a.r2 != nullptr;   // (uniform: conv_layer5)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     if (!(s == 0 ? has0 : has1)) continue;          // (wave-uniform)
@@ -271,41 +293,50 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
         *reinterpret_cast<f4v*>(T + (lane & 31) * TROW + 32 * m + 8 * rg + 4 * (lane >> 5)) =
             (f4v){acc[s][m][4 * rg], acc[s][m][4 * rg + 1], acc[s][m][4 * rg + 2], acc[s][m][4 * rg + 3]};
     const int prow_base = 2 * (s == 0 ? wave : wave + 8);
+    int pixo[NIT];                                  // pixel index inside the image, -1: outside the plane
 #pragma unroll
-    for (int it = 0; it < 32 * QPP / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int h = idx / QPP, co = 4 * (idx - h * QPP);
+    for (int it = 0; it < NIT; ++it) {
+      const int h = (it * 64 + lane) / QPP;
       int pg, pi;
       patch_of(h, pg, pi);
       const int gy = ty * TH + prow_base + pg, gx = tx * CL_TW + pi;
+      pixo[it] = (gy < a.H && gx < a.W) ? gy * a.W + gx : -1;
+    }
+    f4v q1[NIT], q2[NIT];
+    if (resid) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int off = pixo[it] >= 0 ? (pixo[it] * 64 + co) * 4 : -1;
+        q1[it] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r1r, off, 0, 0));
+        q2[it] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r2r, off, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int h = (it * 64 + lane) / QPP;
       f4v v = *reinterpret_cast<const f4v*>(T + h * TROW + co);
-      if (gy >= a.H || gx >= a.W) continue;
-      const long pix = img + (long)gy * a.W + gx;
-      const f4v bv = (f4v){bias[co], bias[co + 1], bias[co + 2], bias[co + 3]};
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += bv[e];
-      if (a.r1) {
-        const f4v r = *reinterpret_cast<const f4v*>(a.r1 + pix * 64 + co);
+      if (resid) {
+        if (a.r1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = a.s1 * v[e] + r[e];
-      }
-      if (a.r2) {
-        const f4v r = *reinterpret_cast<const f4v*>(a.r2 + pix * 64 + co);
+          for (int e = 0; e < 4; ++e) v[e] = a.s1 * v[e] + q1[it][e];
+        }
+        if (a.r2) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = a.s2 * v[e] + r[e];
+          for (int e = 0; e < 4; ++e) v[e] = a.s2 * v[e] + q2[it][e];
+        }
       }
       if (a.act) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : a.slope * v[e];
       }
-      if (a.y32) *reinterpret_cast<f4v*>(a.y32 + pix * 64 + co) = v;
-      if (a.y16) {
-        bf16x4 o;
+      const int p = pixo[it];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), y32r, p >= 0 ? (p * 64 + co) * 4 : -1, 0, 0);
+      bf16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-        __bf16* dst = a.y16 + pix * a.yc + y0 + co;
-        *reinterpret_cast<bf16x4*>(dst) = o;
-      }
+      for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, o), y16r, p >= 0 ? (p * a.yc + y0 + co) * 2 : -1, 0, 0);
     }
   }
 }
@@ -479,7 +510,17 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
   }
 
   // ---- epilogue ----
+  // (round 5: the bias quads are loaded ONCE, before the first store -- a load behind a store is awaited by draining the store,
+  //  vmcnt being in order over both: the per-(patch, tile, quad) loads of the first version cost a write round trip each)
   const long plane = (long)a.H * a.W;
+  f4v bq[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bq[m][rg][e] = a.bias[32 * m + 8 * rg + 4 * (lane >> 5) + e];   // (dword loads: a bias tensor behind an
+                                                                                                   //  18-float one is only 8-byte aligned)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     if (!(s == 0 ? has0 : has1)) continue;
@@ -496,7 +537,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
         f4v v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = acc[s][m][4 * rg + e] + a.bias[co + e];
+          v[e] = acc[s][m][4 * rg + e] + bq[m][rg][e];
           if (a.act) v[e] = v[e] >= 0.f ? v[e] : a.slope * v[e];
         }
         if (a.y32) *reinterpret_cast<f4v*>(a.y32 + pix * a.yc + co) = v;

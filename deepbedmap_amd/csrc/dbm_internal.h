@@ -69,6 +69,8 @@ struct ConvDesc {
   int T;
   signed char dy[DBM_MAX_TAPS];
   signed char dx[DBM_MAX_TAPS];
+  signed char tmap[DBM_MAX_TAPS];  // set by the launcher (conv_tile.hip): window cell (ky, kx), row-major -> tap index t
+  int abl;        // libdbm_measure.so only (conv_tile.hip): 1 = only chunk 0 is staged, 2 = no MFMAs, 4 = no epilogue (results wrong)
   const float* wp;  // packed [T][Cin][CoutP]
   int CoutP;        // multiple of 32
   int Cout;
@@ -117,6 +119,9 @@ struct ConvDesc {
 };
 
 void launch_igemm_conv(const ConvDesc& d, hipStream_t s);
+// the LDS-tiled form for the mid-size training planes (conv_tile.hip); launch_igemm_conv dispatches to it
+int conv_tile_plan(ConvDesc& d, long* wgs);
+void conv_tile_launch(const ConvDesc& d, int cfg, hipStream_t s);
 
 // Per-kernel-family timing with HIP events on the launch stream (bench.py's roofline leg).
 // family 0 = igemm_conv_kernel (forward + data gradient), 1 = weight-gradient kernels, 2 = trunk_fused_kernel,

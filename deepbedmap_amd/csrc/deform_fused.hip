@@ -183,13 +183,18 @@ __global__ __launch_bounds__(256) void deform_conv64_fused_kernel(const float* _
   if (Pm >= total) return;
   const long nm = Pm / plane;
   float* yn = y + nm * 64 * plane + (Pm - nm * plane);
+  // (round 5: every bias value is loaded BEFORE the first store -- vmcnt counts stores too, in order, so a load behind a store is
+  //  awaited by draining the store: the interleaved form paid sixteen write round trips per thread)
   float v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
     v[r] = acc[r] + (bias ? bias[c] : 0.f);
     if (act) v[r] = v[r] >= 0.f ? v[r] : slope * v[r];
-    if (y) yn[(long)c * plane] = v[r];
+  }
+  if (y) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yn[(long)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * plane] = v[r];
   }
   if (yt) {
 #pragma unroll
@@ -350,13 +355,16 @@ __global__ __launch_bounds__(256) void deform_conv64_x3_kernel(const float* __re
   const long Pm = P0 + pt * 32 + j;
   if (Pm >= total) return;
   const long nm = Pm / plane;
-  float v[16];
+  float v[16];   // (all bias loads before the first store: see deform_conv64_fused_kernel)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
     v[r] = acc[r] + (bias ? bias[c] : 0.f);
     if (act) v[r] = v[r] >= 0.f ? v[r] : slope * v[r];
-    if (y) y[nm * 64 * plane + (Pm - nm * plane) + (long)c * plane] = v[r];
+  }
+  if (y) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[nm * 64 * plane + (Pm - nm * plane) + (long)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg) * plane] = v[r];
   }
   if (yt) {
 #pragma unroll

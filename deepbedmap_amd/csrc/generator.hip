@@ -586,7 +586,8 @@ void Generator::backward(const float* gy) {
   DBM_MARK(s, "G:backward_tail_layers");
   ctx->fork_to_side(0);
   static const int iter_abl = DBM_MEASURE_ENV("ITER_ABL");  // (libdbm_measure.so only: 2 = no trunk weight gradients, 4 = none of the tail's)
-  if (!(iter_abl & 4)) wbs[0].launch(ctx->side);
+  const bool inline_wg = wgrad_inline && !ctx->comm_in_step;
+  if (!(iter_abl & 4) && !inline_wg) wbs[0].launch(ctx->side);
   // Data-parallel run: the gradient arena is in construction order (input block | pre | trunk | tail), and the backward
   // pass finishes it from the end: every group of weight gradients that has been enqueued on the side stream is a
   // contiguous range that can be summed over ranks (chain[1]) while the rest of the pass still runs.
@@ -773,11 +774,13 @@ void Generator::backward(const float* gy) {
   //  1008 long workgroups then hold every CU while the eight short dependent launches of this tail and the discriminator's
   //  eval-mode pass each wait for a free slot.  The order below stays.)
   ctx->fork_to_side(6);
-  if (prev_grp >= 0 && !(iter_abl & 2)) wbs[prev_grp].launch(ctx->side);
-  wbs[6].launch(ctx->side);
+  hipStream_t wgs = inline_wg ? s : ctx->side;
+  if (prev_grp >= 0 && !(iter_abl & 2)) wbs[prev_grp].launch(wgs);
+  if (inline_wg && !(iter_abl & 4)) wbs[0].launch(wgs);
+  wbs[6].launch(wgs);
   for (int k = 0; k < nsmall; ++k) {  // the two single-channel 3x3 branches of the input block
     const int i = small_i[k];
-    launch_smallcin_conv_wgrad(small[k], g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), ctx->side);
+    launch_smallcin_conv_wgrad(small[k], g_a0.p + (long)i * 32 * hw, 128 * hw, G(T_in[i][0]), G(T_in[i][1]), wgs);
   }
   // input block, pre-residual conv and the trunk group launched last (layer-wise trunk path: the whole trunk)
   if (ctx->comm_in_step) ctx->comm_bucket(grads, rdb_off(final_hi), ctx->side);

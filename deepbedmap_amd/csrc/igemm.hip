@@ -889,6 +889,25 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
       d.ksplit = 1; d.ks_part = nullptr; d.ks_cnt = nullptr; d.pm_groups = 0;  // (odd channel counts: the general form)
     }
   }
+  {  // mid-size planes of the training step (18 x 18, 36 x 36 outputs): operands staged in LDS, no split-K (conv_tile.hip)
+    long wgs = 0;
+    const int cfg = conv_tile_plan(d, &wgs);
+    if (cfg) {
+      if (g_profiler.enabled) {
+        double bytes = 4.0 * ((double)d.N * d.Cin * d.Hin * d.Win + flop_positions * d.Cout) + 4.0 * d.T * (double)d.Cin * d.CoutP;
+        if (d.r1) bytes += 4.0 * flop_positions * d.r1_nch;
+        if (d.r2) bytes += 4.0 * flop_positions * d.Cout;
+        if (d.mask) bytes += 4.0 * flop_positions * (d.Cout - d.mask_c0);
+        if (d.accumulate) bytes += 4.0 * flop_positions * d.Cout;
+        char tag[40];
+        snprintf(tag, sizeof(tag), "c%d>%d_k%d_%dx%d%s", d.Cin, d.Cout, d.T, d.Hin, d.Win, d.ups ? "u" : "");
+        g_profiler.begin(s, 0, 2.0 * flop_positions * d.Cout * d.Cin * d.T, bytes, tag, wgs);
+      }
+      conv_tile_launch(d, cfg, s);
+      if (g_profiler.enabled) g_profiler.end(s);
+      return;
+    }
+  }
   dim3 grid((unsigned)((total + 31) / 32), (unsigned)((d.Cout + 31) / 32), (unsigned)nph);
   long tiles = (long)grid.x * grid.y * nph;
   // Two output-channel tiles per wavefront (the gathered B operand feeds two MFMA chains): layers with >= 64 output

@@ -219,6 +219,9 @@ struct Generator : dbm_model {
   Generator* owner = nullptr;  // twin only: the model whose arenas and weight images it aliases
   int chain_base = 0;
   bool use_aux = true;  // backward(): the deformable layers' offset-gradient kernel may run on chain[chain_base]
+  bool wgrad_inline = false;  // backward(): every weight-gradient launch goes to the pass's OWN stream, behind the data-gradient chain
+                              // (dbm_train_iteration, DBM_ITER_EARLY_TWIN=2: the side stream carries the discriminator's weight gradients, and
+                              // a launch queued behind them would wait for the whole D-step)
   int max_split = 2;  // image ranges the 9x9 stage may be cut into (1: everything on the caller's stream)
   hipEvent_t ev_prefetch = nullptr;
   hipEvent_t ev_trunk = nullptr;   // forward(): recorded behind the 9x9 stage's trunk launch when mark_trunk is set (dbm_train_iteration:

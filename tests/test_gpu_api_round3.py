@@ -277,6 +277,7 @@ y = g.forward(*xs)
 g.cleargrads()
 g.backward(np.ones(y.shape, np.float32))
 _lib.check(lib.dbm_debug_inject_timeout_async(g.ctx.handle), g.ctx.handle)
+g.ctx.synchronize()   # (the raising kernel has RUN: an update that merely overtakes it on the host is the queued-event case, not this one)
 try:
     opt.update()
     raise SystemExit("update() did not report the void gradients")

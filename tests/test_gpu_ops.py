@@ -88,6 +88,13 @@ CONV_CASES = [
     (1, 96, 1, 1, 32, 1, 1, 0, 0, 0),
     (3, 96, 2, 1, 32, 1, 1, 0, 0, 0),
     (2, 64, 5, 1, 64, 3, 1, 1, 0, 1),
+    # LDS-tiled form (conv_tile.hip, round 5): 3x3 / pad 1 on 36 x 36 and 18 x 18 OUTPUT planes -- four bands of nine rows (36), the
+    # whole image per workgroup (18, >= 256 workgroups) or two bands (18, fewer); ragged output-channel tiles, 32..160 input channels
+    (64, 64, 18, 18, 128, 3, 1, 1, 0, 1),  # D conv_layer2 at the full batch: 64 x 4 = 256 whole-image workgroups
+    (3, 96, 18, 18, 64, 3, 1, 1, 0, 0),    # two bands per image
+    (2, 32, 36, 36, 64, 3, 1, 1, 0, 1),    # the data gradient of an offset convolution's shape (32 padded gradient channels)
+    (2, 160, 36, 36, 96, 3, 1, 1, 0, 0),   # twenty chunks of eight channels, three output tiles
+    (3, 128, 9, 9, 64, 3, 1, 1, 1, 1),     # 9 x 9 folded x2 -> 18 x 18 output (post_upsample_conv_layer_1)
 ]
 
 
