@@ -45,9 +45,40 @@ struct __attribute__((packed, aligned(4))) f32x3 { float x, y, z; };
 // accumulate), shared by the kernel forms below.  ks > 1 (cross-workgroup split-K): the workgroup's partial tile goes to
 // d.ks_part with agent-scope write-through stores; the workgroup that arrives LAST at the tile's counter adds the ks slices
 // in index order -- the result does not depend on who is last -- and runs the epilogue.
+// The epilogue's global operands of one thread (PASSES outputs): loaded by igemm_epilogue_load, consumed by igemm_epilogue.
+template <int WAVES> struct IgemmEpiOps {
+  static constexpr int PASSES = 32 / (2 * WAVES);
+  float r1[PASSES], r2[PASSES], y[PASSES], m[PASSES], b[PASSES], s[PASSES];
+};
+template <int WAVES>
+__device__ __forceinline__ void igemm_epilogue_load(const ConvDesc& d, IgemmEpiOps<WAVES>& o, int tid, bool pv, int n, int a, int b, int cout0,
+                                                    int oy0, int ox0) {
+  constexpr int ROWS_PER_PASS = 2 * WAVES, PASSES = 32 / ROWS_PER_PASS;
+  const long pix = (long)(a * d.so + oy0) * d.OWp + (b * d.so + ox0);
+  const int irow = tid >> 5;
+#pragma unroll
+  for (int q = 0; q < PASSES; ++q) {
+    const int i = irow + ROWS_PER_PASS * q;
+    const int c = cout0 + i;
+    o.r1[q] = o.r2[q] = o.y[q] = o.b[q] = 0.f;
+    o.m[q] = o.s[q] = 1.f;
+    if (!pv || c >= d.Cout) continue;
+    const long co = (long)c * d.ysc + pix;
+    if (d.bias) o.b[q] = d.bias[c];
+    if (d.ch_scale) o.s[q] = d.ch_scale[c];
+    if (d.r1 && c < d.r1_nch) o.r1[q] = d.r1[(long)n * d.r1sn + co];
+    if (d.r2) o.r2[q] = d.r2[(long)n * d.r2sn + co];
+    if (d.accumulate) o.y[q] = d.y[(long)n * d.ysn + co];
+    if (d.mask && c >= d.mask_c0) o.m[q] = d.mask[(long)n * d.masksn + co];
+  }
+}
+
+// pre: operands already requested by the caller (the two-tile form requests BOTH tiles' operands before the first tile's stores: a
+// load issued behind a store is awaited by draining the store -- vmcnt is in order over both -- a write round trip per workgroup)
 template <int WAVES>
 __device__ __forceinline__ bool igemm_epilogue(const ConvDesc& d, float* red, const f32x16& acc, int tid, int wave, int j, int kh, bool pv,
-                                               int n, int a, int b, int cout0, int ks, int kz, unsigned tile, int oy0, int ox0) {
+                                               int n, int a, int b, int cout0, int ks, int kz, unsigned tile, int oy0, int ox0,
+                                               const IgemmEpiOps<WAVES>* pre = nullptr) {
   const long pix = (long)(a * d.so + oy0) * d.OWp + (b * d.so + ox0);
   constexpr int ROWS_PER_PASS = 2 * WAVES;        // threads / 32
   constexpr int PASSES = 32 / ROWS_PER_PASS;      // 4, 2, 1 for WAVES = 4, 8, 16
@@ -57,25 +88,16 @@ __device__ __forceinline__ bool igemm_epilogue(const ConvDesc& d, float* red, co
   // then the arithmetic and the stores.  (One pass at a time, the compiler cannot hoist the next
   // pass's loads above the previous pass's store -- y, r1, r2 and mask may alias -- and a short-K layer then spends
   // more time in PASSES serialised memory round trips than in its MFMAs.)
-  float e_r1[PASSES], e_r2[PASSES], e_y[PASSES], e_m[PASSES], e_b[PASSES], e_s[PASSES];
-  auto load_operands = [&]() {
-#pragma unroll
-    for (int q = 0; q < PASSES; ++q) {
-      const int i = irow + ROWS_PER_PASS * q;
-      const int c = cout0 + i;
-      e_r1[q] = e_r2[q] = e_y[q] = e_b[q] = 0.f;
-      e_m[q] = e_s[q] = 1.f;
-      if (!pv || c >= d.Cout) continue;
-      const long co = (long)c * d.ysc + pix;
-      if (d.bias) e_b[q] = d.bias[c];
-      if (d.ch_scale) e_s[q] = d.ch_scale[c];
-      if (d.r1 && c < d.r1_nch) e_r1[q] = d.r1[(long)n * d.r1sn + co];
-      if (d.r2) e_r2[q] = d.r2[(long)n * d.r2sn + co];
-      if (d.accumulate) e_y[q] = d.y[(long)n * d.ysn + co];
-      if (d.mask && c >= d.mask_c0) e_m[q] = d.mask[(long)n * d.masksn + co];
-    }
-  };
-  if (ks <= 1) load_operands();
+  IgemmEpiOps<WAVES> ops;
+  float (&e_r1)[PASSES] = ops.r1;
+  float (&e_r2)[PASSES] = ops.r2;
+  float (&e_y)[PASSES] = ops.y;
+  float (&e_m)[PASSES] = ops.m;
+  float (&e_b)[PASSES] = ops.b;
+  float (&e_s)[PASSES] = ops.s;
+  auto load_operands = [&]() { igemm_epilogue_load<WAVES>(d, ops, tid, pv, n, a, b, cout0, oy0, ox0); };
+  if (pre) ops = *pre;
+  else if (ks <= 1) load_operands();
   // split-K reduction through LDS
   float* mine = red + wave * 1024;
 #pragma unroll
@@ -492,9 +514,18 @@ __global__ __launch_bounds__(64 * WAVES) void igemm_conv_kernel(const ConvDesc d
     igemm_epilogue_ns(d, acc, kh, pv, n, a, b, cout0, oy0, ox0);
     if constexpr (NPB == -4) igemm_epilogue_ns(d, acc2, kh, pv, n, a, b, cout0 + 32, oy0, ox0);
   } else if constexpr (NPB == -4) {  // two output tiles: partial-tile slots 2 tile, 2 tile + 1
-    igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, 2 * tile, oy0, ox0);
-    __syncthreads();  // the first tile's partial sums (and the arrival word) have been read
-    igemm_epilogue<WAVES>(d, red, acc2, tid, wave, j, kh, pv, n, a, b, cout0 + 32, ks, kz, 2 * tile + 1, oy0, ox0);
+    if (ks <= 1) {  // (both tiles' operands before the first tile's stores)
+      IgemmEpiOps<WAVES> o1, o2;
+      igemm_epilogue_load<WAVES>(d, o1, tid, pv, n, a, b, cout0, oy0, ox0);
+      igemm_epilogue_load<WAVES>(d, o2, tid, pv, n, a, b, cout0 + 32, oy0, ox0);
+      igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, 2 * tile, oy0, ox0, &o1);
+      __syncthreads();  // the first tile's partial sums have been read
+      igemm_epilogue<WAVES>(d, red, acc2, tid, wave, j, kh, pv, n, a, b, cout0 + 32, ks, kz, 2 * tile + 1, oy0, ox0, &o2);
+    } else {
+      igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, 2 * tile, oy0, ox0);
+      __syncthreads();  // the first tile's partial sums (and the arrival word) have been read
+      igemm_epilogue<WAVES>(d, red, acc2, tid, wave, j, kh, pv, n, a, b, cout0 + 32, ks, kz, 2 * tile + 1, oy0, ox0);
+    }
   } else {
     igemm_epilogue<WAVES>(d, red, acc, tid, wave, j, kh, pv, n, a, b, cout0, ks, kz, tile, oy0, ox0);
   }

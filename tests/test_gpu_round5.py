@@ -111,3 +111,46 @@ def test_discriminator_eval_mode_at_the_data_range(n):
     ref = od64.forward(imgs[2].astype(np.float64), train=False)
     assert np.isfinite(got).all()
     assert _rel(got, ref) < 1e-4, _rel(got, ref)
+
+
+_SCHEDULE_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import deepbedmap_amd as d
+np.random.seed(31)
+g, g_opt, dm, d_opt = d.compile_srgan_model(num_residual_blocks=2, residual_scaling=0.3, learning_rate=1e-3)
+rs = np.random.RandomState(32)
+n = 12
+batch = d.device_batch({"X": rs.rand(n, 1, 11, 11), "W1": rs.rand(n, 1, 110, 110), "W2": rs.rand(n, 2, 22, 22),
+                        "W3": rs.rand(n, 1, 11, 11), "Y": rs.rand(n, 1, 36, 36)})
+m = [d.train_minibatch(batch, g, g_opt, dm, d_opt, fused=True) for _ in range(3)]
+np.savez(sys.argv[2], m=np.array(m), **{"g|" + k.replace("/", "|"): v for k, v in g.serialize_dict().items()},
+         **{"d|" + k.replace("/", "|"): v for k, v in dm.serialize_dict().items()})
+"""
+
+
+@pytest.mark.parametrize("env", [{"DBM_ITER_EARLY_TWIN": "1"}, {"DBM_ITER_EARLY_TWIN": "2"}, {"DBM_ITER_WGRAD_INLINE": "1"},
+                                 {"DBM_CONV_TILE": "0"}])
+def test_schedule_switches_of_round5_change_no_number(tmp_path, env):
+    """DBM_ITER_EARLY_TWIN (where the G-step's own forward is released), DBM_ITER_WGRAD_INLINE (which stream carries the generator's
+    weight gradients) only re-order independent work: metrics, parameters, Adam state (through a third iteration) and running
+    statistics of three fused iterations are BITWISE those of the default schedule.  DBM_CONV_TILE=0 (igemm_conv_kernel instead of
+    conv_tile.hip's LDS-tiled form for the 18 x 18 / 36 x 36 planes) changes the summation order: equal to 2e-4 relative."""
+    script = tmp_path / "sched.py"
+    script.write_text(_SCHEDULE_SCRIPT)
+    outs = []
+    for e in ({}, env):
+        out = str(tmp_path / f"s{len(outs)}.npz")
+        res = subprocess.run([sys.executable, str(script), ROOT, out], env=dict(os.environ, **e), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        outs.append(dict(np.load(out)))
+    bitwise = "DBM_CONV_TILE" not in env
+    for k in outs[0]:
+        a, b = outs[0][k], outs[1][k]
+        if bitwise:
+            assert np.array_equal(a, b), k
+        else:
+            # (first Adam steps are alpha * sign(g): a parameter whose gradient is rounding noise may move the other way -- bounded
+            #  by 2 alpha per step; everything else agrees to rounding)
+            assert np.abs(a.astype(np.float64) - b).max() <= 6.1e-3, k
+            assert np.mean(np.abs(a.astype(np.float64) - b) <= 2e-4 * max(np.abs(b).max(), 1e-30) + 1e-7) > 0.97, k
