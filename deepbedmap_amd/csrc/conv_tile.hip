@@ -24,41 +24,42 @@ namespace conv_tile {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
-// T taps (9: 3x3), OW = output (= input) columns of the plane, R = output rows per band, NT = position tiles per wavefront, KC = input
+// T taps (9: 3x3 stride 1; 16: 4x4 stride 2), SIN = input stride, OW = output columns of the plane, R = output rows per band, NT = position tiles per wavefront, KC = input
 // channels per LDS chunk, PW = floats per DMA piece of the patch (4: global_load_lds_dwordx4, rows of 16-byte multiples; 3: dwordx3).
 // Patch layout in LDS: rows of LW = PW + OW floats -- one PAD piece, then the row's OW / PW data pieces --, zero rows above / below
 // the image.  The pad piece is never written by a DMA (it stays zero): its last float is the row's left frame cell, and the NEXT
 // row's first pad float is this row's right frame cell, so a tap is still one immediate offset.  (First version: a 38-float row
 // moved by dword pieces -- 7 instructions per channel plane instead of 2, and the piece rate, not the bytes, is what LDS-DMA pays
 // for: MI355X_MICROARCH.md "ldsdma-fill"; the kernel ran at the SUM of its MFMA and DMA times.)
-template <int T, int OW, int R, int NT, int KC, int PW>
+template <int T, int SIN, int OW, int R, int NT, int KC, int PW>
 struct Geo {
-  static constexpr int KW = 3;
-  static constexpr int LW = OW + PW;                 // patch row (floats)
+  static constexpr int KW = T == 9 ? 3 : 4;          // 3x3 (pad 1, stride 1) or 4x4 (pad 1, stride 2) windows
+  static constexpr int IW = (OW - 1) * SIN + KW - 2; // input columns a band reads, frame excluded: OW (3x3) / 2 OW (4x4 stride 2)
+  static constexpr int LW = IW + PW;                 // patch row (floats): pad piece + data
   static constexpr int PPR = LW / PW;                // pieces per row (pad piece included)
-  static constexpr int PR = R + KW - 1;              // patch rows
+  static constexpr int PR = (R - 1) * SIN + KW;      // patch rows
   static constexpr int CELLS = PR * LW;
   static constexpr int NP = PR * PPR;                // pieces per channel plane
   static constexpr int G = (NP + 63) / 64;           // DMA instructions per channel plane
-  static constexpr int CS = (CELLS + 63) / 64 * 64;  // plane stride (floats)
+  static constexpr int CS = (CELLS + 1 + 63) / 64 * 64;  // plane stride (floats; + the frame cell behind the last row)
   static constexpr int NPOS = R * OW;                // positions of a band
   static constexpr int NTILES = (NPOS + 31) / 32;
   static constexpr int WCH = T * KC * 32;            // weight floats of a chunk: [tap][channel][32 output channels]
   static constexpr int BUF = KC * CS + WCH;          // floats per buffer
   static constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(float);
-  static_assert(T == 9, "3x3 windows");
-  static_assert(OW % PW == 0 && LW % PW == 0, "rows are whole pieces");
+  static_assert((T == 9 && SIN == 1) || (T == 16 && SIN == 2), "3x3 stride 1 or 4x4 stride 2");
+  static_assert(IW % PW == 0 && LW % PW == 0, "rows are whole pieces");
   static_assert(NTILES <= 4 * NT && NTILES > 4 * (NT - 1), "band does not fit the wavefronts' tiles");
-  static_assert(KC % 8 == 0, "a weight DMA instruction moves eight 32-float rows");
+  static_assert(KC % 2 == 0 && (T * KC) % 8 == 0, "a weight DMA instruction moves eight 32-float rows");
 };
 
 template <int V> struct NTsel { static constexpr int value = V; };
 struct B0 { static constexpr int value = 0; };
 struct B1 { static constexpr int value = 1; };
 
-template <int T, int OW, int R, int NT, int KC, int PW>
+template <int T, int SIN, int OW, int R, int NT, int KC, int PW>
 __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const ConvDesc d) {
-  using g = Geo<T, OW, R, NT, KC, PW>;
+  using g = Geo<T, SIN, OW, R, NT, KC, PW>;
   constexpr int KW = g::KW, LW = g::LW, CS = g::CS, G = g::G;
   // TWO distinct LDS objects, not two halves of one array: hipcc's wait-count pass orders every LDS read behind every LDS-DMA in flight
   // that MAY alias it (s_waitcnt vmcnt(0) -- the DMA of the next chunk would never overlap this chunk's MFMAs); run-time offsets into
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const ConvDesc d) {
   for (int q = 0; q < G; ++q) {
     const int e = 64 * q + lane;
     const int pr = e / g::PPR, pp = e - pr * g::PPR;
-    const int iy = a0 + dymin + pr;   // LOGICAL input row (a folded nearest x2 resize -- PW == 1 only -- is resolved here)
+    const int iy = a0 * SIN + dymin + pr;   // LOGICAL input row (a folded nearest x2 resize -- PW == 1 only -- is resolved here)
     const bool ok = e < g::NP && pp >= 1 && (unsigned)iy < (unsigned)(d.Hin << d.ups);
     soff[q] = ok ? (iy >> d.ups) * d.Win + (((pp - 1) * PW) >> d.ups) : 0;
     valid |= ok ? (1u << q) : 0u;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const ConvDesc d) {
       pos[i] = p;
       const int pc = p < g::NPOS ? p : 0;
       const int al = pc / OW, b = pc - al * OW;
-      cell[i] = al * LW + b + (PW - 1) + kh * CS;
+      cell[i] = al * SIN * LW + b * SIN + (PW - 1) + kh * CS;
     }
     f32x16 acc[NTW];
 #pragma unroll
@@ -322,17 +323,21 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const ConvDesc d) {
   };
   // (every wavefront passes the same number of barriers whichever instance it runs)
   const int wu = __builtin_amdgcn_readfirstlane(wave);
-  if (wu + 4 * (NT - 1) < g::NTILES) body(NTsel<NT>{});
-  else body(NTsel<NT - 1>{});
+  if constexpr (NT == 1) {
+    body(NTsel<1>{});   // (a wavefront without a tile multiplies padding lanes: it has to pass the barriers anyway)
+  } else {
+    if (wu + 4 * (NT - 1) < g::NTILES) body(NTsel<NT>{});
+    else body(NTsel<NT - 1>{});
+  }
 }
 
-template <int T, int OW, int R, int NT, int KC, int PW>
+template <int T, int SIN, int OW, int R, int NT, int KC, int PW>
 static void launch_cfg(const ConvDesc& d, hipStream_t s) {
-  using g = Geo<T, OW, R, NT, KC, PW>;
+  using g = Geo<T, SIN, OW, R, NT, KC, PW>;
   static_assert(g::LDS_BYTES <= 64 * 1024, "static LDS");
   const int bands = (d.OHl + R - 1) / R;
   dim3 grid((unsigned)(d.N * bands), (unsigned)((d.Cout + 31) / 32), 1u);
-  hipLaunchKernelGGL((conv_tile_kernel<T, OW, R, NT, KC, PW>), grid, dim3(256), 0, s, d);
+  hipLaunchKernelGGL((conv_tile_kernel<T, SIN, OW, R, NT, KC, PW>), grid, dim3(256), 0, s, d);
 }
 
 }  // namespace conv_tile
@@ -362,8 +367,12 @@ int conv_tile_plan(ConvDesc& d, long* wgs) {
 #ifdef DBM_MEASURE
   d.abl = DBM_MEASURE_ENV("CT_ABL");
 #endif
-  if (!(d.T == 9 && d.sin == 1 && d.OHl == d.OWl && (d.Hin << d.ups) == d.OHl && (d.Win << d.ups) == d.OWl)) return 0;
-  if (!canonical_taps(d, 3) || d.dy[d.tmap[0]] != -1 || d.dx[d.tmap[0]] != -1) return 0;   // (pad 1: the window is centred)
+  const bool k3 = d.T == 9 && d.sin == 1, k4 = d.T == 16 && d.sin == 2 && d.ups == 0;
+  if (!(k3 || k4) || d.OHl != d.OWl) return 0;
+  const int Hl = d.Hin << d.ups, Wl = d.Win << d.ups;
+  if (k3 && !(Hl == d.OHl && Wl == d.OWl)) return 0;
+  if (k4 && !(Hl == 2 * d.OHl && Wl == 2 * d.OWl)) return 0;
+  if (!canonical_taps(d, k3 ? 3 : 4) || d.dy[d.tmap[0]] != -1 || d.dx[d.tmap[0]] != -1) return 0;   // (pad 1)
   {  // the epilogue addresses y / r1 / r2 / mask through 32-bit byte offsets (raw buffer accesses)
     const long lim = (1L << 31) / 4 - 1, per = (long)d.Cout * d.ysc;
     if ((long)(d.N - 1) * d.ysn + per > lim || (d.r1 && (long)(d.N - 1) * d.r1sn + per > lim) || (d.r2 && (long)(d.N - 1) * d.r2sn + per > lim) ||
@@ -372,11 +381,31 @@ int conv_tile_plan(ConvDesc& d, long* wgs) {
   }
   const long mt = (d.Cout + 31) / 32;
   const bool x4 = !d.ups && (reinterpret_cast<uintptr_t>(d.x) & 15) == 0 && (d.xsn & 3) == 0;   // 16-byte DMA pieces
+  // Which plane classes take this form.  Measured INSIDE the training step (tools/experiments/ab_env.sh, two alternations): the 36 x 36
+  // layers (generator tail: the iteration's critical path) and the 18 x 18 ones pay -- 7.92 against 7.98 ms --; the 4x4 stride-2 layers
+  // (51.6 -> 43.8 us, 56.3 -> 47.8 us standalone) and the 9 x 9 planes (34.4 -> 30.7) do NOT: + 0.04 / + 0.02 ms per step.  These are
+  // discriminator layers that run on the 64 CUs a persistent trunk launch leaves, where igemm_conv_kernel's 1296 small workgroups
+  // (up to eight per CU) use a CU better than 256 workgroups of four wavefronts.  Off by default; DBM_CONV_TILE_K4=1 / DBM_CONV_TILE_9=1.
+  static const int k4_enable = getenv("DBM_CONV_TILE_K4") ? atoi(getenv("DBM_CONV_TILE_K4")) : 0;
+  static const int p9_enable = getenv("DBM_CONV_TILE_9") ? atoi(getenv("DBM_CONV_TILE_9")) : 0;
+  static const int p18_enable = getenv("DBM_CONV_TILE_18") ? atoi(getenv("DBM_CONV_TILE_18")) : 1;
+  if (k4) {
+    if (!k4_enable) return 0;
+    if (d.OWl == 18 && x4) {   // 36 x 36 -> 18 x 18 (discriminator conv_layer1): two bands of nine output rows, six tiles each
+      *wgs = (long)d.N * 2 * mt;
+      return 5;
+    }
+    if (d.OWl == 9) {          // 18 x 18 -> 9 x 9 (conv_layer3): the whole image, three tiles
+      *wgs = (long)d.N * mt;
+      return 6;
+    }
+    return 0;
+  }
   if (d.OWl == 36) {   // four bands of nine rows: 324 positions = 11 tiles per workgroup
     *wgs = (long)d.N * 4 * mt;
     return x4 ? 1 : 4;
   }
-  if (d.OWl == 18) {
+  if (d.OWl == 18 && p18_enable) {
     // the whole image per workgroup (324 positions, 11 tiles) when that still makes >= 256 workgroups; else two bands of nine rows
     if ((long)d.N * mt >= 256) {
       *wgs = (long)d.N * mt;
@@ -385,15 +414,23 @@ int conv_tile_plan(ConvDesc& d, long* wgs) {
     *wgs = (long)d.N * 2 * mt;
     return 3;
   }
+  if (d.OWl == 9 && p9_enable && (long)d.N * mt >= 256) {   // 9 x 9 planes (discriminator conv_layer4): one image = three tiles
+    // (fewer workgroups than CUs: igemm_conv_kernel's K split over 8 / 16 wavefronts is faster -- 23.5 vs 29.6 us at 128)
+    *wgs = (long)d.N * mt;
+    return 7;
+  }
   return 0;
 }
 
 void conv_tile_launch(const ConvDesc& d, int cfg, hipStream_t s) {
   switch (cfg) {
-    case 1: launch_cfg<9, 36, 9, 3, 8, 4>(d, s); break;
-    case 2: launch_cfg<9, 18, 18, 3, 8, 1>(d, s); break;   // (dword pieces: 72-byte rows; the 12-byte form gave wrong results)
-    case 3: launch_cfg<9, 18, 9, 2, 8, 1>(d, s); break;
-    case 4: launch_cfg<9, 36, 9, 3, 8, 1>(d, s); break;   // (a folded x2 resize, or rows that are not 16-byte aligned)
+    case 1: launch_cfg<9, 1, 36, 9, 3, 8, 4>(d, s); break;
+    case 2: launch_cfg<9, 1, 18, 18, 3, 8, 1>(d, s); break;   // (dword pieces: 72-byte rows; the 12-byte form gave wrong results)
+    case 3: launch_cfg<9, 1, 18, 9, 2, 8, 1>(d, s); break;
+    case 4: launch_cfg<9, 1, 36, 9, 3, 8, 1>(d, s); break;    // (a folded x2 resize, or rows that are not 16-byte aligned)
+    case 5: launch_cfg<16, 2, 18, 9, 2, 4, 4>(d, s); break;   // 4x4 stride 2 from 36-wide rows (16-byte pieces), four channels per chunk
+    case 6: launch_cfg<16, 2, 9, 9, 1, 8, 1>(d, s); break;    // 4x4 stride 2 from 18-wide rows
+    case 7: launch_cfg<9, 1, 9, 9, 1, 8, 1>(d, s); break;     // 3x3 on 9 x 9 planes
     default: DBM_CHECK(false, "conv_tile_launch: unknown configuration");
   }
   DBM_HIP(hipGetLastError());

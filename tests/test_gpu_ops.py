@@ -95,6 +95,9 @@ CONV_CASES = [
     (2, 32, 36, 36, 64, 3, 1, 1, 0, 1),    # the data gradient of an offset convolution's shape (32 padded gradient channels)
     (2, 160, 36, 36, 96, 3, 1, 1, 0, 0),   # twenty chunks of eight channels, three output tiles
     (3, 128, 9, 9, 64, 3, 1, 1, 1, 1),     # 9 x 9 folded x2 -> 18 x 18 output (post_upsample_conv_layer_1)
+    (5, 128, 18, 18, 128, 4, 2, 1, 0, 1),  # 4x4 stride 2, 18 -> 9 (discriminator conv_layer3): whole-image workgroups, three tiles
+    (7, 64, 36, 36, 96, 4, 2, 1, 0, 0),    # 4x4 stride 2, 36 -> 18 (conv_layer1): two bands, four-channel chunks, three output tiles
+    (64, 128, 9, 9, 128, 3, 1, 1, 0, 1),   # 3x3 on 9 x 9 planes at the full batch (conv_layer4): one image per workgroup
 ]
 
 
