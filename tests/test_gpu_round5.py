@@ -150,6 +150,12 @@ def test_schedule_switches_of_round5_change_no_number(tmp_path, env):
         a, b = outs[0][k], outs[1][k]
         if bitwise:
             assert np.array_equal(a, b), k
+        elif k == "m":
+            # (d_loss, d_accu, g_loss, psnr, ssim) x 3 iterations: the accuracy is a count over 24 logits -- one of them may sit on the
+            # threshold -- the others are smooth
+            assert np.abs(a[:, 1] - b[:, 1]).max() <= 1.0 / 24 + 1e-6
+            cols = [0, 2, 3, 4]
+            assert np.allclose(a[:, cols], b[:, cols], rtol=2e-3, atol=1e-5), (a, b)
         else:
             # (first Adam steps are alpha * sign(g): a parameter whose gradient is rounding noise may move the other way -- bounded
             #  by 2 alpha per step; everything else agrees to rounding)
