@@ -388,7 +388,6 @@ int conv_tile_plan(ConvDesc& d, long* wgs) {
   // (up to eight per CU) use a CU better than 256 workgroups of four wavefronts.  Off by default; DBM_CONV_TILE_K4=1 / DBM_CONV_TILE_9=1.
   static const int k4_enable = getenv("DBM_CONV_TILE_K4") ? atoi(getenv("DBM_CONV_TILE_K4")) : 0;
   static const int p9_enable = getenv("DBM_CONV_TILE_9") ? atoi(getenv("DBM_CONV_TILE_9")) : 0;
-  static const int p18_enable = getenv("DBM_CONV_TILE_18") ? atoi(getenv("DBM_CONV_TILE_18")) : 1;
   if (k4) {
     if (!k4_enable) return 0;
     if (d.OWl == 18 && x4) {   // 36 x 36 -> 18 x 18 (discriminator conv_layer1): two bands of nine output rows, six tiles each
@@ -405,7 +404,7 @@ int conv_tile_plan(ConvDesc& d, long* wgs) {
     *wgs = (long)d.N * 4 * mt;
     return x4 ? 1 : 4;
   }
-  if (d.OWl == 18 && p18_enable) {
+  if (d.OWl == 18) {   // (inside the step: neutral, 7.94-7.96 against 7.95-7.96 without this class -- profiles/r5/ab_conv_tile_18.txt)
     // the whole image per workgroup (324 positions, 11 tiles) when that still makes >= 256 workgroups; else two bands of nine rows
     if ((long)d.N * mt >= 256) {
       *wgs = (long)d.N * mt;

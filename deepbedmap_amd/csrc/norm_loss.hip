@@ -114,6 +114,7 @@ void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const flo
                          float* avg_mean, float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
                          hipStream_t s, const int* hold) {
   if (dbm_abl_skip() & 1) return;  // (libdbm_measure.so only)
+  // (round 5 A/B: 256-thread workgroups everywhere -- easier to place beside other kernels -- cost 8.69-8.71 against 7.91 ms per step)
   if (plane >= 64 && C <= 256)
     hipLaunchKernelGGL(bn_train_fwd_kernel<1024>, dim3(C), dim3(1024), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean,
                        avg_var, N, C, plane, eps, decay, slope, hold);

@@ -4,12 +4,12 @@ def bench(override, base_override=""):
     env = dict(os.environ)
     ov = ";".join(x for x in (base_override, override) if x)
     if ov: env["DBM_IGEMM_OVERRIDE"] = ov
-    out = subprocess.run([sys.executable, "bench.py", "--steps", "150", "--warmup", "15", "--no-cpu-baseline"], cwd=ROOT, env=env,
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "150", "--warmup", "15", "--no-cpu-baseline", "--no-sweep", "--tables", "/tmp/tune_tables.json"], cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1]
     return json.loads(out)["ms_per_step"]
 # distinct launches
 env = dict(os.environ, DBM_IGEMM_LOG="1")
-log = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env,
+log = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sweep", "--tables", "/tmp/tune_tables.json"], cwd=ROOT, env=env,
                      capture_output=True, text=True, timeout=300).stderr
 keys = {}
 for m in re.finditer(r"igemm (\S+) tiles=(\d+) mt2_ok=(\d) -> mt2=(\d) waves=(\d+) ks=(\d+)", log):
