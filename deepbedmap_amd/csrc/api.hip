@@ -186,6 +186,7 @@ int dbm_init(int hip_device, dbm_ctx** out) {
   }
   // (round 5, VERDICT r4 1(c): chain[0] -- the discriminator's fake-batch backward pass -- at the lowest stream priority measured 7.90 / 7.94 ms
   //  against 7.92 / 7.92: no effect; both backward passes on ONE stream: 8.44 ms.  Not kept: profiles/r5/README.md)
+  // (and chain[1] -- the generator's stream in dbm_train_iteration -- at the HIGHEST priority: 7.93-7.97 against 7.94: no effect either)
   for (auto& st : c->chain) DBM_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   for (auto& e : c->ev_fork) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   DBM_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -1594,8 +1595,21 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
   if (O == 1) {
     if (fused) {
       part.ensure(deform_bwd1_partial_floats(N, H, W));
-      launch_deform_bwd1_fused(xt.p, off, w, gy, goff, gw, gb, part.p, N, H, W, 18 * P, s);
-      launch_deform_input_grad(x, off, nullptr, w, gy, gx, N, C, H, W, 18 * P, s, cws.p);
+      // (the premultiplied form the generator's backward pass uses -- round 5 --; DBM_DEFORM1_PREMUL_BWD=0: the gathering kernels)
+      static const bool premul_bwd = !(getenv("DBM_DEFORM1_PREMUL_BWD") && atoi(getenv("DBM_DEFORM1_PREMUL_BWD")) == 0);
+      if (premul_bwd && C == 64) {
+        DevBuf z, gt;
+        z.ensure((size_t)N * 9 * P);
+        gt.ensure((size_t)N * 9 * P);
+        launch_deform1_premul(xt.p, w, z.p, N, H, W, 1, s);
+        launch_deform_bwd1_premul(xt.p, off, w, gy, z.p, goff, gx, gw, gb, part.p, cws.p, gt.p, N, H, W, 18 * P, s);
+        DBM_HIP(hipStreamSynchronize(s));
+        z.release();
+        gt.release();
+      } else {
+        launch_deform_bwd1_fused(xt.p, off, w, gy, goff, gw, gb, part.p, N, H, W, 18 * P, s);
+        launch_deform_input_grad(x, off, nullptr, w, gy, gx, N, C, H, W, 18 * P, s, cws.p);
+      }
     } else {
       launch_deform_backward(x, off, nullptr, w, gy, gx, goff, N, C, H, W, 18 * P, s);
       launch_gemv_cols_wgrad(col.p, gy, gw, gb, N, C * 9, (int)P, s);

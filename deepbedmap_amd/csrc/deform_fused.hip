@@ -730,6 +730,112 @@ __global__ __launch_bounds__(256) void deform_wgrad1_fold_kernel(const float* __
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: the backward pass of the 64 -> 1 layer in the PREMULTIPLIED form the forward already uses (deform1_premul_kernel):
+// with z_t = sum_c w[c][t] x_c (nine planes per image, kept from the forward pass) and G_t[q] = sum over the sampling
+// entries (p, corner) that land on input pixel q of (bilinear weight x gy[p]) (nine planes, a CSR gather of ONE value),
+//   d loss / d offset_t(p)  = gy[p] x (d bilinear z_t / d u, d v)          -- four single-float gathers per (p, t)
+//   d loss / d x_c(q)       = sum_t w[c][t] G_t[q]
+//   d loss / d w[c][t]      = sum_{n, q} x_c(q) G_t[q],   d loss / d b = sum gy
+// -- no gather of 9 x 4 x 256 bytes per position any more (deform_bwd1_fused_kernel: 150 us at batch 64, the iteration's critical
+// path) and the input-gradient gather moves 9 instead of 64 values per list entry.
+// ---------------------------------------------------------------------------------------------------------------
+// goff[n][t | 9 + t][p] from the forward's z planes: one thread per (position, tap)
+__global__ __launch_bounds__(256) void deform1_goff_kernel(const float* __restrict__ z, const float* __restrict__ off,
+                                                           const float* __restrict__ gy, float* __restrict__ goff, long total, int H, int W,
+                                                           long offsn) {
+  const long P = (long)blockIdx.x * 256 + threadIdx.x;
+  if (P >= total) return;
+  const int plane = H * W, t = blockIdx.y;
+  const int n = (int)(P / plane);
+  const int p = (int)(P - (long)n * plane);
+  const int a = p / W, b = p - a * W;
+  const float* on = off + (long)n * offsn + p;
+  const DeformGeom g = deform_geom(on[(long)t * plane], on[(long)(9 + t) * plane], a, b, t / 3, t % 3, H, W, 1);
+  const int o1 = deform_corner(g.v0, g.u0, H, W, 1), o2 = deform_corner(g.v0, g.u0 + 1, H, W, 1);
+  const int o3 = deform_corner(g.v0 + 1, g.u0, H, W, 1), o4 = deform_corner(g.v0 + 1, g.u0 + 1, H, W, 1);
+  const float* zt = z + ((long)n * 9 + t) * plane;
+  const float z1 = o1 >= 0 ? zt[o1] : 0.f, z2 = o2 >= 0 ? zt[o2] : 0.f, z3 = o3 >= 0 ? zt[o3] : 0.f, z4 = o4 >= 0 ? zt[o4] : 0.f;
+  // (coord_grads' expressions on the premultiplied corners)
+  const float du = -g.wv1 * z1 + g.wv1 * z2 - g.wv0 * z3 + g.wv0 * z4;
+  const float dv = -g.wu1 * z1 - g.wu0 * z2 + g.wu1 * z3 + g.wu0 * z4;
+  const float gv = gy[P];
+  float* gn = goff + (long)n * offsn + p;
+  gn[(long)t * plane] = g.mu ? gv * du : 0.f;
+  gn[(long)(9 + t) * plane] = g.mv ? gv * dv : 0.f;
+}
+
+// gx[n][c][q] = sum_t w[c][t] G[n][t][q]; partial (gridDim.x, 580): this workgroup's sums of x_c(q) G_t(q) per (c * 9 + t), then of gy
+// at [576] (folded by deform_wgrad1_fold_kernel in workgroup order).  Lane (q16, pi) owns four channels at four positions, as in the
+// kernels above; xt is the layer input channels-last.
+__global__ __launch_bounds__(256) void deform1_xw_kernel(const float* __restrict__ xt, const float* __restrict__ w, const float* __restrict__ G,
+                                                         const float* __restrict__ gy, float* __restrict__ gx, float* __restrict__ partial,
+                                                         long total, int plane) {
+  __shared__ __attribute__((aligned(16))) float wsh[9 * 64];     // [tap][channel]
+  __shared__ __attribute__((aligned(16))) float red[4][9 * 64];  // per wavefront: [tap][channel] sums of x * G
+  __shared__ float gts[9][DF_POS];
+  __shared__ float gys[DF_POS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long P0 = (long)blockIdx.x * DF_POS;
+  for (int e = tid; e < 576; e += 256) wsh[(e % 9) * 64 + e / 9] = w[e];
+  for (int e = tid; e < 9 * DF_POS; e += 256) {
+    const int t = e / DF_POS, pl = e - t * DF_POS;
+    const long P = P0 + pl;
+    float v = 0.f;
+    if (P < total) {
+      const long n = P / plane;
+      v = G[(n * 9 + t) * plane + (P - n * plane)];
+    }
+    gts[t][pl] = v;
+  }
+  if (tid < DF_POS) gys[tid] = (P0 + tid < total) ? gy[P0 + tid] : 0.f;
+  __syncthreads();
+  const int q = lane & 15, pi = lane >> 4;
+  float4 xv[4];
+  float4 gxv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long P = P0 + 16 * wave + 4 * i + pi;
+    xv[i] = P < total ? *reinterpret_cast<const float4*>(xt + P * 64 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gxv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll 1
+  for (int t = 0; t < 9; ++t) {
+    const float4 wr = *reinterpret_cast<const float4*>(wsh + t * 64 + 4 * q);
+    float4 ws = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float g = gts[t][16 * wave + 4 * i + pi];
+      gxv[i].x = fmaf(wr.x, g, gxv[i].x); gxv[i].y = fmaf(wr.y, g, gxv[i].y); gxv[i].z = fmaf(wr.z, g, gxv[i].z); gxv[i].w = fmaf(wr.w, g, gxv[i].w);
+      ws.x = fmaf(g, xv[i].x, ws.x); ws.y = fmaf(g, xv[i].y, ws.y); ws.z = fmaf(g, xv[i].z, ws.z); ws.w = fmaf(g, xv[i].w, ws.w);
+    }
+    ws.x += __shfl_xor(ws.x, 16, 64); ws.y += __shfl_xor(ws.y, 16, 64); ws.z += __shfl_xor(ws.z, 16, 64); ws.w += __shfl_xor(ws.w, 16, 64);
+    ws.x += __shfl_xor(ws.x, 32, 64); ws.y += __shfl_xor(ws.y, 32, 64); ws.z += __shfl_xor(ws.z, 32, 64); ws.w += __shfl_xor(ws.w, 32, 64);
+    if (pi == 0) *reinterpret_cast<float4*>(&red[wave][t * 64 + 4 * q]) = ws;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {   // gx is (N, 64, plane): a lane's four channels of one position
+    const long P = P0 + 16 * wave + 4 * i + pi;
+    if (P < total) {
+      const long n = P / plane;
+      float* dst = gx + (n * 64 + 4 * q) * plane + (P - n * plane);
+      dst[0] = gxv[i].x; dst[plane] = gxv[i].y; dst[2L * plane] = gxv[i].z; dst[3L * plane] = gxv[i].w;
+    }
+  }
+  __syncthreads();
+  float* po = partial + (long)blockIdx.x * 580;
+  for (int e = tid; e < 576; e += 256) {
+    const int t = e >> 6, c = e & 63;
+    po[c * 9 + t] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  }
+  if (tid < 64) {
+    float v = gys[tid];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (tid == 0) po[576] = v;
+  }
+}
+
 }  // namespace
 
 bool deform_conv_fused_ok(int C, int O) { return C == 64 && (O == 64 || (O >= 1 && O <= 16)); }
@@ -830,5 +936,32 @@ void launch_deform_bwd1_fused(const float* xt, const float* off, const float* w,
   const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
   hipLaunchKernelGGL(deform_bwd1_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, gy, goff, partial, N, H, W, offsn);
   hipLaunchKernelGGL(deform_wgrad1_fold_kernel, dim3(145), dim3(256), 0, s, partial, (int)blocks, gw, gb);
+  DBM_HIP(hipGetLastError());
+}
+
+// Backward of the 64 -> 1 deformable layer in the premultiplied form (round 5; see deform1_goff_kernel).  z: the forward's
+// premultiplied planes (N, 9, plane); Gt: scratch of N * 9 * plane floats; csr_ws: deform_csr_workspace_floats floats;
+// partial: deform_bwd1_partial_floats floats.  goff (N, >= 18, plane with image stride offsn) and gx (N, 64, plane) are overwritten,
+// gw (576) / gb (1) accumulated.
+void launch_deform_bwd1_premul(const float* xt, const float* off, const float* w, const float* gy, const float* z, float* goff, float* gx,
+                               float* gw, float* gb, float* partial, float* csr_ws, float* Gt, int N, int H, int W, long offsn,
+                               hipStream_t s) {
+  const long plane = (long)H * W, total = (long)N * plane;
+  DBM_CHECK(total < (1L << 31), "deformable backward: more than 2^31 positions");
+  const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
+  hipLaunchKernelGGL(deform1_goff_kernel, dim3((unsigned)((total + 255) / 256), 9), dim3(256), 0, s, z, off, gy, goff, total, H, W, offsn);
+  launch_deform_csr_gather1(off, gy, Gt, N, H, W, offsn, s, csr_ws);
+  hipLaunchKernelGGL(deform1_xw_kernel, dim3(blocks), dim3(256), 0, s, xt, w, Gt, gy, gx, partial, total, (int)plane);
+  hipLaunchKernelGGL(deform_wgrad1_fold_kernel, dim3(145), dim3(256), 0, s, partial, (int)blocks, gw, gb);
+  DBM_HIP(hipGetLastError());
+}
+
+// z[n][t][p] = sum_c w[c][t] x_c(p) for the O == 1 layer (the forward's premultiplication alone: the op-level backward entry point)
+void launch_deform1_premul(const float* xt, const float* w, float* z, int N, int H, int W, int O, hipStream_t s) {
+  const long total = (long)N * H * W;
+  const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
+  const int nz = 9 * O;
+  DBM_CHECK(O >= 1 && O <= 7, "launch_deform1_premul: the default 64 KB of dynamic LDS serve up to seven output channels");
+  hipLaunchKernelGGL(deform1_premul_kernel, dim3(blocks), dim3(256), (size_t)2 * nz * 64 * sizeof(float), s, xt, w, z, total, H * W, nz);
   DBM_HIP(hipGetLastError());
 }

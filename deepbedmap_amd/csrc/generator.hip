@@ -466,6 +466,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       if (premul) zdef.ensure((size_t)N * 9 * out_ch * P4);
       launch_deform_conv_fused(a51t.p, off2.p, P(T_def2W), P(T_def2b), y, nullptr, nullptr, N, 64, H4, W4, 32 * P4, out_ch, 0, SLOPE, s,
                                premul ? zdef.p : nullptr);
+      zdef_kept = premul && keep && out_ch == 1;
       // (unfused backward only: the 64 -> 1 layer's weight gradient then reads its sample matrix)
       if (keep && !deform_bwd_fused(H4, W4)) {
         col2.ensure((size_t)N * 576 * P4);
@@ -501,8 +502,19 @@ void Generator::backward(const float* gy) {
     }
     dw2_partial.ensure(deform_bwd1_partial_floats(N, H4, W4));
     csr_ws.ensure(deform_csr_workspace_floats(N, H4, W4));
-    launch_deform_bwd1_fused(a51t.p, off2.p, P(T_def2W), gy, goff2.p, G(T_def2W), G(T_def2b), dw2_partial.p, N, H4, W4, 32 * P4, sg);
-    launch_deform_input_grad(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, N, 64, H4, W4, 32 * P4, s, csr_ws.p);
+    // Round 5: in the premultiplied form of the forward pass (z_t = sum_c w[c][t] x_c kept from it) the layer's whole backward is a
+    // CSR gather of ONE value per list entry, four single-float gathers per (position, tap) and one pass over the input -- instead of
+    // gathering 9 x 4 x 256 bytes per position for the offset / weight gradients (150 us) and 64 values per entry for the input gradient.
+    // DBM_DEFORM1_PREMUL_BWD=0: the gathering kernels (A/B).
+    static const bool premul_bwd = !(getenv("DBM_DEFORM1_PREMUL_BWD") && atoi(getenv("DBM_DEFORM1_PREMUL_BWD")) == 0);
+    if (premul_bwd && zdef_kept) {
+      gt2.ensure((size_t)N * 9 * P4);
+      launch_deform_bwd1_premul(a51t.p, off2.p, P(T_def2W), gy, zdef.p, goff2.p, g_a51.p, G(T_def2W), G(T_def2b), dw2_partial.p, csr_ws.p,
+                                gt2.p, N, H4, W4, 32 * P4, s);
+    } else {
+      launch_deform_bwd1_fused(a51t.p, off2.p, P(T_def2W), gy, goff2.p, G(T_def2W), G(T_def2b), dw2_partial.p, N, H4, W4, 32 * P4, sg);
+      launch_deform_input_grad(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, N, 64, H4, W4, 32 * P4, s, csr_ws.p);
+    }
     if (sg != s) ctx->fork(sg, s, 3);
   } else {
     // (its weight gradient only needs gy and the retained columns: side stream, underneath the sampler's backward)

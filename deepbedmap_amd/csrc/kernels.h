@@ -37,6 +37,13 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
 void launch_deform_bwd64_fused(const float* xt, const float* off, const float* wb, const float* gy, float* gcol, float* goff, int N, int H,
                                int W, long offsn, hipStream_t s);
 size_t deform_bwd1_partial_floats(int N, int H, int W);
+// the 64 -> 1 layer's backward in the premultiplied form (round 5): z = the forward's premultiplied planes (N, 9, plane), Gt = scratch of
+// N * 9 * plane floats, csr_ws = deform_csr_workspace_floats floats; goff and gx (N, 64, plane) overwritten, gw / gb accumulated
+void launch_deform_bwd1_premul(const float* xt, const float* off, const float* w, const float* gy, const float* z, float* goff, float* gx,
+                               float* gw, float* gb, float* partial, float* csr_ws, float* Gt, int N, int H, int W, long offsn,
+                               hipStream_t s);
+void launch_deform1_premul(const float* xt, const float* w, float* z, int N, int H, int W, int O, hipStream_t s);
+void launch_deform_csr_gather1(const float* off, const float* gy, float* G, int N, int H, int W, long offsn, hipStream_t s, float* ws);
 void launch_deform_bwd1_fused(const float* xt, const float* off, const float* w, const float* gy, float* goff, float* gw, float* gb,
                               float* partial, int N, int H, int W, long offsn, hipStream_t s);
 bool deform_input_grad_ok(int C, int H, int W);

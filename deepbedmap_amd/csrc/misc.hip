@@ -694,6 +694,25 @@ __global__ __launch_bounds__(NT) void deform_csr_gather_kernel(const int* __rest
   }
 }
 
+// G[n][t][q] = sum over the list entries of input pixel q of w * gy[n][p]: the transposed sampler applied to ONE value per position and
+// tap (the 64 -> 1 layer's backward in premultiplied form, deform_fused.hip); one thread per (image, tap, input pixel).
+__global__ __launch_bounds__(256) void deform_csr_gather1_kernel(const int* __restrict__ g_offs, const int2* __restrict__ g_ent,
+                                                                 const float* __restrict__ gy, float* __restrict__ G, int plane) {
+  const int n = blockIdx.z, t = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= plane) return;
+  const int* go = g_offs + ((long)n * 9 + t) * (plane + 1);
+  const int2* ge = g_ent + ((long)n * 9 + t) * 4 * plane;
+  const float* gyn = gy + (long)n * plane;
+  const int s0 = go[q], s1 = go[q + 1];
+  float acc = 0.f;
+  for (int sl = s0; sl < s1; ++sl) {   // (entries sorted by position: a fixed summation order)
+    const int2 en = ge[sl];
+    acc += __int_as_float(en.y) * gyn[en.x];
+  }
+  G[((long)n * 9 + t) * plane + q] = acc;
+}
+
 size_t deform_csr_workspace_floats(int N, int H, int W) {  // offsets, then the 8-byte entries (8-byte aligned)
   const size_t plane = (size_t)H * W;
   const size_t no = ((size_t)N * 9 * (plane + 1) + 1) & ~(size_t)1;
@@ -746,6 +765,23 @@ void launch_deform_input_grad(const float* x, const float* off, const float* gco
   else
     hipLaunchKernelGGL((deform_backward_csr_kernel<CH, 1024, true>), dim3(N, C / CH), dim3(1024), lds, s, x, off, gcol, w1o, gy, gx,
                        nullptr, N, C, H, W, offsn);
+  DBM_HIP(hipGetLastError());
+}
+
+// The sampling lists of `off` (built into ws) applied to gy (N, 1, plane): G (N, 9, plane).
+void launch_deform_csr_gather1(const float* off, const float* gy, float* G, int N, int H, int W, long offsn, hipStream_t s, float* ws) {
+  const long plane = (long)H * W;
+  DBM_CHECK(ws != nullptr && sizeof(float) * (10 * (size_t)plane + 1) <= 150 * 1024, "deformable CSR lists: plane too large");
+  int* g_offs = (int*)ws;
+  int2* g_ent = (int2*)(ws + (((size_t)N * 9 * (plane + 1) + 1) & ~(size_t)1));
+  static bool attr2 = false;
+  if (!attr2) {
+    DBM_HIP(hipFuncSetAttribute((const void*)deform_csr_build_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    attr2 = true;
+  }
+  hipLaunchKernelGGL((deform_csr_build_kernel<1024>), dim3(N, 9), dim3(1024), sizeof(float) * (10 * (size_t)plane + 1), s, off, g_offs, g_ent,
+                     H, W, offsn);
+  hipLaunchKernelGGL(deform_csr_gather1_kernel, dim3((unsigned)((plane + 255) / 256), 9, N), dim3(256), 0, s, g_offs, g_ent, gy, G, (int)plane);
   DBM_HIP(hipGetLastError());
 }
 

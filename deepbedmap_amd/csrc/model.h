@@ -204,6 +204,8 @@ struct Generator : dbm_model {
   DevBuf dw2_partial;  // per-workgroup partial sums of final_conv_layer2's weight gradient (deform_bwd1_fused_kernel)
   bool deform_bwd_fused(int H4, int W4) const;
   DevBuf zdef;        // the last layer's premultiplied tap planes (N, 9 * out_ch, 4H, 4W): deform1_premul_kernel
+  bool zdef_kept = false;  // ... of the retained forward pass (the 64 -> 1 layer's backward in premultiplied form reads them)
+  DevBuf gt2;         // backward: the transposed sampler applied to gy, (N, 9, 4H, 4W)
   DevBuf a42t, a51t;  // channels-last copies of the deformable layers' inputs (what the fused sampler gathers from)
   // bf16 sweep mode on large planes (conv_cl16.hip): the dense block's concat as NHWC bf16 (two buffers in ping-pong, 192
   // channels per pixel) and the 64-channel residual stream as NHWC fp32 (block input, block output, RRDB input)
