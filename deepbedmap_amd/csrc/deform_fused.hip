@@ -63,7 +63,7 @@ struct TileGeometry {
 };
 
 __device__ __forceinline__ void build_geometry(TileGeometry& g, const float* __restrict__ off, long offsn, long P0, long total, int plane,
-                                               int H, int W, int tid) {
+                                               int H, int W, int tid, int abl = 0) {
   for (int e = tid; e < 9 * DF_POS; e += 256) {
     const int t = e >> 6, pl = e & 63;
     const long P = P0 + pl;
@@ -82,6 +82,7 @@ __device__ __forceinline__ void build_geometry(TileGeometry& g, const float* __r
       if (o2 >= 0) { id.y = base + o2; wg.y = q.wu0 * q.wv1; }
       if (o3 >= 0) { id.z = base + o3; wg.z = q.wu1 * q.wv0; }
       if (o4 >= 0) { id.w = base + o4; wg.w = q.wu0 * q.wv0; }
+      if (abl) id = make_int4(base, base, base, base);   // (libdbm_measure.so only: every gather hits one cache-resident pixel)
     }
     g.idx[e] = id;
     g.wgt[e] = wg;
@@ -104,14 +105,14 @@ __global__ __launch_bounds__(256) void deform_conv64_fused_kernel(const float* _
                                                                   const float* __restrict__ wf, const float* __restrict__ bias,
                                                                   float* __restrict__ y, float* __restrict__ yt,
                                                                   float* __restrict__ colout, int N, int H, int W, long offsn, int act,
-                                                                  float slope) {
+                                                                  float slope, int abl) {
   __shared__ TileGeometry geo;
   __shared__ float col[2][64 * DF_LD];  // [buffer][channel][position]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int plane = H * W;
   const long total = (long)N * plane;
   const long P0 = (long)blockIdx.x * DF_POS;
-  build_geometry(geo, off, offsn, P0, total, plane, H, W, tid);
+  build_geometry(geo, off, offsn, P0, total, plane, H, W, tid, abl);
   // ---- sampler role ----
   const int q = lane & 15, pi = lane >> 4;
   const float* xq = xt + 4 * q;
@@ -866,7 +867,8 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
     g_profiler.begin(s, 0, 2.0 * (double)total * O * C * 9, bytes, tag, blocks);
   }
   if (O == 64)
-    hipLaunchKernelGGL(deform_conv64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, bias, y, yt, colout, N, H, W, offsn, act, slope);
+    hipLaunchKernelGGL(deform_conv64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, bias, y, yt, colout, N, H, W, offsn, act, slope,
+                       DBM_MEASURE_ENV("DEFORM_ABL"));
   else if (z) {
     const int nz = 9 * O;
     static bool attr = false;   // (O >= 15: 2 * 9 * O * 64 floats exceed the 64 KB default of dynamic LDS)
