@@ -155,7 +155,10 @@ def test_schedule_switches_of_round5_change_no_number(tmp_path, env):
             # threshold -- the others are smooth
             assert np.abs(a[:, 1] - b[:, 1]).max() <= 1.0 / 24 + 1e-6
             cols = [0, 2, 3, 4]
-            assert np.allclose(a[:, cols], b[:, cols], rtol=2e-3, atol=1e-5), (a, b)
+            # first iteration: the same weights on both sides, different summation orders only; later ones: two Adam steps at 1e-3
+            # (alpha * sign(g) for gradients at rounding level) have moved the models apart by then
+            assert np.allclose(a[0, cols], b[0, cols], rtol=2e-4, atol=1e-6), (a, b)
+            assert np.allclose(a[1:, cols], b[1:, cols], rtol=2e-2, atol=1e-4), (a, b)
         else:
             # (first Adam steps are alpha * sign(g): a parameter whose gradient is rounding noise may move the other way -- bounded
             #  by 2 alpha per step; everything else agrees to rounding)
