@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const ConvDesc d) {
       }
     };
 
-    const int nchunk = d.Cin / KC;
+    const int nchunk = ((d.cin_live > 0 && d.cin_live < d.Cin) ? (d.cin_live + KC - 1) / KC * KC : d.Cin) / KC;
     __syncthreads();   // (the frame cells are cleared before any DMA may land beside them -- and before anybody reads)
     stage(0, B0{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -271,14 +271,31 @@ __global__ __launch_bounds__(256, 2) void conv_tile_kernel(const ConvDesc d) {
     };
     const bool extra = d.r1 || d.r2 || d.accumulate || d.mask;   // (uniform: one of two straight-line instances below)
     if (!extra) {
+      // (optional channels-last twin of a 64-channel output -- the next layer's fused deformable sampler reads that layout: registers
+      //  4 g .. 4 g + 3 of a lane are four consecutive channels: one 16-byte store; saves the nchw_to_nhwc64 pass behind this launch)
+      typedef unsigned u4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t ryt = rsrc(d.yt, 256L * d.N * d.OHl * d.OWl);
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
         const int base = tile_off(i);
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = (acc[i][r] * e_s[r] + e_b[r]) * d.s1;
-          if (d.act) v = v >= 0.f ? v : d.slope * v;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, reg_off(base, r), 0, 0);
+          v[r] = (acc[i][r] * e_s[r] + e_b[r]) * d.s1;
+          if (d.act) v[r] = v[r] >= 0.f ? v[r] : d.slope * v[r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ry, reg_off(base, r), 0, 0);
+        }
+        if (d.yt) {
+          const int p = pos[i];
+          const int pq = p < g::NPOS ? p : 0;
+          const int al = pq / OW, b = pq - al * OW;
+          const bool ok = p < g::NPOS && a0 + al < d.OHl;
+          const int pixo = ok ? 4 * (((n * d.OHl + a0 + al) * d.OWl + b) * 64 + cout0 + 4 * kh) : -1;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4)
+            __builtin_amdgcn_raw_buffer_store_b128((u4){__builtin_bit_cast(unsigned, v[4 * q4]), __builtin_bit_cast(unsigned, v[4 * q4 + 1]),
+                                                        __builtin_bit_cast(unsigned, v[4 * q4 + 2]), __builtin_bit_cast(unsigned, v[4 * q4 + 3])},
+                                                   ryt, pixo >= 0 ? pixo + 32 * q4 : -1, 0, 0);
         }
       }
     } else {
@@ -360,6 +377,13 @@ static bool canonical_taps(ConvDesc& d, int K) {
 
 // Plans the LDS-tiled form for a launch: 0 = not served (the caller falls back to igemm_conv_kernel), else the configuration id
 // (> 0); fills d.tmap and *wgs (workgroups of the launch).  DBM_CONV_TILE=0 switches the form off (A/B against igemm.hip).
+bool conv_tile_writes_yt(const ConvDesc& d_in) {
+  ConvDesc d = d_in;
+  long wgs = 0;
+  static const int yt_env = getenv("DBM_CONV_TILE_YT") ? atoi(getenv("DBM_CONV_TILE_YT")) : 1;   // (A/B switch)
+  return yt_env && d.yt != nullptr && conv_tile_plan(d, &wgs) != 0;
+}
+
 int conv_tile_plan(ConvDesc& d, long* wgs) {
   static const int enable = getenv("DBM_CONV_TILE") ? atoi(getenv("DBM_CONV_TILE")) : 1;
   if (!enable) return 0;
@@ -367,6 +391,7 @@ int conv_tile_plan(ConvDesc& d, long* wgs) {
 #ifdef DBM_MEASURE
   d.abl = DBM_MEASURE_ENV("CT_ABL");
 #endif
+  if (d.yt && (d.Cout != 64 || d.so != 1 || d.r1 || d.r2 || d.accumulate || d.mask || 256L * d.N * d.OHl * d.OWl >= (1L << 31))) return 0;
   const bool k3 = d.T == 9 && d.sin == 1, k4 = d.T == 16 && d.sin == 2 && d.ups == 0;
   if (!(k3 || k4) || d.OHl != d.OWl) return 0;
   const int Hl = d.Hin << d.ups, Wl = d.Win << d.ups;

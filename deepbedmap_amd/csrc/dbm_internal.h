@@ -62,6 +62,8 @@ struct ConvDesc {
   long xsn;       // elements between images of x
   int xsc;        // elements between channels of x (Hin*Win)
   int Cin;        // multiple of 32
+  int cin_live;   // 0, or the number of leading input channels that can be non-zero (a multiple of 8 <= Cin): the data gradient of a layer
+                  // whose output channels were padded (the 18 -> 32 offset tensors) -- conv_tile.hip skips the chunks behind it
   int Hin, Win;   // physical input dims
   int ups;        // 0/1: nearest x2 upsample folded into the gather
   int N, OHl, OWl;
@@ -93,6 +95,8 @@ struct ConvDesc {
   const float* mask;
   long masksn;
   int mask_c0;
+  float* yt;      // optional second copy of the output, channels-last (N * OHl * OWl, 64): the fused deformable sampler's input layout.
+                  // Written by conv_tile.hip only (Cout == 64, plain epilogue): ask conv_tile_writes_yt(d) first.
   const float* ch_scale;  // per-output-channel multiplier applied BEFORE the bias (null: 1): v = acc * ch_scale[c] + bias[c] -- an
                           // eval-mode BatchNorm folded into the convolution (ch_scale = gamma / sqrt(avg_var + eps), bias = beta -
                           // avg_mean * ch_scale; discriminator.hip)
@@ -122,6 +126,7 @@ void launch_igemm_conv(const ConvDesc& d, hipStream_t s);
 // the LDS-tiled form for the mid-size training planes (conv_tile.hip); launch_igemm_conv dispatches to it
 int conv_tile_plan(ConvDesc& d, long* wgs);
 void conv_tile_launch(const ConvDesc& d, int cfg, hipStream_t s);
+bool conv_tile_writes_yt(const ConvDesc& d);   // will launch_igemm_conv(d) fill d.yt?
 
 // Per-kernel-family timing with HIP events on the launch stream (bench.py's roofline leg).
 // family 0 = igemm_conv_kernel (forward + data gradient), 1 = weight-gradient kernels, 2 = trunk_fused_kernel,

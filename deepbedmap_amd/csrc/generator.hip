@@ -420,6 +420,15 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     launch_igemm_conv(d, s);
     ConvDesc e = prec(fwd_desc(layers[L_up2], a41.p, 64 * 4 * hw, 2 * h, 2 * w, 1, a42.p, 64 * 16 * hw, N), 8);
     e.act = 1;
+    // (the fused deformable sampler reads a channels-last copy of this output: the LDS-tiled form writes it from its epilogue)
+    static const int fused_env0 = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+    a42t_written = false;
+    if (fused_env0 && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch)) {
+      a42t.ensure((size_t)N * 64 * 16 * hw);
+      e.yt = a42t.p;
+      a42t_written = conv_tile_writes_yt(e);
+      if (!a42t_written) e.yt = nullptr;
+    }
     launch_igemm_conv(e, s);
   }
   // ---- deformable conv 1 + LeakyReLU (:572-573): offset conv, sampler -> col, GEMM over 576 columns ----
@@ -443,7 +452,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     ConvDesc d = prec(fwd_desc(layers[L_off1], a42.p, 64 * P4, H4, W4, 0, off1.p, 32 * P4, N), 16);
     launch_igemm_conv(d, s);
     if (dfused) {
-      launch_nchw_to_nhwc64(a42.p, a42t.p, N, (int)P4, s);
+      if (!a42t_written) launch_nchw_to_nhwc64(a42.p, a42t.p, N, (int)P4, s);
       launch_deform_conv_fused(a42t.p, off1.p, layers[L_def1].wf, P(layers[L_def1].bi), a51.p, a51t.p, keep ? col1.p : nullptr, N, 64, H4,
                                W4, 32 * P4, 64, 1, SLOPE, s);
     } else {

@@ -204,6 +204,7 @@ struct Generator : dbm_model {
   DevBuf dw2_partial;  // per-workgroup partial sums of final_conv_layer2's weight gradient (deform_bwd1_fused_kernel)
   bool deform_bwd_fused(int H4, int W4) const;
   DevBuf zdef;        // the last layer's premultiplied tap planes (N, 9 * out_ch, 4H, 4W): deform1_premul_kernel
+  bool a42t_written = false;  // forward(): post_upsample_conv_layer_2 wrote the channels-last twin of its output itself
   bool zdef_kept = false;  // ... of the retained forward pass (the 64 -> 1 layer's backward in premultiplied form reads them)
   DevBuf gt2;         // backward: the transposed sampler applied to gy, (N, 9, 4H, 4W)
   DevBuf a42t, a51t;  // channels-last copies of the deformable layers' inputs (what the fused sampler gathers from)

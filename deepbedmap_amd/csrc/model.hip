@@ -323,6 +323,8 @@ void dbm_model::run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_
   if (!s) s = ctx->stream;
   const int OH = (Hin_fwd + 2 * L.pad - L.Kview) / L.stride + 1, OW = (Win_fwd + 2 * L.pad - L.Kview) / L.stride + 1;
   base.xsc = OH * OW; base.Cin = L.OP; base.Hin = OH; base.Win = OW; base.ups = 0;
+  static const int cin_live_env = getenv("DBM_CIN_LIVE") ? atoi(getenv("DBM_CIN_LIVE")) : 1;   // (A/B switch)
+  base.cin_live = (cin_live_env && L.O < L.OP) ? ((L.O + 7) & ~7) : 0;   // (gradient channels past the layer's O outputs are zero padding)
   base.sin = 1;
   base.CoutP = L.CP; base.Cout = L.Cview;
   base.bias = nullptr;
