@@ -1241,7 +1241,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
     ~Scope() {
       c->stream = s; c->comm_in_step = false; c->comm_defer = false; c->comm_stream = nullptr; c->comm_pending.clear();
       d->merge_slots = false;
-      if (t) { t->grads_cleared = false; t->use_aux = true; t->max_split = 2; t->wgrad_inline = false; }
+      if (t) { t->grads_cleared = false; t->use_aux = true; t->max_split = 2; t->wgrad_inline = false; t->csr_early = false; }
     }
   } scope{c, s, d};
   c->comm_in_step = dp;
@@ -1255,6 +1255,10 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   // ---- D(real) forward on the side stream, underneath the generator forward (:1145) ----
   c->fork_to_side(0);
   c->stream = c->side;
+  // cleargrads of the G-step (:1255), early: nothing reads or writes the generator's gradient arena between the previous update and this
+  // iteration's backward pass, and 35 MB of fill would otherwise sit between the loss and the backward pass on the critical path
+  DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), c->side));
+  DBM_HIP(hipEventRecord(c->ev_iter[2], c->side));
   if (!no_d) d->forward(N, H4, W4, Y, lr, true, true, 0);
   c->stream = s;
   // (The G-step's own forward goes to chain[1] behind the first forward; one_fwd: it is the only forward, forked here.
@@ -1276,8 +1280,14 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   Generator* t = g->get_twin();
   scope.t = t;
   t->ensure_ws(N, H, W, true);
+  // DBM_ITER_CSR_EARLY (default 1): the deformable layers' sampling lists (they depend on the offsets only) are built on chain[0]
+  // behind the discriminator's fake-batch pass -- i.e. beside the generator's loss -- instead of on the backward pass's own path
+  // (Generator::prebuild_csr; 7.69-7.70 against 7.77-7.78 ms.  On the side stream, which must then wait for the retained forward's
+  // tail, the discriminator's weight gradients start late: 8.07)
+  static const int csr_early_env = getenv("DBM_ITER_CSR_EARLY") ? atoi(getenv("DBM_ITER_CSR_EARLY")) : 1;
   auto twin_forward = [&]() {  // the G-step's own forward (:1222-1227), retained graph, second workspace, on chain[1]
     t->max_split = 1;
+    t->csr_early = csr_early_env != 0;
     c->stream = pf;
     t->forward(N, H, W, X, W1, W2, W3, t->yout.p, true);
     DBM_HIP(hipEventRecord(g->ev_prefetch, pf));  // the twin's fakes are final (the G-step's eval-mode discriminator pass reads them)
@@ -1317,6 +1327,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   c->comm_defer = false;
   if (dp) c->comm_flush();
   c->fork(c->chain[0], s, 7);
+  if (csr_early_env) t->prebuild_csr(c->chain[0]);   // (behind the fake-batch pass, and behind the mark the main stream waits for)
   c->join_side();  // (the discriminator's weight gradients: everything on the side stream so far)
   DBM_MARK(s, "D:weight_gradients_joined");
   if (dp) {  // what launch_group has not sent yet: [0, lo) and [hi, nparam) in one fused group; then the optimizer's wait
@@ -1331,7 +1342,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   c->stream = pf;
   gen_loss_terms(c, t->yout.p, Y, X, N, H4, W4, weights, ssim_window, t->g_y.p);
   DBM_HIP(hipEventRecord(c->ev_iter[0], pf));
-  DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), pf));  // cleargrads (:1255)
+  DBM_HIP(hipStreamWaitEvent(pf, c->ev_iter[2], 0));  // cleargrads (:1255): the fill at the head of the side stream
   mark_grads_cleared(g);
   t->grads_cleared = true;
   // (chain[0] carries the discriminator's fake-batch pass and the gradient exchange.  DBM_ITER_AUX=1, single GPU only: the offset-

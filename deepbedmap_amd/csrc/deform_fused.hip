@@ -947,12 +947,12 @@ void launch_deform_bwd1_fused(const float* xt, const float* off, const float* w,
 // gw (576) / gb (1) accumulated.
 void launch_deform_bwd1_premul(const float* xt, const float* off, const float* w, const float* gy, const float* z, float* goff, float* gx,
                                float* gw, float* gb, float* partial, float* csr_ws, float* Gt, int N, int H, int W, long offsn,
-                               hipStream_t s) {
+                               hipStream_t s, bool lists_built) {
   const long plane = (long)H * W, total = (long)N * plane;
   DBM_CHECK(total < (1L << 31), "deformable backward: more than 2^31 positions");
   const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
   hipLaunchKernelGGL(deform1_goff_kernel, dim3((unsigned)((total + 255) / 256), 9), dim3(256), 0, s, z, off, gy, goff, total, H, W, offsn);
-  launch_deform_csr_gather1(off, gy, Gt, N, H, W, offsn, s, csr_ws);
+  launch_deform_csr_gather1(off, gy, Gt, N, H, W, offsn, s, csr_ws, lists_built);
   hipLaunchKernelGGL(deform1_xw_kernel, dim3(blocks), dim3(256), 0, s, xt, w, Gt, gy, gx, partial, total, (int)plane);
   hipLaunchKernelGGL(deform_wgrad1_fold_kernel, dim3(145), dim3(256), 0, s, partial, (int)blocks, gw, gb);
   DBM_HIP(hipGetLastError());

@@ -73,6 +73,8 @@ Generator::~Generator() {
   if (twin) delete twin;
   if (ev_prefetch) (void)hipEventDestroy(ev_prefetch);
   if (ev_trunk) (void)hipEventDestroy(ev_trunk);
+  if (ev_csr) (void)hipEventDestroy(ev_csr);
+  for (auto& e : ev_off) if (e) (void)hipEventDestroy(e);
   for (auto& e : ev_pack) if (e) (void)hipEventDestroy(e);
   if (!is_view) {
     (void)hipFree(tf_wstream); (void)hipFree(tf_bstream); (void)hipFree(tf_bwd_wstream); (void)hipFree((void*)tf_wsrc); (void)hipFree((void*)tf_bsrc);
@@ -256,7 +258,22 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   {
     struct { const float* in; int Cin, Hin, Win, K, stride; } br[4] = {
         {x, 1, H, W, 3, 1}, {w1, 1, 10 * H, 10 * W, 30, 10}, {w2, 2, 2 * H, 2 * W, 6, 2}, {w3, 1, H, W, 3, 1}};
-    for (int i = 0; i < 4; ++i) {
+    // training tile: one launch (input_block.hip); the wide branches' im2col images are then rebuilt by backward(), off this path.
+    // DBM_INPUT_FUSED=0: layer by layer (A/B, and the form every other tile size takes)
+    static const int in_fused_env = getenv("DBM_INPUT_FUSED") ? atoi(getenv("DBM_INPUT_FUSED")) : 1;
+    const bool in_fused = in_fused_env && input_block_fused_ok(H, W) && !(use_bf16 && !(bf16_keep32 & 1));
+    col_stale = in_fused && keep;
+    if (in_fused) {
+      InputBlockLaunch q;
+      q.x = x; q.w1 = w1; q.w2 = w2; q.w3 = w3;
+      q.wx = P(T_in[0][0]); q.bx = P(T_in[0][1]);
+      q.wf1 = layers[L_in[1]].wf; q.b1 = P(T_in[1][1]);
+      q.wf2 = layers[L_in[2]].wf; q.b2 = P(T_in[2][1]);
+      q.w3w = P(T_in[3][0]); q.b3 = P(T_in[3][1]);
+      q.y = a0.p; q.ysn = 128 * hw; q.N = N;
+      launch_input_block_fused(q, s);
+    }
+    for (int i = 0; i < 4 && !in_fused; ++i) {
       SmallConvDesc d;
       memset(&d, 0, sizeof(d));
       d.x = br[i].in; d.xsn = (long)br[i].Cin * br[i].Hin * br[i].Win; d.Cin = br[i].Cin; d.Hin = br[i].Hin; d.Win = br[i].Win;
@@ -451,6 +468,12 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   } else {
     ConvDesc d = prec(fwd_desc(layers[L_off1], a42.p, 64 * P4, H4, W4, 0, off1.p, 32 * P4, N), 16);
     launch_igemm_conv(d, s);
+    csr_marked = false;
+    if (keep && csr_early) {
+      for (auto& e : ev_off)
+        if (!e) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      DBM_HIP(hipEventRecord(ev_off[0], s));
+    }
     if (dfused) {
       if (!a42t_written) launch_nchw_to_nhwc64(a42.p, a42t.p, N, (int)P4, s);
       launch_deform_conv_fused(a42t.p, off1.p, layers[L_def1].wf, P(layers[L_def1].bi), a51.p, a51t.p, keep ? col1.p : nullptr, N, 64, H4,
@@ -469,6 +492,10 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     } else {
       ConvDesc d = prec(fwd_desc(layers[L_off2], a51.p, 64 * P4, H4, W4, 0, off2.p, 32 * P4, N), 16);
       launch_igemm_conv(d, s);
+      if (keep && csr_early) {
+        DBM_HIP(hipEventRecord(ev_off[1], s));
+        csr_marked = true;
+      }
     }
     if (dfused) {
       static const bool premul = !(getenv("DBM_DEFORM1_PREMUL") && atoi(getenv("DBM_DEFORM1_PREMUL")) == 0);
@@ -492,6 +519,23 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   have_graph = keep;
 }
 
+void Generator::prebuild_csr(hipStream_t aux) {
+  if (!csr_marked || !have_graph) return;
+  csr_marked = false;
+  const int N = wsN, H4 = 4 * (wsH - 2), W4 = 4 * (wsW - 2);
+  const long P4 = (long)H4 * W4;
+  if (!deform_bwd_fused(H4, W4) || !deform_csr_lists_ok(64, H4, W4)) return;
+  csr_ws.ensure(deform_csr_workspace_floats(N, H4, W4));
+  csr_ws2.ensure(deform_csr_workspace_floats(N, H4, W4));
+  if (!ev_csr) DBM_HIP(hipEventCreateWithFlags(&ev_csr, hipEventDisableTiming));
+  DBM_HIP(hipStreamWaitEvent(aux, ev_off[0], 0));
+  launch_deform_csr_build(off1.p, csr_ws.p, N, H4, W4, 32 * P4, aux);
+  DBM_HIP(hipStreamWaitEvent(aux, ev_off[1], 0));
+  launch_deform_csr_build(off2.p, csr_ws2.p, N, H4, W4, 32 * P4, aux);
+  DBM_HIP(hipEventRecord(ev_csr, aux));
+  csr_prebuilt = true;
+}
+
 void Generator::backward(const float* gy) {
   DBM_CHECK(have_graph && wsTrain, "generator backward without a retained forward (DBM_KEEP_GRAPH)");
   hipStream_t s = ctx->stream;
@@ -501,6 +545,8 @@ void Generator::backward(const float* gy) {
   for (auto& b : wbs) b.cleared_target = grads_cleared;
   // ---- final_conv_layer2 (deformable, 64 -> 1) ----
   const bool bfused = deform_bwd_fused(H4, W4);
+  const bool pre_csr = csr_prebuilt && bfused;   // (prebuild_csr: both layers' sampling lists are already being built on another stream)
+  csr_prebuilt = false;
   if (bfused) {
     // offset gradients + the layer's weight / bias gradient from one pass over the channels-last input (no sample matrix);
     // on the aux stream next to the input-gradient gather when the caller has one
@@ -511,6 +557,7 @@ void Generator::backward(const float* gy) {
     }
     dw2_partial.ensure(deform_bwd1_partial_floats(N, H4, W4));
     csr_ws.ensure(deform_csr_workspace_floats(N, H4, W4));
+    if (pre_csr) DBM_HIP(hipStreamWaitEvent(s, ev_csr, 0));
     // Round 5: in the premultiplied form of the forward pass (z_t = sum_c w[c][t] x_c kept from it) the layer's whole backward is a
     // CSR gather of ONE value per list entry, four single-float gathers per (position, tap) and one pass over the input -- instead of
     // gathering 9 x 4 x 256 bytes per position for the offset / weight gradients (150 us) and 64 values per entry for the input gradient.
@@ -518,11 +565,12 @@ void Generator::backward(const float* gy) {
     static const bool premul_bwd = !(getenv("DBM_DEFORM1_PREMUL_BWD") && atoi(getenv("DBM_DEFORM1_PREMUL_BWD")) == 0);
     if (premul_bwd && zdef_kept) {
       gt2.ensure((size_t)N * 9 * P4);
-      launch_deform_bwd1_premul(a51t.p, off2.p, P(T_def2W), gy, zdef.p, goff2.p, g_a51.p, G(T_def2W), G(T_def2b), dw2_partial.p, csr_ws.p,
-                                gt2.p, N, H4, W4, 32 * P4, s);
+      launch_deform_bwd1_premul(a51t.p, off2.p, P(T_def2W), gy, zdef.p, goff2.p, g_a51.p, G(T_def2W), G(T_def2b), dw2_partial.p,
+                                pre_csr ? csr_ws2.p : csr_ws.p, gt2.p, N, H4, W4, 32 * P4, s, pre_csr);
     } else {
       launch_deform_bwd1_fused(a51t.p, off2.p, P(T_def2W), gy, goff2.p, G(T_def2W), G(T_def2b), dw2_partial.p, N, H4, W4, 32 * P4, sg);
-      launch_deform_input_grad(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, N, 64, H4, W4, 32 * P4, s, csr_ws.p);
+      launch_deform_input_grad(a51.p, off2.p, nullptr, P(T_def2W), gy, g_a51.p, N, 64, H4, W4, 32 * P4, s, pre_csr ? csr_ws2.p : csr_ws.p,
+                               pre_csr);
     }
     if (sg != s) ctx->fork(sg, s, 3);
   } else {
@@ -549,7 +597,7 @@ void Generator::backward(const float* gy) {
     if (bfused) {
       // column gradients W^T gy on the MFMAs, offset gradients from the same LDS tile; then the input-gradient gather
       launch_deform_bwd64_fused(a42t.p, off1.p, L.wb[1], g_a51.p, gcol.p, goff1.p, N, H4, W4, 32 * P4, s);
-      launch_deform_input_grad(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, N, 64, H4, W4, 32 * P4, s, csr_ws.p);
+      launch_deform_input_grad(a42.p, off1.p, gcol.p, nullptr, nullptr, g_a42.p, N, 64, H4, W4, 32 * P4, s, csr_ws.p, pre_csr);
     } else {
       ConvDesc d;
       memset(&d, 0, sizeof(d));
@@ -609,6 +657,12 @@ void Generator::backward(const float* gy) {
   static const int iter_abl = DBM_MEASURE_ENV("ITER_ABL");  // (libdbm_measure.so only: 2 = no trunk weight gradients, 4 = none of the tail's)
   const bool inline_wg = wgrad_inline && !ctx->comm_in_step;
   if (!(iter_abl & 4) && !inline_wg) wbs[0].launch(ctx->side);
+  if (col_stale) {  // (fused input block: the im2col images the wide branches' weight gradients read -- wbs[6], launched last)
+    hipStream_t cs = inline_wg ? s : ctx->side;
+    launch_im2col(bw_in[1] ? bw_in[1] : in_w1.p, colW1.p, N, 1, 10 * H, 10 * W, 30, 30, 10, h, w, layers[L_in[1]].CinP, cs);
+    launch_im2col(bw_in[2] ? bw_in[2] : in_w2.p, colW2.p, N, 2, 2 * H, 2 * W, 6, 6, 2, h, w, layers[L_in[2]].CinP, cs);
+    col_stale = false;
+  }
   // Data-parallel run: the gradient arena is in construction order (input block | pre | trunk | tail), and the backward
   // pass finishes it from the end: every group of weight gradients that has been enqueued on the side stream is a
   // contiguous range that can be summed over ranks (chain[1]) while the rest of the pass still runs.

@@ -1,0 +1,146 @@
+// DeepbedmapInputBlock (srgan_train.py:223-266) on the training tile -- X 11x11, W1 110x110, W2 2 x 22x22, W3 11x11 -> four valid
+// convolutions of 32 channels each on the 9x9 grid, concatenated -- as ONE launch.
+//
+// Layer by layer the block is eight dependent launches (two single-channel 3x3 convolutions, im2col + GEMM for the 30x30 / stride-10
+// and the 6x6 / stride-2 branch) of 6-34 us each: 0.13-0.19 ms at the head of BOTH generator forwards of a training iteration, i.e. on
+// its critical path twice, for 0.33 GFLOP.  Here a workgroup (eight wavefronts) owns three output rows of one image -- the trunk
+// kernels' band: 27 of a tile's 32 MFMA columns -- stages the input rows those reach in LDS (W1: 50 contiguous rows of 110 = 22 KB) and
+// forms every branch as v_mfma_f32_32x32x2_f32 tiles (rows = the branch's 32 output channels) whose B operand is one ds_read_b32 at
+// `position base + immediate`: no im2col image.  The 900-long K axis of the W1 branch is split over six wavefronts (five kernel rows =
+// 75 MFMAs each, partial tiles reduced through LDS in wavefront order: deterministic); the seventh forms the W2 branch (36 MFMAs), the
+// eighth X and W3 (5 each).  A operands: the packed forward images of the two wide branches (IgLayer::wf, [k][32]: one coalesced dword
+// per lane and MFMA) and the OIHW tensors of the 3x3 branches.
+// The wide branches' weight gradients still read an im2col image: a retained pass rebuilds it off the critical path
+// (Generator::backward, side stream).
+#include "kernels.h"
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr int OW = 9, BAND = 3, TP = BAND * OW;   // 27 positions per workgroup
+constexpr int W1W = 110, W1S = 10, W1K = 30;      // conv_on_W1: 30x30, stride 10
+constexpr int W2W = 22, W2S = 2, W2K = 6;         // conv_on_W2: 6x6, stride 2, two input channels
+constexpr int XW = 11;                            // conv_on_X / conv_on_W3: 3x3
+constexpr int R1 = (BAND - 1) * W1S + W1K;        // 50 input rows of W1 per band
+constexpr int R2 = (BAND - 1) * W2S + W2K;        // 10 of W2
+constexpr int RX = BAND + 2;                      // 5 of X / W3
+constexpr int NW1 = 6, KY_PER_WAVE = W1K / NW1;   // K split of the W1 branch: five kernel rows per wavefront
+constexpr int STEPS1 = KY_PER_WAVE * W1K / 2;     // 75 MFMAs (two k per MFMA: the lane half picks the odd kernel column)
+
+__global__ __launch_bounds__(512) void input_block_fused_kernel(const InputBlockLaunch a) {
+  __shared__ __attribute__((aligned(16))) float in1[R1 * W1W];
+  __shared__ __attribute__((aligned(16))) float in2[2 * R2 * W2W];
+  __shared__ float inx[2][64];
+  __shared__ float red[NW1][16][64];
+  const int band = blockIdx.x, n = blockIdx.y, oy0 = BAND * band;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---- stage: whole input rows, contiguous in memory; every request is out before the first LDS store ----
+  {
+    constexpr int Q1 = R1 * W1W / 4, Q2 = R2 * W2W / 4;   // 16-byte pieces: 1375 of W1, 55 per W2 channel
+    const f4v* g1 = reinterpret_cast<const f4v*>(a.w1 + (long)n * (W1W * W1W) + oy0 * W1S * W1W);
+    const f4v t0 = g1[tid], t1 = g1[tid + 512];
+    const int i2 = tid + 1024 < Q1 ? tid + 1024 : Q1 - 1;
+    const f4v t2 = g1[i2];
+    const int c = tid < Q2 ? 0 : 1, i = tid < 2 * Q2 ? tid - c * Q2 : 0;
+    const f4v u = reinterpret_cast<const f4v*>(a.w2 + ((long)n * 2 + c) * (W2W * W2W) + oy0 * W2S * W2W)[i];
+    const int ix = (tid & 63) < RX * XW ? (tid & 63) : 0;
+    const float vx = (wave == 2 ? a.x : a.w3)[(long)n * (XW * XW) + oy0 * XW + ix];
+    reinterpret_cast<f4v*>(in1)[tid] = t0;
+    reinterpret_cast<f4v*>(in1)[tid + 512] = t1;
+    reinterpret_cast<f4v*>(in1)[i2] = t2;
+    if (tid < 2 * Q2) reinterpret_cast<f4v*>(in2)[tid] = u;
+    if (wave == 2 || wave == 3) inx[wave - 2][tid & 63] = vx;
+  }
+  __syncthreads();
+  const int p = lane & 31, hh = lane >> 5;
+  const int pv = p < TP ? p : 0;   // (padding columns repeat position 0; never stored)
+  const int oyr = pv / OW, ox = pv - OW * oyr;
+  float* yb = a.y + (long)n * a.ysn + TP * band + p;
+  // rows of this lane's 16 accumulator registers: (r & 3) + 8 (r >> 2) + 4 hh
+  auto store_tile = [&](const f16v& acc, int ch0, const float* bias) {
+    float b[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * hh];
+    if (p < TP) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yb[(long)(ch0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * (OW * OW)] = acc[r] + b[r];
+    }
+  };
+  f16v acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  if (wave < NW1) {
+    // k = (KY_PER_WAVE wave + kyr) * 30 + 2 j + hh  ->  packed row k, column o = lane & 31: element 32 k + o = const + 64 step + lane
+    const float* A = a.wf1 + (long)wave * (KY_PER_WAVE * W1K) * 32 + lane;
+    const float* B = in1 + (oyr * W1S + wave * KY_PER_WAVE) * W1W + ox * W1S + hh;
+    float av[STEPS1];
+#pragma unroll
+    for (int s = 0; s < STEPS1; ++s) av[s] = A[64 * s];
+#pragma unroll
+    for (int kyr = 0; kyr < KY_PER_WAVE; ++kyr)
+#pragma unroll
+      for (int j = 0; j < W1K / 2; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kyr * (W1K / 2) + j], B[kyr * W1W + 2 * j], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  } else if (wave == NW1) {
+    // conv_on_W2: k = c * 36 + ky * 6 + kx = 2 s + hh (kx even + hh: never crosses a kernel row)
+    const float* A = a.wf2 + lane;
+    const float* B = in2 + oyr * W2S * W2W + ox * W2S + hh;
+    float av[W2K * W2K];
+#pragma unroll
+    for (int s = 0; s < W2K * W2K; ++s) av[s] = A[64 * s];
+#pragma unroll
+    for (int s = 0; s < W2K * W2K; ++s) {
+      const int k = 2 * s, c = k / (W2K * W2K), ky = (k % (W2K * W2K)) / W2K, kx = k % W2K;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], B[c * (R2 * W2W) + ky * W2W + kx], acc, 0, 0, 0);
+    }
+    store_tile(acc, 64, a.b2);
+  } else {
+    // conv_on_X, then conv_on_W3: k = ky * 3 + kx = 2 s + hh, k = 9 is padding (A = 0)
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+      const float* wt = (br ? a.w3w : a.wx) + (lane & 31) * 9;
+      const float* B = inx[br] + oyr * XW + ox;
+      float av[5];
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const int k = 2 * s + hh;
+        av[s] = k < 9 ? wt[k] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const int k0 = 2 * s, k1 = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
+        const int off = hh ? (k1 / 3) * XW + k1 % 3 : (k0 / 3) * XW + k0 % 3;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], B[off], acc, 0, 0, 0);
+      }
+      store_tile(acc, br ? 96 : 0, br ? a.b3 : a.bx);
+    }
+  }
+  __syncthreads();
+  // ---- conv_on_W1: the six partial tiles, summed in wavefront order ----
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + 512 * q, r = idx >> 6, l = idx & 63;
+    float v = red[0][r][l];
+#pragma unroll
+    for (int w = 1; w < NW1; ++w) v += red[w][r][l];
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+    if (col < TP) a.y[(long)n * a.ysn + (long)(32 + row) * (OW * OW) + TP * band + col] = v + a.b1[row];
+  }
+}
+
+}  // namespace
+
+bool input_block_fused_ok(int H, int W) { return H == XW && W == XW; }
+
+void launch_input_block_fused(const InputBlockLaunch& a, hipStream_t s) {
+  if (a.N <= 0) return;
+  hipLaunchKernelGGL(input_block_fused_kernel, dim3(OW / BAND, (unsigned)a.N), dim3(512), 0, s, a);
+  DBM_HIP(hipGetLastError());
+}

@@ -18,6 +18,18 @@ void launch_smallcin_conv_wgrad(const SmallConvDesc& d, const float* dy, long dy
                                 float* scratch = nullptr);
 size_t smallcin_wgrad_scratch_floats(int Cout);
 
+// DeepbedmapInputBlock on the training tile (11 x 11 -> 9 x 9) as one launch (input_block.hip)
+struct InputBlockLaunch {
+  const float *x, *w1, *w2, *w3;   // (N,1,11,11), (N,1,110,110), (N,2,22,22), (N,1,11,11), contiguous
+  const float *wx, *bx;            // conv_on_X: OIHW (32,1,3,3), bias
+  const float *wf1, *b1;           // conv_on_W1: packed forward image [900 (+pad)][32] (IgLayer::wf), bias
+  const float *wf2, *b2;           // conv_on_W2: [72 (+pad)][32]
+  const float *w3w, *b3;           // conv_on_W3: OIHW
+  float* y; long ysn;              // the 128-channel concat (N, 128, 81)
+  int N;
+};
+bool input_block_fused_ok(int H, int W);
+void launch_input_block_fused(const InputBlockLaunch& a, hipStream_t s);
 void launch_im2col(const float* x, float* col, int N, int Cin, int Hin, int Win, int KH, int KW, int stride, int OH, int OW,
                    int KP, hipStream_t s);
 void launch_deform_sample(const float* x, const float* off, float* col, int N, int C, int H, int W, long offsn, hipStream_t s);
@@ -41,9 +53,14 @@ size_t deform_bwd1_partial_floats(int N, int H, int W);
 // N * 9 * plane floats, csr_ws = deform_csr_workspace_floats floats; goff and gx (N, 64, plane) overwritten, gw / gb accumulated
 void launch_deform_bwd1_premul(const float* xt, const float* off, const float* w, const float* gy, const float* z, float* goff, float* gx,
                                float* gw, float* gb, float* partial, float* csr_ws, float* Gt, int N, int H, int W, long offsn,
-                               hipStream_t s);
+                               hipStream_t s, bool lists_built = false);
 void launch_deform1_premul(const float* xt, const float* w, float* z, int N, int H, int W, int O, hipStream_t s);
-void launch_deform_csr_gather1(const float* off, const float* gy, float* G, int N, int H, int W, long offsn, hipStream_t s, float* ws);
+void launch_deform_csr_gather1(const float* off, const float* gy, float* G, int N, int H, int W, long offsn, hipStream_t s, float* ws,
+                               bool lists_built = false);
+// the sampling lists alone (what launch_deform_csr_gather1 / launch_deform_input_grad build first unless told `lists_built`): they depend on
+// the offsets only, so a retained forward can have them built beside its own tail instead of inside the backward pass
+bool deform_csr_lists_ok(int C, int H, int W);
+void launch_deform_csr_build(const float* off, float* ws, int N, int H, int W, long offsn, hipStream_t s);
 void launch_deform_bwd1_fused(const float* xt, const float* off, const float* w, const float* gy, float* goff, float* gw, float* gb,
                               float* partial, int N, int H, int W, long offsn, hipStream_t s);
 bool deform_input_grad_ok(int C, int H, int W);
@@ -51,7 +68,7 @@ bool deform_input_grad_ok(int C, int H, int W);
 // register-only kernel gathers (otherwise every channel-group workgroup rebuilds them in LDS)
 size_t deform_csr_workspace_floats(int N, int H, int W);
 void launch_deform_input_grad(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy, float* gx, int N,
-                              int C, int H, int W, long offsn, hipStream_t s, float* ws = nullptr);
+                              int C, int H, int W, long offsn, hipStream_t s, float* ws = nullptr, bool lists_built = false);
 void launch_gemv_cols(const float* col, const float* w, const float* bias, float* y, int N, int K, int plane, hipStream_t s);
 void launch_gemv_cols_wgrad(const float* col, const float* gy, float* gw, float* gb, int N, int K, int plane, hipStream_t s);
 void launch_sumpool2(const float* g, const float* mask, float* out, long nc, int H, int W, float slope, hipStream_t s);

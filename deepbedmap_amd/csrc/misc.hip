@@ -727,22 +727,36 @@ bool deform_input_grad_ok(int C, int H, int W) {
   return C % 8 == 0 && sizeof(float) * ((size_t)8 * plane + 10 * plane + 1) <= 150 * 1024;
 }
 
+bool deform_csr_lists_ok(int C, int H, int W) {
+  static const int split_env = getenv("DBM_DEFORM_CSR_SPLIT") ? atoi(getenv("DBM_DEFORM_CSR_SPLIT")) : 1;
+  return split_env && C % 16 == 0 && sizeof(float) * (10 * (size_t)H * W + 1) <= 150 * 1024;
+}
+
+void launch_deform_csr_build(const float* off, float* ws, int N, int H, int W, long offsn, hipStream_t s) {
+  const long plane = (long)H * W;
+  DBM_CHECK(ws != nullptr && sizeof(float) * (10 * (size_t)plane + 1) <= 150 * 1024, "deformable CSR lists: plane too large");
+  int* g_offs = (int*)ws;
+  int2* g_ent = (int2*)(ws + (((size_t)N * 9 * (plane + 1) + 1) & ~(size_t)1));
+  static bool attr2 = false;
+  if (!attr2) {
+    DBM_HIP(hipFuncSetAttribute((const void*)deform_csr_build_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
+    attr2 = true;
+  }
+  hipLaunchKernelGGL((deform_csr_build_kernel<1024>), dim3(N, 9), dim3(1024), sizeof(float) * (10 * (size_t)plane + 1), s, off, g_offs, g_ent,
+                     H, W, offsn);
+  DBM_HIP(hipGetLastError());
+}
+
 void launch_deform_input_grad(const float* x, const float* off, const float* gcol, const float* w1o, const float* gy, float* gx, int N,
-                              int C, int H, int W, long offsn, hipStream_t s, float* ws) {
+                              int C, int H, int W, long offsn, hipStream_t s, float* ws, bool lists_built) {
   DBM_CHECK(deform_input_grad_ok(C, H, W), "deformable input gradient: plane too large for the CSR kernel");
   const long plane = (long)H * W;
-  static const int split_env = getenv("DBM_DEFORM_CSR_SPLIT") ? atoi(getenv("DBM_DEFORM_CSR_SPLIT")) : 1;
-  if (ws && split_env && C % 16 == 0 && sizeof(float) * (10 * (size_t)plane + 1) <= 150 * 1024) {
+  DBM_CHECK(!lists_built || (ws && deform_csr_lists_ok(C, H, W)), "deformable input gradient: no prebuilt lists for this shape");
+  if (ws && deform_csr_lists_ok(C, H, W)) {
     // lists built once per (image, tap), then a register-only gather per (image, 16 channels)
     int* g_offs = (int*)ws;
     int2* g_ent = (int2*)(ws + (((size_t)N * 9 * (plane + 1) + 1) & ~(size_t)1));
-    static bool attr2 = false;
-    if (!attr2) {
-      DBM_HIP(hipFuncSetAttribute((const void*)deform_csr_build_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-      attr2 = true;
-    }
-    hipLaunchKernelGGL((deform_csr_build_kernel<1024>), dim3(N, 9), dim3(1024), sizeof(float) * (10 * (size_t)plane + 1), s, off, g_offs,
-                       g_ent, H, W, offsn);
+    if (!lists_built) launch_deform_csr_build(off, ws, N, H, W, offsn, s);
     hipLaunchKernelGGL((deform_csr_gather_kernel<16, 1024>), dim3(N, C / 16), dim3(1024), 0, s, g_offs, g_ent, gcol, w1o, gy, gx, C,
                        (int)plane);
     DBM_HIP(hipGetLastError());
@@ -769,18 +783,13 @@ void launch_deform_input_grad(const float* x, const float* off, const float* gco
 }
 
 // The sampling lists of `off` (built into ws) applied to gy (N, 1, plane): G (N, 9, plane).
-void launch_deform_csr_gather1(const float* off, const float* gy, float* G, int N, int H, int W, long offsn, hipStream_t s, float* ws) {
+void launch_deform_csr_gather1(const float* off, const float* gy, float* G, int N, int H, int W, long offsn, hipStream_t s, float* ws,
+                               bool lists_built) {
   const long plane = (long)H * W;
   DBM_CHECK(ws != nullptr && sizeof(float) * (10 * (size_t)plane + 1) <= 150 * 1024, "deformable CSR lists: plane too large");
   int* g_offs = (int*)ws;
   int2* g_ent = (int2*)(ws + (((size_t)N * 9 * (plane + 1) + 1) & ~(size_t)1));
-  static bool attr2 = false;
-  if (!attr2) {
-    DBM_HIP(hipFuncSetAttribute((const void*)deform_csr_build_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024));
-    attr2 = true;
-  }
-  hipLaunchKernelGGL((deform_csr_build_kernel<1024>), dim3(N, 9), dim3(1024), sizeof(float) * (10 * (size_t)plane + 1), s, off, g_offs, g_ent,
-                     H, W, offsn);
+  if (!lists_built) launch_deform_csr_build(off, ws, N, H, W, offsn, s);
   hipLaunchKernelGGL(deform_csr_gather1_kernel, dim3((unsigned)((plane + 255) / 256), 9, N), dim3(256), 0, s, g_offs, g_ent, gy, G, (int)plane);
   DBM_HIP(hipGetLastError());
 }

@@ -48,7 +48,7 @@ struct dbm_ctx {
   void comm_flush();
   hipEvent_t ev_comm = nullptr, ev_comm_done = nullptr;
   hipEvent_t ev_timer[2] = {nullptr, nullptr};  // dbm_timer
-  hipEvent_t ev_iter[2] = {nullptr, nullptr};   // dbm_train_iteration: loss scratch cleared / generator backward done
+  hipEvent_t ev_iter[3] = {nullptr, nullptr, nullptr};   // dbm_train_iteration: loss scratch cleared / generator backward done / G grads cleared
   // The persistent trunk kernels need every workgroup of a launch resident at once: two of them on different streams, each
   // holding part of the chip, would wait for each other's compute units until their spin limits.  Every persistent launch
   // therefore waits for the previous one (whatever its stream) and leaves its own completion here.
@@ -193,6 +193,7 @@ struct Generator : dbm_model {
   long graph_version = -1;
   long graph_epoch = -1;   // dbm_ctx::data_epoch at the time of that forward
   const float* graph_in[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool col_stale = false;   // the retained forward ran the fused input block: colW1 / colW2 are rebuilt by backward()
   const float* bw_in[4] = {nullptr, nullptr, nullptr, nullptr};  // forward inputs, needed by the input-block wgrad
   static const int NWB = 7;
   bool grads_cleared = false;  // set by dbm_generator_step around backward(): cleargrads has just run (WgradBatch::cleared_target)
@@ -201,6 +202,13 @@ struct Generator : dbm_model {
   std::vector<DevBuf> cat, dA;
   DevBuf in_x, in_w1, in_w2, in_w3, a0, a3, a41, a42, off1, off2, col1, col2, a51, yout;
   DevBuf csr_ws;       // sampling lists of the deformable layers' input-gradient gather (deform_csr_build_kernel)
+  // The lists depend on the layers' offsets only.  csr_early (set by dbm_train_iteration around the retained forward): forward() marks
+  // the two offset tensors (ev_off), prebuild_csr(aux) builds both lists on `aux` beside the generator's loss (the 64 -> 64 layer's in
+  // csr_ws, the 64 -> 1 layer's in csr_ws2) and backward() only waits for them (ev_csr) instead of building them on its own path.
+  DevBuf csr_ws2;
+  bool csr_early = false, csr_marked = false, csr_prebuilt = false;
+  hipEvent_t ev_off[2] = {nullptr, nullptr}, ev_csr = nullptr;
+  void prebuild_csr(hipStream_t aux);
   DevBuf dw2_partial;  // per-workgroup partial sums of final_conv_layer2's weight gradient (deform_bwd1_fused_kernel)
   bool deform_bwd_fused(int H4, int W4) const;
   DevBuf zdef;        // the last layer's premultiplied tap planes (N, 9 * out_ch, 4H, 4W): deform1_premul_kernel
