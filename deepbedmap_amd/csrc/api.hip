@@ -1047,6 +1047,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
     // (with the persistent trunk kernel the prefetched forward occupies ONE stream, chain[1]: chain[0] is free again)
     const bool twin_one_stream = g->trunk_fused_ok(H - 2, W - 2);
     const bool two_streams = (!(prefetch && train) || twin_one_stream) && !sync;
+    d->ensure_packed_bwd(s);   // (before the fork: both passes read the data-gradient images)
     if (two_streams) {
       c->fork(s, c->chain[0], 7);
       c->stream = c->chain[0];
@@ -1253,12 +1254,17 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   static const int iter_abl = DBM_MEASURE_ENV("ITER_ABL");
   const bool no_d = (iter_abl & 1) != 0;
   // ---- D(real) forward on the side stream, underneath the generator forward (:1145) ----
+  g->ensure_packed();   // (normally done behind the previous update; never on the side stream: the forward below reads these images)
   c->fork_to_side(0);
   c->stream = c->side;
   // cleargrads of the G-step (:1255), early: nothing reads or writes the generator's gradient arena between the previous update and this
   // iteration's backward pass, and 35 MB of fill would otherwise sit between the loss and the backward pass on the critical path
   DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), c->side));
-  DBM_HIP(hipEventRecord(c->ev_iter[2], c->side));
+  // the data-gradient weight images of both models (stale since their updates; first read by this iteration's backward passes): here,
+  // beside the generator's input block, instead of between the discriminator's update and its eval-mode pass in the previous iteration
+  g->ensure_packed_bwd(c->side);
+  DBM_HIP(hipEventRecord(c->ev_iter[2], c->side));   // (what the generator's backward pass on chain[1] waits for)
+  d->ensure_packed_bwd(c->side);
   if (!no_d) d->forward(N, H4, W4, Y, lr, true, true, 0);
   c->stream = s;
   // (The G-step's own forward goes to chain[1] behind the first forward; one_fwd: it is the only forward, forked here.
@@ -1342,7 +1348,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   c->stream = pf;
   gen_loss_terms(c, t->yout.p, Y, X, N, H4, W4, weights, ssim_window, t->g_y.p);
   DBM_HIP(hipEventRecord(c->ev_iter[0], pf));
-  DBM_HIP(hipStreamWaitEvent(pf, c->ev_iter[2], 0));  // cleargrads (:1255): the fill at the head of the side stream
+  DBM_HIP(hipStreamWaitEvent(pf, c->ev_iter[2], 0));  // cleargrads (:1255): the fill at the head of the side stream (+ the weight images)
   mark_grads_cleared(g);
   t->grads_cleared = true;
   // (chain[0] carries the discriminator's fake-batch pass and the gradient exchange.  DBM_ITER_AUX=1, single GPU only: the offset-
@@ -1442,6 +1448,7 @@ int dbm_op_conv2d_backward(dbm_ctx* ctx, const float* x, const float* w, const f
       memset(&d, 0, sizeof(d));
       d.x = gy; d.xsn = (long)O * OH * OW; d.N = N;
       d.y = gx; d.ysn = (long)C * Hl * Wl; d.s1 = 1.f; d.s2 = 1.f;
+      holder.ensure_packed_bwd();
       holder.run_dgrad(L, d, Hl, Wl);  // gradient w.r.t. the (upsampled) conv input
     }
     DBM_HIP(hipStreamSynchronize(ctx->stream));
@@ -1635,6 +1642,7 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
     DBM_HIP(hipMemcpyAsync(holder.params, w, sizeof(float) * (size_t)O * C * 9, hipMemcpyDeviceToDevice, s));
     holder.add_iglayer("op", O, C, 3, 1, 0, true, true);
     holder.ensure_packed();
+    holder.ensure_packed_bwd();
     const IgLayer& L = holder.layers[0];
     gcol.ensure((size_t)N * C * 9 * P);
     if (fused) {

@@ -164,6 +164,7 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
   Cache& c = cache[slot];
   DBM_CHECK(c.valid, "discriminator backward without a retained training-mode forward");
   hipStream_t s = ctx->stream;
+  ensure_packed_bwd();   // (callers that run the two graphs' passes on two streams have done this before their fork)
   const int N = c.N;
   int hs[11], ws[11];
   layer_dims(c.H, c.W, hs, ws);

@@ -150,6 +150,7 @@ Generator* Generator::get_twin() {
   t->is_view = true;
   t->owner = this;
   t->packed_dirty = false;
+  t->bwd_dirty = false;
   t->chain_base = 0;  // its main stream is chain[1] (set by the caller); the second image range shares chain[0]
   twin = t;
   return t;
@@ -539,6 +540,7 @@ void Generator::prebuild_csr(hipStream_t aux) {
 void Generator::backward(const float* gy) {
   DBM_CHECK(have_graph && wsTrain, "generator backward without a retained forward (DBM_KEEP_GRAPH)");
   hipStream_t s = ctx->stream;
+  (owner ? owner : this)->ensure_packed_bwd();   // (a no-op inside dbm_train_iteration, which rebuilds them at its head)
   const int N = wsN, H = wsH, W = wsW, h = H - 2, w = W - 2;
   const long hw = (long)h * w, P4 = 16 * hw;
   const int H4 = 4 * h, W4 = 4 * w, nrdb = 3 * n_rrdb;

@@ -150,8 +150,16 @@ struct dbm_model {
   void ensure_packed_bf16();
   bool is_view = false;    // arenas and packed weight images belong to another model (Generator::twin)
   std::vector<IgLayer> layers;
-  PackJob* d_pack_jobs = nullptr;  // device job table of the one-launch weight repack
+  PackJob* d_pack_jobs = nullptr;  // device job table of the one-launch weight repack: the FORWARD images (IgLayer::wf)
   int n_pack_jobs = 0, n_pack_blocks = 0;
+  // The data-gradient images (IgLayer::wb) are first read by the NEXT backward pass, not by the forward pass that follows an update --
+  // in dbm_train_iteration the discriminator's eval-mode pass right behind its update: they have their own table and are rebuilt by
+  // ensure_packed_bwd (head of the next iteration, side stream; every backward entry point calls it as well).  DBM_PACK_SPLIT=0: one
+  // launch builds both, as before round 5.
+  PackJob* d_bwd_jobs = nullptr;
+  int n_bwd_jobs = 0, n_bwd_blocks = 0;
+  bool bwd_dirty = true;
+  void ensure_packed_bwd(hipStream_t on = nullptr);
   PackJob* d_lazy_jobs = nullptr;  // the same for the layers marked lazy
   int n_lazy_jobs = 0, n_lazy_blocks = 0;
   bool pack_tables_built = false;

@@ -71,6 +71,7 @@ dbm_model::~dbm_model() {
   if (adam_v) (void)hipFree(adam_v);
   if (pers) (void)hipFree(pers);
   if (d_pack_jobs) (void)hipFree(d_pack_jobs);
+  if (d_bwd_jobs) (void)hipFree(d_bwd_jobs);
   if (d_lazy_jobs) (void)hipFree(d_lazy_jobs);
 }
 
@@ -165,7 +166,8 @@ int dbm_model::add_iglayer(const std::string& name, int O, int C, int K, int str
 }
 
 // job table of the one-launch repack for the layers with lazy == want_lazy
-static void build_pack_table(const dbm_model& m, bool want_lazy, PackJob** d_jobs, int* njobs, int* nblocks) {
+// which: 1 = the forward images, 2 = the data-gradient images, 3 = both
+static void build_pack_table(const dbm_model& m, bool want_lazy, int which, PackJob** d_jobs, int* njobs, int* nblocks) {
   std::vector<PackJob> jobs;
   int blocks = 0;
   auto add = [&](const IgLayer& L, int T, const signed char* ky, const signed char* kx, int transpose, int KP, int MP,
@@ -189,7 +191,8 @@ static void build_pack_table(const dbm_model& m, bool want_lazy, PackJob** d_job
     const int T = L.Kview * L.Kview;
     signed char ky[DBM_MAX_TAPS], kx[DBM_MAX_TAPS];
     for (int t = 0; t < T; ++t) { ky[t] = (signed char)(t / L.Kview); kx[t] = (signed char)(t % L.Kview); }
-    add(L, T, ky, kx, 0, L.CinP, L.CoutP, L.wf);
+    if (which & 1) add(L, T, ky, kx, 0, L.CinP, L.CoutP, L.wf);
+    if (!(which & 2)) continue;
     const int nph = L.stride == 1 ? 1 : 4;
     for (int ph = 0; ph < nph; ++ph) add(L, L.Tb, L.bky[ph], L.bkx[ph], 1, L.OP, L.CP, L.wb[ph]);
     if (L.stride == 1 && L.wb[1]) {  // per-tap transposed image of a 1x1-viewed K x K layer: dst[t][o][c] = W[o][c][ky][kx]
@@ -219,23 +222,36 @@ static void build_pack_table(const dbm_model& m, bool want_lazy, PackJob** d_job
 void dbm_model::ensure_packed(hipStream_t on) {
   if (!packed_dirty) return;
   static const int abl_nopack = DBM_MEASURE_ENV("ABL_NOPACK");  // (libdbm_measure.so only; results wrong)
-  if (pack_tables_built && type == 1 && (abl_nopack & 1)) { packed_dirty = false; return; }
+  if (pack_tables_built && type == 1 && (abl_nopack & 1)) { packed_dirty = false; bwd_dirty = false; return; }
   if (pack_tables_built && type == 0 && (abl_nopack & 6)) {
     hipStream_t s2 = on ? on : ctx->stream;
     if (!(abl_nopack & 2) && n_pack_jobs) launch_pack_jobs(d_pack_jobs, n_pack_jobs, n_pack_blocks, s2);
     if (!(abl_nopack & 4)) pack_extra(s2);
     packed_dirty = false;
+    bwd_dirty = !(abl_nopack & 2);
     return;
   }
   hipStream_t s = on ? on : ctx->stream;
   if (!pack_tables_built) {  // the job tables only depend on the layer list: build and upload them once
-    build_pack_table(*this, false, &d_pack_jobs, &n_pack_jobs, &n_pack_blocks);
-    build_pack_table(*this, true, &d_lazy_jobs, &n_lazy_jobs, &n_lazy_blocks);
+    build_pack_table(*this, false, 1, &d_pack_jobs, &n_pack_jobs, &n_pack_blocks);
+    build_pack_table(*this, false, 2, &d_bwd_jobs, &n_bwd_jobs, &n_bwd_blocks);
+    build_pack_table(*this, true, 3, &d_lazy_jobs, &n_lazy_jobs, &n_lazy_blocks);
     pack_tables_built = true;
   }
   if (n_pack_jobs) launch_pack_jobs(d_pack_jobs, n_pack_jobs, n_pack_blocks, s);
   pack_extra(s);
   packed_dirty = false;
+  bwd_dirty = true;
+  static const bool split = !(getenv("DBM_PACK_SPLIT") && atoi(getenv("DBM_PACK_SPLIT")) == 0);
+  if (!split) ensure_packed_bwd(s);
+}
+
+void dbm_model::ensure_packed_bwd(hipStream_t on) {
+  if (is_view) return;
+  if (packed_dirty) ensure_packed(on);
+  if (!bwd_dirty) return;
+  if (n_bwd_jobs) launch_pack_jobs(d_bwd_jobs, n_bwd_jobs, n_bwd_blocks, on ? on : ctx->stream);
+  bwd_dirty = false;
 }
 
 // Layers marked lazy (the generator's trunk when the persistent kernels serve it) keep their per-layer images only for
@@ -321,6 +337,7 @@ ConvDesc dbm_model::fwd_desc(const IgLayer& L, const float* x, long xsn, int Hin
 // (after upsample), i.e. the dims of the gradient being produced.
 void dbm_model::run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_fwd, hipStream_t s) const {
   if (!s) s = ctx->stream;
+  DBM_CHECK(is_view || !bwd_dirty, "run_dgrad: the data-gradient weight images are stale (ensure_packed_bwd was not called)");
   const int OH = (Hin_fwd + 2 * L.pad - L.Kview) / L.stride + 1, OW = (Win_fwd + 2 * L.pad - L.Kview) / L.stride + 1;
   base.xsc = OH * OW; base.Cin = L.OP; base.Hin = OH; base.Win = OW; base.ups = 0;
   static const int cin_live_env = getenv("DBM_CIN_LIVE") ? atoi(getenv("DBM_CIN_LIVE")) : 1;   // (A/B switch)
