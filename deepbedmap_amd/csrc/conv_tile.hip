@@ -407,11 +407,12 @@ int conv_tile_plan(ConvDesc& d, long* wgs) {
   const long mt = (d.Cout + 31) / 32;
   const bool x4 = !d.ups && (reinterpret_cast<uintptr_t>(d.x) & 15) == 0 && (d.xsn & 3) == 0;   // 16-byte DMA pieces
   // Which plane classes take this form.  Measured INSIDE the training step (tools/experiments/ab_env.sh, two alternations): the 36 x 36
-  // layers (generator tail: the iteration's critical path) and the 18 x 18 ones pay -- 7.92 against 7.98 ms --; the 4x4 stride-2 layers
-  // (51.6 -> 43.8 us, 56.3 -> 47.8 us standalone) and the 9 x 9 planes (34.4 -> 30.7) do NOT: + 0.04 / + 0.02 ms per step.  These are
-  // discriminator layers that run on the 64 CUs a persistent trunk launch leaves, where igemm_conv_kernel's 1296 small workgroups
-  // (up to eight per CU) use a CU better than 256 workgroups of four wavefronts.  Off by default; DBM_CONV_TILE_K4=1 / DBM_CONV_TILE_9=1.
-  static const int k4_enable = getenv("DBM_CONV_TILE_K4") ? atoi(getenv("DBM_CONV_TILE_K4")) : 0;
+  // layers (generator tail: the iteration's critical path) and the 18 x 18 ones pay -- 7.92 against 7.98 ms.  The 4x4 stride-2 layers
+  // (51.6 -> 43.8 us, 56.3 -> 47.8 us standalone) cost + 0.04 ms per step when first measured and nothing on the final round-5 schedule
+  // (7.66 / 7.68 against 7.67 / 7.69): on.  The 9 x 9 planes (34.4 -> 30.7 us standalone) cost + 0.02 then and + 0.23 ms now: these
+  // discriminator layers run on the 64 CUs a persistent trunk launch leaves, where igemm_conv_kernel's small workgroups (up to eight
+  // per CU) use a CU better than 256 workgroups of four wavefronts.  Off; DBM_CONV_TILE_K4=0 / DBM_CONV_TILE_9=1 for the A/B.
+  static const int k4_enable = getenv("DBM_CONV_TILE_K4") ? atoi(getenv("DBM_CONV_TILE_K4")) : 1;
   static const int p9_enable = getenv("DBM_CONV_TILE_9") ? atoi(getenv("DBM_CONV_TILE_9")) : 0;
   if (k4) {
     if (!k4_enable) return 0;

@@ -544,13 +544,13 @@ __device__ __forceinline__ float quad_sum16(float v) {  // over the sixteen chan
 
 // gcol (N, 576, plane) = W^T gy (row c * 9 + t), goff (N, 18.., plane)[0:18] = offset gradients.  wb = the layer's
 // per-tap transposed image [t][o][c] (IgLayer::wb[1] of the layer viewed as a 1x1 convolution): coalesced A operands.
-__global__ __launch_bounds__(256) void deform_bwd64_fused_kernel(const float* __restrict__ xt, const float* __restrict__ off,
+__global__ __launch_bounds__(256, 2) void deform_bwd64_fused_kernel(const float* __restrict__ xt, const float* __restrict__ off,
                                                                  const float* __restrict__ wb, const float* __restrict__ gy,
                                                                  float* __restrict__ gcol, float* __restrict__ goff, int N, int H, int W,
                                                                  long offsn) {
   __shared__ TileGeometryBwd geo;
   __shared__ float dys[64 * DF_LD];  // [out channel][position]
-  __shared__ float dcl[64 * DF_LD];  // [in channel][position] of the current tap
+  __shared__ float dcl[2][64 * DF_LD];  // [in channel][position] of the current tap, and of the previous one (its stores go out late)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int plane = H * W;
   const long total = (long)N * plane;
@@ -569,20 +569,59 @@ __global__ __launch_bounds__(256) void deform_bwd64_fused_kernel(const float* __
   const int ct = wave & 1, pt = wave >> 1, j = lane & 31, kh = lane >> 5;
   const float* wl = wb + (long)kh * 64 + ct * 32 + j;  // + (t * 64 + 2 op) * 64
   __syncthreads();
-  // B operands (gy) do not depend on the tap: kept in registers
-  float bv[32];
-#pragma unroll
-  for (int op = 0; op < 32; ++op) bv[op] = dys[(2 * op + kh) * DF_LD + pt * 32 + j];
+  // B operands (gy) do not depend on the tap; they are re-read from LDS in every tap (one ds_read_b32 per MFMA): 32 registers the
+  // two-deep A operand needs
+  const float* bsrc = dys + kh * DF_LD + pt * 32 + j;
   const long Ps = P0 + lane;
   const bool pvs = Ps < total;
   const long nsp = pvs ? Ps / plane : 0;
-  float* gcl = gcol + nsp * 576 * plane + (pvs ? Ps - nsp * plane : 0);
-#pragma unroll 1
-  for (int t = 0; t < 9; ++t) {
-    float av[32];
+  // vmcnt counts loads AND stores, in order: a load issued behind a store can only be awaited by draining the store (a write round
+  // trip, ~2 us) -- the first version of this loop did that nine times per workgroup (A operand of tap t + 1 behind the stores of tap t).
+  // Now the column-gradient tile is double buffered in LDS and a tap's stores are issued inside the NEXT tap, behind that tap's
+  // requests (corner gathers, the A operand of the tap AFTER it: two register sets) and in front of its MFMAs; every store is a
+  // branch-free buffer store (offset -1 = dropped) so that hipcc keeps exact counts, and one barrier per tap is left.
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rgc = __builtin_amdgcn_make_buffer_rsrc(gcol, 0, (int)(4L * N * 576 * plane), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rgo = __builtin_amdgcn_make_buffer_rsrc(goff, 0, (int)(4L * ((long)(N - 1) * offsn + 18L * plane)), 0x00020000);
+  // (buffer loads: 32-bit offsets, the tap / k part in an SGPR -- the 64-bit addresses of the flat forms cost this loop 40 registers)
+  const __amdgpu_buffer_rsrc_t rwb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wb), 0, 9 * 64 * 64 * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rxt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xt), 0, (int)(256L * total), 0x00020000);
+  const int wl_off = 4 * (kh * 64 + ct * 32 + j);
+  const int gcl0 = pvs ? (int)(4 * (nsp * 576 * plane + (Ps - nsp * plane))) : -1;
+  const int pstride = 4 * plane;
+  int go0[4];   // byte offset of (image, tap 0, position) of this thread's four offset-gradient positions; -1: not this lane's / outside
 #pragma unroll
-    for (int op = 0; op < 32; ++op) av[op] = wl[(t * 64 + 2 * op) * 64];
-    __builtin_amdgcn_sched_barrier(0);
+  for (int i = 0; i < 4; ++i) {
+    const long P = P0 + 16 * wave + 4 * i + pi;
+    const long n = P < total ? P / plane : 0;
+    go0[i] = (q == 0 && P < total) ? (int)(4 * (n * offsn + (P - n * plane))) : -1;
+  }
+  auto load_x = [&](int pix) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rxt, pix * 256 + 16 * q, 0, 0));
+  };
+  float gus[4], gvs[4];
+  auto stores = [&](int t) {   // tap t's column gradients (256-byte runs along the positions) and offset gradients
+    const float* src = dcl[t & 1] + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = 16 * wave + i;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, src[c * DF_LD]), rgc, gcl0 >= 0 ? gcl0 + (c * 9 + t) * pstride : -1, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gus[i]), rgo, go0[i] >= 0 ? go0[i] + t * pstride : -1, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gvs[i]), rgo, go0[i] >= 0 ? go0[i] + (9 + t) * pstride : -1, 0, 0);
+    }
+  };
+  // A operand of tap t, k pairs [16 h, 16 h + 16)
+  auto load_a = [&](float (&a)[16], int t, int h) {
+#pragma unroll
+    for (int op = 0; op < 16; ++op)
+      a[op] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rwb, wl_off, 4 * (t * 64 + 2 * (16 * h + op)) * 64, 0));
+  };
+  // one tap: av = the first half of its A operand (requested a whole tap ago), avn = the next tap's first half, requested here with this
+  // tap's second half (which has the first sixteen MFMAs to arrive) -- two full register sets do not fit beside the corner gathers
+  auto tap = [&](int t, const float (&av)[16], float (&avn)[16]) {
     float4 c1[4], c2[4], c3[4], c4[4], cw[4];
     int fl[4];
 #pragma unroll
@@ -591,51 +630,53 @@ __global__ __launch_bounds__(256) void deform_bwd64_fused_kernel(const float* __
       const int4 id = geo.idx[e];
       cw[i] = geo.wuv[e];
       fl[i] = geo.flags[e];
-      c1[i] = *reinterpret_cast<const float4*>(xq + (long)id.x * 64);
-      c2[i] = *reinterpret_cast<const float4*>(xq + (long)id.y * 64);
-      c3[i] = *reinterpret_cast<const float4*>(xq + (long)id.z * 64);
-      c4[i] = *reinterpret_cast<const float4*>(xq + (long)id.w * 64);
+      c1[i] = load_x(id.x);
+      c2[i] = load_x(id.y);
+      c3[i] = load_x(id.z);
+      c4[i] = load_x(id.w);
     }
+    float avh[16];
+    load_a(avh, t, 1);
+    load_a(avn, t < 8 ? t + 1 : 8, 0);   // (the last tap re-reads its own: nothing uses it)
+    __builtin_amdgcn_sched_barrier(0);
+    if (t > 0) stores(t - 1);
     __builtin_amdgcn_sched_barrier(0);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int op = 0; op < 32; ++op) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[op], bv[op], acc, 0, 0, 0);
+    for (int op = 0; op < 16; ++op) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[op], bsrc[2 * op * DF_LD], acc, 0, 0, 0);
+#pragma unroll
+    for (int op = 0; op < 16; ++op) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(avh[op], bsrc[2 * (16 + op) * DF_LD], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    float* dc = dcl[t & 1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dcl[(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * DF_LD + pt * 32 + j] = acc[r];
+    for (int r = 0; r < 16; ++r) dc[(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * DF_LD + pt * 32 + j] = acc[r];
     __syncthreads();
-    // (a) the tap's column gradients to memory, 256-byte runs along the positions
-    if (pvs) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int c = 16 * wave + i;
-        gcl[((long)c * 9 + t) * plane] = dcl[c * DF_LD + lane];
-      }
-    }
-    // (b) offset gradients
+    // offset gradients
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pl = 16 * wave + 4 * i + pi;
-      const float* dq = dcl + (4 * q) * DF_LD + pl;
+      const float* dq = dc + (4 * q) * DF_LD + pl;
       const float4 g4 = make_float4(dq[0], dq[DF_LD], dq[2 * DF_LD], dq[3 * DF_LD]);
       float4 du, dv;
       coord_grads(cw[i], mask4(c1[i], fl[i] & 1), mask4(c2[i], fl[i] & 2), mask4(c3[i], fl[i] & 4), mask4(c4[i], fl[i] & 8), du, dv);
-      float gu = (g4.x * du.x + g4.y * du.y) + (g4.z * du.z + g4.w * du.w);
-      float gv = (g4.x * dv.x + g4.y * dv.y) + (g4.z * dv.z + g4.w * dv.w);
-      gu = quad_sum16(gu);
-      gv = quad_sum16(gv);
-      const long P = P0 + pl;
-      if (q == 0 && P < total) {
-        const long n = P / plane;
-        float* gn = goff + n * offsn + (P - n * plane);
-        gn[(long)t * plane] = (fl[i] & 16) ? gu : 0.f;
-        gn[(long)(9 + t) * plane] = (fl[i] & 32) ? gv : 0.f;
-      }
+      const float gu = (g4.x * du.x + g4.y * du.y) + (g4.z * du.z + g4.w * du.w);
+      const float gv = (g4.x * dv.x + g4.y * dv.y) + (g4.z * dv.z + g4.w * dv.w);
+      const float su = quad_sum16(gu), sv = quad_sum16(gv);
+      gus[i] = (fl[i] & 16) ? su : 0.f;
+      gvs[i] = (fl[i] & 32) ? sv : 0.f;
     }
-    __syncthreads();  // the tile is rewritten by the next tap
+  };
+  float a0[16], a1[16];
+  load_a(a0, 0, 0);
+#pragma unroll 1
+  for (int t = 0; t < 8; t += 2) {
+    tap(t, a0, a1);
+    tap(t + 1, a1, a0);
   }
+  tap(8, a0, a1);
+  stores(8);
 }
 
 // goff as above with gcol = w[c*9+t] * gy[n][p]; partial (gridDim.x, 580): this workgroup's sums of gy * sample per
@@ -916,6 +957,7 @@ void launch_deform_bwd64_fused(const float* xt, const float* off, const float* w
                                int W, long offsn, hipStream_t s) {
   const long total = (long)N * H * W;
   DBM_CHECK(total < (1L << 31), "fused deformable backward: more than 2^31 positions");
+  DBM_CHECK(4L * total * 576 < (1L << 31) && 4L * N * offsn < (1L << 31), "fused deformable backward: column gradients beyond 2 GB (buffer accesses)");
   const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
   if (g_profiler.enabled) {
     char tag[40];
