@@ -12,6 +12,7 @@
 // per lane and MFMA) and the OIHW tensors of the 3x3 branches.
 // The wide branches' weight gradients still read an im2col image: a retained pass rebuilds it off the critical path
 // (Generator::backward, side stream).
+#include <cstdio>
 #include "kernels.h"
 
 namespace {
@@ -141,6 +142,13 @@ bool input_block_fused_ok(int H, int W) { return H == XW && W == XW; }
 
 void launch_input_block_fused(const InputBlockLaunch& a, hipStream_t s) {
   if (a.N <= 0) return;
+  if (g_profiler.enabled) {   // four valid convolutions: 32 x (9 + 900 + 72 + 9) MACs per position; inputs + weights in, 128 channels out
+    char tag[40];
+    snprintf(tag, sizeof(tag), "input_block_11x11_n%d", a.N);
+    g_profiler.begin(s, 0, 2.0 * 32 * 990 * 81.0 * a.N, 4.0 * (a.N * (121.0 + 12100 + 968 + 121 + 128 * 81) + 32 * 990 + 128), tag,
+                     (OW / BAND) * a.N);
+  }
   hipLaunchKernelGGL(input_block_fused_kernel, dim3(OW / BAND, (unsigned)a.N), dim3(512), 0, s, a);
+  if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
 }
