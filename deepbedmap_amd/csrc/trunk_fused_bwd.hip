@@ -28,8 +28,10 @@ constexpr int NPOS0 = 14;            // positions of the first half (the second 
 #ifndef TFB_NWAVE
 #define TFB_NWAVE 8
 #endif
-constexpr int NWAVE = TFB_NWAVE;     // 8 or 16 (16 wavefronts, four per SIMD at <= 128 VGPRs: measured 8 % SLOWER; 4 would
-                                     // need a second skipv set: conv_layer1 then has two sub-tiles per wavefront)
+constexpr int NWAVE = TFB_NWAVE;     // 8, 16 (four wavefronts per SIMD at <= 128 VGPRs: measured 8 % SLOWER) or 4 (one per SIMD at <= 256
+                                     // VGPRs: half of every SIMD's register file stays free for other kernels' wavefronts; conv_layer1
+                                     // then has two sub-tiles per wavefront: SK sets of skip values)
+constexpr int SK = NWAVE >= 8 ? 1 : 8 / NWAVE;
 constexpr int NTHREADS = NWAVE * 64;
 constexpr int QU = NWAVE == 16 ? 2 : 4;  // input-channel quads per weight unit
 constexpr int AU = QU * 9;           // floats per lane per unit: QU quads x 9 taps
@@ -96,7 +98,7 @@ struct Wave {
 #ifdef TFB_TIMING
   long long tsum[8];
 #endif
-  float skipv[4];   // gradient of the RRDB output at this thread's conv_layer1 outputs (the `x` skip of :402)
+  float skipv[SK][4];   // gradient of the RRDB output at this thread's conv_layer1 outputs (the `x` skip of :402), per sub-tile
 };
 
 #define DI __device__ __forceinline__
@@ -324,14 +326,14 @@ DI void sub_tile(const Args& a, Wave& W, float (&A0)[AU], float (&A1)[AU], int s
         if (ch < 64) v += r1s * lds[gin_region + ch * CS + W.pofs];  // d out / d a0  (:358, :402)
       } else {
         if (KL == 0) {
-          if (first) v += W.skipv[r];          // d (RRDB out) / d x  (:402)
+          if (first) v += W.skipv[SK > 1 ? s : 0][r];          // d (RRDB out) / d x  (:402)
           if (j == 0) v += a.g_a3[(unsigned)((W.img * 64 + ch) * 81 + W.band * 27 + W.pos)];  // a3 = a1 + ...  (:551)
         }
         v += lds[cell];
       }
       if (use_mask) v = maskv[r] >= 0.f ? v : a.slope * v;
       lds[cell] = v;
-      if (KL == 0 && first) W.skipv[r] = v;
+      if (KL == 0 && first) W.skipv[SK > 1 ? s : 0][r] = v;
       if (fin) {
         gdst[gofs + r * 81] = v;
         if (publish) {
@@ -398,7 +400,7 @@ template <int KL> DI void layer(const Args& a, Wave& W, float (&A0)[AU], float (
 
 }  // namespace
 
-__global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
+__global__ __launch_bounds__(NTHREADS, NWAVE == 4 ? 2 : 1) void trunk_fused_bwd_kernel(Args a) {
   Wave W;
   W.t = threadIdx.x; W.lane = W.t & 63; W.w = W.t >> 6;
   const int B = blockIdx.x;
@@ -441,10 +443,13 @@ __global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
     if (row >= 0 && row < 9) lds[P0 + ch * CS + r * 10 + c + 1] = gin[ch * 81 + row * 9 + c];
   }
   {  // launches cover whole RRDBs: the skip source of the first RRDB is the launch's Gout itself
-    const int ch0 = 16 * (W.w >> 1) + 4 * (W.lane >> 4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)  // (only the wavefronts that own conv_layer1 sub-tiles: channels < 64)
-      W.skipv[r] = (W.st_ok && ch0 < 64) ? gin[(ch0 + r) * 81 + W.band * 27 + W.pos] : 0.f;
+    for (int k = 0; k < SK; ++k) {
+      const int ch0 = 16 * ((W.w >> 1) + (NWAVE / 2) * k) + 4 * (W.lane >> 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)  // (only the wavefronts that own conv_layer1 sub-tiles: channels < 64)
+        W.skipv[k][r] = (W.st_ok && ch0 < 64) ? gin[(ch0 + r) * 81 + W.band * 27 + W.pos] : 0.f;
+    }
   }
   __syncthreads();
 
@@ -455,6 +460,9 @@ __global__ __launch_bounds__(NTHREADS) void trunk_fused_bwd_kernel(Args a) {
 #ifdef TF_PRIO
   // the second wavefront of every SIMD (dispatched later = the loser of every issue arbitration by age) gets a static priority
   if (W.w >= NWAVE / 2) __builtin_amdgcn_s_setprio(TF_PRIO);
+#endif
+#ifdef TFB_PRIO_ALL
+  __builtin_amdgcn_s_setprio(TFB_PRIO_ALL);   // (measurement: every wavefront of the chain above the co-resident kernels' wavefronts)
 #endif
   float A0[AU], A1[AU];
   issue_unit(A0, W.wp, W.lane);
