@@ -1260,11 +1260,6 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   // cleargrads of the G-step (:1255), early: nothing reads or writes the generator's gradient arena between the previous update and this
   // iteration's backward pass, and 35 MB of fill would otherwise sit between the loss and the backward pass on the critical path
   DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), c->side));
-  // the data-gradient weight images of both models (stale since their updates; first read by this iteration's backward passes): here,
-  // beside the generator's input block, instead of between the discriminator's update and its eval-mode pass in the previous iteration
-  g->ensure_packed_bwd(c->side);
-  DBM_HIP(hipEventRecord(c->ev_iter[2], c->side));   // (what the generator's backward pass on chain[1] waits for)
-  d->ensure_packed_bwd(c->side);
   if (!no_d) d->forward(N, H4, W4, Y, lr, true, true, 0);
   c->stream = s;
   // (The G-step's own forward goes to chain[1] behind the first forward; one_fwd: it is the only forward, forked here.
@@ -1313,6 +1308,14 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   if (early != 2) twin_forward();
   // ---- D(fake) forward, RaGAN loss, cleargrads (:1146-1162) ----
   c->join_side();
+  // The data-gradient weight images of both models (stale since their updates; first read by this iteration's backward passes) are rebuilt
+  // HERE on the side stream -- behind D(real)'s forward and behind the join, i.e. beside D(fake)'s forward -- instead of between the
+  // discriminator's update and its eval-mode pass in the previous iteration.  (At the head of the side stream they sat in front of
+  // D(real)'s forward, and the whole queue waits while the helper-form trunk holds every CU: D(real) started 0.09 ms later.)
+  g->ensure_packed_bwd(c->side);
+  DBM_HIP(hipEventRecord(c->ev_iter[2], c->side));   // (what the generator's backward pass on chain[1] waits for: cleargrads + images)
+  d->ensure_packed_bwd(c->side);
+  DBM_HIP(hipEventRecord(c->ev_iter[3], c->side));   // (what the discriminator's backward passes wait for)
   if (one_fwd) DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));  // (the fakes are the retained forward's, written on chain[1])
   if (!no_d) d->forward(N, H4, W4, one_fwd ? t->yout.p : g->yout.p, lf, true, true, 1);
   launch_ragan_loss(lr, lf, N, 1, 0, metrics, gr, gf, s);
@@ -1320,6 +1323,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   DBM_HIP(hipMemsetAsync(d->grads, 0, d->nparam * sizeof(float), s));
   mark_grads_cleared(d);
   // ---- d_loss.backward() (:1163): real batch on the main stream, fake batch on chain[0], weight gradients on side ----
+  DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[3], 0));   // (before the fork: both passes read the data-gradient images)
   c->fork(s, c->chain[0], 7);
   d->merge_slots = true;
   d->merge_launcher = 1;

@@ -48,7 +48,8 @@ struct dbm_ctx {
   void comm_flush();
   hipEvent_t ev_comm = nullptr, ev_comm_done = nullptr;
   hipEvent_t ev_timer[2] = {nullptr, nullptr};  // dbm_timer
-  hipEvent_t ev_iter[3] = {nullptr, nullptr, nullptr};   // dbm_train_iteration: loss scratch cleared / generator backward done / G grads cleared
+  hipEvent_t ev_iter[4] = {nullptr, nullptr, nullptr, nullptr};   // dbm_train_iteration: loss scratch cleared / generator backward done /
+                                                                // G grads cleared + its data-gradient images / D's data-gradient images
   // The persistent trunk kernels need every workgroup of a launch resident at once: two of them on different streams, each
   // holding part of the chip, would wait for each other's compute units until their spin limits.  Every persistent launch
   // therefore waits for the previous one (whatever its stream) and leaves its own completion here.
