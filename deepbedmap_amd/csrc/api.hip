@@ -1288,7 +1288,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   static const int csr_early_env = getenv("DBM_ITER_CSR_EARLY") ? atoi(getenv("DBM_ITER_CSR_EARLY")) : 1;
   auto twin_forward = [&]() {  // the G-step's own forward (:1222-1227), retained graph, second workspace, on chain[1]
     t->max_split = 1;
-    t->csr_early = csr_early_env != 0;
+    t->csr_early = csr_early_env != 0 && !dp;   // (data-parallel: chain[0] also carries the gradient exchange -- the lists stay on the backward pass's own path)
     c->stream = pf;
     t->forward(N, H, W, X, W1, W2, W3, t->yout.p, true);
     DBM_HIP(hipEventRecord(g->ev_prefetch, pf));  // the twin's fakes are final (the G-step's eval-mode discriminator pass reads them)
@@ -1337,7 +1337,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   c->comm_defer = false;
   if (dp) c->comm_flush();
   c->fork(c->chain[0], s, 7);
-  if (csr_early_env) t->prebuild_csr(c->chain[0]);   // (behind the fake-batch pass, and behind the mark the main stream waits for)
+  if (csr_early_env && !dp) t->prebuild_csr(c->chain[0]);   // (behind the fake-batch pass, and behind the mark the main stream waits for)
   c->join_side();  // (the discriminator's weight gradients: everything on the side stream so far)
   DBM_MARK(s, "D:weight_gradients_joined");
   if (dp) {  // what launch_group has not sent yet: [0, lo) and [hi, nparam) in one fused group; then the optimizer's wait
