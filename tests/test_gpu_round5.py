@@ -173,3 +173,13 @@ def test_schedule_switches_of_round5_change_no_number(tmp_path, env):
             err = np.abs(a.astype(np.float64) - b)
             assert err.max() <= 2e-2, (k, err.max())
             assert np.median(err) <= 2e-4 * max(np.abs(b).max(), 1e-30) + 1e-7, (k, np.median(err), err.max())
+
+
+def test_fused_iteration_soak_is_bitwise_reproducible():
+    """tools/experiments/soak_determinism.py (120 iterations, three alternating batches, twice from one seed): parameters of both models and
+    the metrics log come out BITWISE equal and no time-out is raised -- a race between the iteration's four streams (the round-5 events:
+    early cleargrads, weight images behind the side stream's join, sampling lists on chain[0]) would show up as a difference.
+    profiles/r5/soak_determinism.txt holds the 1500-iteration run."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "experiments", "soak_determinism.py"), "120"], capture_output=True, text=True,
+                         timeout=900)
+    assert res.returncode == 0 and "BITWISE EQUAL" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
