@@ -110,12 +110,262 @@ __global__ __launch_bounds__(NT) void bn_train_fwd_kernel(const float* __restric
   }
 }
 
+
+// Register-resident, BRANCH-FREE form of the two kernels for the launches of the training step (round 5): 1024 threads, one wavefront
+// per image quadruple, CP slots of 64 positions per image (planes of <= 64 CP positions, <= 64 images, tensor < 2 GB).  The general
+// kernels above guard every element of their cached path with `if (valid)`: hipcc then waits with vmcnt(0) inside every guarded block
+// -- from the second block on for the PREVIOUS block's store -- and their fixed 8 slots per image are mostly empty on the 9 x 9 planes.
+// Here every access is a raw buffer access (offset -1: reads zero / is dropped), the slot count is a template parameter (2: 9 x 9,
+// 6: 18 x 18), the per-channel scalars are requested first, and nothing stands between the loads or between the stores.  Same
+// element -> thread mapping and the same summation order as the general kernels (the results differ in the last bit where hipcc
+// contracts a multiply-add in one form and not in the other).
+template <int CP>
+__global__ __launch_bounds__(1024) void bn_train_fwd_reg_kernel(const float* __restrict__ z, float* __restrict__ y, const float* gamma,
+                                                                const float* beta, float* mean_o, float* istd_o, float* avg_mean,
+                                                                float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
+                                                                const int* hold) {
+  constexpr int NT = 1024, CI = 4;
+  __shared__ float sh[NT / 64];
+  const int c = blockIdx.x;
+  const long m = (long)N * plane;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nbytes = (int)(4L * N * C * plane);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, nbytes, 0x00020000);
+  const float g = gamma[c], b = beta[c];
+  const bool upd = threadIdx.x == 0 && !(hold && *hold);  // (no running-average update from a pass the timeout flag has declared void)
+  const float am0 = threadIdx.x == 0 ? avg_mean[c] : 0.f, av0 = threadIdx.x == 0 ? avg_var[c] : 0.f;
+  auto zo = [&](int i, int jj) {   // byte offset of slot (i, jj), -1: no element
+    const bool ok = wave + (NT / 64) * i < N && lane + 64 * jj < plane;
+    return ok ? 4 * (((wave + (NT / 64) * i) * C + c) * plane + lane + 64 * jj) : -1;
+  };
+  float zc[CI][CP];
+#pragma unroll
+  for (int i = 0; i < CI; ++i)
+#pragma unroll
+    for (int jj = 0; jj < CP; ++jj) zc[i][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zo(i, jj), 0, 0));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CI; ++i)
+#pragma unroll
+    for (int jj = 0; jj < CP; ++jj) s += zc[i][jj];   // (absent slots hold zero)
+  const float mean = block_sum<NT>(s, sh) / (float)m;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CI; ++i)
+#pragma unroll
+    for (int jj = 0; jj < CP; ++jj) {
+      const float d = zc[i][jj] - mean;
+      q += zo(i, jj) >= 0 ? d * d : 0.f;
+    }
+  const float var = block_sum<NT>(q, sh) / (float)m;
+  const float istd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_o[c] = mean;
+    istd_o[c] = istd;
+    if (upd) {
+      const float adjust = (float)((double)m / (m - 1 > 1 ? (double)(m - 1) : 1.0));
+      avg_mean[c] = am0 * decay + (1.f - decay) * mean;
+      avg_var[c] = av0 * decay + ((1.f - decay) * adjust) * var;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CI; ++i)
+#pragma unroll
+    for (int jj = 0; jj < CP; ++jj) {
+      const float v = g * ((zc[i][jj] - mean) * istd) + b;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v >= 0.f ? v : slope * v), ry, zo(i, jj), 0, 0);
+    }
+}
+
+template <int CP>
+__global__ __launch_bounds__(1024) void bn_train_bwd_reg_kernel(const float* __restrict__ z, const float* __restrict__ gh, const float* gamma,
+                                                                const float* beta, const float* mean_i, const float* istd_i,
+                                                                float* __restrict__ gz, float* ggamma, float* gbeta, int N, int C, int plane,
+                                                                float slope) {
+  constexpr int NT = 1024, CI = 4;
+  __shared__ float sh[NT / 64];
+  const int c = blockIdx.x;
+  const long m = (long)N * plane;
+  const float mean = mean_i[c], istd = istd_i[c], g = gamma[c], b = beta[c];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nbytes = (int)(4L * N * C * plane);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gh), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(gz, 0, nbytes, 0x00020000);
+  auto zo = [&](int i, int jj) {
+    const bool ok = wave + (NT / 64) * i < N && lane + 64 * jj < plane;
+    return ok ? 4 * (((wave + (NT / 64) * i) * C + c) * plane + lane + 64 * jj) : -1;
+  };
+  float xc[CI][CP], gc[CI][CP];
+#pragma unroll
+  for (int i = 0; i < CI; ++i)
+#pragma unroll
+    for (int jj = 0; jj < CP; ++jj) {
+      xc[i][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zo(i, jj), 0, 0));
+      gc[i][jj] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, zo(i, jj), 0, 0));
+    }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CI; ++i)
+#pragma unroll
+    for (int jj = 0; jj < CP; ++jj) {
+      const bool ok = zo(i, jj) >= 0;
+      const float xh = ok ? (xc[i][jj] - mean) * istd : 0.f;
+      const float yv = g * xh + b;
+      const float gt = ok ? (yv >= 0.f ? gc[i][jj] : slope * gc[i][jj]) : 0.f;
+      s1 += gt;
+      s2 += gt * xh;
+      xc[i][jj] = xh;
+      gc[i][jj] = gt;
+    }
+  const float sg = block_sum<NT>(s1, sh);
+  const float sgx = block_sum<NT>(s2, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(ggamma + c, sgx);  // atomics: the real- and fake-batch backward passes run concurrently
+    atomicAdd(gbeta + c, sg);
+  }
+  const float k = g * istd, im = 1.f / (float)m;
+#pragma unroll
+  for (int i = 0; i < CI; ++i)
+#pragma unroll
+    for (int jj = 0; jj < CP; ++jj)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, k * (gc[i][jj] - (sg + xc[i][jj] * sgx) * im)), ro, zo(i, jj), 0, 0);
+}
+
+// The same for the deep layers (planes of 4 x 4 .. 1 x 1, 256 - 512 channels): 256 threads, flat index e = thread + 256 k over (image,
+// position), K elements per thread in registers (N * plane <= 256 K) instead of three dependent passes over memory.  Element -> thread
+// mapping and summation order are those of the general 256-thread kernels.
+template <int K>
+__global__ __launch_bounds__(256) void bn_train_fwd_flat_kernel(const float* __restrict__ z, float* __restrict__ y, const float* gamma,
+                                                                const float* beta, float* mean_o, float* istd_o, float* avg_mean,
+                                                                float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
+                                                                const int* hold) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x, m = N * plane;
+  const int nbytes = (int)(4L * N * C * plane);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, nbytes, 0x00020000);
+  const float g = gamma[c], b = beta[c];
+  const bool upd = threadIdx.x == 0 && !(hold && *hold);
+  const float am0 = threadIdx.x == 0 ? avg_mean[c] : 0.f, av0 = threadIdx.x == 0 ? avg_var[c] : 0.f;
+  int zo[K];
+  float zc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    const int n = e / plane, p = e - n * plane;
+    zo[k] = e < m ? 4 * ((n * C + c) * plane + p) : -1;
+    zc[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zo[k], 0, 0));
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) s += zc[k];
+  const float mean = block_sum<256>(s, sh) / (float)m;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float d = zc[k] - mean;
+    q += zo[k] >= 0 ? d * d : 0.f;
+  }
+  const float var = block_sum<256>(q, sh) / (float)m;
+  const float istd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_o[c] = mean;
+    istd_o[c] = istd;
+    if (upd) {
+      const float adjust = (float)((double)m / (m - 1 > 1 ? (double)(m - 1) : 1.0));
+      avg_mean[c] = am0 * decay + (1.f - decay) * mean;
+      avg_var[c] = av0 * decay + ((1.f - decay) * adjust) * var;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const float v = g * ((zc[k] - mean) * istd) + b;
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v >= 0.f ? v : slope * v), ry, zo[k], 0, 0);
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void bn_train_bwd_flat_kernel(const float* __restrict__ z, const float* __restrict__ gh, const float* gamma,
+                                                                const float* beta, const float* mean_i, const float* istd_i,
+                                                                float* __restrict__ gz, float* ggamma, float* gbeta, int N, int C, int plane,
+                                                                float slope) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x, m = N * plane;
+  const float mean = mean_i[c], istd = istd_i[c], g = gamma[c], b = beta[c];
+  const int nbytes = (int)(4L * N * C * plane);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gh), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(gz, 0, nbytes, 0x00020000);
+  int zo[K];
+  float xc[K], gc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    const int n = e / plane, p = e - n * plane;
+    zo[k] = e < m ? 4 * ((n * C + c) * plane + p) : -1;
+    xc[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zo[k], 0, 0));
+    gc[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, zo[k], 0, 0));
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const bool ok = zo[k] >= 0;
+    const float xh = ok ? (xc[k] - mean) * istd : 0.f;
+    const float yv = g * xh + b;
+    const float gt = ok ? (yv >= 0.f ? gc[k] : slope * gc[k]) : 0.f;
+    s1 += gt;
+    s2 += gt * xh;
+    xc[k] = xh;
+    gc[k] = gt;
+  }
+  const float sg = block_sum<256>(s1, sh);
+  const float sgx = block_sum<256>(s2, sh);
+  if (threadIdx.x == 0) {
+    atomicAdd(ggamma + c, sgx);
+    atomicAdd(gbeta + c, sg);
+  }
+  const float k2 = g * istd, im = 1.f / (float)m;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, k2 * (gc[k] - (sg + xc[k] * sgx) * im)), ro, zo[k], 0, 0);
+}
+
+// elements per thread of the flat register-resident form for (N, C, plane), 0: none
+static int bn_flat_slots(int N, int C, int plane) {
+  static const bool on = !(getenv("DBM_BN_REG") && atoi(getenv("DBM_BN_REG")) == 0);
+  const long m = (long)N * plane;
+  if (!on || (plane >= 64 && C <= 256) || 4L * m * C >= (1L << 31)) return 0;
+  return m <= 256 ? 1 : m <= 1024 ? 4 : 0;
+}
+
+// which register-resident form serves (N, C, plane): its slots per image, 0: none (DBM_BN_REG=0: never -- A/B)
+static int bn_reg_slots(int N, int C, int plane) {
+  static const bool on = !(getenv("DBM_BN_REG") && atoi(getenv("DBM_BN_REG")) == 0);
+  if (!on || N > 64 || plane < 64 || C > 256 || 4L * N * C * plane >= (1L << 31)) return 0;
+  return plane <= 128 ? 2 : plane <= 384 ? 6 : 0;
+}
+
 void launch_bn_train_fwd(const float* z, float* y, const float* gamma, const float* beta, float* mean, float* inv_std,
                          float* avg_mean, float* avg_var, int N, int C, int plane, float eps, float decay, float slope,
                          hipStream_t s, const int* hold) {
   if (dbm_abl_skip() & 1) return;  // (libdbm_measure.so only)
   // (round 5 A/B: 256-thread workgroups everywhere -- easier to place beside other kernels -- cost 8.69-8.71 against 7.91 ms per step)
-  if (plane >= 64 && C <= 256)
+  const int cp = bn_reg_slots(N, C, plane);
+  if (cp == 2)
+    hipLaunchKernelGGL(bn_train_fwd_reg_kernel<2>, dim3(C), dim3(1024), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean, avg_var, N, C,
+                       plane, eps, decay, slope, hold);
+  else if (cp == 6)
+    hipLaunchKernelGGL(bn_train_fwd_reg_kernel<6>, dim3(C), dim3(1024), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean, avg_var, N, C,
+                       plane, eps, decay, slope, hold);
+  else if (bn_flat_slots(N, C, plane) == 1)
+    hipLaunchKernelGGL(bn_train_fwd_flat_kernel<1>, dim3(C), dim3(256), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean, avg_var, N, C,
+                       plane, eps, decay, slope, hold);
+  else if (bn_flat_slots(N, C, plane) == 4)
+    hipLaunchKernelGGL(bn_train_fwd_flat_kernel<4>, dim3(C), dim3(256), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean, avg_var, N, C,
+                       plane, eps, decay, slope, hold);
+  else if (plane >= 64 && C <= 256)
     hipLaunchKernelGGL(bn_train_fwd_kernel<1024>, dim3(C), dim3(1024), 0, s, z, y, gamma, beta, mean, inv_std, avg_mean,
                        avg_var, N, C, plane, eps, decay, slope, hold);
   else
@@ -231,7 +481,20 @@ void launch_bn_train_bwd(const float* z, const float* gh, const float* gamma, co
                          int plane, float slope, hipStream_t s) {
   if (dbm_abl_skip() & 1) return;  // (libdbm_measure.so only)
   (void)scratch;
-  if (plane >= 64 && C <= 256)
+  const int cp = bn_reg_slots(N, C, plane);
+  if (cp == 2)
+    hipLaunchKernelGGL(bn_train_bwd_reg_kernel<2>, dim3(C), dim3(1024), 0, s, z, gh, gamma, beta, mean, inv_std, gz, ggamma, gbeta, N, C,
+                       plane, slope);
+  else if (cp == 6)
+    hipLaunchKernelGGL(bn_train_bwd_reg_kernel<6>, dim3(C), dim3(1024), 0, s, z, gh, gamma, beta, mean, inv_std, gz, ggamma, gbeta, N, C,
+                       plane, slope);
+  else if (bn_flat_slots(N, C, plane) == 1)
+    hipLaunchKernelGGL(bn_train_bwd_flat_kernel<1>, dim3(C), dim3(256), 0, s, z, gh, gamma, beta, mean, inv_std, gz, ggamma, gbeta, N, C,
+                       plane, slope);
+  else if (bn_flat_slots(N, C, plane) == 4)
+    hipLaunchKernelGGL(bn_train_bwd_flat_kernel<4>, dim3(C), dim3(256), 0, s, z, gh, gamma, beta, mean, inv_std, gz, ggamma, gbeta, N, C,
+                       plane, slope);
+  else if (plane >= 64 && C <= 256)
     hipLaunchKernelGGL(bn_train_bwd_kernel<1024>, dim3(C), dim3(1024), 0, s, z, gh, gamma, beta, mean, inv_std, gz, ggamma,
                        gbeta, N, C, plane, slope);
   else

@@ -129,7 +129,7 @@ np.savez(sys.argv[2], m=np.array(m), **{"g|" + k.replace("/", "|"): v for k, v i
 """
 
 
-@pytest.mark.parametrize("env", [{"DBM_ITER_EARLY_TWIN": "1"}, {"DBM_ITER_EARLY_TWIN": "2"}, {"DBM_ITER_CSR_EARLY": "0", "DBM_PACK_SPLIT": "0"}, {"DBM_CONV_TILE": "0"},
+@pytest.mark.parametrize("env", [{"DBM_ITER_EARLY_TWIN": "1"}, {"DBM_ITER_EARLY_TWIN": "2"}, {"DBM_ITER_CSR_EARLY": "0", "DBM_PACK_SPLIT": "0"}, {"DBM_CONV_TILE": "0", "DBM_BN_REG": "0"},
                                  {"DBM_CONV_TILE_K4": "0", "DBM_CONV_TILE_9": "1"}, {"DBM_INPUT_FUSED": "0", "DBM_CONV_TILE_YT": "0"}])
 def test_schedule_switches_of_round5_change_no_number(tmp_path, env):
     """DBM_ITER_EARLY_TWIN (where the G-step's own forward is released; 2 also moves the generator's weight gradients to its own
@@ -137,7 +137,8 @@ def test_schedule_switches_of_round5_change_no_number(tmp_path, env):
     generator's loss; with it DBM_PACK_SPLIT=0: forward and data-gradient weight images rebuilt in one launch behind each update) only
     re-order independent work: metrics, parameters, Adam state (through a third iteration) and running statistics of
     three fused iterations are BITWISE those of the default schedule.  DBM_CONV_TILE=0 (igemm_conv_kernel instead of conv_tile.hip's
-    LDS-tiled form for the 18 x 18 / 36 x 36 planes) and DBM_CONV_TILE_K4=0 / _9=1 (that form not for the 4x4 stride-2 layers / for the
+    LDS-tiled form for the 18 x 18 / 36 x 36 planes; with it DBM_BN_REG=0: the general BatchNorm kernels -- same summation order as the
+    branch-free ones, other fused multiply-adds) and DBM_CONV_TILE_K4=0 / _9=1 (that form not for the 4x4 stride-2 layers / for the
     9 x 9 planes as well) and DBM_INPUT_FUSED=0 (the input block layer by layer instead of input_block.hip's one launch; with it
     DBM_CONV_TILE_YT=0: the deformable sampler's channels-last input from its own transposing launch) change the summation order:
     equal to 2e-4 relative."""

@@ -4,12 +4,10 @@ draining the store (a write round trip, ~2 us).  For every kernel of every .hip 
     <global / buffer store> ... <global / buffer load> ... s_waitcnt vmcnt(N)   with N smaller than the loads issued since that store
 i.e. waits that cannot be satisfied without the store having completed.  Loop back-edges and branches are ignored (linear order), so the
 count is a lower bound inside loops and an upper bound across exclusive branches: a pointer to read the ISA, not a measurement.
-(Round 5: real and costly in conv_tile's first epilogue, conv_cl16, the fused deformable kernels -- fixed there.  Flagged but NOT costly:
-the training-mode BatchNorm kernels, whose guarded stores each sit behind a vmcnt(0) -- a branch-free rewrite with buffer accesses measured
-SLOWER standalone, 18.2 against 13.5 us (backward, 128-register budget: spills) and 11.9 against 10.2 us (forward): sixteen wavefronts per CU
-hide the acknowledgements.)
-
-    python tools/scan_store_drains.py [file.hip ...]        (default: every source under deepbedmap_amd/csrc)
+(Round 5: real and costly in conv_tile's first epilogue, conv_cl16, the fused deformable kernels and the training-mode BatchNorm
+kernels, whose guarded stores each sat behind a vmcnt(0): the branch-free forms with as many register slots as the plane needs are
+25-30 % shorter.  A first branch-free BatchNorm rewrite that kept the general kernel's eight slots per image was SLOWER -- three
+quarters of its buffer accesses were dummies on the 9 x 9 planes -- so: a pointer to read the ISA, then measure.)
 """
 import os
 import re
