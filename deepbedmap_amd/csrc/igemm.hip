@@ -1046,7 +1046,7 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
 // floats, transposed through LDS and written in runs along the packed image's fastest axis (the element-wise gather this
 // replaces read every float from a different cache line: discriminator repack 278 -> ~60 us).
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackJob* __restrict__ jobs, int njobs) {
-  __shared__ float tile[32 * (32 * 9 + 1)];
+  __shared__ float tile[32 * (32 * 9 + 1) + 1];   // (+ 1: the slot that absorbs the batched loop's out-of-range elements)
   int lo = 0, hi = njobs - 1;
   const int blk = blockIdx.x;
   while (lo < hi) {
@@ -1063,12 +1063,27 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackJob* __rest
   const int ob = tix / ctiles, cb = tix - ob * ctiles;
   (void)oR;
   const int row = TC * taps, rs = row + 1;
-  for (int idx = threadIdx.x; idx < 32 * row; idx += 256) {
-    const int ol = idx / row, rem = idx - ol * row;
-    const int o = ob * 32 + ol, c = cb * TC + rem / taps;
-    float v = 0.f;
-    if (o < p.O && c < p.C) v = p.w[((long)o * p.C + cb * TC) * taps + rem];
-    tile[ol * rs + rem] = v;
+  // (eight elements per thread and trip, every load requested before the first LDS store: the one-element form was 36 dependent
+  //  round trips per thread -- 49 us per repack launch of 82 MB)
+  constexpr int DUMMY = 32 * (32 * 9 + 1);
+  const int nelem = 32 * row;
+  for (int base = 0; base < nelem; base += 256 * 8) {
+    float v[8];
+    int di[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + 256 * u + (int)threadIdx.x;
+      const bool in = idx < nelem;
+      const int ii = in ? idx : 0;
+      const int ol = ii / row, rem = ii - ol * row;
+      const int o = ob * 32 + ol, c = cb * TC + rem / taps;
+      const bool ok = in && o < p.O && c < p.C;
+      const float t = p.w[ok ? ((long)o * p.C + cb * TC) * taps + rem : 0];
+      v[u] = ok ? t : 0.f;
+      di[u] = in ? ol * rs + rem : DUMMY;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) tile[di[u]] = v[u];
   }
   __syncthreads();
   const int per_t = 32 * TC;
