@@ -1341,12 +1341,18 @@ __global__ __launch_bounds__(256) void wgrad_pair_fold_kernel(const WgradPlan* _
   const long wsize = p.pair_stride - p.d.Cout;
   const long i = (long)(wg - fstarts[lo]) * 256 + threadIdx.x;
   if (i >= p.pair_stride) return;
+  // (every buffer is read before the first one is cleared: `v += *q; *q = 0` per buffer put each load behind the previous store --
+  //  vmcnt is in order over both, so every iteration waited for a write round trip)
   float v = 0.f;
-  for (int k = 0; k < p.pair_n; ++k) {
-    float* q = p.pairW + (long)k * p.pair_stride + i;
-    v += *q;
-    *q = 0.f;
+  const int n = p.pair_n;
+  for (int k0 = 0; k0 < n; k0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = p.pairW[(long)(k0 + u < n ? k0 + u : k0) * p.pair_stride + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += k0 + u < n ? t[u] : 0.f;   // (buffer order: the sum is the one the sequential loop formed)
   }
+  for (int k = 0; k < n; ++k) p.pairW[(long)k * p.pair_stride + i] = 0.f;
   if (i < wsize) atomicAdd(p.d.gW + i, v);
   else if (p.d.gb) atomicAdd(p.d.gb + (i - wsize), v);
 }
