@@ -11,6 +11,10 @@
 // Convolution with 1 or 2 input channels (reference srgan_train.py:223-254 input block, :617-625
 // discriminator conv_layer0).  Each thread owns one output position and 8 output channels.
 // ----------------------------------------------------------------------------------------------
+// K3: 3x3 kernels (the discriminator's conv_layer0, the input block's 3x3 branches) with the tap loops unrolled and branch-free -- every
+// input value and every weight of a channel requested together (the general form's run-time loops with their `continue` made nine
+// dependent round trips of a 1-channel 3x3 layer: 14.8 us for a 21 MB output).
+template <bool K3>
 __global__ __launch_bounds__(256) void smallcin_conv_fwd_kernel(const SmallConvDesc d) {
   const int plane = d.OH * d.OW;
   const long P = (long)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -24,6 +28,24 @@ __global__ __launch_bounds__(256) void smallcin_conv_fwd_kernel(const SmallConvD
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = d.bias ? d.bias[co0 + i] : 0.f;
   const int K = d.Cin * d.KH * d.KW;
+  if (K3) {
+    for (int c = 0; c < d.Cin; ++c) {
+      const float* xc = d.x + (long)n * d.xsn + (long)c * d.Hin * d.Win;
+      float xv[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = a * d.stride - d.pad + t / 3, ix = b * d.stride - d.pad + t % 3;
+        const bool in = (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+        const float v = xc[in ? (long)iy * d.Win + ix : 0];
+        xv[t] = in ? v : 0.f;
+      }
+      const float* wr = d.w + (long)co0 * K + c * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)   // (tap order ky, kx as in the general form: the same sums)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(wr[(long)i * K + t], xv[t], acc[i]);
+    }
+  } else
   for (int c = 0; c < d.Cin; ++c) {
     const float* xc = d.x + (long)n * d.xsn + (long)c * d.Hin * d.Win;
     for (int ky = 0; ky < d.KH; ++ky) {
@@ -52,7 +74,8 @@ void launch_smallcin_conv_fwd(const SmallConvDesc& d, hipStream_t s) {
   DBM_CHECK(d.Cout % 8 == 0, "smallcin conv: Cout must be a multiple of 8");
   const long total = (long)d.N * d.OH * d.OW;
   dim3 grid((unsigned)((total + 63) / 64), (unsigned)((d.Cout + 31) / 32));
-  hipLaunchKernelGGL(smallcin_conv_fwd_kernel, grid, dim3(256), 0, s, d);
+  if (d.KH == 3 && d.KW == 3) hipLaunchKernelGGL(smallcin_conv_fwd_kernel<true>, grid, dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(smallcin_conv_fwd_kernel<false>, grid, dim3(256), 0, s, d);
   DBM_HIP(hipGetLastError());
 }
 
