@@ -1373,12 +1373,13 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   if (!no_d && !(iter_abl & 8)) d->forward(N, H4, W4, t->yout.p, lf_eval, false, false, 1);  // (repacks the updated weights first)
   DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[0], 0));  // the loss scratch was cleared on chain[1]
   gen_loss_adv(c, nullptr, lf_eval, N, 0, 1);
+  gen_loss_finish(c, N, H4, W4, weights, metrics + 2);   // (the loss terms are final: not behind the backward pass's join -- it sat between the
+                                                         //  last weight gradient and the update, 12 us on the iteration's critical path)
   DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[1], 0));  // generator backward (and its weight gradients) done
   if (dp) {
     c->comm_join(s);  // ... and its last bucket summed over ranks
     DBM_MARK(s, "G:gradients_exchanged");
   }
-  gen_loss_finish(c, N, H4, W4, weights, metrics + 2);
   DBM_MARK(s, "G:generator_backward_joined");
   adam_update_impl(g, gscale);  // (:1257)
   DBM_API_END

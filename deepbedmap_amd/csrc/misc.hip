@@ -98,21 +98,33 @@ __global__ __launch_bounds__(256) void smallcin_conv_wgrad_kernel(const SmallCon
   const unsigned total = (unsigned)d.N * (unsigned)plane;
   const unsigned planeM = 0xffffffffu / (unsigned)plane, owM = 0xffffffffu / (unsigned)d.OW;  // floor((2^32-1)/d): <= 1 short
   float acc = 0.f;
-  for (unsigned P = threadIdx.x; P < total; P += 256) {
-    unsigned n = __umulhi(P, planeM);
-    unsigned r = P - n * (unsigned)plane;
-    if (r >= (unsigned)plane) { ++n; r -= (unsigned)plane; }
-    const float g = dy[(long)n * dysn + (long)o * plane + r];
-    if (bias) {
-      acc += g;
-      continue;
+  // (eight positions per thread and trip, all sixteen loads requested before the first multiply-add: the one-position form was twenty
+  //  dependent pairs of round trips per thread -- 14.5 us, twice, at the very end of a training iteration.  Same order of sums.)
+  for (unsigned P0 = threadIdx.x; P0 < total; P0 += 256 * 8) {
+    float g[8], xv[8];
+    bool use[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const unsigned Pu = P0 + 256u * (unsigned)u;
+      const bool in = Pu < total;
+      const unsigned P = in ? Pu : 0u;
+      unsigned n = __umulhi(P, planeM);
+      unsigned r = P - n * (unsigned)plane;
+      if (r >= (unsigned)plane) { ++n; r -= (unsigned)plane; }
+      g[u] = dy[(long)n * dysn + (long)o * plane + r];
+      unsigned a = __umulhi(r, owM);
+      unsigned b = r - a * (unsigned)d.OW;
+      if (b >= (unsigned)d.OW) { ++a; b -= (unsigned)d.OW; }
+      const int iy = (int)a * d.stride - d.pad + ky, ix = (int)b * d.stride - d.pad + kx;
+      const bool inside = !bias && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+      xv[u] = d.x[inside ? (long)n * d.xsn + (long)c * d.Hin * d.Win + (long)iy * d.Win + ix : 0];
+      use[u] = in && (bias || inside);
     }
-    unsigned a = __umulhi(r, owM);
-    unsigned b = r - a * (unsigned)d.OW;
-    if (b >= (unsigned)d.OW) { ++a; b -= (unsigned)d.OW; }
-    const int iy = (int)a * d.stride - d.pad + ky, ix = (int)b * d.stride - d.pad + kx;
-    if ((unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
-      acc = fmaf(g, d.x[(long)n * d.xsn + (long)c * d.Hin * d.Win + (long)iy * d.Win + ix], acc);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float t = bias ? acc + g[u] : fmaf(g[u], xv[u], acc);
+      acc = use[u] ? t : acc;
+    }
   }
   for (int s2 = 32; s2 > 0; s2 >>= 1) acc += __shfl_down(acc, s2, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
