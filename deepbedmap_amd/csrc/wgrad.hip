@@ -1736,7 +1736,9 @@ void WgradBatch::build() {
       }
       // (deterministic mode: no finer K split than necessary -- every extra slice is a pair buffer to write and fold --
       // but a launch of a few dozen workgroups, e.g. the 4x4 layers of the deep discriminator, is split as well)
-      static const int det_min = getenv("DBM_WGRAD_DET_MINWG") ? atoi(getenv("DBM_WGRAD_DET_MINWG")) : 128;
+      // (256 since round 5 -- the input block's GEMM-shaped launch, 144 workgroups at 128, ends the iteration behind the trunk's launch:
+      //  62.6 -> 46 us; 7.61-7.64 against 7.62-7.68 ms per step, 448: 7.64-7.67, 64: 7.68-7.71)
+      static const int det_min = getenv("DBM_WGRAD_DET_MINWG") ? atoi(getenv("DBM_WGRAD_DET_MINWG")) : 256;
       if (total >= 448 || plans.empty() || g >= 3 || (g_wgrad_deterministic && total >= det_min)) break;
     }
     std::vector<int> fstarts;
