@@ -262,7 +262,8 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     // training tile: one launch (input_block.hip); the wide branches' im2col images are then rebuilt by backward(), off this path.
     // DBM_INPUT_FUSED=0: layer by layer (A/B, and the form every other tile size takes)
     static const int in_fused_env = getenv("DBM_INPUT_FUSED") ? atoi(getenv("DBM_INPUT_FUSED")) : 1;
-    const bool in_fused = in_fused_env && input_block_fused_ok(H, W) && !(use_bf16 && !(bf16_keep32 & 1));
+    const bool in_rows = in_fused_env && !input_block_fused_ok(H, W) && input_block_rows_ok(H, W) && !(use_bf16 && !(bf16_keep32 & 1));
+    const bool in_fused = in_rows || (in_fused_env && input_block_fused_ok(H, W) && !(use_bf16 && !(bf16_keep32 & 1)));
     col_stale = in_fused && keep;
     if (in_fused) {
       InputBlockLaunch q;
@@ -272,7 +273,8 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       q.wf2 = layers[L_in[2]].wf; q.b2 = P(T_in[2][1]);
       q.w3w = P(T_in[3][0]); q.b3 = P(T_in[3][1]);
       q.y = a0.p; q.ysn = 128 * hw; q.N = N;
-      launch_input_block_fused(q, s);
+      if (in_rows) launch_input_block_rows(q, H, W, s);
+      else launch_input_block_fused(q, s);
     }
     for (int i = 0; i < 4 && !in_fused; ++i) {
       SmallConvDesc d;

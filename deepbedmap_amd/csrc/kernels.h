@@ -30,6 +30,9 @@ struct InputBlockLaunch {
 };
 bool input_block_fused_ok(int H, int W);
 void launch_input_block_fused(const InputBlockLaunch& a, hipStream_t s);
+// ... on large planes (H x W inputs, the sweep's crops): 32 positions of one output row per workgroup, no im2col image
+bool input_block_rows_ok(int H, int W);
+void launch_input_block_rows(const InputBlockLaunch& a, int H, int W, hipStream_t s);
 void launch_im2col(const float* x, float* col, int N, int Cin, int Hin, int Win, int KH, int KW, int stride, int OH, int OW,
                    int KP, hipStream_t s);
 void launch_deform_sample(const float* x, const float* off, float* col, int N, int C, int H, int W, long offsn, hipStream_t s);

@@ -155,6 +155,21 @@ def test_generator_is_fully_convolutional(dbm):  # features/steps/test_deepbedma
     assert rel(y, ref) < TOL
 
 
+@pytest.mark.parametrize("h,w", [(20, 72), (19, 101)])
+def test_generator_input_block_on_wide_planes(dbm, h, w):
+    """Planes at least 64 positions wide take input_block_rows_kernel (one launch, 32 positions of one output row per workgroup, no
+    im2col image): even widths stage 16-byte pieces, odd ones single floats; the last tile of a row is ragged (70 = 2 x 32 + 6,
+    99 = 3 x 32 + 3).  Against the oracle; the layer-by-layer path being what every narrower plane still takes (test_generator_is_fully_convolutional)."""
+    og = scaled_oracle_generator(1, 1.0)
+    g = copy_params(dbm.GeneratorModel(num_residual_blocks=1, initialize=False), og.params)
+    ins = tile_inputs(2, 13, h=h, w=w)
+    ref = og.forward(*ins)
+    with dbm.using_config("enable_backprop", False):
+        y = g.forward(*ins).array
+    assert y.shape == ref.shape
+    assert rel(y, ref) < TOL
+
+
 def test_generator_bf16_inference_mode(dbm):
     """BASELINE.json config 5's arithmetic: convolutions multiply in bf16 (operands rounded to nearest-even), fp32
     accumulation and storage.  Against the fp32 oracle the error is that of 8-bit significands (tolerance 3e-2 of
