@@ -363,6 +363,7 @@ struct ClX3Args {
   const bf16x8* w;                   // packed [chunk][tap][mtile][hi | lo][lane][8]  (launch_pack_cl16x3)
   const float* bias;
   float* y32; int yc;                // NHWC fp32 output, yc channels per pixel (may be null)
+  const float* r1; int r1c;          // residual added before the activation: NHWC fp32, r1c channels per pixel (may be null)
   float* yp; long ysn; int ypc;      // channel-plane output yp[n * ysn + co * H * W + pixel], co < ypc (may be null)
   int act; float slope;
   int N, H, W, nslots, tilesX, tilesY;
@@ -529,6 +530,12 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
     if (gy >= a.H || gx >= a.W) continue;
     const long pin = (long)gy * a.W + gx;
     const long pix = (long)n * plane + pin;
+    f4v rq[MT][4];   // the patch's residual quads: all requested before its first store
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg)
+        rq[m][rg] = a.r1 ? *reinterpret_cast<const f4v*>(a.r1 + pix * a.r1c + 32 * m + 8 * rg + 4 * (lane >> 5)) : (f4v){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
         f4v v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = acc[s][m][4 * rg + e] + bq[m][rg][e];
+          v[e] = acc[s][m][4 * rg + e] + bq[m][rg][e] + rq[m][rg][e];
           if (a.act) v[e] = v[e] >= 0.f ? v[e] : a.slope * v[e];
         }
         if (a.y32) *reinterpret_cast<f4v*>(a.y32 + pix * a.yc + co) = v;
@@ -757,7 +764,8 @@ void launch_conv_cl16x3(const ClX3Launch& L, hipStream_t s) {
   }();
   ClX3Args a;
   a.x = L.x; a.xc = L.xc; a.Cin = L.Cin; a.ups = L.ups; a.w = (const bf16x8*)L.w; a.bias = L.bias;
-  a.y32 = L.y32; a.yc = L.yc; a.yp = L.yp; a.ysn = L.ysn; a.ypc = L.ypc; a.act = L.act; a.slope = L.slope;
+  a.y32 = L.y32; a.yc = L.yc; a.r1 = L.r1; a.r1c = L.r1c; a.yp = L.yp; a.ysn = L.ysn; a.ypc = L.ypc; a.act = L.act; a.slope = L.slope;
+  DBM_CHECK(!L.r1 || (L.r1c % 4 == 0 && L.Cout % 32 == 0), "cl16x3 conv: the residual needs whole 32-channel tiles and 16-byte alignment");
   a.N = L.N; a.H = L.H; a.W = L.W;
   a.nslots = cl16_choose_slots(L.N, L.H, L.W, n_cus);
   a.tilesX = (L.W + CL_TW - 1) / CL_TW;

@@ -45,6 +45,7 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
       }
   conv("post_residual_conv_layer", 64, 64, 3, 3);  // :478-485
   L_post = add_iglayer("post_residual_conv_layer", 64, 64, 3, 1, 1, true);
+  layers.back().want_x3 = true;
   conv("post_upsample_conv_layer_1", 64, 64, 3, 3);  // :488-495
   L_up1 = add_iglayer("post_upsample_conv_layer_1", 64, 64, 3, 1, 1, true);
   layers.back().want_x3 = true;
@@ -347,12 +348,24 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   // (conv_cl16.hip).  DBM_CL16=0 (read per call): the per-layer implicit GEMM in its bf16 form instead.
   const bool cl16 = !fused && use_bf16 && !(bf16_keep32 & 4) && layers[L_rdb[0]].wcl16 != nullptr &&
                     !(getenv("DBM_CL16") && atoi(getenv("DBM_CL16")) == 0);
+  // (bf16 sweep mode, decided here because the trunk's hand-over depends on it: the post-residual convolution and the full-resolution
+  //  tail in split-bf16 on NHWC fp32 activations -- see below)
+  static const int fused_env_x3 = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  const bool x3_tail = use_bf16 && !keep && fused_env_x3 && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch) &&
+                       layers[L_up1].wx3 != nullptr && !(getenv("DBM_CL16X3") && atoi(getenv("DBM_CL16X3")) == 0);
+  // DBM_POST_X3=0: the post-residual convolution in fp32 (igemm) between two layout conversions, as before round 5's last change
+  const bool post_x3 = cl16 && x3_tail && layers[L_post].wx3 != nullptr && !(bf16_keep32 & 32) &&
+                       !(getenv("DBM_POST_X3") && atoi(getenv("DBM_POST_X3")) == 0);
   if (cl16) {
     const size_t n = (size_t)N;
     for (auto& b : catb) b.ensure(n * 96 * hw);   // 192 bf16 = 96 floats per pixel
     for (auto& b : resb) b.ensure(n * 64 * hw);
     for (int c = 1; c < nsplit; ++c) ctx->fork(cstream(c), s, 4 + c);  // (the pre-residual conv's image ranges)
     launch_nchw_to_cl(cat[0].p, 192 * hw, resb[0].p, catb[0].p, 192, N, (int)hw, s);
+    if (post_x3) {   // (resb[0] is recycled by the fourth dense block: the skip operand of the post-residual convolution keeps its own copy)
+      a1t.ensure(n * 64 * hw);
+      DBM_HIP(hipMemcpyAsync(a1t.p, resb[0].p, sizeof(float) * n * 64 * hw, hipMemcpyDeviceToDevice, s));
+    }
     for (int j = 0; j < nrdb; ++j) {
       void* C16 = catb[j & 1].p;
       for (int k = 0; k < 5; ++k) {
@@ -372,7 +385,17 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
         launch_conv_cl16(q, s);
       }
     }
-    launch_cl_to_nchw(resb[nrdb & 3].p, cat[slot(nrdb)].p, 192 * hw, N, (int)hw, s);
+    if (post_x3) {
+      // a3 = a1 + conv(a2) (:550-551) straight from / to NHWC fp32 in split-bf16: no cl_to_nchw, no fp32 igemm launch, no nchw_to_cl
+      a3t.ensure(n * 64 * hw);
+      ClX3Launch q;
+      memset(&q, 0, sizeof(q));
+      q.x = resb[nrdb & 3].p; q.xc = 64; q.Cin = 64; q.Cout = 64; q.ups = 0; q.w = layers[L_post].wx3; q.bias = P(layers[L_post].bi);
+      q.y32 = a3t.p; q.yc = 64; q.r1 = a1t.p; q.r1c = 64; q.act = 0; q.slope = SLOPE; q.N = N; q.H = h; q.W = w;
+      launch_conv_cl16x3(q, s);
+    } else {
+      launch_cl_to_nchw(resb[nrdb & 3].p, cat[slot(nrdb)].p, 192 * hw, N, (int)hw, s);
+    }
     for (int c = 1; c < nsplit; ++c) ctx->fork(s, cstream(c), c);  // the post-residual conv's ranges continue behind it
   }
   if (!fused && !cl16) (owner ? owner : this)->ensure_packed_lazy();
@@ -400,7 +423,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     }
   }
   // ---- post-residual conv, a3 = a1 + conv(a2)  (:550-551) ----
-  for (int c = 0; c < nsplit; ++c) {
+  for (int c = 0; c < (post_x3 ? 0 : nsplit); ++c) {
     const long n0 = cn0(c);
     ConvDesc d = prec(fwd_desc(layers[L_post], cat[slot(nrdb)].p + n0 * 192 * hw, 192 * hw, h, w, 0, a3.p + n0 * 64 * hw, 64 * hw, cnc(c)), 2);
     d.r1 = cat[0].p + n0 * 192 * hw; d.r1sn = 192 * hw; d.r1_nch = 64;
@@ -431,7 +454,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     a41t.ensure((size_t)N * 64 * 4 * hw);
     a42t.ensure((size_t)N * 64 * P4);
     a51t.ensure((size_t)N * 64 * P4);
-    launch_nchw_to_cl(a3.p, 64 * hw, a3t.p, nullptr, 0, N, (int)hw, s);
+    if (!post_x3) launch_nchw_to_cl(a3.p, 64 * hw, a3t.p, nullptr, 0, N, (int)hw, s);
     x3_launch(layers[L_up1], a3t.p, 1, 2 * h, 2 * w, a41t.p, nullptr, 1);
     x3_launch(layers[L_up2], a41t.p, 1, H4, W4, a42t.p, nullptr, 1);
   } else {

@@ -222,6 +222,7 @@ struct ClX3Launch {
   const void* w;             // packed by launch_pack_cl16x3
   const float* bias;
   float* y32; int yc;        // NHWC fp32 output (yc channels per pixel; all 32 * ceil(Cout / 32) channels are written) or null
+  const float* r1; int r1c;  // optional residual, NHWC fp32 (r1c channels per pixel): v = conv + bias + r1 (before the activation)
   float* yp; long ysn; int ypc;  // channel planes yp[n * ysn + co * H * W + pixel], co < ypc, or null
   int act; float slope;
   int N, H, W;               // output plane
