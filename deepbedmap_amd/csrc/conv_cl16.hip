@@ -364,6 +364,7 @@ struct ClX3Args {
   const float* bias;
   float* y32; int yc;                // NHWC fp32 output, yc channels per pixel (may be null)
   const float* r1; int r1c;          // residual added before the activation: NHWC fp32, r1c channels per pixel (may be null)
+  __bf16* y16; int y16c;             // the output once more as bf16, NHWC with y16c channels per pixel (may be null)
   float* yp; long ysn; int ypc;      // channel-plane output yp[n * ysn + co * H * W + pixel], co < ypc (may be null)
   int act; float slope;
   int N, H, W, nslots, tilesX, tilesY;
@@ -548,6 +549,12 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
           if (a.act) v[e] = v[e] >= 0.f ? v[e] : a.slope * v[e];
         }
         if (a.y32) *reinterpret_cast<f4v*>(a.y32 + pix * a.yc + co) = v;
+        if (a.y16) {
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+          *reinterpret_cast<bf16x4*>(a.y16 + pix * a.y16c + co) = o;
+        }
         if (a.yp) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -764,7 +771,7 @@ void launch_conv_cl16x3(const ClX3Launch& L, hipStream_t s) {
   }();
   ClX3Args a;
   a.x = L.x; a.xc = L.xc; a.Cin = L.Cin; a.ups = L.ups; a.w = (const bf16x8*)L.w; a.bias = L.bias;
-  a.y32 = L.y32; a.yc = L.yc; a.r1 = L.r1; a.r1c = L.r1c; a.yp = L.yp; a.ysn = L.ysn; a.ypc = L.ypc; a.act = L.act; a.slope = L.slope;
+  a.y32 = L.y32; a.yc = L.yc; a.r1 = L.r1; a.r1c = L.r1c; a.y16 = (__bf16*)L.y16; a.y16c = L.y16c; a.yp = L.yp; a.ysn = L.ysn; a.ypc = L.ypc; a.act = L.act; a.slope = L.slope;
   DBM_CHECK(!L.r1 || (L.r1c % 4 == 0 && L.Cout % 32 == 0), "cl16x3 conv: the residual needs whole 32-channel tiles and 16-byte alignment");
   a.N = L.N; a.H = L.H; a.W = L.W;
   a.nslots = cl16_choose_slots(L.N, L.H, L.W, n_cus);

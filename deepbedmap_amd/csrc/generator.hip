@@ -33,6 +33,7 @@ Generator::Generator(dbm_ctx* c, int n, float r, int oc) {
   L_in[2] = add_iglayer(in_names[2], 32, 2, 6, 1, 0, true, /*as_1x1=*/true);   // 72 rows
   conv("pre_residual_conv_layer", 64, 128, 3, 3);  // :467-474
   L_pre = add_iglayer("pre_residual_conv_layer", 64, 128, 3, 1, 1, true);
+  layers.back().want_x3 = true;
   const int cin[5] = {64, 96, 128, 160, 192}, cout[5] = {32, 32, 32, 32, 64};
   for (int i = 0; i < n; ++i)      // .repeat(n) -> Sequential children "0".."n-1"  :475-477
     for (int d = 1; d <= 3; ++d)   // ResInResDenseBlock  :383-391
@@ -245,7 +246,9 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   const long hw = (long)h * w;
   const int nrdb = 3 * n_rrdb;
   // bf16 sweep mode (DBM_BF16): layers that keep the fp32 arithmetic.  Bits: 1 input-block GEMMs, 2 pre- / post-residual
-  // convs, 4 trunk, 8 upsampling convs, 16 offset convs of the deformable layers (the deformable GEMMs are always fp32).
+  // convs, 4 trunk, 8 upsampling convs, 16 offset convs of the deformable layers (the deformable GEMMs are always fp32);
+  // 32 / 64: the post- / pre-residual conv in fp32 igemm instead of split-bf16 on the channels-last planes (round 5: bit 2 alone
+  // now means "not in plain bf16" for them -- they run like the other signal-path layers, three bf16 MFMAs per product).
   // Default 27 = ONLY THE TRUNK multiplies in bf16 (83 % of the forward FLOPs).  Measured in metres at the reference's data
   // range (tools/bf16_error_study.py, DESIGN.md "bf16 at the data range"): the trunk's residual branches enter the signal
   // through two 0.1 scalings, its bf16 rounding costs 1 m rms of 2000 m of relief; every layer ON the signal path costs
@@ -256,6 +259,21 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     if (bf16_keep32 & bit) d.wp16 = nullptr;
     return d;
   };
+  // Which trunk / tail forms this forward takes (decided up front: the bf16 sweep mode's layouts start at the input block).
+  const bool fused = trunk_fused_ok(h, w);  // the whole trunk as one persistent launch (trunk_fused.hip)
+  // bf16 sweep mode on planes the persistent kernels do not serve: the trunk on channels-last bf16 activations
+  // (conv_cl16.hip).  DBM_CL16=0 (read per call): the per-layer implicit GEMM in its bf16 form instead.
+  const bool cl16 = !fused && use_bf16 && !(bf16_keep32 & 4) && layers[L_rdb[0]].wcl16 != nullptr &&
+                    !(getenv("DBM_CL16") && atoi(getenv("DBM_CL16")) == 0);
+  // ... with the post-residual convolution and the full-resolution tail in split-bf16 on NHWC fp32 activations (see below)
+  static const int fused_env_x3 = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  const bool x3_tail = use_bf16 && !keep && fused_env_x3 && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch) &&
+                       layers[L_up1].wx3 != nullptr && !(getenv("DBM_CL16X3") && atoi(getenv("DBM_CL16X3")) == 0);
+  // DBM_POST_X3=0 / DBM_PRE_X3=0 (or bits 32 / 64 of DBM_BF16_FP32_LAYERS): the post- / pre-residual convolution in fp32 (igemm)
+  // between layout conversions, as before round 5's last changes
+  const bool post_x3 = cl16 && x3_tail && layers[L_post].wx3 != nullptr && !(bf16_keep32 & 32) &&
+                       !(getenv("DBM_POST_X3") && atoi(getenv("DBM_POST_X3")) == 0);
+  bool pre_x3 = post_x3 && layers[L_pre].wx3 != nullptr && !(bf16_keep32 & 64) && !(getenv("DBM_PRE_X3") && atoi(getenv("DBM_PRE_X3")) == 0);
   // ---- input block: four valid convolutions written straight into the 128-channel concat (:256-266) ----
   {
     struct { const float* in; int Cin, Hin, Win, K, stride; } br[4] = {
@@ -266,8 +284,14 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     const bool in_rows = in_fused_env && !input_block_fused_ok(H, W) && input_block_rows_ok(H, W) && !(use_bf16 && !(bf16_keep32 & 1));
     const bool in_fused = in_rows || (in_fused_env && input_block_fused_ok(H, W) && !(use_bf16 && !(bf16_keep32 & 1)));
     col_stale = in_fused && keep;
+    pre_x3 = pre_x3 && in_rows;   // (the split-bf16 pre-residual convolution reads the rows kernel's channels-last output)
     if (in_fused) {
       InputBlockLaunch q;
+      q.yt = nullptr;
+      if (pre_x3) {
+        a0t.ensure((size_t)N * 128 * hw);
+        q.yt = a0t.p;
+      }
       q.x = x; q.w1 = w1; q.w2 = w2; q.w3 = w3;
       q.wx = P(T_in[0][0]); q.bx = P(T_in[0][1]);
       q.wf1 = layers[L_in[1]].wf; q.b1 = P(T_in[1][1]);
@@ -301,14 +325,24 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   // has no cross-sample coupling, so the batch is cut into `nsplit` image ranges that run the same chain on
   // separate HIP streams: while one range's kernel is in its prologue / epilogue the other's feeds the MFMA pipes.
   DBM_MARK(s, "  gen_forward:input_block");
-  const bool fused = trunk_fused_ok(h, w);  // the whole trunk as one persistent launch (trunk_fused.hip)
   const int nsplit = fused ? 1 : std::min(trunk_split(N, hw), max_split);
   auto cn0 = [&](int c) { return (long)(((long)c * N) / nsplit); };          // first image of range c
   auto cnc = [&](int c) { return (int)(cn0(c + 1) - cn0(c)); };                // images in range c
   auto cstream = [&](int c) { return c == 0 ? s : ctx->chain[chain_base + c - 1]; };
   for (int c = 1; c < nsplit; ++c) ctx->fork(s, cstream(c), c);
   // ---- pre-residual conv + LeakyReLU -> cat[0][:, :64]  (:541-542) ----
-  for (int c = 0; c < nsplit; ++c) {
+  if (pre_x3) {
+    // bf16 sweep: split-bf16 on the channels-last concat, straight into the trunk's two operands (the fp32 residual stream and the bf16
+    // concat's channels 0..63): no fp32 igemm launch, no nchw_to_cl
+    for (auto& b : catb) b.ensure((size_t)N * 96 * hw);   // 192 bf16 = 96 floats per pixel
+    for (auto& b : resb) b.ensure((size_t)N * 64 * hw);
+    ClX3Launch q;
+    memset(&q, 0, sizeof(q));
+    q.x = a0t.p; q.xc = 128; q.Cin = 128; q.Cout = 64; q.ups = 0; q.w = layers[L_pre].wx3; q.bias = P(layers[L_pre].bi);
+    q.y32 = resb[0].p; q.yc = 64; q.y16 = catb[0].p; q.y16c = 192; q.act = 1; q.slope = SLOPE; q.N = N; q.H = h; q.W = w;
+    launch_conv_cl16x3(q, s);
+  }
+  for (int c = 0; c < (pre_x3 ? 0 : nsplit); ++c) {
     const long n0 = cn0(c);
     ConvDesc d = prec(fwd_desc(layers[L_pre], a0.p + n0 * 128 * hw, 128 * hw, h, w, 0, cat[0].p + n0 * 192 * hw, 192 * hw, cnc(c)), 2);
     d.act = 1;
@@ -344,24 +378,12 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
       DBM_HIP(hipEventRecord(ev_trunk, s));
     }
   }
-  // bf16 sweep mode on planes the persistent kernels do not serve: the trunk on channels-last bf16 activations
-  // (conv_cl16.hip).  DBM_CL16=0 (read per call): the per-layer implicit GEMM in its bf16 form instead.
-  const bool cl16 = !fused && use_bf16 && !(bf16_keep32 & 4) && layers[L_rdb[0]].wcl16 != nullptr &&
-                    !(getenv("DBM_CL16") && atoi(getenv("DBM_CL16")) == 0);
-  // (bf16 sweep mode, decided here because the trunk's hand-over depends on it: the post-residual convolution and the full-resolution
-  //  tail in split-bf16 on NHWC fp32 activations -- see below)
-  static const int fused_env_x3 = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
-  const bool x3_tail = use_bf16 && !keep && fused_env_x3 && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch) &&
-                       layers[L_up1].wx3 != nullptr && !(getenv("DBM_CL16X3") && atoi(getenv("DBM_CL16X3")) == 0);
-  // DBM_POST_X3=0: the post-residual convolution in fp32 (igemm) between two layout conversions, as before round 5's last change
-  const bool post_x3 = cl16 && x3_tail && layers[L_post].wx3 != nullptr && !(bf16_keep32 & 32) &&
-                       !(getenv("DBM_POST_X3") && atoi(getenv("DBM_POST_X3")) == 0);
   if (cl16) {
     const size_t n = (size_t)N;
     for (auto& b : catb) b.ensure(n * 96 * hw);   // 192 bf16 = 96 floats per pixel
     for (auto& b : resb) b.ensure(n * 64 * hw);
     for (int c = 1; c < nsplit; ++c) ctx->fork(cstream(c), s, 4 + c);  // (the pre-residual conv's image ranges)
-    launch_nchw_to_cl(cat[0].p, 192 * hw, resb[0].p, catb[0].p, 192, N, (int)hw, s);
+    if (!pre_x3) launch_nchw_to_cl(cat[0].p, 192 * hw, resb[0].p, catb[0].p, 192, N, (int)hw, s);
     if (post_x3) {   // (resb[0] is recycled by the fourth dense block: the skip operand of the post-residual convolution keeps its own copy)
       a1t.ensure(n * 64 * hw);
       DBM_HIP(hipMemcpyAsync(a1t.p, resb[0].p, sizeof(float) * n * 64 * hw, hipMemcpyDeviceToDevice, s));

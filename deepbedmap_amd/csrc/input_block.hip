@@ -211,13 +211,22 @@ __global__ __launch_bounds__(512) void input_block_rows_kernel(const InputBlockL
   const int pv = pok ? p : 0;
   const long plane = (long)OHp * OWp;
   float* yb = a.y + (long)n * a.ysn + (long)oy * OWp + ox0 + p;
+  // channels-last output (a.yt): registers 4 g .. 4 g + 3 of a lane are four consecutive channels of its position -- one 16-byte store
+  float* ytb = a.yt ? a.yt + (((long)n * OHp + oy) * OWp + ox0 + p) * 128 : nullptr;
   auto store_tile = [&](const f16v& acc, int ch0, const float* bias) {
     float b[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) b[r] = bias[(r & 3) + 8 * (r >> 2) + 4 * hh];
     if (pok) {
+      if (ytb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) yb[(long)(ch0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * plane] = acc[r] + b[r];
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f4v*>(ytb + ch0 + 8 * g + 4 * hh) =
+              (f4v){acc[4 * g] + b[4 * g], acc[4 * g + 1] + b[4 * g + 1], acc[4 * g + 2] + b[4 * g + 2], acc[4 * g + 3] + b[4 * g + 3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yb[(long)(ch0 + (r & 3) + 8 * (r >> 2) + 4 * hh) * plane] = acc[r] + b[r];
+      }
     }
   };
   f16v acc;
@@ -271,6 +280,21 @@ __global__ __launch_bounds__(512) void input_block_rows_kernel(const InputBlockL
     }
   }
   __syncthreads();
+  if (a.yt) {   // channels-last: a thread sums one register quad (four consecutive channels) of one lane's position
+    if (tid < 256) {
+      const int g = tid >> 6, l = tid & 63, col = l & 31;
+      f4v v;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float t = red[0][4 * g + rr][l];
+#pragma unroll
+        for (int w = 1; w < NW1; ++w) t += red[w][4 * g + rr][l];
+        v[rr] = t + a.b1[rr + 8 * g + 4 * (l >> 5)];
+      }
+      if (ox0 + col < OWp) *reinterpret_cast<f4v*>(a.yt + (((long)n * OHp + oy) * OWp + ox0 + col) * 128 + 32 + 8 * g + 4 * (l >> 5)) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int idx = tid + 512 * q, r = idx >> 6, l = idx & 63;

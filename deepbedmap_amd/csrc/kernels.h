@@ -25,7 +25,8 @@ struct InputBlockLaunch {
   const float *wf1, *b1;           // conv_on_W1: packed forward image [900 (+pad)][32] (IgLayer::wf), bias
   const float *wf2, *b2;           // conv_on_W2: [72 (+pad)][32]
   const float *w3w, *b3;           // conv_on_W3: OIHW
-  float* y; long ysn;              // the 128-channel concat (N, 128, 81)
+  float* y; long ysn;              // the 128-channel concat (N, 128, plane)
+  float* yt;                       // rows form only: the same concat channels-last (N * plane, 128) INSTEAD of y (null: y)
   int N;
 };
 bool input_block_fused_ok(int H, int W);
@@ -223,6 +224,7 @@ struct ClX3Launch {
   const float* bias;
   float* y32; int yc;        // NHWC fp32 output (yc channels per pixel; all 32 * ceil(Cout / 32) channels are written) or null
   const float* r1; int r1c;  // optional residual, NHWC fp32 (r1c channels per pixel): v = conv + bias + r1 (before the activation)
+  void* y16; int y16c;       // optional second output: the same values as bf16, NHWC with y16c channels per pixel (channels [0, 32 MT))
   float* yp; long ysn; int ypc;  // channel planes yp[n * ysn + co * H * W + pixel], co < ypc, or null
   int act; float slope;
   int N, H, W;               // output plane

@@ -229,6 +229,7 @@ struct Generator : dbm_model {
   // channels per pixel) and the 64-channel residual stream as NHWC fp32 (block input, block output, RRDB input)
   DevBuf catb[2], resb[4];
   DevBuf a3t, a41t;  // NHWC fp32 inputs of the two upsampling convolutions in the sweep's split-bf16 tail (conv_cl16x3_kernel)
+  DevBuf a0t;        // the input block's 128-channel concat channels-last (the split-bf16 pre-residual convolution of the sweep)
   DevBuf a1t;        // NHWC fp32 copy of the trunk's input (the post-residual convolution's skip operand in that tail)
   DevBuf g_a0, g_a3, g_u1, g_z41, g_u2, g_a42, goff1, goff2, gcol, g_a51, g_y;
   // A second workspace on the same parameters: the G-step's generator forward can be enqueued while the D-step's
