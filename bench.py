@@ -397,10 +397,9 @@ def compose_line(*, tiles, dt, steps, warmup, world, batch, ev_ms, config, fam, 
     if traffic is not None:
         roof["traffic"] = traffic.get("hbm_bytes_per_launch")
         if roof["traffic"]:
-            # ONE denominator: the counter pass's own join of its launches to the brackets' algorithmic bytes (tools/pmc_traffic.sh:
-            # launch-weighted over the shapes it sampled) -- the ratio profiles/<round>/traffic_pmc.json states; this run's bracket
-            # average only when the file carries none
-            roof["traffic_over_algorithmic_bytes"] = _r(traffic.get("traffic_over_algorithmic") or roof["traffic"] / max(dom["bytes"] / n, 1.0), 3)
+            # ONE denominator: the ratio of the two figures THIS line states, traffic / algorithmic_bytes_per_launch
+            # (the counter pass's own launch-weighted join stays in profiles/<round>/traffic_pmc.json)
+            roof["traffic_over_algorithmic_bytes"] = _r(roof["traffic"] / max(dom["bytes"] / n, 1.0), 3)
         roof["traffic_source"] = traffic.get("source")
     roof["other_kernels"] = [{"kernel": f["key"], "ms": _r(f["ms_per_step"], 3), "ms_standalone": _r(f["standalone_ms_per_step"], 3),
                               "launches": f["launches_per_step"], "frac": _r(tf(f["flop"], f["ms_per_step"]) / PEAK_FP32_MFMA_TFLOPS),
@@ -695,7 +694,8 @@ def main():
     step()
     recs_s = ctx.profile_records()
     FAMILIES = [   # (key in the line, what it is) -- family index = KernelProfiler family (csrc/dbm_internal.h)
-        ("igemm_conv_kernel", "igemm_conv_kernel / igemm_pm_kernel + the fused deformable-convolution GEMMs: per-layer conv forward + data gradient, v_mfma_f32_32x32x2_f32"),
+        ("per_layer_conv_family", "every convolution that is one launch per layer, forward + data gradient: igemm_conv_kernel / igemm_pm_kernel / conv_tile_kernel / "
+                                  "input_block_fused_kernel / disc_deep_kernel + the fused deformable-convolution GEMMs (v_mfma_f32_32x32x2_f32)"),
         ("wgrad_kernel", "weight gradients: wgrad_wave_dma_kernel, wgrad_band_dma_kernel, wgrad_direct_kernel, wgrad_kernel"),
         ("trunk_fused_kernel<retained>", "RRDB trunk forward of a retained pass, one persistent launch"),
         ("trunk_fused_bwd_kernel", "RRDB trunk data-gradient chain, persistent"),
@@ -788,7 +788,8 @@ def main():
         traffic = None
         try:  # HBM bytes per launch of the dominant kernel: PMC FETCH_SIZE (x2, gfx950) + WRITE_SIZE, from the committed pass
             with open(TRAFFIC_JSON) as f:
-                tj = json.load(f)[dom_key.split("<")[0]]
+                tjs = json.load(f)
+                tj = tjs.get(dom_key.split("<")[0]) or tjs[{"per_layer_conv_family": "igemm_conv_kernel"}[dom_key]]   # (key of the files up to round 5)
                 traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "traffic_over_algorithmic": tj.get("traffic_over_algorithmic"),
                            "source": "static: " + os.path.relpath(TRAFFIC_JSON, ROOT) + " (rocprofv3 --pmc, separate passes; not this run)"}
         except Exception:

@@ -33,7 +33,7 @@ static void dbm_handle_persistent_timeout(dbm_ctx* c) {
     if (m->type == 0) static_cast<Generator*>(m)->graph_version = -1;  // retained / prefetched passes are void
     // ... and so is whatever a backward pass has summed into the gradient arenas since the event (the observing call may be a
     // host-synchronising forward, long before the update that would apply them): marked until the next cleargrads
-    m->grads_void = true;
+    if (m->grads_touched) m->grads_void = true;
     if (m->is_view || !m->d_adam_skipped) continue;
     if (hipMemcpy(&n, m->d_adam_skipped, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && n > 0) {
       m->adam_t -= n;
@@ -56,7 +56,7 @@ static void dbm_handle_persistent_timeout(dbm_ctx* c) {
 // the gradient arena of `m` (shared with its views) has just been cleared on the stream: whatever a void pass left there is gone
 static void mark_grads_cleared(dbm_model* m) {
   for (dbm_model* o : m->ctx->models)
-    if (o->grads == m->grads) o->grads_void = false;
+    if (o->grads == m->grads) { o->grads_void = false; o->grads_touched = false; }
 }
 
 // entry of a step entry point: re-arm the persistent kernels when their pause is over, then observe the condition
@@ -1058,7 +1058,7 @@ int dbm_discriminator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, co
       // The pass on the MAIN stream (real batch) is enqueued first: the main stream is the one the step's tail waits
       // for (measured: D-step 5.72 -> 5.39 ms against enqueueing the fake batch's pass first); whichever pass is enqueued
       // second launches the merged weight-gradient groups behind both passes' events.
-      static const bool fake_first = getenv("DBM_DBWD_ORDER") && atoi(getenv("DBM_DBWD_ORDER")) == 0;
+      static const bool fake_first = DBM_TUNE_GETENV("DBWD_ORDER") && atoi(DBM_TUNE_GETENV("DBWD_ORDER")) == 0;
       hipStream_t other = c->stream;  // chain[0] when two streams are used, else the main stream
       if (fake_first) {
         d->merge_launcher = 0;
@@ -1242,7 +1242,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
     ~Scope() {
       c->stream = s; c->comm_in_step = false; c->comm_defer = false; c->comm_stream = nullptr; c->comm_pending.clear();
       d->merge_slots = false;
-      if (t) { t->grads_cleared = false; t->use_aux = true; t->max_split = 2; t->wgrad_inline = false; t->csr_early = false; }
+      if (t) { t->grads_cleared = false; t->use_aux = true; t->max_split = 2; t->wgrad_inline = false; t->csr_early = false; t->csr_prebuilt = false; }
     }
   } scope{c, s, d};
   c->comm_in_step = dp;
@@ -1357,7 +1357,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   t->grads_cleared = true;
   // (chain[0] carries the discriminator's fake-batch pass and the gradient exchange.  DBM_ITER_AUX=1, single GPU only: the offset-
   // gradient kernel of final_conv_layer2 goes there all the same, next to the input-gradient gather)
-  static const int iter_aux = getenv("DBM_ITER_AUX") ? atoi(getenv("DBM_ITER_AUX")) : 0;
+  static const int iter_aux = DBM_TUNE_GETENV("ITER_AUX") ? atoi(DBM_TUNE_GETENV("ITER_AUX")) : 0;
   t->use_aux = iter_aux && !dp;
   t->wgrad_inline = early == 2;   // (the side stream carries the discriminator's weight gradients: see Generator::wgrad_inline)
   t->backward(t->g_y.p);
@@ -1556,7 +1556,7 @@ int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const f
                          int N, int C, int H, int W, int O) {
   DBM_API_BEGIN(ctx)
   DBM_CHECK(C % 32 == 0, "deform conv op: C % 32 == 0");
-  static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  static const int fused_env = DBM_TUNE_GETENV("DEFORM_FUSED") ? atoi(DBM_TUNE_GETENV("DEFORM_FUSED")) : 1;
   const bool fused = fused_env && deform_conv_fused_ok(C, O);
   DevBuf col;
   if (!fused) {
@@ -1603,7 +1603,7 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
   DBM_CHECK(C % 32 == 0, "deform conv op: C % 32 == 0");
   hipStream_t s = ctx->stream;
   const long P = (long)H * W;
-  static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  static const int fused_env = DBM_TUNE_GETENV("DEFORM_FUSED") ? atoi(DBM_TUNE_GETENV("DEFORM_FUSED")) : 1;
   const bool fused = fused_env && deform_conv_fused_ok(C, O) && deform_input_grad_ok(C, H, W);
   DevBuf col, gcol, xt, part, cws;
   if (fused) {

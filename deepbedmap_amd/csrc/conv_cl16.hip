@@ -268,7 +268,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   // patch's first store, and every access is a raw buffer access whose bounds check replaces the branches: offset -1 reads zero /
   // drops the store (pixels outside the plane), a zero-length buffer stands for an absent operand.
   auto rsrc = [](const void* ptr, long bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, ptr ? (int)(bytes > 0x7fffffffL ? 0x7fffffffL : bytes) : 0, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, ptr ? (int)bytes : 0, 0x00020000);   // (bytes < 2^31: launch_conv_cl16 checks)
   };
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
@@ -674,7 +674,7 @@ void launch_cl_to_nchw(const float* res, float* y, long ysn, int N, int plane, h
 
 // patches (of 2 rows) per tile: the plane in as few rounds of <= n_cus workgroups as possible, then the least work per SIMD
 static int cl16_choose_slots(int N, int H, int W, int n_cus, int maxs = CL_MAXSLOTS, int per_cu = 1) {
-  static const int forced = getenv("DBM_CL16_SLOTS") ? atoi(getenv("DBM_CL16_SLOTS")) : 0;
+  static const int forced = DBM_TUNE_GETENV("CL16_SLOTS") ? atoi(DBM_TUNE_GETENV("CL16_SLOTS")) : 0;
   if (forced >= 1 && forced <= maxs) return forced;
   const int tilesX = (W + CL_TW - 1) / CL_TW;
   int best = 8;
@@ -698,6 +698,10 @@ static int cl16_choose_slots(int N, int H, int W, int n_cus, int maxs = CL_MAXSL
 void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   DBM_CHECK(L.Cin % 32 == 0 && L.Cin >= 32 && (L.Cout == 32 || L.Cout == 64), "cl16 conv: Cin % 32 == 0, Cout 32 or 64");
   DBM_CHECK(L.xc % 8 == 0 && (!L.y16 || (L.yc % 4 == 0 && L.y0 % 4 == 0)), "cl16 conv: channel strides must keep 16- / 8-byte alignment");
+  // the epilogue addresses r1 / r2 / y32 / y16 through raw buffer accesses with 32-bit byte offsets relative to the image's first
+  // pixel (and a 31-bit buffer size): refuse planes those cannot reach instead of dropping their stores
+  DBM_CHECK(256L * L.H * L.W < (1L << 31) && (!L.y16 || 2L * L.yc * L.H * L.W < (1L << 31)),
+            "cl16 conv: one image plane must stay below 2 GiB per operand (32-bit epilogue offsets)");
   static const int n_cus = [] {
     int dev = 0;
     hipDeviceProp_t prop;

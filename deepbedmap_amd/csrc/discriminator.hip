@@ -163,6 +163,7 @@ static inline int wgroup(int layer) { return layer >= 6 ? 0 : layer >= 4 ? 1 : l
 void Discriminator::backward(int slot, const float* glogits, bool join) {
   Cache& c = cache[slot];
   DBM_CHECK(c.valid, "discriminator backward without a retained training-mode forward");
+  mark_grads_touched();
   hipStream_t s = ctx->stream;
   ensure_packed_bwd();   // (callers that run the two graphs' passes on two streams have done this before their fork)
   const int N = c.N;

@@ -122,7 +122,7 @@ void Generator::pack_extra(hipStream_t s) {
   // the trunk's weight streams only by the persistent kernels behind it, the backward one not before the G-step: they are
   // rebuilt on chain[0] (idle at this point of a step) and the persistent launches wait for their events (~90 us off the
   // critical path of a training step).
-  static const int aside = getenv("DBM_PACK_ASIDE") ? atoi(getenv("DBM_PACK_ASIDE")) : 1;
+  static const int aside = DBM_TUNE_GETENV("PACK_ASIDE") ? atoi(DBM_TUNE_GETENV("PACK_ASIDE")) : 1;
   hipStream_t ps = (aside && ctx->chain[0] && ctx->chain[0] != s) ? ctx->chain[0] : s;
   if (!ev_pack[0]) for (auto& e : ev_pack) DBM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (ps != s) {
@@ -161,7 +161,7 @@ Generator* Generator::get_twin() {
 // number of image ranges the 9x9 stage is cut into (1 or 2): only when a single range would leave the chip
 // mostly idle (few tiles) and the ranges stay equal
 static int trunk_split(int N, long hw) {
-  static const int forced = getenv("DBM_TRUNK_SPLIT") ? atoi(getenv("DBM_TRUNK_SPLIT")) : 0;
+  static const int forced = DBM_TUNE_GETENV("TRUNK_SPLIT") ? atoi(DBM_TUNE_GETENV("TRUNK_SPLIT")) : 0;
   const long tiles = ((long)N * hw + 31) / 32;
   // two ranges: measured +4 % on the training step; more streams than hardware queues (four) serialise: 2.4x slower
   int ns = 1;
@@ -173,7 +173,7 @@ static int trunk_split(int N, long hw) {
 // The backward of the two deformable layers runs on the fused kernels (deform_fused.hip) when the forward did and the
 // planes fit the CSR input-gradient kernel.
 bool Generator::deform_bwd_fused(int H4, int W4) const {
-  static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  static const int fused_env = DBM_TUNE_GETENV("DEFORM_FUSED") ? atoi(DBM_TUNE_GETENV("DEFORM_FUSED")) : 1;
   return fused_env && out_ch == 1 && deform_conv_fused_ok(64, 64) && deform_input_grad_ok(64, H4, W4);
 }
 
@@ -241,6 +241,9 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
                         float* y, bool keep) {
   ensure_ws(N, H, W, keep);
   ensure_packed();
+  // by-products of an EARLIER retained pass (sampling lists built ahead of its backward pass, premultiplied tap planes, the channels-last
+  // twin) never survive into this one: a pass that threw between prebuild_csr and backward() would otherwise hand stale lists to the next
+  csr_prebuilt = false; csr_marked = false; zdef_kept = false; a42t_written = false;
   hipStream_t s = ctx->stream;
   const int h = H - 2, w = W - 2;
   const long hw = (long)h * w;
@@ -266,9 +269,9 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   const bool cl16 = !fused && use_bf16 && !(bf16_keep32 & 4) && layers[L_rdb[0]].wcl16 != nullptr &&
                     !(getenv("DBM_CL16") && atoi(getenv("DBM_CL16")) == 0);
   // ... with the post-residual convolution and the full-resolution tail in split-bf16 on NHWC fp32 activations (see below)
-  static const int fused_env_x3 = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  static const int fused_env_x3 = DBM_TUNE_GETENV("DEFORM_FUSED") ? atoi(DBM_TUNE_GETENV("DEFORM_FUSED")) : 1;
   const bool x3_tail = use_bf16 && !keep && fused_env_x3 && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch) &&
-                       layers[L_up1].wx3 != nullptr && !(getenv("DBM_CL16X3") && atoi(getenv("DBM_CL16X3")) == 0);
+                       layers[L_up1].wx3 != nullptr && !(DBM_TUNE_GETENV("CL16X3") && atoi(DBM_TUNE_GETENV("CL16X3")) == 0);
   // DBM_POST_X3=0 / DBM_PRE_X3=0 (or bits 32 / 64 of DBM_BF16_FP32_LAYERS): the post- / pre-residual convolution in fp32 (igemm)
   // between layout conversions, as before round 5's last changes
   const bool post_x3 = cl16 && x3_tail && layers[L_post].wx3 != nullptr && !(bf16_keep32 & 32) &&
@@ -282,7 +285,9 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     // DBM_INPUT_FUSED=0: layer by layer (A/B, and the form every other tile size takes)
     static const int in_fused_env = getenv("DBM_INPUT_FUSED") ? atoi(getenv("DBM_INPUT_FUSED")) : 1;
     const bool in_rows = in_fused_env && !input_block_fused_ok(H, W) && input_block_rows_ok(H, W) && !(use_bf16 && !(bf16_keep32 & 1));
-    const bool in_fused = in_rows || (in_fused_env && input_block_fused_ok(H, W) && !(use_bf16 && !(bf16_keep32 & 1)));
+    // (input_block_fused_kernel stages W1 / W2 with 16-byte loads and has no scalar form: 4-byte-aligned caller views take the layer-wise path)
+    const bool in_al16 = (reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2)) % 16 == 0;
+    const bool in_fused = in_rows || (in_fused_env && input_block_fused_ok(H, W) && in_al16 && !(use_bf16 && !(bf16_keep32 & 1)));
     col_stale = in_fused && keep;
     pre_x3 = pre_x3 && in_rows;   // (the split-bf16 pre-residual convolution reads the rows kernel's channels-last output)
     if (in_fused) {
@@ -458,12 +463,12 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   const long P4 = 16 * hw;
   // The sampler is fused into the GEMM (deform_fused.hip), fed from a channels-last copy of the layer input; the
   // (N, 576, H, W) sample matrices exist only in a retained pass, as a by-product for the two weight gradients.
-  static const int fused_env = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+  static const int fused_env = DBM_TUNE_GETENV("DEFORM_FUSED") ? atoi(DBM_TUNE_GETENV("DEFORM_FUSED")) : 1;
   const bool dfused = fused_env && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch);
   // bf16 sweep mode: the upsampling and offset convolutions -- on the signal path, where plain bf16 costs ~100 m rms at the
   // data range -- run in split-bf16 arithmetic (conv_cl16x3_kernel: three bf16 MFMAs per product, 2^-16 operand precision) on
   // NHWC fp32 activations, which is also what the fused deformable sampler reads.  DBM_CL16X3=0 (read per call): fp32 igemm.
-  const bool x3 = use_bf16 && !keep && dfused && layers[L_up1].wx3 != nullptr && !(getenv("DBM_CL16X3") && atoi(getenv("DBM_CL16X3")) == 0);
+  const bool x3 = use_bf16 && !keep && dfused && layers[L_up1].wx3 != nullptr && !(DBM_TUNE_GETENV("CL16X3") && atoi(DBM_TUNE_GETENV("CL16X3")) == 0);
   auto x3_launch = [&](const IgLayer& L, const float* xin, int ups, int Ho, int Wo, float* y32, float* yp, int act) {
     ClX3Launch q;
     memset(&q, 0, sizeof(q));
@@ -486,7 +491,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     ConvDesc e = prec(fwd_desc(layers[L_up2], a41.p, 64 * 4 * hw, 2 * h, 2 * w, 1, a42.p, 64 * 16 * hw, N), 8);
     e.act = 1;
     // (the fused deformable sampler reads a channels-last copy of this output: the LDS-tiled form writes it from its epilogue)
-    static const int fused_env0 = getenv("DBM_DEFORM_FUSED") ? atoi(getenv("DBM_DEFORM_FUSED")) : 1;
+    static const int fused_env0 = DBM_TUNE_GETENV("DEFORM_FUSED") ? atoi(DBM_TUNE_GETENV("DEFORM_FUSED")) : 1;
     a42t_written = false;
     if (fused_env0 && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch)) {
       a42t.ensure((size_t)N * 64 * 16 * hw);
@@ -507,7 +512,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
   if (x3) {
     x3_launch(layers[L_off1], a42t.p, 0, H4, W4, nullptr, off1.p, 0);
     // (the split-bf16 tail reads channels-last only: the NCHW copy of this layer's output is not written)
-    static const bool dx3 = !(getenv("DBM_DEFORM_X3") && atoi(getenv("DBM_DEFORM_X3")) == 0);
+    static const bool dx3 = !(DBM_TUNE_GETENV("DEFORM_X3") && atoi(DBM_TUNE_GETENV("DEFORM_X3")) == 0);
     if (dx3 && layers[L_def1].wdx3)
       launch_deform_conv64_x3(a42t.p, off1.p, layers[L_def1].wdx3, P(layers[L_def1].bi), nullptr, a51t.p, N, H4, W4, 32 * P4, 1, SLOPE, s);
     else
@@ -557,7 +562,7 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
         launch_deform_sample(a51.p, off2.p, col2.p, N, 64, H4, W4, 32 * P4, s);
       }
     } else {
-      DBM_CHECK(out_ch == 1, "DBM_DEFORM_FUSED=0 serves out_channels == 1 only");
+      DBM_CHECK(out_ch == 1, "the unfused deformable tail serves out_channels == 1 only");
       float* col = keep ? col2.p : col1.p;
       launch_deform_sample(a51.p, off2.p, col, N, 64, H4, W4, 32 * P4, s);
       launch_gemv_cols(col, P(T_def2W), P(T_def2b), y, N, 576, (int)P4, s);
@@ -586,6 +591,7 @@ void Generator::prebuild_csr(hipStream_t aux) {
 
 void Generator::backward(const float* gy) {
   DBM_CHECK(have_graph && wsTrain, "generator backward without a retained forward (DBM_KEEP_GRAPH)");
+  mark_grads_touched();
   hipStream_t s = ctx->stream;
   (owner ? owner : this)->ensure_packed_bwd();   // (a no-op inside dbm_train_iteration, which rebuilds them at its head)
   const int N = wsN, H = wsH, W = wsW, h = H - 2, w = W - 2;

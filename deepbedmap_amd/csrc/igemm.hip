@@ -723,7 +723,7 @@ std::string KernelProfiler::dump_marks() {
 }
 
 static bool igemm_tap_skip(const ConvDesc& d) {
-  static const int skip_plane = getenv("DBM_IGEMM_SKIP_PLANE") ? atoi(getenv("DBM_IGEMM_SKIP_PLANE")) : 4;
+  static const int skip_plane = DBM_TUNE_GETENV("IGEMM_SKIP_PLANE") ? atoi(DBM_TUNE_GETENV("IGEMM_SKIP_PLANE")) : 4;
   return (d.T == 16 || d.T == 4) && d.Hin * d.Win <= skip_plane;
 }
 
@@ -780,7 +780,7 @@ static void launch_tw(const ConvDesc& d, dim3 grid, hipStream_t s, bool mt2) {
     const bool row = d.sin == 1 && d.ups == 0 && d.dy[0] == d.dy[1] && d.dy[1] == d.dy[2] && d.dx[1] == 0 &&
                      d.dx[0] == -d.dx[2] && (d.dx[0] == 1 || d.dx[0] == -1) && d.dy[3] == d.dy[5] && d.dy[6] == d.dy[8] &&
                      d.dx[3] == d.dx[0] && d.dx[6] == d.dx[0] && d.dx[4] == 0 && d.dx[7] == 0;
-    static const int bf16_row = getenv("DBM_BF16_ROW") ? atoi(getenv("DBM_BF16_ROW")) : 1;
+    static const int bf16_row = DBM_TUNE_GETENV("BF16_ROW") ? atoi(DBM_TUNE_GETENV("BF16_ROW")) : 1;
     if (row && (!d.wp16 || bf16_row)) {
       launch_twr<T, WAVES, true>(d, grid, s, mt2);
       return;
@@ -827,7 +827,7 @@ typedef std::array<long, 5> IgemmKey;
 static const std::map<IgemmKey, IgemmForce>& igemm_overrides() {
   static std::map<IgemmKey, IgemmForce> tab = [] {
     std::map<IgemmKey, IgemmForce> t;
-    if (const char* e = getenv("DBM_IGEMM_OVERRIDE")) {
+    if (const char* e = DBM_TUNE_GETENV("IGEMM_OVERRIDE")) {
       std::string str(e);
       size_t pos = 0;
       while (pos < str.size()) {
@@ -870,12 +870,12 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   DBM_CHECK(d.CoutP % 32 == 0 && d.Cout <= d.CoutP, "igemm: bad CoutP");
   DBM_CHECK(d.T == 1 || d.T == 4 || d.T == 9 || d.T == 16, "igemm: tap count must be 1, 4, 9 or 16");
   {  // the deep discriminator layers (planes of <= 4 x 4): position-major tiles, live taps only (igemm_pm_kernel)
-    const int pm_enable = getenv("DBM_IGEMM_PM") ? atoi(getenv("DBM_IGEMM_PM")) : 1;          // (read per call: A/B in one process)
-    const int pm_target = getenv("DBM_IGEMM_PM_KSTARGET") ? atoi(getenv("DBM_IGEMM_PM_KSTARGET")) : 512;
-    const int pm_min_n = getenv("DBM_IGEMM_PM_MIN_N") ? atoi(getenv("DBM_IGEMM_PM_MIN_N")) : 16;
+    const int pm_enable = DBM_TUNE_GETENV("IGEMM_PM") ? atoi(DBM_TUNE_GETENV("IGEMM_PM")) : 1;          // (read per call: A/B in one process)
+    const int pm_target = DBM_TUNE_GETENV("IGEMM_PM_KSTARGET") ? atoi(DBM_TUNE_GETENV("IGEMM_PM_KSTARGET")) : 512;
+    const int pm_min_n = DBM_TUNE_GETENV("IGEMM_PM_MIN_N") ? atoi(DBM_TUNE_GETENV("IGEMM_PM_MIN_N")) : 16;
     // (3x3 on 4 x 4 planes -- 6.25 of 9 taps live on average -- stays with the general form: measured 35.5 against 30.7 us;
     //  DBM_IGEMM_PM_K3_PLANE: largest plane of a 3x3 layer that takes this form)
-    const int pm_k3_plane = getenv("DBM_IGEMM_PM_K3_PLANE") ? atoi(getenv("DBM_IGEMM_PM_K3_PLANE")) : 4;
+    const int pm_k3_plane = DBM_TUNE_GETENV("IGEMM_PM_K3_PLANE") ? atoi(DBM_TUNE_GETENV("IGEMM_PM_K3_PLANE")) : 4;
     if (pm_enable && !d.wp16 && d.ups == 0 && nph == 1 && (d.T == 9 || d.T == 16) && d.Hin * d.Win <= (d.T == 9 ? pm_k3_plane : 16) && d.OHl * d.OWl <= 16 &&
         d.N >= pm_min_n && d.Cin % 32 == 0 && 4L * d.T * d.Cin * d.CoutP < (1L << 31) && 4L * (d.N + 32) * d.xsn < (1L << 31)) {  // (32-bit byte offsets)
       d.pm_groups = (d.N + 31) / 32;
@@ -944,15 +944,15 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   // Two output-channel tiles per wavefront (the gathered B operand feeds two MFMA chains): layers with >= 64 output
   // channels on large grids -- or, with the cross-workgroup split-K below restoring the workgroup count, any layer
   // with a long K (DBM_IGEMM_MT2: 0 never, 1 large grids only, 2 also with split-K).
-  static const int mt2_mode = getenv("DBM_IGEMM_MT2") ? atoi(getenv("DBM_IGEMM_MT2")) : 2;
-  static const int ks_enable = getenv("DBM_IGEMM_KSPLIT") ? atoi(getenv("DBM_IGEMM_KSPLIT")) : 1;
-  static const int ks_target = getenv("DBM_IGEMM_KSTARGET") ? atoi(getenv("DBM_IGEMM_KSTARGET")) : 256;
+  static const int mt2_mode = DBM_TUNE_GETENV("IGEMM_MT2") ? atoi(DBM_TUNE_GETENV("IGEMM_MT2")) : 2;
+  static const int ks_enable = DBM_TUNE_GETENV("IGEMM_KSPLIT") ? atoi(DBM_TUNE_GETENV("IGEMM_KSPLIT")) : 1;
+  static const int ks_target = DBM_TUNE_GETENV("IGEMM_KSTARGET") ? atoi(DBM_TUNE_GETENV("IGEMM_KSTARGET")) : 256;
   // (round 3: 1024 -> 256 workgroups per split launch, 512 for the position-major form: inside the step these launches live on
   // the 64 CUs a persistent trunk launch leaves, where the number of workgroups, not the length of a K slice, is what they
   // pay for -- 8.22-8.30 ms per step with 1024 / the general form only, 8.13-8.16 with 256 / 512 and the position-major form)
   // (2048: conv_layer2 of the discriminator -- 1296 two-tile workgroups = 5.06 per CU, a sixth round on sixteen CUs -- stays
   // on one tile per wavefront, the 36 x 36 generator layers (2592) take two: 8.56 -> 8.47 ms per step against 1024)
-  static const int mt2_tiles = getenv("DBM_IGEMM_MT2_TILES") ? atoi(getenv("DBM_IGEMM_MT2_TILES")) : 2048;
+  static const int mt2_tiles = DBM_TUNE_GETENV("IGEMM_MT2_TILES") ? atoi(DBM_TUNE_GETENV("IGEMM_MT2_TILES")) : 2048;
   const bool mt2_ok = mt2_mode && !d.wp16 && d.CoutP % 64 == 0 && grid.y % 2 == 0 && !igemm_tap_skip(d);
   bool mt2 = mt2_ok && tiles / 2 >= mt2_tiles;
   if (!mt2 && mt2_ok && mt2_mode >= 2 && ks_enable && (long)d.Cin * d.T >= 1024 && tiles / 2 <= 512 && tiles >= 64) mt2 = true;
@@ -967,13 +967,13 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   // few tiles -> more wavefronts per tile (Cin % 32 == 0 keeps Cin / WAVES even for every choice)
   // (1536 -- eight wavefronts for the 1296-tile layers, 5.06 four-wavefront workgroups per CU -- measured -0.04 ms per step; not
   // taken: the other summation order moves one discriminator gradient of the batch-64 fixture past its bound, a slope flip)
-  static const int w4_tiles = getenv("DBM_IGEMM_W4_TILES") ? atoi(getenv("DBM_IGEMM_W4_TILES")) : 1024;
-  static const int w8_tiles = getenv("DBM_IGEMM_W8_TILES") ? atoi(getenv("DBM_IGEMM_W8_TILES")) : 512;
+  static const int w4_tiles = DBM_TUNE_GETENV("IGEMM_W4_TILES") ? atoi(DBM_TUNE_GETENV("IGEMM_W4_TILES")) : 1024;
+  static const int w8_tiles = DBM_TUNE_GETENV("IGEMM_W8_TILES") ? atoi(DBM_TUNE_GETENV("IGEMM_W8_TILES")) : 512;
   int waves = (tiles >= w4_tiles || mt2) ? 4 : (tiles >= w8_tiles ? 8 : 16);
   // ... but a wavefront should own a few channel pairs: with a short K (the 32-channel data gradients of the dense
   // blocks) the cross-wavefront reduction and a 1024-thread workgroup cost more than the MFMAs they spread
-  static const int min_pairs = getenv("DBM_IGEMM_MINPAIRS") ? atoi(getenv("DBM_IGEMM_MINPAIRS")) : 4;  // (re-measured at the end of round 2: 6 -> 4, -0.08 ms per step)
-  static const int min_tiles = getenv("DBM_IGEMM_MINTILES") ? atoi(getenv("DBM_IGEMM_MINTILES")) : 96;
+  static const int min_pairs = DBM_TUNE_GETENV("IGEMM_MINPAIRS") ? atoi(DBM_TUNE_GETENV("IGEMM_MINPAIRS")) : 4;  // (re-measured at the end of round 2: 6 -> 4, -0.08 ms per step)
+  static const int min_tiles = DBM_TUNE_GETENV("IGEMM_MINTILES") ? atoi(DBM_TUNE_GETENV("IGEMM_MINTILES")) : 96;
   while (tiles > min_tiles && waves > 4 && d.Cin / (2 * waves) < min_pairs) waves >>= 1;
   if (force.waves > 0 && !(mt2 && force.waves != 4)) waves = force.waves;
   // Few tiles and a long K (the deep discriminator layers: 32..512 tiles, K = 2048..8192): the input channels are also split
@@ -995,7 +995,7 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   }
   if (mt2 && waves != 4) { mt2 = false; grid.y *= 2; }
   {
-    static const bool log = getenv("DBM_IGEMM_LOG") != nullptr;
+    static const bool log = DBM_TUNE_GETENV("IGEMM_LOG") != nullptr;
     if (log) {
       static std::map<IgemmKey, int> seen;
       if (!seen.count(key)) {
@@ -1010,8 +1010,8 @@ void launch_igemm_conv(const ConvDesc& d_in, hipStream_t s) {
   // accumulators go out from the registers.  (With sixteen channels per 32-cycle MFMA a K slice is a handful of
   // instructions and the cross-wavefront reduction costs more than it spreads: 14.2 -> 13.2 ms per 288 x 288 crop.  The
   // fp32 layers keep the split: 88 vs 93-100 us on the 36 x 36 layers, 22.0 vs 25.4 ms per fp32 crop -- DBM_IGEMM_NOSPLIT_F32=1.)
-  static const int ns_tiles = getenv("DBM_IGEMM_NOSPLIT") ? atoi(getenv("DBM_IGEMM_NOSPLIT")) : 2048;
-  static const int ns_f32 = getenv("DBM_IGEMM_NOSPLIT_F32") ? atoi(getenv("DBM_IGEMM_NOSPLIT_F32")) : 0;
+  static const int ns_tiles = DBM_TUNE_GETENV("IGEMM_NOSPLIT") ? atoi(DBM_TUNE_GETENV("IGEMM_NOSPLIT")) : 2048;
+  static const int ns_f32 = DBM_TUNE_GETENV("IGEMM_NOSPLIT_F32") ? atoi(DBM_TUNE_GETENV("IGEMM_NOSPLIT_F32")) : 0;
   d.nosplit = 0;
   if (ns_tiles > 0 && (d.wp16 || ns_f32) && d.ksplit <= 1 && waves == 4 && (long)grid.x >= ns_tiles) {
     d.nosplit = 1;

@@ -763,7 +763,7 @@ bool deform_input_grad_ok(int C, int H, int W) {
 }
 
 bool deform_csr_lists_ok(int C, int H, int W) {
-  static const int split_env = getenv("DBM_DEFORM_CSR_SPLIT") ? atoi(getenv("DBM_DEFORM_CSR_SPLIT")) : 1;
+  static const int split_env = DBM_TUNE_GETENV("DEFORM_CSR_SPLIT") ? atoi(DBM_TUNE_GETENV("DEFORM_CSR_SPLIT")) : 1;
   return split_env && C % 16 == 0 && sizeof(float) * (10 * (size_t)H * W + 1) <= 150 * 1024;
 }
 

@@ -144,6 +144,10 @@ struct dbm_model {
   // backward pass: dbm_adam_update answers status 9 until the arena has been cleared (dbm_model_cleargrads, or the cleargrads
   // inside the step entry points) -- whichever call observed the event, and however many host-synchronising calls lie between
   bool grads_void = false;
+  // a backward pass has been enqueued into this model's gradient arena since it was last cleared (set by Generator / Discriminator::backward
+  // for every model sharing the arena, reset by mark_grads_cleared): a time-out observed while the arena is still clean voids nothing
+  bool grads_touched = false;
+  void mark_grads_touched();
   bool packed_dirty = true;
   long param_version = 0;  // bumped by every write to the parameter arena
   long packed16_version = -1;  // param_version the bf16 forward images were built from

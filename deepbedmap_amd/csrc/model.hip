@@ -75,6 +75,12 @@ dbm_model::~dbm_model() {
   if (d_lazy_jobs) (void)hipFree(d_lazy_jobs);
 }
 
+void dbm_model::mark_grads_touched() {
+  for (dbm_model* o : ctx->models)
+    if (o->grads == grads) o->grads_touched = true;
+  grads_touched = true;
+}
+
 int dbm_model::add_tensor(const std::string& key, std::vector<int64_t> shape, int kind) {
   Tensor t;
   t.key = key;
@@ -357,7 +363,7 @@ void dbm_model::run_dgrad(const IgLayer& L, ConvDesc base, int Hin_fwd, int Win_
   } else {
     // the four phases (py, px) of the stride-2 gradient -- output positions (2a + py, 2b + px), 2x2 taps each -- as ONE launch
     // (blockIdx.z = phase); planes that lack a phase (a single row or column) fall back to one launch per phase
-    static const int merge = getenv("DBM_IGEMM_MERGE_PHASES") ? atoi(getenv("DBM_IGEMM_MERGE_PHASES")) : 1;
+    static const int merge = DBM_TUNE_GETENV("IGEMM_MERGE_PHASES") ? atoi(DBM_TUNE_GETENV("IGEMM_MERGE_PHASES")) : 1;
     base.so = 2; base.T = 4;
     if (merge && Hin_fwd >= 2 && Win_fwd >= 2) {
       base.nphase = 4;

@@ -821,7 +821,7 @@ size_t trunk_fused_inbox_bytes(int nimg) {
 size_t trunk_fused_xcc_offset(int nimg_alloc) { return trunk_fused_inbox_bytes(nimg_alloc) / sizeof(unsigned long long) - (size_t)4 * nimg_alloc; }
 bool g_trunk_local_off = false;  // set by the first time-out event of the process: from then on agent-scope exchange stores only
 int trunk_local_stores() {
-  static const int v = getenv("DBM_TRUNK_LOCAL_ST") ? atoi(getenv("DBM_TRUNK_LOCAL_ST")) : 1;
+  static const int v = DBM_TUNE_GETENV("TRUNK_LOCAL_ST") ? atoi(DBM_TUNE_GETENV("TRUNK_LOCAL_ST")) : 1;
   return v && !g_trunk_local_off;
 }
 

@@ -1315,9 +1315,9 @@ __global__ __launch_bounds__(256) void wgrad_s2tiny_kernel(const TinyPlan* __res
 }
 
 static bool s2tiny_eligible(const WgradDesc& d) {
-  static const int on = getenv("DBM_WGRAD_TINY") ? atoi(getenv("DBM_WGRAD_TINY")) : 1;   // bit 0: 4x4 stride 2, bit 1: 3x3 stride 1
+  static const int on = DBM_TUNE_GETENV("WGRAD_TINY") ? atoi(DBM_TUNE_GETENV("WGRAD_TINY")) : 1;   // bit 0: 4x4 stride 2, bit 1: 3x3 stride 1
   const bool k4 = (on & 1) && d.KH == 4 && d.KW == 4 && d.stride == 2;
-  static const int on3 = getenv("DBM_WGRAD_TINY3") ? atoi(getenv("DBM_WGRAD_TINY3")) : 1;
+  static const int on3 = DBM_TUNE_GETENV("WGRAD_TINY3") ? atoi(DBM_TUNE_GETENV("WGRAD_TINY3")) : 1;
   const bool k3 = on3 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.Hin == d.OH && d.Win == d.OW;
   return (k4 || k3) && d.pad == 1 && d.ups == 0 && d.OW <= 4 && d.OH <= 4 && d.gb == nullptr &&
          d.Cin % 32 == 0 && d.Cout % 32 == 0 && d.xsc == d.Hin * d.Win && d.dysc == d.OH * d.OW && d.Win >= 2 &&
@@ -1580,7 +1580,7 @@ void WgradBatch::reset() {
 static int direct_form_enabled() {  // DBM_WGRAD_DIRECT: 1 (default) = wgrad_direct_kernel for the large-plane 3x3 / 4x4 layers
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("DBM_WGRAD_DIRECT");
+    const char* e = DBM_TUNE_GETENV("WGRAD_DIRECT");
     v = e ? atoi(e) : 1;
   }
   return v;
@@ -1589,7 +1589,7 @@ static int direct_form_enabled() {  // DBM_WGRAD_DIRECT: 1 (default) = wgrad_dir
 static int dma_forms_enabled() {  // DBM_WGRAD_WAVE: 0 = workgroup form only, 1 = + trunk LDS-DMA tasks, 2 (default) = + row-band LDS-DMA
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("DBM_WGRAD_WAVE");
+    const char* e = DBM_TUNE_GETENV("WGRAD_WAVE");
     v = e ? atoi(e) : 2;
   }
   return v;
@@ -1683,7 +1683,7 @@ void WgradBatch::build() {
         const WgradDesc& d = descs[i];
         work += (long)((d.Cin + 127) / 128) * ((d.Cout + 63) / 64) * d.N * ((d.OH * d.OW + 31) / 32);
       }
-      static const int slots_env = getenv("DBM_WGRAD_1X1_WGS") ? atoi(getenv("DBM_WGRAD_1X1_WGS")) : 512;
+      static const int slots_env = DBM_TUNE_GETENV("WGRAD_1X1_WGS") ? atoi(DBM_TUNE_GETENV("WGRAD_1X1_WGS")) : 512;
       segs_per_wg = std::max(8L, (work + slots_env - 1) / slots_env);   // bands of 32 positions per workgroup
     } else if (g >= 6) {
       // direct form: equally long workgroups, about two per CU over the whole launch (a workgroup's K range should stay
@@ -1694,7 +1694,7 @@ void WgradBatch::build() {
         const WgradDesc& d = descs[i];
         work += (long)((d.Cin + 31) / 32) * ((d.Cout + 31) / 32) * (g == 8 ? 2 : 1) * d.N * d.OH * ((d.OW + 7) / 8);
       }
-      static const int slots_env = getenv("DBM_WGRAD_DIRECT_WGS") ? atoi(getenv("DBM_WGRAD_DIRECT_WGS")) : 512;
+      static const int slots_env = DBM_TUNE_GETENV("WGRAD_DIRECT_WGS") ? atoi(DBM_TUNE_GETENV("WGRAD_DIRECT_WGS")) : 512;
       segs_per_wg = std::max(64L, (work + slots_env - 1) / slots_env);
     } else if (g >= 3) {
       long units = 0;
@@ -1705,10 +1705,10 @@ void WgradBatch::build() {
         need = std::max(need, wgrad_plan(descs[i], p, 0, MODE[g], 1));
         units += (long)p.groups * p.coutTiles;
       }
-      static const int slots_env = getenv("DBM_WGRAD_SLOTS") ? atoi(getenv("DBM_WGRAD_SLOTS")) : 0;
+      static const int slots_env = DBM_TUNE_GETENV("WGRAD_SLOTS") ? atoi(DBM_TUNE_GETENV("WGRAD_SLOTS")) : 0;
       // (few-layer launches -- the discriminator's conv_layer4: 16 units -- take a coarser K split: 256 workgroups of four images
       // instead of 1024 of one, a quarter of the partial tiles to write and fold: 116 -> 90 us standalone, round 3)
-      static const int slots_small = getenv("DBM_WGRAD_SLOTS_SMALL") ? atoi(getenv("DBM_WGRAD_SLOTS_SMALL")) : 256;
+      static const int slots_small = DBM_TUNE_GETENV("WGRAD_SLOTS_SMALL") ? atoi(DBM_TUNE_GETENV("WGRAD_SLOTS_SMALL")) : 256;
       int slots = slots_env ? slots_env : (need > 40 * 1024 ? 512 : 1024);
       // (<= 32 units: in data-parallel runs the trunk's launches are cut into four groups of 126 units each -- those keep the fine split)
       if (g == 3 && slots_small && units > 0 && units <= 32) slots = std::min(slots, slots_small);  // (the row-band forms lose: 164 -> 204 us)
@@ -1738,7 +1738,7 @@ void WgradBatch::build() {
       // but a launch of a few dozen workgroups, e.g. the 4x4 layers of the deep discriminator, is split as well)
       // (256 since round 5 -- the input block's GEMM-shaped launch, 144 workgroups at 128, ends the iteration behind the trunk's launch:
       //  62.6 -> 46 us; 7.61-7.64 against 7.62-7.68 ms per step, 448: 7.64-7.67, 64: 7.68-7.71)
-      static const int det_min = getenv("DBM_WGRAD_DET_MINWG") ? atoi(getenv("DBM_WGRAD_DET_MINWG")) : 256;
+      static const int det_min = DBM_TUNE_GETENV("WGRAD_DET_MINWG") ? atoi(DBM_TUNE_GETENV("WGRAD_DET_MINWG")) : 256;
       if (total >= 448 || plans.empty() || g >= 3 || (g_wgrad_deterministic && total >= det_min)) break;
     }
     std::vector<int> fstarts;
@@ -1746,7 +1746,7 @@ void WgradBatch::build() {
     if (g_wgrad_deterministic && !plans.empty()) {
       static const int SLOTS[NCAT] = {4, 4, 8, 2, 2, 2, 0, 0, 0, 0}, CTS[NCAT] = {4, 4, 4, 2, 2, 1, 0, 0, 0, 0},
                        TPWS[NCAT] = {1, 9, 8, 9, 9, 8, 0, 0, 0, 0};
-      static const int pairs_env = getenv("DBM_WGRAD_PAIRS") ? atoi(getenv("DBM_WGRAD_PAIRS")) : 1;
+      static const int pairs_env = DBM_TUNE_GETENV("WGRAD_PAIRS") ? atoi(DBM_TUNE_GETENV("WGRAD_PAIRS")) : 1;
       pair_mode[g] = pairs_env != 0 || g >= 6;  // (the direct form folds through pair buffers only)
       size_t floats = 0, bfloats = 0;
       int fw = 0;

@@ -96,3 +96,24 @@ def test_product_library_has_no_work_skipping_switches(built):
         _lib.library_path({"DBM_LIB": "/tmp/some_other_library.so"})
     with pytest.raises(_lib.DbmError, match="libdbm_measure.so"):
         _lib.library_path({"DBM_LIB": _lib.LIB_PATH})   # (not even the product library under that switch)
+
+
+def test_environment_switches_of_the_product_library_are_few_and_exercised(built):
+    """VERDICT round 5 #8a (knob sprawl: 64 getenv("DBM_*") in libdbm.so).  Round 6: the tuning switches (launch-size rules, kernel-form
+    overrides: DBM_IGEMM_*, DBM_WGRAD_*, ...) exist only in libdbm_measure.so (DBM_TUNE_GETENV, csrc/dbm_internal.h).  What the PRODUCT
+    library still reads -- every DBM_* name in its strings that is not an API flag of include/dbm.h -- must stay at or below 32 names, and
+    every one of them must be set by a parity test under tests/ (a code path the test suite runs) -- not merely mentioned by a tool."""
+    blob = open(built.LIB_PATH, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"DBM_[A-Z0-9_]+", blob))
+    header = open(os.path.join(ROOT, "include", "dbm.h")).read()
+    api_names = set(re.findall(r"\b(DBM_[A-Z0-9_]+)\b", header)) | {"DBM_MAX_TAPS", "DBM_HIP", "DBM_CHECK"}
+    knobs = sorted(names - api_names)
+    assert len(knobs) <= 32, knobs
+    tests_src = "".join(open(os.path.join(ROOT, "tests", f)).read() for f in os.listdir(os.path.join(ROOT, "tests")) if f.endswith(".py"))
+    this = open(__file__).read()
+    tests_src = tests_src.replace(this, "")
+    unexercised = [k for k in knobs if not re.search(r'"%s"|\b%s="' % (k, k), tests_src)]   # {"NAME": "v"} or NAME="v" (os.environ.update)
+    assert not unexercised, f"switches read by libdbm.so that no test sets: {unexercised}"
+    # ... and the tuning names are really gone from the product library
+    for name in (b"DBM_IGEMM_", b"DBM_WGRAD_", b"DBM_CL16_SLOTS", b"DBM_TRUNK_SPLIT", b"DBM_ITER_AUX", b"DBM_DBWD_ORDER"):
+        assert name not in blob, name

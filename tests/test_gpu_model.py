@@ -32,36 +32,36 @@ def grad_errors(model, G, floor=1e-6):
     return sorted(out, reverse=True)
 
 
-def grad_errors_flip_aware(model, G, tol, floor=1e-6, cap=5e-2):
-    """grad_errors' criterion for the discriminator, except that ONE LeakyReLU input within float32 rounding of zero may take the other
-    slope.  Signature: in some conv_layer{L}/W the entries above `tol` are confined to one or two OUTPUT channels (the flipped
-    activation's channel) and reach >= 5 tol.  Then the tensors of layer L and of the layers in front of it (which see the changed
-    gradient spread over a receptive field) may differ by up to `cap`, with their bulk (median) inside `tol`; the layers behind L are
-    untouched by such a flip and keep the strict criterion, as does everything when no such signature exists.
-    Returns the offending (error, key) entries."""
-    import re
+def near_zero_activations(caches, rel_thr=2e-5, limit=8):
+    """The LeakyReLU outputs of a float64 oracle pass that lie within float32 rounding of zero: (cache index, layer index into
+    cache["acts"] or "l1", flat index), closest first.  These are the only elements whose slope a float32 implementation can
+    legitimately take from the other branch (which one does depends on the last bit of the producing convolution's sum)."""
+    cand = []
+    for ci, cache in enumerate(caches):
+        for li in list(range(1, 11)) + ["l1"]:
+            a = cache["l1"] if li == "l1" else cache["acts"][li]
+            scale = float(np.sqrt(np.mean(a * a))) or 1.0
+            flat = np.abs(a).ravel()
+            for j in np.nonzero(flat < rel_thr * scale)[0]:
+                cand.append((flat[j] / scale, ci, li, int(j)))
+    return [c[1:] for c in sorted(cand)[:limit]]
 
-    gmax = max(float(np.abs(v).max()) for v in G.values())
-    err = {k: np.abs(model._tensors[k].grad - ref) / max(np.abs(ref).max(), floor * gmax) for k, ref in G.items()}
 
-    def layer(k):
-        m = re.search(r"(?:conv_layer|batch_norm)(\d+)/", k)
-        return int(m.group(1)) if m else 99  # linear_*: behind every convolution
-
-    flipped = -1
-    for k, e in err.items():
-        if k.startswith("conv_layer") and k.endswith("/W") and e.max() >= 5 * tol:
-            rows = (e.reshape(e.shape[0], -1) >= tol).any(axis=1)
-            if 1 <= rows.sum() <= 2:
-                flipped = max(flipped, layer(k))
-    bad = []
-    for k, e in err.items():
-        if e.max() < tol:
-            continue
-        if layer(k) <= flipped and e.max() < cap and np.median(e) < tol:
-            continue
-        bad.append((float(e.max()), k))
-    return sorted(bad, reverse=True)
+def flip_activation_sign(cache, li, j):
+    """The same cache with ONE LeakyReLU output on the other side of zero (magnitude unchanged, ~1e-7 of its plane's scale: only the
+    slope the backward pass takes for it changes)."""
+    out = dict(cache)
+    if li == "l1":
+        a = cache["l1"].copy()
+        out["l1"] = a
+    else:
+        acts = list(cache["acts"])
+        a = acts[li].copy()
+        acts[li] = a
+        out["acts"] = acts
+    v = a.ravel()[j]
+    a.ravel()[j] = -v if v != 0 else -1e-300
+    return out
 
 
 @pytest.fixture(scope="module")
@@ -319,8 +319,9 @@ def test_discriminator_forward_backward_parity(dbm, n):
     its slope is then 1 in one implementation and 0.2 in the other, and the gradients of that one channel differ by ~1e-2 -- the
     float32 oracle shows that against its own float64 run at n = 9 and 16.  Which input is that close depends on the last bit of
     every convolution's sum, i.e. on the kernel that formed it -- round 5's LDS-tiled stride-2 form moved it at n = 9 --: the check
-    therefore accepts that signature (grad_errors_flip_aware: one or two output channels of one convolution's weight gradient, and a
-    bounded spread in the layers in front of it) and asks for 1e-3 of float64 everywhere else; the HIP path typically agrees to ~1e-5.)
+    therefore asks for 1e-3 of float64 everywhere, and if that fails re-runs the float64 oracle with the slope of ONE activation that
+    lies within float32 rounding of zero forced to the other branch (near_zero_activations / flip_activation_sign) and asks for 1e-3
+    against THAT run -- a localized kernel bug with the same signature does not pass; the HIP path typically agrees to ~1e-5.)
     n = 2: BatchNorm over two samples on the 1 x 1 planes behind conv_layer9 (x-hat is +-1 whatever the input);
     n = 1: over ONE sample -- zero variance, Chainer's m / max(m - 1, 1) correction of the running variance, every gradient zero;
     n = 9: ragged tiles."""
@@ -356,8 +357,24 @@ def test_discriminator_forward_backward_parity(dbm, n):
             got = d._tensors[k].grad
             assert np.isfinite(got).all() and np.abs(got).max() < 1e-5 and np.abs(ref).max() < 1e-12, k
     else:
-        bad = grad_errors_flip_aware(d, G, 1e-3, floor=1e-3)
-        assert not bad, bad
+        # strict: every gradient within 1e-3 of the float64 oracle.  If that fails, the ONLY accepted explanation is a single LeakyReLU
+        # input within float32 rounding of zero that took the other slope: it is confirmed EXPLICITLY -- the float64 oracle is re-run with
+        # that one element's slope forced, and the strict criterion must hold against that run (no median / cap leniency).
+        bad = [(e, k) for e, k in grad_errors(d, G, floor=1e-3) if e >= 1e-3]
+        if bad:
+            caches = (c_real, c_fake)
+            g_out = (g_real, g_fake)
+            tried = []
+            for ci, li, j in near_zero_activations(caches):
+                G2 = {}
+                for k in (0, 1):
+                    od64.backward(g_out[k], flip_activation_sign(caches[k], li, j) if k == ci else caches[k], G2)
+                bad2 = [(e, k) for e, k in grad_errors(d, G2, floor=1e-3) if e >= 1e-3]
+                tried.append((ci, li, j, bad2[:1]))
+                if not bad2:
+                    bad = []
+                    break
+            assert not bad, (bad[:4], "no single near-zero LeakyReLU input explains it", tried)
     # eval-mode BatchNorm (srgan_train.py:1228)
     with dbm.using_config("train", False):
         le = d.forward(fake).array

@@ -120,7 +120,7 @@ def test_bench_shape_table_aggregates_profiler_records():
                rec(2, "trunk_fwd_36rdb_n64_keep", 8.94e10, 1.8e8, 1.3, 192)]
     serial = [rec(0, "c64>64_k9_36x36", 6.1e9, 4.0e7, 0.08, 2592), rec(0, "c64>64_k9_36x36", 6.1e9, 4.0e7, 0.09, 2592),
               rec(2, "trunk_fwd_36rdb_n64_keep", 8.94e10, 1.8e8, 1.25, 192)]
-    rows = bench.shape_table(in_step, serial, ["igemm_conv_kernel", "wgrad_kernel", "trunk_fused_kernel"])
+    rows = bench.shape_table(in_step, serial, ["per_layer_conv_family", "wgrad_kernel", "trunk_fused_kernel"])
     assert [r["shape"] for r in rows] == ["trunk_fwd_36rdb_n64_keep", "c64>64_k9_36x36"]  # sorted by standalone time
     conv = rows[1]
     assert conv["launches"] == 2 and conv["workgroups"] == 2592 and abs(conv["ms"] - 0.22) < 1e-9 and abs(conv["ms_standalone"] - 0.17) < 1e-9
@@ -131,7 +131,7 @@ def test_bench_shape_table_aggregates_profiler_records():
 
 
 def _canned_bench_inputs():
-    fam = [{"key": "igemm_conv_kernel", "label": "x" * 150, "ms_per_step": 5.61234567, "launches_per_step": 72, "flop": 134.8e9, "bytes": 1.55e9,
+    fam = [{"key": "per_layer_conv_family", "label": "x" * 150, "ms_per_step": 5.61234567, "launches_per_step": 72, "flop": 134.8e9, "bytes": 1.55e9,
             "standalone_ms_per_step": 2.94123},
            {"key": "wgrad_kernel", "label": "y" * 90, "ms_per_step": 3.9, "launches_per_step": 13, "flop": 138.3e9, "bytes": 0.9e9, "standalone_ms_per_step": 2.26},
            {"key": "trunk_fused_kernel<retained>", "label": "", "ms_per_step": 1.286, "launches_per_step": 1, "flop": 89.44e9, "bytes": 1.8e8,
@@ -180,7 +180,7 @@ def test_bench_line_is_short_and_complete():
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_standalone", "frac_step", "traffic", "traffic_over_algorithmic_bytes",
               "rrdb_forward", "other_kernels"):
         assert k in rf, k
-    assert rf["kernel"] == "igemm_conv_kernel" and rf["bound"] == "mfma" and rf["peak"] == bench.PEAK_FP32_MFMA_TFLOPS
+    assert rf["kernel"] == "per_layer_conv_family" and rf["bound"] == "mfma" and rf["peak"] == bench.PEAK_FP32_MFMA_TFLOPS
     assert abs(rf["achieved"] - 134.8 / 5.61234567) < 1e-2 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert abs(rf["frac_standalone"] - 134.8 / 2.94123 / 157.3) < 1e-3
     assert abs(rf["frac_step"] - 8.43 * 64 / 8.144 / 157.3) < 1e-3

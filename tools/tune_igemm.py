@@ -1,15 +1,20 @@
+"""Per-shape A/B of igemm_conv_kernel's launch rules inside the training iteration.  Round 6: the switches it drives (DBM_IGEMM_OVERRIDE,
+DBM_IGEMM_LOG) are TUNING switches and exist only in libdbm_measure.so (csrc/dbm_internal.h, DBM_TUNE_GETENV): build it first
+(tools/build_measure.sh); the iterations are timed with tools/step_only.py (bench.py refuses any library but the product's)."""
 import os, subprocess, sys, json, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MEASURE = os.path.join(ROOT, "deepbedmap_amd", "libdbm_measure.so")
+assert os.path.exists(MEASURE), "build deepbedmap_amd/libdbm_measure.so first: tools/build_measure.sh"
 def bench(override, base_override=""):
-    env = dict(os.environ)
+    env = dict(os.environ, DBM_LIB=MEASURE)
     ov = ";".join(x for x in (base_override, override) if x)
     if ov: env["DBM_IGEMM_OVERRIDE"] = ov
-    out = subprocess.run([sys.executable, "bench.py", "--steps", "150", "--warmup", "15", "--no-cpu-baseline", "--no-sweep", "--tables", "/tmp/tune_tables.json"], cwd=ROOT, env=env,
+    out = subprocess.run([sys.executable, "tools/step_only.py", "150"], cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1]
-    return json.loads(out)["ms_per_step"]
+    return float(out.split()[1])
 # distinct launches
-env = dict(os.environ, DBM_IGEMM_LOG="1")
-log = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-sweep", "--tables", "/tmp/tune_tables.json"], cwd=ROOT, env=env,
+env = dict(os.environ, DBM_IGEMM_LOG="1", DBM_LIB=MEASURE)
+log = subprocess.run([sys.executable, "tools/step_only.py", "2"], cwd=ROOT, env=env,
                      capture_output=True, text=True, timeout=300).stderr
 keys = {}
 for m in re.finditer(r"igemm (\S+) tiles=(\d+) mt2_ok=(\d) -> mt2=(\d) waves=(\d+) ks=(\d+)", log):
