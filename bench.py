@@ -660,6 +660,10 @@ def main():
     lib = dbm._lib.lib()
     for _ in range(args.warmup):
         step()
+    # (round 6: the last warm-up iteration's deferred eval-mode discriminator pass -- include/dbm.h, dbm_train_iteration -- is enqueued
+    #  by the next library call: flush it HERE, outside the timed region.  The K timed iterations then contain exactly K such passes:
+    #  K - 1 beside the following iteration's forwards, the last one alone, flushed by dbm_timer(1) / log.fetch() below.)
+    ctx.synchronize()
     if comm is not None:
         comm.barrier()
     torch.cuda.synchronize()
@@ -728,11 +732,13 @@ def main():
                                            log=log_s, fused=not args.no_fused_iteration)
             for _ in range(5):
                 step_shared()
+            ctx.synchronize()   # (flushes the deferred eval-mode pass: the loop below then holds exactly n_shared of them)
             torch.cuda.synchronize()
             ts = time.perf_counter()
             n_shared = 40
             for _ in range(n_shared):
                 step_shared()
+            ctx.synchronize()
             torch.cuda.synchronize()
             dts = (time.perf_counter() - ts) / n_shared
             shared = {"ms_per_step": 1e3 * dts, "tiles_per_s": args.batch / dts, "steps": n_shared,

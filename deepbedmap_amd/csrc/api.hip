@@ -4,10 +4,15 @@
 
 static thread_local std::string g_last_error;
 
-#define DBM_API_BEGIN(ctxptr) \
+static void run_deferred_eval(dbm_ctx* c, hipStream_t on);   // (dbm_ctx::DeferredEval; defined next to dbm_train_iteration)
+#define DBM_API_BEGIN_NOFLUSH(ctxptr) \
   dbm_ctx* _ectx = (ctxptr);  \
   (void)_ectx;                \
   try {
+// every entry point but dbm_train_iteration first enqueues a pending deferred eval-mode pass on the main stream
+#define DBM_API_BEGIN(ctxptr) \
+  DBM_API_BEGIN_NOFLUSH(ctxptr) \
+  if (_ectx && _ectx->deferred.pending) run_deferred_eval(_ectx, _ectx->stream);
 // ---- a persistent trunk kernel that gives up (bounded spins: another process starving the GPU, a partitioned device) ----
 // It raises the context's error word (host-mapped) and a STICKY device flag.  While the flag is up, every kernel that commits
 // training state is a no-op: the optimizer launches (gated ONCE per launch by adam_gate_kernel, so an update is all or
@@ -229,6 +234,9 @@ int dbm_shutdown(dbm_ctx* ctx) {
   if (ctx->ev_comm_done) (void)hipEventDestroy(ctx->ev_comm_done);
   for (auto& e : ctx->comm_ev_pool) (void)hipEventDestroy(e);
   ctx->loss_tmp.release();
+  ctx->deferred.pending = false;   // (a pass nobody waited for: its metrics row dies with the context)
+  ctx->deferred.fakes.release(); ctx->deferred.scratch.release(); ctx->deferred.logits.release();
+  if (ctx->deferred.ev_ready) (void)hipEventDestroy(ctx->deferred.ev_ready);
   for (auto& b : ctx->stage) b.release();
   (void)hipStreamSynchronize(ctx->side);
   (void)hipStreamDestroy(ctx->side);
@@ -677,6 +685,7 @@ int dbm_disc_forward(dbm_model* dm, int N, int H, int W, const float* img, float
   dbm_ctx* c = d->ctx;
   const size_t n = (size_t)N;
   // the image is retained by pointer for the backward pass: host input goes to a per-slot staging buffer
+  DBM_CHECK(slot == 0 || slot == 1, "dbm_disc_forward: cache slot must be 0 or 1");
   const float* dimg = stage_in(c, 4 + slot, img, n * H * W, flags);
   float* dlog = stage_out(c, 6 + slot, logits, n, flags);
   d->forward(N, H, W, dimg, dlog, flags & DBM_BN_TRAIN, flags & DBM_KEEP_GRAPH, slot);
@@ -745,20 +754,22 @@ static void gen_loss_terms(dbm_ctx* ctx, const float* y, const float* t, const f
 }
 // adversarial term: calculate_discriminator_loss(real=ones, fake=D(fake) detached, targets swapped) (:874-879, :1233-1237)
 static void gen_loss_adv(dbm_ctx* ctx, const float* real_logits, const float* fake_logits, int N, int t_rf, int t_fr,
-                         const int* t_rf_arr = nullptr, const int* t_fr_arr = nullptr) {
+                         const int* t_rf_arr = nullptr, const int* t_fr_arr = nullptr, float* base = nullptr) {
   hipStream_t s = ctx->stream;
-  float* adv = ctx->loss_tmp.p + 8;    // [8..9]
-  float* ones = ctx->loss_tmp.p + 16;  // N
+  if (!base) base = ctx->loss_tmp.p;   // (the deferred eval-mode pass brings its own copy of the scratch)
+  float* adv = base + 8;    // [8..9]
+  float* ones = base + 16;  // N
   if (!real_logits) {
     launch_fill(ones, N, 1.f, s);
     real_logits = ones;
   }
   launch_ragan_loss(real_logits, fake_logits, N, t_rf, t_fr, adv, nullptr, nullptr, s, t_rf_arr, t_fr_arr);
 }
-static void gen_loss_finish(dbm_ctx* ctx, int N, int H, int W, const float w[4], float* out3) {
+static void gen_loss_finish(dbm_ctx* ctx, int N, int H, int W, const float w[4], float* out3, const float* base = nullptr) {
   hipStream_t s = ctx->stream;
-  const float* adv = ctx->loss_tmp.p + 8;
-  const float* sums = ctx->loss_tmp.p + 16 + N;
+  if (!base) base = ctx->loss_tmp.p;
+  const float* adv = base + 8;
+  const float* sums = base + 16 + N;
   const float nhw = (float)N * H * W, npool = (float)N * (H / 4) * (W / 4), nwin = (float)N * (H - 8) * (W - 8);
   hipLaunchKernelGGL(gen_metrics_kernel, dim3(1), dim3(64), 0, s, sums, N, adv, out3, nhw, npool, nwin, w[0], w[1], w[2], w[3]);
   DBM_HIP(hipGetLastError());
@@ -1203,9 +1214,22 @@ int dbm_generator_step(dbm_model* gm, dbm_model* dm, int N, int H, int W, const 
 // that stream carries, its remainder after the join, then the generator's buckets (tail, trunk groups, input block) as
 // its backward pass on chain[1] finishes them -- and both Adam launches take 1 / world.  Same collectives in the same order
 // as the two step calls, hence the same numbers bit for bit.
+static void run_deferred_eval(dbm_ctx* c, hipStream_t on) {
+  dbm_ctx::DeferredEval& q = c->deferred;
+  if (!q.pending) return;
+  q.pending = false;
+  struct Restore { dbm_ctx* c; hipStream_t s; ~Restore() { c->stream = s; } } restore{c, c->stream};
+  DBM_HIP(hipStreamWaitEvent(on, q.ev_ready, 0));
+  c->stream = on;
+  // (the discriminator's forward weight images were rebuilt behind its update; coefficients: prepare_eval_coeffs(2) at the snapshot)
+  q.d->forward(q.N, q.H4, q.W4, q.fakes.p, q.logits.p, false, false, 2, true);
+  gen_loss_adv(c, nullptr, q.logits.p, q.N, 0, 1, nullptr, nullptr, q.scratch.p);
+  gen_loss_finish(c, q.N, q.H4, q.W4, q.w, q.out3, q.scratch.p);
+}
+
 int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const float* X, const float* W1, const float* W2,
                         const float* W3, const float* Y, const float weights[4], int ssim_window, int flags, float* metrics) {
-  DBM_API_BEGIN(gm->ctx)
+  DBM_API_BEGIN_NOFLUSH(gm->ctx)
   DBM_CHECK(gm->type == 0 && dm->type == 1, "dbm_train_iteration: (generator, discriminator) expected");
   Generator* g = static_cast<Generator*>(gm);
   Discriminator* d = static_cast<Discriminator*>(dm);
@@ -1248,6 +1272,16 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   c->comm_in_step = dp;
   c->comm_stream = dp ? c->chain[0] : nullptr;
   DBM_MARK(s, "D:begin");
+  // DBM_ITER_DEFER_EVAL (round 6, default 1): the G-step's detached eval-mode discriminator pass of THIS iteration is snapshotted at its
+  // end and enqueued by the next library call (dbm_ctx::DeferredEval); =0: inside this call, behind the discriminator's update, as before.
+  // Where a pending pass of the PREVIOUS iteration goes (tuning switch, libdbm_measure.so only): 0 main stream, first thing; 1 side
+  // stream, in front of D(real)'s forward; 2 (default) side stream, behind D(real)'s forward and the weight-image rebuilds -- beside
+  // D(fake)'s forward, in the shadow of the retained trunk forward; 3 chain[0], first thing.
+  static const int defer_env = getenv("DBM_ITER_DEFER_EVAL") ? atoi(getenv("DBM_ITER_DEFER_EVAL")) : 1;
+  static const int defer_at = DBM_TUNE_GETENV("ITER_DEFER_AT") ? atoi(DBM_TUNE_GETENV("ITER_DEFER_AT")) : 2;
+  static const int defer_pack = DBM_TUNE_GETENV("ITER_DEFER_PACK") ? atoi(DBM_TUNE_GETENV("ITER_DEFER_PACK")) : 1;
+  if (c->deferred.pending && (defer_at == 0 || c->deferred.d != d)) run_deferred_eval(c, s);
+  if (c->deferred.pending && defer_at == 3) run_deferred_eval(c, c->chain[0]);
   // (libdbm_measure.so only; results are then wrong -- what a part of the iteration costs INSIDE it: 1 = no discriminator work at all
   //  (forwards, backward passes, weight gradients, update, repack, eval-mode pass), 2 = no trunk weight-gradient launch (generator.hip),
   //  4 = no weight gradients of the generator's tail, 8 = no eval-mode discriminator pass)
@@ -1260,6 +1294,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   // cleargrads of the G-step (:1255), early: nothing reads or writes the generator's gradient arena between the previous update and this
   // iteration's backward pass, and 35 MB of fill would otherwise sit between the loss and the backward pass on the critical path
   DBM_HIP(hipMemsetAsync(g->grads, 0, g->nparam * sizeof(float), c->side));
+  if (c->deferred.pending && defer_at == 1) run_deferred_eval(c, c->side);
   if (!no_d) d->forward(N, H4, W4, Y, lr, true, true, 0);
   c->stream = s;
   // (The G-step's own forward goes to chain[1] behind the first forward; one_fwd: it is the only forward, forked here.
@@ -1316,6 +1351,7 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   DBM_HIP(hipEventRecord(c->ev_iter[2], c->side));   // (what the generator's backward pass on chain[1] waits for: cleargrads + images)
   d->ensure_packed_bwd(c->side);
   DBM_HIP(hipEventRecord(c->ev_iter[3], c->side));   // (what the discriminator's backward passes wait for)
+  if (c->deferred.pending) run_deferred_eval(c, c->side);   // (defer_at == 2; the main stream joins the side stream before the update below)
   if (one_fwd) DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));  // (the fakes are the retained forward's, written on chain[1])
   if (!no_d) d->forward(N, H4, W4, one_fwd ? t->yout.p : g->yout.p, lf, true, true, 1);
   launch_ragan_loss(lr, lf, N, 1, 0, metrics, gr, gf, s);
@@ -1370,11 +1406,29 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   // ---- discriminator update (:1164), then the G-step's detached eval-mode discriminator pass (:1228-1237) ----
   if (!no_d) adam_update_impl(d, gscale);
   DBM_HIP(hipStreamWaitEvent(s, g->ev_prefetch, 0));  // the twin's fakes (written on chain[1]: nothing else orders this read)
-  if (!no_d && !(iter_abl & 8)) d->forward(N, H4, W4, t->yout.p, lf_eval, false, false, 1);  // (repacks the updated weights first)
-  DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[0], 0));  // the loss scratch was cleared on chain[1]
-  gen_loss_adv(c, nullptr, lf_eval, N, 0, 1);
-  gen_loss_finish(c, N, H4, W4, weights, metrics + 2);   // (the loss terms are final: not behind the backward pass's join -- it sat between the
-                                                         //  last weight gradient and the update, 12 us on the iteration's critical path)
+  if (defer_env && !no_d && !(iter_abl & 8)) {
+    // snapshot what the eval-mode pass reads; the pass itself goes out with the next library call (run_deferred_eval)
+    dbm_ctx::DeferredEval& q = c->deferred;
+    if (defer_pack) d->ensure_packed(s);   // (the forward weight images of the updated parameters: D(real)'s next forward needs them as well)
+    d->prepare_eval_coeffs(2, s);
+    const size_t nimg = (size_t)N * H4 * W4;
+    q.fakes.ensure(nimg); q.scratch.ensure(16 + 5 * (size_t)N); q.logits.ensure((size_t)N);
+    DBM_HIP(hipMemcpyAsync(q.fakes.p, t->yout.p, nimg * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[0], 0));  // the loss terms' partial sums (chain[1])
+    DBM_HIP(hipMemsetAsync(q.scratch.p, 0, 16 * sizeof(float), s));
+    DBM_HIP(hipMemcpyAsync(q.scratch.p + 16 + N, c->loss_tmp.p + 16 + N, 4 * (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!q.ev_ready) DBM_HIP(hipEventCreateWithFlags(&q.ev_ready, hipEventDisableTiming));
+    DBM_HIP(hipEventRecord(q.ev_ready, s));
+    q.d = d; q.N = N; q.H4 = H4; q.W4 = W4; q.out3 = metrics + 2;
+    for (int k = 0; k < 4; ++k) q.w[k] = weights[k];
+    q.pending = true;
+  } else {
+    if (!no_d && !(iter_abl & 8)) d->forward(N, H4, W4, t->yout.p, lf_eval, false, false, 1);  // (repacks the updated weights first)
+    DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[0], 0));  // the loss scratch was cleared on chain[1]
+    gen_loss_adv(c, nullptr, lf_eval, N, 0, 1);
+    gen_loss_finish(c, N, H4, W4, weights, metrics + 2);   // (the loss terms are final: not behind the backward pass's join -- it sat between the
+                                                           //  last weight gradient and the update, 12 us on the iteration's critical path)
+  }
   DBM_HIP(hipStreamWaitEvent(s, c->ev_iter[1], 0));  // generator backward (and its weight gradients) done
   if (dp) {
     c->comm_join(s);  // ... and its last bucket summed over ranks

@@ -52,8 +52,29 @@ static void layer_dims(int H, int W, int hs[11], int ws[11]) {
   }
 }
 
-void Discriminator::forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot) {
-  DBM_CHECK(slot == 0 || slot == 1, "discriminator cache slot must be 0 or 1");
+// Eval-mode coefficients of cache slot `slot` (scale = gamma / sqrt(avg_var + eps), shift = beta - avg_mean * scale for the nine
+// BatchNorm layers): ONE launch.  forward(bn_train = false) calls it itself unless the caller has done so (coef_ready) -- the deferred
+// eval-mode pass of dbm_train_iteration takes its coefficients right behind the discriminator's update, while the running statistics
+// and the parameters are still those the reference's call (srgan_train.py:1228) sees, and runs its convolutions later.
+void Discriminator::prepare_eval_coeffs(int slot, hipStream_t s) {
+  BnEvalJobs ej;
+  memset(&ej, 0, sizeof(ej));
+  ej.n = 9;
+  for (int i = 1; i < 10; ++i) {
+    ej.start[i - 1] = ej.total;
+    ej.gamma[i - 1] = P(T_bn[i][0]); ej.beta[i - 1] = P(T_bn[i][1]);
+    ej.avg_mean[i - 1] = S(T_bn[i][2]); ej.avg_var[i - 1] = S(T_bn[i][3]);
+    ej.total += DC_O[i];
+  }
+  ej.start[9] = ej.total;
+  DevBuf& coef = bn_coef[slot];
+  coef.ensure(2 * (size_t)ej.total);
+  ej.scale = coef.p; ej.shift = coef.p + ej.total;
+  launch_bn_eval_coeffs(ej, 1e-5f, s);
+}
+
+void Discriminator::forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot, bool coef_ready) {
+  DBM_CHECK(slot >= 0 && slot <= 2 && (slot < 2 || !bn_train), "discriminator cache slot must be 0 or 1 (2: the library's own deferred eval-mode pass)");
   int hs[11], ws[11];
   layer_dims(H, W, hs, ws);  // hs[i+1] = spatial size of h_i
   DBM_CHECK(hs[10] == 1 && ws[10] == 1, "discriminator input must reduce to 1x1 (linear_1 expects 512 features)");
@@ -77,18 +98,14 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
   BnEvalJobs ej;
   memset(&ej, 0, sizeof(ej));
   if (!bn_train) {
-    ej.n = 9;
+    if (!coef_ready) prepare_eval_coeffs(slot, s);
     for (int i = 1; i < 10; ++i) {
       ej.start[i - 1] = ej.total;
-      ej.gamma[i - 1] = P(T_bn[i][0]); ej.beta[i - 1] = P(T_bn[i][1]);
-      ej.avg_mean[i - 1] = S(T_bn[i][2]); ej.avg_var[i - 1] = S(T_bn[i][3]);
       ej.total += DC_O[i];
     }
     ej.start[9] = ej.total;
-    DevBuf& coef = bn_coef[slot & 1];
-    coef.ensure(2 * (size_t)ej.total);
-    ej.scale = coef.p; ej.shift = coef.p + ej.total;
-    launch_bn_eval_coeffs(ej, 1e-5f, s);
+    DBM_CHECK(bn_coef[slot].n >= 2 * (size_t)ej.total, "eval-mode coefficients of this cache slot were never prepared");
+    ej.scale = bn_coef[slot].p; ej.shift = bn_coef[slot].p + ej.total;
   }
   for (int i = 1; i < 10; ++i) {  // conv -> BatchNorm -> LeakyReLU  (:663-689)
     const IgLayer& L = layers[L_conv[i]];
@@ -118,7 +135,7 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
       launch_bn_train_fwd(c.z[i].p, c.h[i].p, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, S(T_bn[i][2]),
                           S(T_bn[i][3]), N, DC_O[i], ho * wo, 1e-5f, 0.9f, SLOPE, s, ctx->dev_err_flag);
   }
-  if (c.N != N || c.H != H || c.W != W) {
+  if ((c.N != N || c.H != H || c.W != W) && slot < 2) {
     for (auto& b : wb[slot]) b.reset();
     for (auto& b : wbm) b.reset();
   }  // buffers may move: re-plan the batched weight gradients

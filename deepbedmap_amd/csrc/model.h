@@ -88,6 +88,22 @@ struct dbm_ctx {
   float* zeros = nullptr;     // 256 B of zeros (igemm out-of-image taps)
   float* ssim_win[2] = {nullptr, nullptr};  // 9-tap 1-D windows: gaussian(1.5), uniform
   DevBuf loss_tmp;            // scratch for the loss entry points
+  // dbm_train_iteration (round 6): the G-step's detached eval-mode discriminator pass (srgan_train.py:1228) feeds a LOGGED value only
+  // (the adversarial term of g_loss; its gradient never reaches the generator).  Iteration i therefore only SNAPSHOTS what that pass
+  // reads -- the eval-mode BatchNorm coefficients right behind the discriminator's update (parameters and running statistics as the
+  // reference's call sees them), the generator's fakes, the loss terms' partial sums -- and the pass itself (nine convolutions, two
+  // linear layers, the loss value -> that iteration's metrics row) is enqueued by the NEXT library call: inside iteration i + 1 beside
+  // its generator forwards, or on the main stream at the entry of any other entry point (every DBM_API_BEGIN flushes; dbm_synchronize
+  // and every copy the caller reads metrics with are entry points).  Same kernels, same inputs: the logged numbers are bitwise the same.
+  struct DeferredEval {
+    bool pending = false;
+    struct Discriminator* d = nullptr;
+    int N = 0, H4 = 0, W4 = 0;
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    float* out3 = nullptr;          // device: [g_loss, psnr, ssim] of that iteration's metrics row
+    DevBuf fakes, scratch, logits;  // scratch: loss_tmp's layout (16 + 5 N floats)
+    hipEvent_t ev_ready = nullptr;  // the snapshots are complete (recorded on the main stream)
+  } deferred;
   DevBuf stage[8];            // host<->device staging for the non-DEVICE_PTRS entry points
 };
 
@@ -280,8 +296,8 @@ struct Discriminator : dbm_model {
     int N = 0, H = 0, W = 0;
     bool valid = false;
     DevBuf img, h[10], z[10], mean[10], istd[10], l1, out;
-  } cache[2];
-  DevBuf bn_coef[2];  // eval-mode passes: [scale | shift] of all nine BatchNorm layers (launch_bn_eval_coeffs), one buffer per cache
+  } cache[3];         // [2]: the deferred eval-mode pass of dbm_train_iteration (never retained: no backward reads it)
+  DevBuf bn_coef[3];  // eval-mode passes: [scale | shift] of all nine BatchNorm layers (launch_bn_eval_coeffs), one buffer per cache
                       // slot: two eval-mode passes in flight on different streams never share coefficients
   DevBuf g_h[2][2], g_z[2][10], g_l1[2], g_out, c0_scratch[2];  // per retained graph: the two backward passes overlap
   static const int NWG = 4;
@@ -293,6 +309,7 @@ struct Discriminator : dbm_model {
   void launch_group(int slot, int g);
   WgradBatch wb[2][NWG];  // batched weight gradients per retained graph (real / fake batch): layers 9..6, 5..4, 3..2, 1
   Discriminator(dbm_ctx* c);
-  void forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot);
+  void forward(int N, int H, int W, const float* img, float* logits, bool bn_train, bool keep, int slot, bool coef_ready = false);
+  void prepare_eval_coeffs(int slot, hipStream_t s);
   void backward(int slot, const float* glogits, bool join = true);
 };
