@@ -1272,12 +1272,19 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   c->comm_in_step = dp;
   c->comm_stream = dp ? c->chain[0] : nullptr;
   DBM_MARK(s, "D:begin");
-  // DBM_ITER_DEFER_EVAL (round 6, default 1): the G-step's detached eval-mode discriminator pass of THIS iteration is snapshotted at its
-  // end and enqueued by the next library call (dbm_ctx::DeferredEval); =0: inside this call, behind the discriminator's update, as before.
+  // DBM_ITER_DEFER_EVAL=1 (round 6; default 0): the G-step's detached eval-mode discriminator pass of THIS iteration is snapshotted at its
+  // end and enqueued by the next library call (dbm_ctx::DeferredEval); 0: inside this call, behind the discriminator's update.
+  // MEASURED (profiles/r6/ab_defer_eval.txt, two alternations on one box): inside the call 7.616-7.618 ms per step; deferred to the side
+  // stream beside D(fake)'s forward 7.68-7.69, in front of D(real)'s forward or first thing on the main stream 7.84-7.85, first thing on
+  // chain[0] 7.68-7.72 (7.66-7.69 with the weight repack left to D(real)'s forward).  Removing the pass is worth 0.32 ms (round 5's
+  // ablation), but every other place it can go costs more than the place it has: behind the update it runs on the main stream while that
+  // stream only waits for the generator's backward pass, squeezed into whatever the chain and the trunk's weight gradients leave; anywhere
+  // in the next iteration it competes with a forward pass on the critical path.  The mechanism stays (bitwise the same metrics:
+  // tests/test_gpu_round5.py) for callers whose next call is NOT a training iteration -- the pass then costs nothing until it is read.
   // Where a pending pass of the PREVIOUS iteration goes (tuning switch, libdbm_measure.so only): 0 main stream, first thing; 1 side
   // stream, in front of D(real)'s forward; 2 (default) side stream, behind D(real)'s forward and the weight-image rebuilds -- beside
   // D(fake)'s forward, in the shadow of the retained trunk forward; 3 chain[0], first thing.
-  static const int defer_env = getenv("DBM_ITER_DEFER_EVAL") ? atoi(getenv("DBM_ITER_DEFER_EVAL")) : 1;
+  static const int defer_env = getenv("DBM_ITER_DEFER_EVAL") ? atoi(getenv("DBM_ITER_DEFER_EVAL")) : 0;
   static const int defer_at = DBM_TUNE_GETENV("ITER_DEFER_AT") ? atoi(DBM_TUNE_GETENV("ITER_DEFER_AT")) : 2;
   static const int defer_pack = DBM_TUNE_GETENV("ITER_DEFER_PACK") ? atoi(DBM_TUNE_GETENV("ITER_DEFER_PACK")) : 1;
   if (c->deferred.pending && (defer_at == 0 || c->deferred.d != d)) run_deferred_eval(c, s);

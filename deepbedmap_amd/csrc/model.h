@@ -88,7 +88,7 @@ struct dbm_ctx {
   float* zeros = nullptr;     // 256 B of zeros (igemm out-of-image taps)
   float* ssim_win[2] = {nullptr, nullptr};  // 9-tap 1-D windows: gaussian(1.5), uniform
   DevBuf loss_tmp;            // scratch for the loss entry points
-  // dbm_train_iteration (round 6): the G-step's detached eval-mode discriminator pass (srgan_train.py:1228) feeds a LOGGED value only
+  // dbm_train_iteration with DBM_ITER_DEFER_EVAL=1 (round 6, opt-in): the G-step's detached eval-mode discriminator pass (srgan_train.py:1228) feeds a LOGGED value only
   // (the adversarial term of g_loss; its gradient never reaches the generator).  Iteration i therefore only SNAPSHOTS what that pass
   // reads -- the eval-mode BatchNorm coefficients right behind the discriminator's update (parameters and running statistics as the
   // reference's call sees them), the generator's fakes, the loss terms' partial sums -- and the pass itself (nine convolutions, two

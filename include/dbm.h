@@ -297,14 +297,15 @@ int dbm_lzw_decode(const void* src, size_t nbytes, void* dst, size_t cap, size_t
  * it (on library stream chain[0], underneath the generator's backward pass) and both updates take 1 / world -- the same
  * collectives in the same order as the two step calls.  Refused with sync_batch_stats (use the two step calls).
  * flags: 0 or DBM_ONE_GEN_FORWARD.
- * DEFERRED METRIC (round 6): g_loss / psnr / ssim (metrics_dev[2..4]) need the G-step's detached eval-mode discriminator pass
- * (:1228-1237), which feeds that logged value and nothing else.  The call snapshots what the pass reads (eval-mode BatchNorm
+ * DEFERRED METRIC (round 6; opt-in: DBM_ITER_DEFER_EVAL=1 in the environment -- measured slower inside a training loop, see api.hip):
+ * g_loss / psnr / ssim (metrics_dev[2..4]) need the G-step's detached eval-mode discriminator pass
+ * (:1228-1237), which feeds that logged value and nothing else.  The call then snapshots what the pass reads (eval-mode BatchNorm
  * coefficients behind the discriminator's update, the fakes, the loss terms' sums) and the NEXT library call on the context
  * enqueues the pass itself: the next dbm_train_iteration beside its generator forwards, or ANY other entry point (dbm_synchronize,
  * dbm_memcpy_d2h, ...) on the context's stream before doing its own work.  So: metrics_dev[0..1] are complete when this call's work
  * is; metrics_dev[2..4] once the next library call's work is -- read them through the library (dbm_memcpy_d2h, or dbm_synchronize
- * first), and keep metrics_dev allocated until then.  Bitwise the same numbers (same kernels, same inputs).  DBM_ITER_DEFER_EVAL=0 in
- * the environment: the pass runs inside the call, as before round 6. */
+ * first), and keep metrics_dev allocated until then.  Bitwise the same numbers (same kernels, same inputs).  Default: the pass runs
+ * inside the call and all five metrics are complete when its work is. */
 int dbm_train_iteration(dbm_model* g, dbm_model* d, int N, int H, int W, const float* X, const float* W1, const float* W2,
                         const float* W3, const float* Y, const float weights[4], int ssim_window, int flags,
                         float* metrics_dev);

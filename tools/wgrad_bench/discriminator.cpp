@@ -2,7 +2,7 @@
 #include "wgrad_abl.hip"
 #include <cstdlib>
 KernelProfiler g_profiler;
-void KernelProfiler::begin(hipStream_t, int, double) {}
+void KernelProfiler::begin(hipStream_t, int, double, double, const char*, long) {}
 void KernelProfiler::end(hipStream_t) {}
 void KernelProfiler::collect(double*, int) {}
 int main(int argc, char** argv) {
