@@ -107,8 +107,14 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
     DBM_CHECK(bn_coef[slot].n >= 2 * (size_t)ej.total, "eval-mode coefficients of this cache slot were never prepared");
     ej.scale = bn_coef[slot].p; ej.shift = bn_coef[slot].p + ej.total;
   }
+  // (libdbm_measure.so only, results wrong: what the deep end -- conv_layer5..9, their BatchNorm launches, the linear layers -- costs INSIDE
+  //  the iteration, i.e. the upper bound of what fusing it can bring.  1: training-mode forwards, 2: backward passes, 8: eval-mode forward)
+  static const int d_abl = DBM_MEASURE_ENV("D_ABL");
+  const bool skip_deep = (d_abl & (bn_train ? 1 : 8)) != 0;
   for (int i = 1; i < 10; ++i) {  // conv -> BatchNorm -> LeakyReLU  (:663-689)
     const IgLayer& L = layers[L_conv[i]];
+    if (skip_deep && i >= 5) { c.h[i].ensure((size_t)N * DC_O[i] * hs[i + 1] * ws[i + 1]); c.z[i].ensure((size_t)N * DC_O[i] * hs[i + 1] * ws[i + 1]);
+                               c.mean[i].ensure(DC_O[i]); c.istd[i].ensure(DC_O[i]); continue; }
     const int hin = hs[i], win = ws[i], ho = hs[i + 1], wo = ws[i + 1];
     const size_t cnt = n * DC_O[i] * ho * wo;
     c.h[i].ensure(cnt);
@@ -140,8 +146,10 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
     for (auto& b : wbm) b.reset();
   }  // buffers may move: re-plan the batched weight gradients
   c.l1.ensure(n * 100);
+  if (!skip_deep) {
   launch_linear_fwd(c.h[9].p, P(T_l1W), P(T_l1b), c.l1.p, N, 512, 100, 1, SLOPE, s);  // :693-695
   launch_linear_fwd(c.l1.p, P(T_l2W), P(T_l2b), logits, N, 100, 1, 0, SLOPE, s);       // :696
+  }
   c.N = N; c.H = H; c.W = W;
   c.valid = keep && bn_train;
   if (c.valid) {  // conv_layer0's weight gradient needs the input image: keep a private copy
@@ -192,13 +200,23 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
   g_h[slot][1].ensure(n * 64 * c.H * c.W);
   for (int i = 1; i < 10; ++i) g_z[slot][i].ensure(n * DC_O[i] * hs[i + 1] * ws[i + 1]);
   // linear_2, then linear_1 (through its LeakyReLU)
-  launch_linear_bwd(c.l1.p, P(T_l2W), glogits, nullptr, g_l1[slot].p, G(T_l2W), G(T_l2b), N, 100, 1, SLOPE, s);
+  static const int d_abl = DBM_MEASURE_ENV("D_ABL");   // (libdbm_measure.so only: see forward())
+  const bool skip_deep = (d_abl & 2) != 0;
   float* gh = g_h[slot][0].p;
   float* gh_next = g_h[slot][1].p;
+  if (!skip_deep) {
+  launch_linear_bwd(c.l1.p, P(T_l2W), glogits, nullptr, g_l1[slot].p, G(T_l2W), G(T_l2b), N, 100, 1, SLOPE, s);
   launch_linear_bwd(c.h[9].p, P(T_l1W), g_l1[slot].p, c.l1.p, gh, G(T_l1W), G(T_l1b), N, 512, 100, SLOPE, s);
+  }
   for (int i = 9; i >= 1; --i) {
     const IgLayer& L = layers[L_conv[i]];
     const int hin = hs[i], win = ws[i], ho = hs[i + 1], wo = ws[i + 1];
+    if (skip_deep && i >= 5) {   // (the layers' weight gradients stay: they run on the side stream and are not what a fused deep end replaces)
+      run_wgrad(L, c.h[i - 1].p, (long)DC_C[i] * hin * win, hin, win, 0, g_z[slot][i].p, (long)DC_O[i] * ho * wo, ho, wo, N, 1.f,
+                merge_slots ? &wbm[wgroup(i)] : &wb[slot][wgroup(i)]);
+      if (wgroup(i - 1) != wgroup(i)) launch_group(slot, wgroup(i));
+      continue;
+    }
     if (ctx->sync_stats()) {
       ctx->sync_buf.ensure(3 * 512 + 4);
       launch_bn_sync_bwd_sums(c.z[i].p, gh, P(T_bn[i][0]), P(T_bn[i][1]), c.mean[i].p, c.istd[i].p, ctx->sync_buf.p,
