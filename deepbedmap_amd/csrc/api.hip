@@ -1265,12 +1265,18 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
     dbm_ctx* c; hipStream_t s; Discriminator* d; Generator* t = nullptr;
     ~Scope() {
       c->stream = s; c->comm_in_step = false; c->comm_defer = false; c->comm_stream = nullptr; c->comm_pending.clear();
-      d->merge_slots = false;
+      d->merge_slots = false; d->borrow_images = false;
       if (t) { t->grads_cleared = false; t->use_aux = true; t->max_split = 2; t->wgrad_inline = false; t->csr_early = false; t->csr_prebuilt = false; }
     }
   } scope{c, s, d};
   c->comm_in_step = dp;
   c->comm_stream = dp ? c->chain[0] : nullptr;
+  // (tuning switch, libdbm_measure.so only: DBM_DISC_BORROW=0 private image copies again.  profiles/r6/ab_disc_launch_trims.txt, three
+  //  alternations on one box, medians: all three trims of round 6 on 7.668 ms per step; the head as two launches per pass 7.695; image copies
+  //  7.681; the D-step's cleargrads at the head of the side stream instead of between the loss and the backward passes 7.668 against 7.656
+  //  WITHOUT it -- that one lost and is gone again: 77 MB of fills in front of D(real)'s forward cost more than 41 MB behind the loss.)
+  static const int borrow_env = DBM_TUNE_GETENV("DISC_BORROW") ? atoi(DBM_TUNE_GETENV("DISC_BORROW")) : 1;
+  d->borrow_images = borrow_env != 0;   // (Y and the generator's output buffers outlive this call; both backward passes run inside it)
   DBM_MARK(s, "D:begin");
   // DBM_ITER_DEFER_EVAL=1 (round 6; default 0): the G-step's detached eval-mode discriminator pass of THIS iteration is snapshotted at its
   // end and enqueued by the next library call (dbm_ctx::DeferredEval); 0: inside this call, behind the discriminator's update.

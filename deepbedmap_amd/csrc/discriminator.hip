@@ -147,14 +147,26 @@ void Discriminator::forward(int N, int H, int W, const float* img, float* logits
   }  // buffers may move: re-plan the batched weight gradients
   c.l1.ensure(n * 100);
   if (!skip_deep) {
-  launch_linear_fwd(c.h[9].p, P(T_l1W), P(T_l1b), c.l1.p, N, 512, 100, 1, SLOPE, s);  // :693-695
-  launch_linear_fwd(c.l1.p, P(T_l2W), P(T_l2b), logits, N, 100, 1, 0, SLOPE, s);       // :696
+  // linear_1 -> LeakyReLU -> linear_2 (:693-696) as ONE launch (round 6: bitwise the two linear_fwd launches)
+  // (DBM_DISC_HEAD_FUSED=0, libdbm_measure.so only: the two-launch form -- A/B)
+  static const int head_fused = DBM_TUNE_GETENV("DISC_HEAD_FUSED") ? atoi(DBM_TUNE_GETENV("DISC_HEAD_FUSED")) : 1;
+  if (head_fused) {
+    launch_disc_head_fwd(c.h[9].p, P(T_l1W), P(T_l1b), P(T_l2W), P(T_l2b), c.l1.p, logits, N, 512, 100, SLOPE, s);
+  } else {
+    launch_linear_fwd(c.h[9].p, P(T_l1W), P(T_l1b), c.l1.p, N, 512, 100, 1, SLOPE, s);  // :693-695
+    launch_linear_fwd(c.l1.p, P(T_l2W), P(T_l2b), logits, N, 100, 1, 0, SLOPE, s);       // :696
+  }
   }
   c.N = N; c.H = H; c.W = W;
   c.valid = keep && bn_train;
   if (c.valid) {  // conv_layer0's weight gradient needs the input image: keep a private copy
-    c.img.ensure(n * H * W);
-    DBM_HIP(hipMemcpyAsync(c.img.p, img, n * H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (borrow_images) {   // (the fused steps: the backward pass runs inside the same call, the images outlive it -- no copy launch)
+      c.img_src = img;
+    } else {
+      c.img.ensure(n * H * W);
+      DBM_HIP(hipMemcpyAsync(c.img.p, img, n * H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
+      c.img_src = c.img.p;
+    }
   }
 }
 
@@ -205,8 +217,13 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
   float* gh = g_h[slot][0].p;
   float* gh_next = g_h[slot][1].p;
   if (!skip_deep) {
-  launch_linear_bwd(c.l1.p, P(T_l2W), glogits, nullptr, g_l1[slot].p, G(T_l2W), G(T_l2b), N, 100, 1, SLOPE, s);
-  launch_linear_bwd(c.h[9].p, P(T_l1W), g_l1[slot].p, c.l1.p, gh, G(T_l1W), G(T_l1b), N, 512, 100, SLOPE, s);
+  static const int head_fused = DBM_TUNE_GETENV("DISC_HEAD_FUSED") ? atoi(DBM_TUNE_GETENV("DISC_HEAD_FUSED")) : 1;
+  if (head_fused && disc_head_bwd_fused_ok(N, 100)) {  // both linear layers' backward as ONE launch (round 6: bitwise the two linear_bwd launches)
+    launch_disc_head_bwd(c.h[9].p, P(T_l1W), P(T_l2W), glogits, c.l1.p, gh, G(T_l1W), G(T_l1b), G(T_l2W), G(T_l2b), N, 512, 100, SLOPE, s);
+  } else {
+    launch_linear_bwd(c.l1.p, P(T_l2W), glogits, nullptr, g_l1[slot].p, G(T_l2W), G(T_l2b), N, 100, 1, SLOPE, s);
+    launch_linear_bwd(c.h[9].p, P(T_l1W), g_l1[slot].p, c.l1.p, gh, G(T_l1W), G(T_l1b), N, 512, 100, SLOPE, s);
+  }
   }
   for (int i = 9; i >= 1; --i) {
     const IgLayer& L = layers[L_conv[i]];
@@ -246,11 +263,12 @@ void Discriminator::backward(int slot, const float* glogits, bool join) {
   {  // conv_layer0 weight / bias gradient
     SmallConvDesc q;
     memset(&q, 0, sizeof(q));
-    q.x = c.img.p; q.xsn = (long)c.H * c.W; q.Cin = 1; q.Hin = c.H; q.Win = c.W;
+    q.x = c.img_src; q.xsn = (long)c.H * c.W; q.Cin = 1; q.Hin = c.H; q.Win = c.W;
     q.Cout = 64; q.OH = c.H; q.OW = c.W; q.KH = q.KW = 3; q.stride = 1; q.pad = 1; q.N = N;
     c0_scratch[slot].ensure(smallcin_wgrad_scratch_floats(64));
     launch_smallcin_conv_wgrad(q, gh, 64L * c.H * c.W, G(T_c0W), G(T_c0b), s, c0_scratch[slot].p);
   }
   // (conv_layer1..9 weight gradients: one launch per kernel form and layer group, on the side stream -- see the loop)
+  if (borrow_images) { c.valid = false; c.img_src = nullptr; }   // (a borrowed image is good for ONE backward pass, inside the borrowing call)
   if (join) ctx->join_side();
 }

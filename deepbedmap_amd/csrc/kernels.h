@@ -102,6 +102,12 @@ void launch_linear_fwd(const float* x, const float* W, const float* b, float* y,
 // where gyz = gy * lrelu'(y) if y_act != null else gy
 void launch_linear_bwd(const float* x, const float* W, const float* gy, const float* y_act, float* gx, float* gW,
                        float* gb, int N, int K, int O, float slope, hipStream_t s);
+// the discriminator's head (linear_1 -> LeakyReLU -> linear_2) as one launch per pass; bitwise the two-launch results
+void launch_disc_head_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* l1, float* logits,
+                          int N, int K, int O, float slope, hipStream_t s);
+bool disc_head_bwd_fused_ok(int N, int O);
+void launch_disc_head_bwd(const float* x, const float* W1, const float* W2, const float* glogits, const float* l1, float* gx, float* gW1,
+                          float* gb1, float* gW2, float* gb2, int N, int K, int O, float slope, hipStream_t s);
 
 // RaGAN discriminator loss (srgan_train.py:960-1009) on N real + N fake logits.
 // out[0] = loss, out[1] = binary accuracy (train_eval_discriminator :1156-1158); g_real/g_fake may be null.

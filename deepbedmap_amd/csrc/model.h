@@ -296,6 +296,7 @@ struct Discriminator : dbm_model {
     int N = 0, H = 0, W = 0;
     bool valid = false;
     DevBuf img, h[10], z[10], mean[10], istd[10], l1, out;
+    const float* img_src = nullptr;   // the retained pass's input image: the private copy `img`, or the caller's buffer (borrow_images)
   } cache[3];         // [2]: the deferred eval-mode pass of dbm_train_iteration (never retained: no backward reads it)
   DevBuf bn_coef[3];  // eval-mode passes: [scale | shift] of all nine BatchNorm layers (launch_bn_eval_coeffs), one buffer per cache
                       // slot: two eval-mode passes in flight on different streams never share coefficients
@@ -306,6 +307,9 @@ struct Discriminator : dbm_model {
   size_t comm_sent_lo = 0, comm_sent_hi = 0;  // gradient range already handed to the exchange by launch_group (this step)
   int merge_launcher = 0;    // merged mode: the slot whose backward pass is enqueued SECOND (it launches the groups)
   bool merge_slots = false;  // set by dbm_discriminator_step around its two backward calls (fake first, then real)
+  // set by the fused steps around their retained forwards: conv_layer0's weight gradient reads the caller's image buffer directly (it
+  // outlives the call, and the backward pass runs inside it) instead of a private copy -- one 332 KB copy launch less per pass (round 6)
+  bool borrow_images = false;
   void launch_group(int slot, int g);
   WgradBatch wb[2][NWG];  // batched weight gradients per retained graph (real / fake batch): layers 9..6, 5..4, 3..2, 1
   Discriminator(dbm_ctx* c);

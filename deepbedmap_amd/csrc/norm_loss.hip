@@ -697,6 +697,125 @@ void launch_linear_bwd(const float* x, const float* W, const float* gy, const fl
   DBM_HIP(hipGetLastError());
 }
 
+// ---- the discriminator's head as ONE launch per pass (round 6) ----
+// linear_1 -> LeakyReLU -> linear_2 (:693-696) used to be two launches of linear_fwd_kernel at the end of every discriminator forward
+// (three per iteration) and two of linear_bwd_kernel at the head of every backward pass, i.e. of both serial chains the D-step waits for;
+// inside the iteration a launch of that size costs 20-40 us of queueing whatever it computes.  Same arithmetic in the same order as the
+// two-launch form (every sum below is linear_fwd_kernel's / linear_bwd_kernel's own): results are bitwise the same.
+// Forward: one workgroup per image; wavefront w computes outputs w, w + 4, ... of linear_1 (lanes stride the 512 inputs, shuffle tree),
+// the row goes to memory (the backward pass reads it) and to LDS, wavefront 0 then forms the logit.
+template <int K, int NW>
+__global__ __launch_bounds__(64 * NW) void disc_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
+                                                                const float* __restrict__ b1, const float* __restrict__ W2,
+                                                                const float* __restrict__ b2, float* __restrict__ l1,
+                                                                float* __restrict__ logits, int O, float slope) {
+  // (first version: four wavefronts, 25 outputs each, one after the other -- 25 dependent L2 round trips per wavefront: 7.75-7.78
+  //  against 7.65-7.67 ms per step for the two launches it replaced, profiles/r6/ab_disc_head.txt.  Now sixteen wavefronts per image,
+  //  the image's row in registers, and the weight rows of a wavefront's outputs requested four at a time.)
+  __shared__ float row[256];
+  constexpr int KP = K / 64;
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* xr = x + (long)n * K;
+  float xv[KP];
+#pragma unroll
+  for (int i = 0; i < KP; ++i) xv[i] = xr[lane + 64 * i];
+  for (int o0 = wave; o0 < O; o0 += 4 * NW) {
+    float wv[4][KP];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + u * NW < O ? o0 + u * NW : o0;
+#pragma unroll
+      for (int i = 0; i < KP; ++i) wv[u][i] = W1[(long)o * K + lane + 64 * i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + u * NW;
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < KP; ++i) a = fmaf(xv[i], wv[u][i], a);   // (k = lane, lane + 64, ...: linear_fwd_kernel's order)
+      for (int s = 32; s > 0; s >>= 1) a += __shfl_down(a, s, 64);
+      if (lane == 0 && o < O) {
+        float v = a + b1[o];
+        v = v >= 0.f ? v : slope * v;
+        l1[(long)n * O + o] = v;
+        row[o] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float a = 0.f;
+    for (int k = lane; k < O; k += 64) a = fmaf(row[k], W2[k], a);
+    for (int s = 32; s > 0; s >>= 1) a += __shfl_down(a, s, 64);
+    if (lane == 0) logits[n] = a + b2[0];
+  }
+}
+
+void launch_disc_head_fwd(const float* x, const float* W1, const float* b1, const float* W2, const float* b2, float* l1, float* logits,
+                          int N, int K, int O, float slope, hipStream_t s) {
+  if (dbm_abl_skip() & 32) return;  // (libdbm_measure.so only)
+  DBM_CHECK(O <= 256 && K == 512, "discriminator head: linear_1 is 512 -> at most 256");
+  hipLaunchKernelGGL((disc_head_fwd_kernel<512, 16>), dim3(N), dim3(1024), 0, s, x, W1, b1, W2, b2, l1, logits, O, slope);
+  DBM_HIP(hipGetLastError());
+}
+
+// Backward: linear_2's input gradient g_l1[n][o] = glogit[n] * W2[o] needs no reduction, so every workgroup forms the masked gradient
+// gz[n][o] = lrelu'(l1[n][o]) * g_l1[n][o] in LDS itself (N x O floats) and then runs linear_bwd_kernel's element mapping for linear_1
+// (gx, gW1, gb1) plus O + 1 more elements for linear_2's own gW2 / gb2.  g_l1 is not written: nothing else reads it.
+__global__ __launch_bounds__(256) void disc_head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W1,
+                                                            const float* __restrict__ W2, const float* __restrict__ glogits,
+                                                            const float* __restrict__ l1, float* gx, float* gW1, float* gb1,
+                                                            float* gW2, float* gb2, int N, int K, int O, float slope) {
+  extern __shared__ float gzs[];
+  for (int i = threadIdx.x; i < N * O; i += 256) {
+    const int n = i / O, o = i - n * O;
+    const float g = fmaf(glogits[n], W2[o], 0.f);   // (linear_bwd_kernel's gx of linear_2: one multiply-add onto zero)
+    gzs[i] = l1[i] >= 0.f ? g : slope * g;
+  }
+  __syncthreads();
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int nx = N * K, nw = O * K;
+  if (e < nx) {  // gx[n][k]
+    const int n = e / K, k = e - n * K;
+    float a = 0.f;
+#pragma unroll 10
+    for (int o = 0; o < O; ++o) a = fmaf(gzs[n * O + o], W1[(long)o * K + k], a);
+    gx[e] = a;
+  } else if (e < nx + nw) {  // gW1[o][k]
+    const int q = e - nx;
+    const int o = q / K, k = q - o * K;
+    float a = 0.f;
+#pragma unroll 8
+    for (int n = 0; n < N; ++n) a = fmaf(gzs[n * O + o], x[(long)n * K + k], a);
+    atomicAdd(gW1 + q, a);
+  } else if (e < nx + nw + O) {  // gb1[o]
+    const int o = e - nx - nw;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += gzs[n * O + o];
+    atomicAdd(gb1 + o, a);
+  } else if (e < nx + nw + 2 * O) {  // gW2[o] = sum_n glogit[n] * l1[n][o]
+    const int o = e - nx - nw - O;
+    float a = 0.f;
+#pragma unroll 8
+    for (int n = 0; n < N; ++n) a = fmaf(glogits[n], l1[(long)n * O + o], a);
+    atomicAdd(gW2 + o, a);
+  } else if (e == nx + nw + 2 * O) {  // gb2
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += glogits[n];
+    atomicAdd(gb2, a);
+  }
+}
+
+bool disc_head_bwd_fused_ok(int N, int O) { return sizeof(float) * (size_t)N * O <= 48 * 1024; }
+void launch_disc_head_bwd(const float* x, const float* W1, const float* W2, const float* glogits, const float* l1, float* gx, float* gW1,
+                          float* gb1, float* gW2, float* gb2, int N, int K, int O, float slope, hipStream_t s) {
+  if (dbm_abl_skip() & 32) return;  // (libdbm_measure.so only)
+  const int total = N * K + O * K + 2 * O + 1;
+  hipLaunchKernelGGL(disc_head_bwd_kernel, dim3((total + 255) / 256), dim3(256), sizeof(float) * (size_t)N * O, s, x, W1, W2, glogits, l1, gx,
+                     gW1, gb1, gW2, gb2, N, K, O, slope);
+  DBM_HIP(hipGetLastError());
+}
+
 // ----------------------------------------------------------------------------------------------
 // calculate_discriminator_loss (srgan_train.py:960-1009) + F.binary_accuracy (:1156-1158)
 // ----------------------------------------------------------------------------------------------
