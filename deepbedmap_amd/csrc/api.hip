@@ -1727,12 +1727,19 @@ int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off
       holder.run_dgrad(L, d, H, W);
       launch_deform_backward(x, off, gcol.p, nullptr, nullptr, gx, goff, N, C, H, W, 18 * P, s);
     }
-    WgradDesc wd;
-    memset(&wd, 0, sizeof(wd));
-    wd.x = col.p; wd.xsn = C * 9 * P; wd.xsc = (int)P; wd.Cin = C * 9; wd.Hin = H; wd.Win = W;
-    wd.dy = gy; wd.dysn = O * P; wd.dysc = (int)P; wd.Cout = O; wd.OH = H; wd.OW = W;
-    wd.KH = wd.KW = 1; wd.stride = 1; wd.pad = 0; wd.N = N; wd.scale = 1.f; wd.gW = gw; wd.gb = gb;
-    launch_wgrad(wd, s);
+    // (the generator's own form since round 6: the sampler-fused weight gradient, no sample matrix; DBM_DEFORM_WGRAD_FUSED=0: the 1x1 form)
+    static const int wg_fused_env = getenv("DBM_DEFORM_WGRAD_FUSED") ? atoi(getenv("DBM_DEFORM_WGRAD_FUSED")) : 1;
+    if (fused && wg_fused_env && C == 64 && O == 64) {
+      part.ensure(deform_wgrad64_partial_floats(N, H, W));
+      launch_deform_wgrad64_fused(xt.p, off, gy, gw, gb, part.p, N, H, W, 18 * P, s);
+    } else {
+      WgradDesc wd;
+      memset(&wd, 0, sizeof(wd));
+      wd.x = col.p; wd.xsn = C * 9 * P; wd.xsc = (int)P; wd.Cin = C * 9; wd.Hin = H; wd.Win = W;
+      wd.dy = gy; wd.dysn = O * P; wd.dysc = (int)P; wd.Cout = O; wd.OH = H; wd.OW = W;
+      wd.KH = wd.KW = 1; wd.stride = 1; wd.pad = 0; wd.N = N; wd.scale = 1.f; wd.gW = gw; wd.gb = gb;
+      launch_wgrad(wd, s);
+    }
     DBM_HIP(hipStreamSynchronize(s));
   }
   DBM_HIP(hipStreamSynchronize(s));

@@ -25,6 +25,7 @@
 #include "dbm_internal.h"
 #include "kernels.h"
 #include "deform_geom.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -201,6 +202,132 @@ __global__ __launch_bounds__(256) void deform_conv64_fused_kernel(const float* _
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<float4*>(yt + Pm * 64 + ct * 32 + 8 * g + 4 * kh) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+  }
+}
+
+// ---- weight gradient of the 64 -> 64 layer with the sampler fused in (round 6) ----
+// gW[o][c][t] += sum_{n,p} gy[n][o][p] * sample(c, t, n, p);  gb[o] += sum gy.
+// Until round 5 the retained forward wrote Chainer's sample matrix x_st (N, 576, plane): 191 MB at batch 64, written from the forward
+// kernel's tap loop on the generator's critical path (deform64 "keep": 128 us against 112 without, 250 against 117 us INSIDE the
+// iteration) and read back by a 1x1 weight-gradient GEMM on the side stream (102 us standalone, 212 MB).  This kernel re-samples instead:
+// the forward kernel's sampler (corner table of the tile, sixteen lanes per 256-byte corner run, blend into a [channel][position] LDS
+// tile, the next tap's gathers in flight under this tap's MFMAs) feeds MFMAs that contract over the tile's 64 POSITIONS: D[o][c] +=
+// gy[o][p] * sample[c][p], one 32 x 32 accumulator tile per tap and wavefront (quadrant (o tile, c tile) = (wave & 1, wave >> 1)): nine
+// tiles that live across the workgroup's tiles (persistent workgroups, strided tile assignment).  blockIdx.y = 0 / 1 takes taps 0..4 /
+// 5..8: nine tiles (144 registers) beside the sampler's 80 spilled at two workgroups per CU; five fit.  Partial sums go to
+// `partial` [workgroup][tap][o][c] (+ 64 bias sums), deform_wgrad64_fold_kernel adds them in workgroup order: deterministic.
+__global__ __launch_bounds__(256, 2) void deform_wgrad64_fused_kernel(const float* __restrict__ xt, const float* __restrict__ off,
+                                                                   const float* __restrict__ gy, float* __restrict__ partial, int N, int H,
+                                                                   int W, long offsn, int ntiles) {
+  __shared__ TileGeometry geo;
+  __shared__ float col[2][64 * DF_LD];   // [buffer][channel][position]
+  __shared__ float gys[64 * DF_LD];      // [out channel][position]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int plane = H * W;
+  const long total = (long)N * plane;
+  const int q = lane & 15, pi = lane >> 4;
+  const float* xq = xt + 4 * q;
+  const int ct = wave & 1, cq = wave >> 1, j = lane & 31, kh = lane >> 5;
+  const int half = blockIdx.y;        // taps [5 half, 5 half + NT)
+  f32x16 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;   // (half 0, threads 0..63: the bias gradient of out channel tid)
+  float4 c1[4], c2[4], c3[4], c4[4], cw[4];
+  auto gather = [&](int t) {  // requests the four corners of this lane's channel quad at its four positions
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = t * DF_POS + 16 * wave + 4 * i + pi;
+      const int4 id = geo.idx[e];
+      cw[i] = geo.wgt[e];
+      c1[i] = *reinterpret_cast<const float4*>(xq + (long)id.x * 64);
+      c2[i] = *reinterpret_cast<const float4*>(xq + (long)id.y * 64);
+      c3[i] = *reinterpret_cast<const float4*>(xq + (long)id.z * 64);
+      c4[i] = *reinterpret_cast<const float4*>(xq + (long)id.w * 64);
+    }
+  };
+  auto blend = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = blend4(cw[i], c1[i], c2[i], c3[i], c4[i]);
+      float* d = dst + (4 * q) * DF_LD + 16 * wave + 4 * i + pi;
+      d[0] = v.x; d[DF_LD] = v.y; d[2 * DF_LD] = v.z; d[3 * DF_LD] = v.w;
+    }
+  };
+  const float* asrc = gys + (ct * 32 + j) * DF_LD + kh;   // A[i = out channel][k = position parity]
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long P0 = (long)tile * DF_POS;
+    __syncthreads();   // the previous tile's readers of geo / col / gys are done
+    build_geometry(geo, off, offsn, P0, total, plane, H, W, tid);
+    {  // the tile of gy: wavefront w stages out channels 16 w .., 256-byte runs along the positions (positions past the end: zero)
+      const long P = P0 + lane;
+      const bool pv = P < total;
+      const long n = pv ? P / plane : 0;
+      const float* src = gy + n * 64 * plane + (pv ? P - n * plane : 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) gys[(16 * wave + i) * DF_LD + lane] = pv ? src[(long)(16 * wave + i) * plane] : 0.f;
+    }
+    __syncthreads();
+    gather(5 * half);
+    blend(col[0]);
+    __syncthreads();
+    if (half == 0 && tid < 64) {   // bias gradient: this tile's 64 positions of out channel tid
+      float a = 0.f;
+#pragma unroll 8
+      for (int pl = 0; pl < DF_POS; ++pl) a += gys[tid * DF_LD + pl];
+      bsum += a;
+    }
+    // local tap u = 0..4 (u == 4 only in half 0): tap 5 half + u, LDS buffer u & 1
+    auto multiply = [&](auto U_, bool more) {
+      constexpr int u = decltype(U_)::value;
+      if (more) gather(5 * half + u + 1);
+      __builtin_amdgcn_sched_barrier(0);  // the requests above stay in front of the MFMA block they overlap
+      const float* bsrc = col[u & 1] + (cq * 32 + j) * DF_LD + kh;   // B[k = position parity][j = in channel]
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(asrc[2 * kk], bsrc[2 * kk], acc[u], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) blend(col[(u + 1) & 1]);
+      __syncthreads();
+    };
+    multiply(std::integral_constant<int, 0>{}, true);
+    multiply(std::integral_constant<int, 1>{}, true);
+    multiply(std::integral_constant<int, 2>{}, true);
+    if (half == 0) {   // (uniform per workgroup)
+      multiply(std::integral_constant<int, 3>{}, true);
+      multiply(std::integral_constant<int, 4>{}, false);
+    } else {
+      multiply(std::integral_constant<int, 3>{}, false);
+    }
+  }
+  // ---- this workgroup's partial sums: [tap][o][c], 128-byte runs along c ----
+  float* pw = partial + (size_t)blockIdx.x * (9 * 64 * 64 + 64);
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int t = 5 * half + u;
+    if (t < 9) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pw[(t * 64 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * 64 + cq * 32 + j] = acc[u][r];
+    }
+  }
+  if (half == 0 && tid < 64) pw[9 * 64 * 64 + tid] = bsum;
+}
+
+// gw (64, 64, 3, 3) += sum over the workgroups' partial tiles, in workgroup order; gb (64) likewise
+__global__ __launch_bounds__(256) void deform_wgrad64_fold_kernel(const float* __restrict__ partial, int nwg, float* gw, float* gb) {
+  const int e = blockIdx.x * 256 + threadIdx.x;   // index into a partial block: (t * 64 + o) * 64 + c, then 64 bias sums
+  constexpr int PB = 9 * 64 * 64 + 64;
+  if (e >= PB) return;
+  float a = 0.f;
+#pragma unroll 8
+  for (int w = 0; w < nwg; ++w) a += partial[(size_t)w * PB + e];
+  if (e < 9 * 64 * 64) {
+    const int t = e / 4096, o = (e >> 6) & 63, c = e & 63;
+    gw[(o * 64 + c) * 9 + t] += a;
+  } else if (gb) {
+    gb[e - 9 * 64 * 64] += a;
   }
 }
 
@@ -965,6 +1092,38 @@ void launch_deform_bwd64_fused(const float* xt, const float* off, const float* w
     g_profiler.begin(s, 0, 2.0 * (double)total * 64 * 576, 4.0 * ((double)total * (64 + 18 + 64 + 576 + 18) + 576.0 * 64), tag, blocks);
   }
   hipLaunchKernelGGL(deform_bwd64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, wb, gy, gcol, goff, N, H, W, offsn);
+  if (g_profiler.enabled) g_profiler.end(s);
+  DBM_HIP(hipGetLastError());
+}
+
+// Weight gradient of the 64 -> 64 deformable layer from the channels-last input, the offsets and gy (no sample matrix): gw (64, 64, 3, 3)
+// and gb (64, may be null) are accumulated (+=) through `partial` (deform_wgrad64_partial_floats floats of scratch).
+static int deform_wgrad64_wgs(long ntiles) {
+  static const int n_cus = [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount;
+  }();
+  return (int)(ntiles < n_cus ? ntiles : n_cus);   // x 2 tap halves = two resident workgroups per CU (68 KB of LDS each)
+}
+size_t deform_wgrad64_partial_floats(int N, int H, int W) {
+  const long ntiles = ((long)N * H * W + DF_POS - 1) / DF_POS;
+  return (size_t)deform_wgrad64_wgs(ntiles) * (9 * 64 * 64 + 64);
+}
+void launch_deform_wgrad64_fused(const float* xt, const float* off, const float* gy, float* gw, float* gb, float* partial, int N, int H, int W,
+                                 long offsn, hipStream_t s) {
+  const long total = (long)N * H * W;
+  DBM_CHECK(total < (1L << 31), "fused deformable weight gradient: more than 2^31 positions");
+  const long ntiles = (total + DF_POS - 1) / DF_POS;
+  const int wgs = deform_wgrad64_wgs(ntiles);
+  if (g_profiler.enabled) {
+    char tag[40];
+    snprintf(tag, sizeof(tag), "deform_wgrad64_%dx%d_n%d", H, W, N);  // in: x, offsets, gy; out: the partial tiles, the gradient
+    g_profiler.begin(s, 1, 2.0 * (double)total * 64 * 576, 4.0 * ((double)total * (64 + 18 + 64) + 2.0 * wgs * (9 * 64 * 64 + 64) + 576.0 * 64), tag, wgs);
+  }
+  hipLaunchKernelGGL(deform_wgrad64_fused_kernel, dim3(wgs, 2), dim3(256), 0, s, xt, off, gy, partial, N, H, W, offsn, (int)ntiles);
+  hipLaunchKernelGGL(deform_wgrad64_fold_kernel, dim3((9 * 64 * 64 + 64 + 255) / 256), dim3(256), 0, s, partial, wgs, gw, gb);
   if (g_profiler.enabled) g_profiler.end(s);
   DBM_HIP(hipGetLastError());
 }

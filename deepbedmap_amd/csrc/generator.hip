@@ -177,6 +177,13 @@ bool Generator::deform_bwd_fused(int H4, int W4) const {
   return fused_env && out_ch == 1 && deform_conv_fused_ok(64, 64) && deform_input_grad_ok(64, H4, W4);
 }
 
+// final_conv_layer1's weight gradient from the channels-last input and the offsets (deform_wgrad64_fused_kernel) instead of from the retained
+// sample matrix.  DBM_DEFORM_WGRAD_FUSED=0: the sample matrix + the 1x1 form (A/B; both are parity-tested).
+bool Generator::deform_wgrad_fused(int H4, int W4) const {
+  static const int env = getenv("DBM_DEFORM_WGRAD_FUSED") ? atoi(getenv("DBM_DEFORM_WGRAD_FUSED")) : 1;
+  return env != 0 && deform_bwd_fused(H4, W4) && deform_conv_fused_ok(64, 64) && deform_conv_fused_ok(64, out_ch);
+}
+
 void Generator::ensure_ws(int N, int H, int W, bool train) {
   const bool same = (N == wsN && H == wsH && W == wsW);
   if (same && (wsTrain || !train)) return;
@@ -529,7 +536,10 @@ void Generator::forward(int N, int H, int W, const float* x, const float* w1, co
     }
     if (dfused) {
       if (!a42t_written) launch_nchw_to_nhwc64(a42.p, a42t.p, N, (int)P4, s);
-      launch_deform_conv_fused(a42t.p, off1.p, layers[L_def1].wf, P(layers[L_def1].bi), a51.p, a51t.p, keep ? col1.p : nullptr, N, 64, H4,
+      // (round 6: the layer's weight gradient re-samples -- deform_wgrad64_fused_kernel -- so a retained pass no longer writes the
+      //  191 MB sample matrix from this kernel's tap loop; only the unfused backward path still reads it)
+      float* colout = (keep && !deform_wgrad_fused(H4, W4)) ? col1.p : nullptr;
+      launch_deform_conv_fused(a42t.p, off1.p, layers[L_def1].wf, P(layers[L_def1].bi), a51.p, a51t.p, colout, N, 64, H4,
                                W4, 32 * P4, 64, 1, SLOPE, s);
     } else {
       launch_deform_sample(a42.p, off1.p, col1.p, N, 64, H4, W4, 32 * P4, s);
@@ -648,7 +658,9 @@ void Generator::backward(const float* gy) {
   // ---- final_conv_layer1 (deformable, 64 -> 64): g_a51 now holds d loss / d (pre-activation) ----
   {
     const IgLayer& L = layers[L_def1];
-    run_wgrad(L, col1.p, 576 * P4, H4, W4, 0, g_a51.p, 64 * P4, H4, W4, N, 1.f, &wbs[0]);
+    // (its weight gradient: sampler-fused, launched with the tail's batch on the side stream below -- deform_wgrad_fused; else from the
+    //  retained sample matrix through the batched 1x1 form)
+    if (!deform_wgrad_fused(H4, W4)) run_wgrad(L, col1.p, 576 * P4, H4, W4, 0, g_a51.p, 64 * P4, H4, W4, N, 1.f, &wbs[0]);
     if (bfused) {
       // column gradients W^T gy on the MFMAs, offset gradients from the same LDS tile; then the input-gradient gather
       launch_deform_bwd64_fused(a42t.p, off1.p, L.wb[1], g_a51.p, gcol.p, goff1.p, N, H4, W4, 32 * P4, s);
@@ -712,6 +724,11 @@ void Generator::backward(const float* gy) {
   static const int iter_abl = DBM_MEASURE_ENV("ITER_ABL");  // (libdbm_measure.so only: 2 = no trunk weight gradients, 4 = none of the tail's)
   const bool inline_wg = wgrad_inline && !ctx->comm_in_step;
   if (!(iter_abl & 4) && !inline_wg) wbs[0].launch(ctx->side);
+  if (deform_wgrad_fused(H4, W4) && !(iter_abl & 4)) {   // final_conv_layer1's weight / bias gradient (g_a51 and the offsets are final)
+    dw1_partial.ensure(deform_wgrad64_partial_floats(N, H4, W4));
+    launch_deform_wgrad64_fused(a42t.p, off1.p, g_a51.p, G(layers[L_def1].wi), G(layers[L_def1].bi), dw1_partial.p, N, H4, W4, 32 * P4,
+                                inline_wg ? s : ctx->side);
+  }
   if (col_stale) {  // (fused input block: the im2col images the wide branches' weight gradients read -- wbs[6], launched last)
     hipStream_t cs = inline_wg ? s : ctx->side;
     launch_im2col(bw_in[1] ? bw_in[1] : in_w1.p, colW1.p, N, 1, 10 * H, 10 * W, 30, 30, 10, h, w, layers[L_in[1]].CinP, cs);

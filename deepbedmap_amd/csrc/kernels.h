@@ -50,6 +50,10 @@ bool deform_conv_fused_ok(int C, int O);
 void launch_nchw_to_nhwc64(const float* x, float* xt, int N, int plane, hipStream_t s);
 void launch_deform_conv_fused(const float* xt, const float* off, const float* w, const float* bias, float* y, float* yt, float* colout,
                               int N, int C, int H, int W, long offsn, int O, int act, float slope, hipStream_t s, float* z = nullptr);
+// weight gradient of the 64 -> 64 deformable layer with the sampler fused in (no sample matrix): gw (64, 64, 3, 3) / gb (64 or null) += ...
+size_t deform_wgrad64_partial_floats(int N, int H, int W);
+void launch_deform_wgrad64_fused(const float* xt, const float* off, const float* gy, float* gw, float* gb, float* partial, int N, int H, int W,
+                                 long offsn, hipStream_t s);
 void launch_deform_bwd64_fused(const float* xt, const float* off, const float* wb, const float* gy, float* gcol, float* goff, int N, int H,
                                int W, long offsn, hipStream_t s);
 size_t deform_bwd1_partial_floats(int N, int H, int W);

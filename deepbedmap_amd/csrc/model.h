@@ -240,6 +240,8 @@ struct Generator : dbm_model {
   void prebuild_csr(hipStream_t aux);
   DevBuf dw2_partial;  // per-workgroup partial sums of final_conv_layer2's weight gradient (deform_bwd1_fused_kernel)
   bool deform_bwd_fused(int H4, int W4) const;
+  bool deform_wgrad_fused(int H4, int W4) const;
+  DevBuf dw1_partial;  // per-workgroup partial tiles of final_conv_layer1's weight gradient (deform_wgrad64_fused_kernel)
   DevBuf zdef;        // the last layer's premultiplied tap planes (N, 9 * out_ch, 4H, 4W): deform1_premul_kernel
   bool a42t_written = false;  // forward(): post_upsample_conv_layer_2 wrote the channels-last twin of its output itself
   bool zdef_kept = false;  // ... of the retained forward pass (the 64 -> 1 layer's backward in premultiplied form reads them)
