@@ -1399,7 +1399,9 @@ int dbm_train_iteration(dbm_model* gm, dbm_model* dm, int N, int H, int W, const
   }
   // ---- the generator's loss terms and backward pass (:1248-1256) on chain[1], behind its forward ----
   c->stream = pf;
+  DBM_MARK(pf, "G:retained_forward_done");
   gen_loss_terms(c, t->yout.p, Y, X, N, H4, W4, weights, ssim_window, t->g_y.p);
+  DBM_MARK(pf, "G:loss_terms");
   DBM_HIP(hipEventRecord(c->ev_iter[0], pf));
   DBM_HIP(hipStreamWaitEvent(pf, c->ev_iter[2], 0));  // cleargrads (:1255): the fill at the head of the side stream (+ the weight images)
   mark_grads_cleared(g);

@@ -623,6 +623,7 @@ void Generator::backward(const float* gy) {
     dw2_partial.ensure(deform_bwd1_partial_floats(N, H4, W4));
     csr_ws.ensure(deform_csr_workspace_floats(N, H4, W4));
     if (pre_csr) DBM_HIP(hipStreamWaitEvent(s, ev_csr, 0));
+    DBM_MARK(s, "G:backward_begin");   // (behind the wait for the prebuilt sampling lists)
     // Round 5: in the premultiplied form of the forward pass (z_t = sum_c w[c][t] x_c kept from it) the layer's whole backward is a
     // CSR gather of ONE value per list entry, four single-float gathers per (position, tap) and one pass over the input -- instead of
     // gathering 9 x 4 x 256 bytes per position for the offset / weight gradients (150 us) and 64 values per entry for the input gradient.
@@ -922,7 +923,9 @@ void Generator::backward(const float* gy) {
   //  eval-mode pass each wait for a free slot.  The order below stays.)
   ctx->fork_to_side(6);
   hipStream_t wgs = inline_wg ? s : ctx->side;
+  DBM_MARK(wgs, "G:side_backlog_done");   // (phase marks on the weight-gradient stream: what stood in front of the trunk's launch is done)
   if (prev_grp >= 0 && !(iter_abl & 2)) wbs[prev_grp].launch(wgs);
+  DBM_MARK(wgs, "G:trunk_weight_gradients");
   if (inline_wg && !(iter_abl & 4)) wbs[0].launch(wgs);
   wbs[6].launch(wgs);
   for (int k = 0; k < nsmall; ++k) {  // the two single-channel 3x3 branches of the input block
