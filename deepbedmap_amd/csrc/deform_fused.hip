@@ -64,8 +64,8 @@ struct TileGeometry {
 };
 
 __device__ __forceinline__ void build_geometry(TileGeometry& g, const float* __restrict__ off, long offsn, long P0, long total, int plane,
-                                               int H, int W, int tid, int abl = 0) {
-  for (int e = tid; e < 9 * DF_POS; e += 256) {
+                                               int H, int W, int tid, int abl = 0, int t_lo = 0, int t_hi = 9) {
+  for (int e = t_lo * DF_POS + tid; e < t_hi * DF_POS; e += 256) {
     const int t = e >> 6, pl = e & 63;
     const long P = P0 + pl;
     int4 id = make_int4(0, 0, 0, 0);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void deform_wgrad64_fused_kernel(const floa
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long P0 = (long)tile * DF_POS;
     __syncthreads();   // the previous tile's readers of geo / col / gys are done
-    build_geometry(geo, off, offsn, P0, total, plane, H, W, tid);
+    build_geometry(geo, off, offsn, P0, total, plane, H, W, tid, 0, 5 * half, half ? 9 : 5);   // (this half's taps only)
     {  // the tile of gy: wavefront w stages out channels 16 w .., 256-byte runs along the positions (positions past the end: zero)
       const long P = P0 + lane;
       const bool pv = P < total;

@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 6, call 17: the whole -m gpu suite on the round's code, then everything profiles/r6/ holds for it (tools/collect_profiles.sh)
+cd "${GRAFT_REPO_ROOT:?}"
+O=gpurun_out/r6c17; mkdir -p $O
+timeout 2400 python3 -m pytest tests -x -q -m gpu > $O/full_tests.log 2>&1; echo "pytest rc $?" >> $O/full_tests.log; tail -4 $O/full_tests.log
+bash tools/collect_profiles.sh r6z z_round6 > $O/collect.log 2>&1; tail -25 $O/collect.log
+cut -c1-600 gpurun_out/r6z/z_round6_bench.json

@@ -21,14 +21,15 @@ def family(kn):
     return ("igemm_conv_kernel" if ("igemm_conv_kernel" in kn or "igemm_pm_kernel" in kn or "conv_tile_kernel" in kn or "input_block_fused_kernel" in kn or "deform_conv64_fused" in kn or "deform_bwd64_fused" in kn)
             else "trunk_fused_bwd_kernel" if "trunk_fused_bwd_kernel" in kn
             else "trunk_fused_kernel_helper" if "trunk_fused_kernel<27, true>" in kn  # the form with a helper workgroup per image
-            else "trunk_fused_kernel" if "trunk_fused_kernel" in kn and "pack" not in kn else "wgrad_kernel" if "wgrad_" in kn else None)
+            else "trunk_fused_kernel" if "trunk_fused_kernel" in kn and "pack" not in kn
+            else "wgrad_kernel" if ("wgrad_" in kn or "deform_wgrad64_fused" in kn) else None)
 
 
 def shape_class(kn):
     """the class a launch belongs to in bench.py's per-shape tables (roofline.per_shape / extras.sweep.*.per_shape_standalone)"""
     for pat, c in (("igemm_conv_kernel", "igemm"), ("igemm_pm_kernel", "igemm"), ("conv_tile_kernel", "igemm"), ("input_block_fused_kernel", "igemm"), ("deform_conv64_fused", "deform64"), ("deform_conv64_x3", "deform64x3"), ("deform_conv1_fused", "deform1"),
                    ("deform1_premul", "deform1"), ("deform1_sample", None),
-                   ("deform_bwd64_fused", "deform_bwd64"), ("conv_cl16x3_kernel", "x3"), ("conv_cl16_kernel", "cl16"),
+                   ("deform_bwd64_fused", "deform_bwd64"), ("deform_wgrad64_fused", "wgrad"), ("deform_wgrad64_fold", None), ("conv_cl16x3_kernel", "x3"), ("conv_cl16_kernel", "cl16"),
                    ("trunk_fused_bwd_kernel", "trunk_bwd"), ("trunk_fused_kernel", "trunk_fwd"), ("wgrad_pair_fold", None), ("wgrad_fold", None),
                    ("wgrad_", "wgrad")):
         if pat in kn and "pack" not in kn:
@@ -37,7 +38,7 @@ def shape_class(kn):
 
 
 def tag_class(tag):
-    for pre, c in (("deform_bwd64", "deform_bwd64"), ("deform64x3", "deform64x3"), ("deform64", "deform64"), ("deform", "deform1"), ("x3_", "x3"), ("cl16_", "cl16"),
+    for pre, c in (("deform_bwd64", "deform_bwd64"), ("deform_wgrad64", "wgrad"), ("deform64x3", "deform64x3"), ("deform64", "deform64"), ("deform", "deform1"), ("x3_", "x3"), ("cl16_", "cl16"),
                    ("trunk_fwd", "trunk_fwd"), ("trunk_bwd", "trunk_bwd"), ("input_block", "igemm"), ("c", "igemm")):
         if tag.startswith(pre):
             return c
