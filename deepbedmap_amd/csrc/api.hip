@@ -1602,7 +1602,8 @@ int dbm_op_conv2d_cl16x3(dbm_ctx* ctx, const float* x, const float* w, const flo
 int dbm_op_deform_conv2d_form(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y, int N, int H,
                               int W, int O, int form, int lrelu) {
   DBM_API_BEGIN(ctx)
-  DBM_CHECK((form == 1 && O >= 1 && O <= 16) || (form == 2 && O == 64), "deform conv op: form 1 (O <= 16, premultiplied) or 2 (O = 64, split-bf16)");
+  DBM_CHECK((form == 1 && O >= 1 && O <= 16) || ((form == 2 || form == 3 || form == 4) && O == 64),
+            "deform conv op: form 1 (O <= 16, premultiplied) or 2 (O = 64, split-bf16; 3: its LDS-window kernel, 4: its gathering kernel)");
   hipStream_t s = ctx->stream;
   const long plane = (long)H * W;
   DevBuf xt, z, wx;
@@ -1614,7 +1615,7 @@ int dbm_op_deform_conv2d_form(dbm_ctx* ctx, const float* x, const float* off, co
   } else {
     wx.ensure((deform_x3_packed_elems() + 1) / 2);
     launch_pack_deform_x3(w, wx.p, s);
-    launch_deform_conv64_x3(xt.p, off, wx.p, b, y, nullptr, N, H, W, 18L * plane, lrelu, 0.2f, s);
+    launch_deform_conv64_x3(xt.p, off, wx.p, b, y, nullptr, N, H, W, 18L * plane, lrelu, 0.2f, s, form == 3 ? 1 : form == 4 ? 0 : -1);
   }
   DBM_HIP(hipStreamSynchronize(s));
   xt.release(); z.release(); wx.release();

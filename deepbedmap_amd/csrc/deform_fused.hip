@@ -501,6 +501,278 @@ __global__ __launch_bounds__(256) void deform_conv64_x3_kernel(const float* __re
   }
 }
 
+// ---- the same layer with the sampler reading an LDS WINDOW of the input (round 6; the bf16 sweep's full-resolution planes) ----
+// deform_conv64_x3_kernel gathers four corners x 256 bytes per position and tap from the vector L1: 12 GB per 1144 x 1144 plane, 0.8 of the
+// 4.8 ms of a crop.  Neighbouring positions and taps share almost all of those corners as long as the offsets are a few pixels: here a
+// workgroup owns a 16 x 16 tile of positions and stages the input pixels every sample with offsets in [-2, 3) can touch -- the tile, one
+// ring for the 3 x 3 taps, DW_R rings for the offsets, one more row / column for the bilinear neighbour: 23 x 23 pixels x 256 bytes (fp32,
+// all 64 channels) = 132 KB, once -- 2.07 pixels staged per position instead of 36 gathered.
+//   * LDS layout: pixel p (row-major in the window) at p * 272: its 256 bytes + 16 of padding.  The lanes of a ds_read_b128 group hold
+//     sixteen consecutive positions of a row, whose corners are (for smooth offsets) consecutive pixels: 272 bytes apart = four banks
+//     further each, sixteen of them = all 64 banks.  Padding, not an XOR swizzle: a lane's 32 reads per tap (four corners x eight
+//     16-byte parts) are then ONE base register + immediate offsets -- the first version spent two VALU instructions per read on swizzled
+//     addresses (2 700 VALU instructions per lane and tile, more cycles than its MFMAs, LDS reads or weight loads);
+//     staged through registers (LDS-DMA writes a wavefront's 1 KB contiguously: no padding).
+//   * no sample tile, no geometry table, no barrier inside the tap loop: a wavefront owns two rows of the tile (32 positions, dealt to
+//     the lanes by the ds_read_b128 groups as in conv_cl16.hip) and BOTH output-channel tiles; lane (j, kg) samples the eight channels
+//     16 ks + 8 kg .. + 7 of its position straight into the B operand of the k step (blend in fp32, split hi / lo in registers).
+//   * 36 steps (tap, k step), software-pipelined by hand: the corner reads and weight fragments of step s + 1 are requested before the
+//     blend of step s, whose MFMAs run under the blend of step s + 1 (hipcc left to itself waits for every read right behind its issue).
+//   * arithmetic and summation order are deform_conv64_x3_kernel's (same blend expression, same split, taps outer, k steps inner, the
+//     three products small terms first): the results are the same bits.
+//   * a wavefront one of whose samples leaves the window (offsets beyond DW_R: rare) takes the generic loop instead: per tap either the
+//     window or, like the older kernel, global memory -- any offset is served, the window is an accelerator.
+constexpr int DW_T = 16;                          // tile edge (positions)
+constexpr int DW_R = 2;                           // offsets in [-DW_R, DW_R + 1) stay inside the window
+constexpr int DW_WIN = DW_T + 2 * DW_R + 3;       // 23
+constexpr int DW_NPIX = DW_WIN * DW_WIN;          // 529
+constexpr int DW_PIX = 272;                       // bytes between pixels in LDS
+constexpr int DW_LDS = DW_NPIX * DW_PIX;          // 143 888 bytes
+constexpr int DW_STEPS = (DW_NPIX * 16 + 511) / 512;   // 16-byte pieces per thread
+
+// half-lane h (0..31) -> (row 0/1, column 0..15) of the wavefront's 2 x 16 patch: each 16-lane group of a ds_read_b128
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}: MI355X_MICROARCH.md, LDS) covers one row (conv_cl16.hip's patch_of)
+__device__ __forceinline__ void dw_patch_of(int h, int& g, int& i) {
+  if (h < 4) { g = 0; i = h; }
+  else if (h < 12) { g = 1; i = h - 4; }
+  else if (h < 16) { g = 0; i = h - 8; }
+  else if (h < 20) { g = 1; i = h - 8; }
+  else if (h < 28) { g = 0; i = h - 12; }
+  else { g = 1; i = h - 16; }
+}
+
+__global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __restrict__ xt, const float* __restrict__ off,
+                                                                const dbf16x8* __restrict__ wx, const float* __restrict__ bias,
+                                                                float* __restrict__ y, float* __restrict__ yt, int N, int H, int W,
+                                                                long offsn, int act, float slope, int tilesX, int tilesY) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char win[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // workgroup -> tile: every XCD (workgroups are dealt to the eight XCDs round robin) takes one contiguous run of tiles -- neighbouring
+  // tiles share window rows and columns in that XCD's L2
+  unsigned b = blockIdx.x;
+  {
+    const unsigned per = gridDim.x >> 3, rem = gridDim.x & 7, x = b & 7, k = b >> 3;
+    b = x * per + (x < rem ? x : rem) + k;
+  }
+  const int tx = (int)(b % (unsigned)tilesX);
+  b /= (unsigned)tilesX;
+  const int ty = (int)(b % (unsigned)tilesY), n = (int)(b / (unsigned)tilesY);
+  const int plane = H * W;
+  const int wy0 = ty * DW_T - 1 - DW_R, wx0 = tx * DW_T - 1 - DW_R;   // image coordinates of window pixel (0, 0)
+  const float* xn = xt + (long)n * plane * 64;
+  {  // ---- the window: sixteen lanes per pixel (256 contiguous bytes), zeros outside the image ----
+    float4 st[DW_STEPS];
+#pragma unroll
+    for (int it = 0; it < DW_STEPS; ++it) {
+      const int u = it * 512 + tid, px = u >> 4, part = u & 15;
+      const int hy = px / DW_WIN, hx = px - hy * DW_WIN;
+      const int gy = wy0 + hy, gx = wx0 + hx;
+      const bool inside = px < DW_NPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      st[it] = inside ? *reinterpret_cast<const float4*>(xn + ((long)gy * W + gx) * 64 + 4 * part) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < DW_STEPS; ++it) {
+      const int u = it * 512 + tid, px = u >> 4, part = u & 15;
+      if (px < DW_NPIX) *reinterpret_cast<float4*>(win + px * DW_PIX + part * 16) = st[it];
+    }
+  }
+  // ---- this lane's position, its eighteen offsets, the nine taps' geometry ----
+  int g, i;
+  dw_patch_of(lane & 31, g, i);
+  const int kg = lane >> 5;
+  const int a = ty * DW_T + 2 * wave + g, bcol = tx * DW_T + i;
+  const bool valid = a < H && bcol < W;
+  const int p = a * W + bcol;
+  int pc[9];        // LDS byte address of the top-left corner's pixel (+ this lane's k group), if every corner is inside the window
+  float4 cw[9];     // bilinear weights (build_geometry's: a corner outside the image has weight 0)
+  bool far = false;
+  {
+    const float* on = off + (long)n * offsn + (valid ? p : 0);
+    float ox[9], oy[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      ox[t] = on[(long)t * plane];
+      oy[t] = on[(long)(9 + t) * plane];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const DeformGeom q = deform_geom(ox[t], oy[t], a, bcol, t / 3, t % 3, H, W, 1);
+      const int y0 = q.v0 - 2, x0 = q.u0 - 2;   // image coordinates of the top-left corner (deform_corner: - pad - 1)
+      const bool iy0 = (unsigned)y0 < (unsigned)H, iy1 = (unsigned)(y0 + 1) < (unsigned)H;
+      const bool ix0 = (unsigned)x0 < (unsigned)W, ix1 = (unsigned)(x0 + 1) < (unsigned)W;
+      cw[t].x = (valid && iy0 && ix0) ? q.wu1 * q.wv1 : 0.f;
+      cw[t].y = (valid && iy0 && ix1) ? q.wu0 * q.wv1 : 0.f;
+      cw[t].z = (valid && iy1 && ix0) ? q.wu1 * q.wv0 : 0.f;
+      cw[t].w = (valid && iy1 && ix1) ? q.wu0 * q.wv0 : 0.f;
+      const int ry = y0 - wy0, rx = x0 - wx0;
+      const bool near = (unsigned)ry < (unsigned)(DW_WIN - 1) && (unsigned)rx < (unsigned)(DW_WIN - 1);
+      far |= valid && !near;
+      pc[t] = near ? (ry * DW_WIN + rx) * DW_PIX + kg * 32 : valid ? -1 : kg * 32;   // (-1: this tap of this lane leaves the window)
+    }
+  }
+  const bool wave_far = __builtin_amdgcn_ballot_w64(far) != 0;   // wave-uniform
+  const dbf16x8* wl = wx + lane;   // + ((t * 4 + ks) * 2 + hl) * 128 + ct * 64
+  f32x16 acc[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  __syncthreads();
+
+  auto split = [](const float4& v0, const float4& v1, dbf16x8& bh, dbf16x8& bl) {
+    const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const __bf16 hi = (__bf16)f[u];
+      bh[u] = hi;
+      bl[u] = (__bf16)(f[u] - (float)hi);
+    }
+  };
+  auto mfmas = [&](const dbf16x8 (&A)[4], const dbf16x8& bh, const dbf16x8& bl) {   // A: hi ct 0, hi ct 1, lo ct 0, lo ct 1
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ct], bl, acc[ct], 0, 0, 0);   // small terms first
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2 + ct], bh, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ct], bh, acc[ct], 0, 0, 0);
+    }
+  };
+  auto weights = [&](int st, dbf16x8 (&A)[4]) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      A[ct] = wl[(st * 2 + 0) * 128 + ct * 64];
+      A[2 + ct] = wl[(st * 2 + 1) * 128 + ct * 64];
+    }
+  };
+  if (!wave_far) {
+    // ---- every sample of this wavefront inside the window: 36 pipelined steps ----
+    // The reads are inline asm with hand-placed wait counts: left to hipcc every read ends up right in front of its first use (its IR
+    // passes sink loads through __builtin_amdgcn_sched_barrier; volatile loads turn into flat loads with a wait each).  A step requests
+    // the eight corner pieces and four weight fragments of step s + 1, waits for step s's (vmcnt / lgkmcnt count in order: "all but the
+    // twelve just issued"; the values pass through the wait as "+v" operands, so that nothing using them can move above it), blends,
+    // splits, multiplies.
+    typedef float f4t __attribute__((ext_vector_type(4)));
+    f4t C[2][8], A[2][4];
+    const unsigned lbase = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)win;
+    const unsigned char* wp = reinterpret_cast<const unsigned char*>(wl);   // + 4096 per step; hi ct 0 / hi ct 1 / lo ct 0 / lo ct 1: + 0 / 1024 / 2048 / 3072
+    auto request = [&](int st, f4t (&c)[8], f4t (&aw)[4]) {
+      const unsigned ad = lbase + (unsigned)pc[st >> 2] + (st & 3) * 64;
+      asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\t"
+                   "ds_read_b128 %2, %8 offset:%9\n\tds_read_b128 %3, %8 offset:%10\n\t"
+                   "ds_read_b128 %4, %8 offset:%11\n\tds_read_b128 %5, %8 offset:%12\n\t"
+                   "ds_read_b128 %6, %8 offset:%13\n\tds_read_b128 %7, %8 offset:%14"
+                   : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+                   : "v"(ad), "n"(DW_PIX), "n"(DW_PIX + 16), "n"(DW_WIN * DW_PIX), "n"(DW_WIN * DW_PIX + 16), "n"((DW_WIN + 1) * DW_PIX),
+                     "n"((DW_WIN + 1) * DW_PIX + 16));
+      const unsigned char* q = wp + (long)st * 4096;
+      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"
+                   "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"
+                   : "=&v"(aw[0]), "=&v"(aw[1]), "=&v"(aw[2]), "=&v"(aw[3])
+                   : "v"(q));
+    };
+    auto arrived = [&](f4t (&c)[8], f4t (&aw)[4], bool last) {
+      if (last)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(aw[0]), "+v"(aw[1]),
+                       "+v"(aw[2]), "+v"(aw[3]));
+      else
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(8)"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(aw[0]), "+v"(aw[1]),
+                       "+v"(aw[2]), "+v"(aw[3]));
+    };
+    auto f4 = [](const f4t& v) { return make_float4(v[0], v[1], v[2], v[3]); };
+    request(0, C[0], A[0]);
+#pragma unroll
+    for (int st = 0; st < 36; ++st) {
+      f4t (&c)[8] = C[st & 1];
+      f4t (&aw)[4] = A[st & 1];
+      if (st + 1 < 36) request(st + 1, C[(st + 1) & 1], A[(st + 1) & 1]);
+      arrived(c, aw, st + 1 >= 36);
+      const float4 v0 = blend4(cw[st >> 2], f4(c[0]), f4(c[2]), f4(c[4]), f4(c[6]));
+      const float4 v1 = blend4(cw[st >> 2], f4(c[1]), f4(c[3]), f4(c[5]), f4(c[7]));
+      dbf16x8 bh, bl;
+      split(v0, v1, bh, bl);
+      const dbf16x8 Aw[4] = {__builtin_bit_cast(dbf16x8, aw[0]), __builtin_bit_cast(dbf16x8, aw[1]), __builtin_bit_cast(dbf16x8, aw[2]),
+                             __builtin_bit_cast(dbf16x8, aw[3])};
+      mfmas(Aw, bh, bl);
+    }
+  } else {
+    // ---- the generic loop: per tap the window, or global memory when a lane's sample leaves it ----
+#pragma unroll   // (a run-time tap index would send pc[] and cw[] to scratch -- for the pipelined side as well)
+    for (int t = 0; t < 9; ++t) {
+      const bool tap_far = __builtin_amdgcn_ballot_w64(valid && pc[t] < 0) != 0;   // wave-uniform
+      // a far lane's corners: image offsets from the encoded top-left corner; a corner outside the image: offset 0 (its weight is 0)
+      long go[4] = {0, 0, 0, 0};
+      if (tap_far) {
+        const DeformGeom q = deform_geom(off[(long)n * offsn + (long)t * plane + (valid ? p : 0)],
+                                         off[(long)n * offsn + (long)(9 + t) * plane + (valid ? p : 0)], a, bcol, t / 3, t % 3, H, W, 1);
+        const int y0 = q.v0 - 2, x0 = q.u0 - 2;
+        const bool iy0 = (unsigned)y0 < (unsigned)H, iy1 = (unsigned)(y0 + 1) < (unsigned)H;
+        const bool ix0 = (unsigned)x0 < (unsigned)W, ix1 = (unsigned)(x0 + 1) < (unsigned)W;
+        go[0] = (iy0 && ix0) ? ((long)y0 * W + x0) * 64 : 0;
+        go[1] = (iy0 && ix1) ? ((long)y0 * W + x0 + 1) * 64 : 0;
+        go[2] = (iy1 && ix0) ? ((long)(y0 + 1) * W + x0) * 64 : 0;
+        go[3] = (iy1 && ix1) ? ((long)(y0 + 1) * W + x0 + 1) * 64 : 0;
+      }
+      const int pb = pc[t] >= 0 ? pc[t] : kg * 32;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        float4 c[8];
+        if (!tap_far) {
+          const unsigned char* bp = win + pb + ks * 64;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            c[0 + e] = *reinterpret_cast<const float4*>(bp + 16 * e);
+            c[2 + e] = *reinterpret_cast<const float4*>(bp + DW_PIX + 16 * e);
+            c[4 + e] = *reinterpret_cast<const float4*>(bp + DW_WIN * DW_PIX + 16 * e);
+            c[6 + e] = *reinterpret_cast<const float4*>(bp + (DW_WIN + 1) * DW_PIX + 16 * e);
+          }
+        } else {
+          const float* gp = xn + 16 * ks + 8 * kg;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            c[0 + e] = *reinterpret_cast<const float4*>(gp + go[0] + 4 * e);
+            c[2 + e] = *reinterpret_cast<const float4*>(gp + go[1] + 4 * e);
+            c[4 + e] = *reinterpret_cast<const float4*>(gp + go[2] + 4 * e);
+            c[6 + e] = *reinterpret_cast<const float4*>(gp + go[3] + 4 * e);
+          }
+        }
+        dbf16x8 A[4];
+        weights(t * 4 + ks, A);
+        const float4 v0 = blend4(cw[t], c[0], c[2], c[4], c[6]);
+        const float4 v1 = blend4(cw[t], c[1], c[3], c[5], c[7]);
+        dbf16x8 bh, bl;
+        split(v0, v1, bh, bl);
+        mfmas(A, bh, bl);
+      }
+    }
+  }
+  if (!valid) return;
+  const long Pm = (long)n * plane + p;
+  float v[2][16];   // (all bias loads before the first store: see deform_conv64_fused_kernel)
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      v[ct][r] = acc[ct][r] + (bias ? bias[c] : 0.f);
+      if (act) v[ct][r] = v[ct][r] >= 0.f ? v[ct][r] : slope * v[ct][r];
+    }
+  if (y) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[(long)n * 64 * plane + p + (long)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg) * plane] = v[ct][r];
+  }
+  if (yt) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<float4*>(yt + Pm * 64 + ct * 32 + 8 * gq + 4 * kg) =
+            make_float4(v[ct][4 * gq], v[ct][4 * gq + 1], v[ct][4 * gq + 2], v[ct][4 * gq + 3]);
+  }
+}
+
 // w: canonical OIHW (64, 64, 3, 3) -> wx [tap][k step][hi | lo][channel tile][lane][8]
 __global__ __launch_bounds__(256) void pack_deform_x3_kernel(const float* __restrict__ w, __bf16* __restrict__ wx) {
   const int idx = blockIdx.x * 256 + threadIdx.x;   // (t, ks, ct, lane, e)
@@ -1061,17 +1333,34 @@ void launch_pack_deform_x3(const float* w_oihw, void* dst, hipStream_t s) {
   DBM_HIP(hipGetLastError());
 }
 // the 64 -> 64 layer in split-bf16 arithmetic (forward only): wx from launch_pack_deform_x3; y and / or yt
+// window: 0 the gathering kernel, 1 the LDS-window kernel, -1 the launcher's choice (DBM_DEFORM_X3_WINDOW, default: the window on planes
+// with at least one workgroup per CU)
 void launch_deform_conv64_x3(const float* xt, const float* off, const void* wx, const float* bias, float* y, float* yt, int N, int H, int W,
-                             long offsn, int act, float slope, hipStream_t s) {
+                             long offsn, int act, float slope, hipStream_t s, int window) {
   const long total = (long)N * H * W;
   DBM_CHECK(total < (1L << 31), "fused deformable convolution: more than 2^31 positions");
-  const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
+  const int tilesX = (W + DW_T - 1) / DW_T, tilesY = (H + DW_T - 1) / DW_T;
+  const long tiles = (long)N * tilesX * tilesY;
+  if (window < 0) {
+    static const int env = getenv("DBM_DEFORM_X3_WINDOW") ? atoi(getenv("DBM_DEFORM_X3_WINDOW")) : 1;
+    window = env && tiles >= 256 ? 1 : 0;
+  }
+  const unsigned blocks = window ? (unsigned)tiles : (unsigned)((total + DF_POS - 1) / DF_POS);
   if (g_profiler.enabled) {
     const double bytes = 4.0 * (double)total * (64 + 18 + (y ? 64 : 0) + (yt ? 64 : 0)) + 2.0 * 2.0 * 9 * 64 * 64;
     char tag[40];
-    snprintf(tag, sizeof(tag), "deform64x3_%dx%d_n%d", H, W, N);
+    snprintf(tag, sizeof(tag), "deform64x3%s_%dx%d_n%d", window ? "w" : "", H, W, N);
     g_profiler.begin(s, 0, 2.0 * (double)total * 64 * 64 * 9, bytes, tag, blocks);
   }
+  if (window) {
+    static bool attr = false;
+    if (!attr) {
+      DBM_HIP(hipFuncSetAttribute((const void*)deform_conv64_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    hipLaunchKernelGGL(deform_conv64_x3w_kernel, dim3(blocks), dim3(512), DW_LDS, s, xt, off, (const dbf16x8*)wx, bias, y, yt, N, H, W, offsn,
+                       act, slope, tilesX, tilesY);
+  } else
   hipLaunchKernelGGL(deform_conv64_x3_kernel, dim3(blocks), dim3(256), 0, s, xt, off, (const dbf16x8*)wx, bias, y, yt, N, H, W, offsn, act,
                      slope);
   if (g_profiler.enabled) g_profiler.end(s);

@@ -45,7 +45,7 @@ void launch_deform_backward(const float* x, const float* off, const float* gcol,
 size_t deform_x3_packed_elems();   // bf16 elements of the split-bf16 weight image of a 64 -> 64 deformable layer
 void launch_pack_deform_x3(const float* w_oihw, void* dst, hipStream_t s);
 void launch_deform_conv64_x3(const float* xt, const float* off, const void* wx, const float* bias, float* y, float* yt, int N, int H, int W,
-                             long offsn, int act, float slope, hipStream_t s);
+                             long offsn, int act, float slope, hipStream_t s, int window = -1);
 bool deform_conv_fused_ok(int C, int O);
 void launch_nchw_to_nhwc64(const float* x, float* xt, int N, int plane, hipStream_t s);
 void launch_deform_conv_fused(const float* xt, const float* off, const float* w, const float* bias, float* y, float* yt, float* colout,

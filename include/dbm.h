@@ -333,7 +333,9 @@ int dbm_op_deform_conv2d(dbm_ctx* ctx, const float* x, const float* off, const f
                          int N, int C, int H, int W, int O);
 /* the two other forms of the forward pass the generator uses, 64 input channels: form 1 = the few-output-channel layer
  * (O <= 16; srgan_train.py:574, the DEM itself) with the multiplication BEFORE the sampler -- nine premultiplied tap planes,
- * scalar gathers --, form 2 = the 64 -> 64 layer (:572) in the sweep's split-bf16 arithmetic (+ LeakyReLU 0.2 if lrelu) */
+ * scalar gathers --, form 2 = the 64 -> 64 layer (:572) in the sweep's split-bf16 arithmetic (+ LeakyReLU 0.2 if lrelu); forms 3 and 4
+ * name form 2's two kernels explicitly -- 3: the sampler reads an LDS window of the input (what the sweep's full-resolution planes take),
+ * 4: it gathers every corner from memory (small planes); same arithmetic, same bits */
 int dbm_op_deform_conv2d_form(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* b, float* y, int N, int H,
                               int W, int O, int form, int lrelu);
 int dbm_op_deform_conv2d_backward(dbm_ctx* ctx, const float* x, const float* off, const float* w, const float* gy,

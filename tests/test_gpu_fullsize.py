@@ -249,16 +249,18 @@ def test_config3_other_forms_of_the_trunk_forward_match_the_fixture(form):
     assert res.returncode == 0 and "2 passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
-@pytest.mark.parametrize("form", ["post_residual_in_fp32_igemm", "pre_and_post_residual_in_fp32_igemm"])
+@pytest.mark.parametrize("form", ["post_residual_in_fp32_igemm", "pre_and_post_residual_in_fp32_igemm", "deformable_layer_gathers_from_memory"])
 def test_config5_other_forms_of_the_sweep_tail_match_the_fixture(form):
     """The bf16 sweep's switchable layer forms (read once per process) against the same 288 x 288 crop fixture: bit 32 of
     DBM_BF16_FP32_LAYERS (the post-residual convolution as an fp32 igemm launch between layout conversions instead of split-bf16 on the
-    channels-last planes) and DBM_POST_X3=0 / DBM_PRE_X3=0 (both of them; round 5's A/B switches)."""
+    channels-last planes), DBM_POST_X3=0 / DBM_PRE_X3=0 (both of them; round 5's A/B switches) and DBM_DEFORM_X3_WINDOW=0 (round 6: the
+    64 -> 64 deformable layer's sampler gathers every corner from memory instead of reading an LDS window)."""
     import subprocess
 
     env = dict(os.environ)
     env.update({"post_residual_in_fp32_igemm": {"DBM_BF16_FP32_LAYERS": "59"},
-                "pre_and_post_residual_in_fp32_igemm": {"DBM_POST_X3": "0", "DBM_PRE_X3": "0"}}[form])
+                "pre_and_post_residual_in_fp32_igemm": {"DBM_POST_X3": "0", "DBM_PRE_X3": "0"},
+                "deformable_layer_gathers_from_memory": {"DBM_DEFORM_X3_WINDOW": "0"}}[form])
     here = os.path.abspath(__file__)
     res = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider", "-k",
                           "config5_full_crop_fp32_and_bf16_match_oracle_fixture"],

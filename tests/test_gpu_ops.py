@@ -237,6 +237,34 @@ def test_deform_conv_forward_backward(dbm, O, scale, shape):
     assert rel(gb.get(), gb_ref) < TOL
 
 
+@pytest.mark.parametrize("shape,scale,lrelu", [((1, 40, 56), 0.5, 1),     # offsets well inside the LDS window
+                                               ((2, 37, 21), 1.0, 0),     # ragged tiles, two images, a few samples past the window
+                                               ((1, 64, 64), 4.0, 1),     # most taps leave the window: the global fallback
+                                               ((1, 5, 3), 0.3, 0),       # a plane smaller than one tile
+                                               ((1, 130, 140), 0.8, 1)])  # 81 tiles: the XCD-contiguous tile order
+def test_deform_conv_x3_window_kernel_is_bitwise_the_gathering_kernel(dbm, shape, scale, lrelu):
+    """The 64 -> 64 deformable layer of the bf16 sweep (srgan_train.py:572) in split-bf16 arithmetic: the kernel whose sampler reads an
+    LDS window of the input (form 3; what the sweep's full-resolution planes take) against the kernel that gathers every corner from
+    memory (form 4) -- same blend, same split, same summation order: the same bits, whatever the offsets -- and against the oracle."""
+    d, _lib, ctx = dbm
+    N, H, W = shape
+    rs = np.random.RandomState(int(scale * 10) + H + W)
+    x = rs.normal(size=(N, 64, H, W)).astype(np.float32)
+    off = rs.normal(scale=scale, size=(N, 18, H, W)).astype(np.float32)
+    w = (rs.normal(size=(64, 64, 3, 3)) / np.sqrt(64 * 9)).astype(np.float32)
+    b = rs.normal(size=(64,)).astype(np.float32)
+    ref = ops.deform_conv2d(x, off, w, b)
+    if lrelu:
+        ref = np.where(ref >= 0, ref, np.float32(0.2) * ref)
+    l = _lib.lib()
+    dx, doff, dw, db = dev(d, x), dev(d, off), dev(d, w), dev(d, b)
+    y3, y4 = d.DeviceArray(ref.shape), d.DeviceArray(ref.shape)
+    _lib.check(l.dbm_op_deform_conv2d_form(ctx.handle, dx.ptr, doff.ptr, dw.ptr, db.ptr, y3.ptr, N, H, W, 64, 3, lrelu), ctx.handle)
+    _lib.check(l.dbm_op_deform_conv2d_form(ctx.handle, dx.ptr, doff.ptr, dw.ptr, db.ptr, y4.ptr, N, H, W, 64, 4, lrelu), ctx.handle)
+    assert rel(y4.get(), ref) < 1e-4
+    assert np.array_equal(y3.get(), y4.get())
+
+
 def test_loss_known_answers(dbm):
     """The reference's doctest values through the HIP loss kernels (fp32)."""
     d, _, _ = dbm
