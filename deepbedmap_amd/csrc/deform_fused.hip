@@ -544,7 +544,8 @@ __device__ __forceinline__ void dw_patch_of(int h, int& g, int& i) {
 __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __restrict__ xt, const float* __restrict__ off,
                                                                 const dbf16x8* __restrict__ wx, const float* __restrict__ bias,
                                                                 float* __restrict__ y, float* __restrict__ yt, int N, int H, int W,
-                                                                long offsn, int act, float slope, int tilesX, int tilesY) {
+                                                                long offsn, int act, float slope, int tilesX, int tilesY, int abl) {
+  // (abl: libdbm_measure.so only, DBM_X3W_ABL, results wrong: 1 no step loop, 2 no window staging, 4 no geometry, 8 no stores)
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // workgroup -> tile: every XCD (workgroups are dealt to the eight XCDs round robin) takes one contiguous run of tiles -- neighbouring
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
   const int plane = H * W;
   const int wy0 = ty * DW_T - 1 - DW_R, wx0 = tx * DW_T - 1 - DW_R;   // image coordinates of window pixel (0, 0)
   const float* xn = xt + (long)n * plane * 64;
-  {  // ---- the window: sixteen lanes per pixel (256 contiguous bytes), zeros outside the image ----
+  if (!(abl & 2)) {  // ---- the window: sixteen lanes per pixel (256 contiguous bytes), zeros outside the image ----
     float4 st[DW_STEPS];
 #pragma unroll
     for (int it = 0; it < DW_STEPS; ++it) {
@@ -586,7 +587,10 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
   int pc[9];        // LDS byte address of the top-left corner's pixel (+ this lane's k group), if every corner is inside the window
   float4 cw[9];     // bilinear weights (build_geometry's: a corner outside the image has weight 0)
   bool far = false;
-  {
+  if (abl & 4) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { pc[t] = kg * 32; cw[t] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  } else {
     const float* on = off + (long)n * offsn + (valid ? p : 0);
     float ox[9], oy[9];
 #pragma unroll
@@ -643,7 +647,8 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
       A[2 + ct] = wl[(st * 2 + 1) * 128 + ct * 64];
     }
   };
-  if (!wave_far) {
+  if (abl & 1) {
+  } else if (!wave_far) {
     // ---- every sample of this wavefront inside the window: 36 pipelined steps ----
     // The reads are inline asm with hand-placed wait counts: left to hipcc every read ends up right in front of its first use (its IR
     // passes sink loads through __builtin_amdgcn_sched_barrier; volatile loads turn into flat loads with a wait each).  A step requests
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
       }
     }
   }
-  if (!valid) return;
+  if (!valid || (abl & 8)) return;
   const long Pm = (long)n * plane + p;
   float v[2][16];   // (all bias loads before the first store: see deform_conv64_fused_kernel)
 #pragma unroll
@@ -1359,7 +1364,7 @@ void launch_deform_conv64_x3(const float* xt, const float* off, const void* wx, 
       attr = true;
     }
     hipLaunchKernelGGL(deform_conv64_x3w_kernel, dim3(blocks), dim3(512), DW_LDS, s, xt, off, (const dbf16x8*)wx, bias, y, yt, N, H, W, offsn,
-                       act, slope, tilesX, tilesY);
+                       act, slope, tilesX, tilesY, DBM_MEASURE_ENV("X3W_ABL"));
   } else
   hipLaunchKernelGGL(deform_conv64_x3_kernel, dim3(blocks), dim3(256), 0, s, xt, off, (const dbf16x8*)wx, bias, y, yt, N, H, W, offsn, act,
                      slope);
