@@ -544,8 +544,15 @@ __device__ __forceinline__ void dw_patch_of(int h, int& g, int& i) {
 __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __restrict__ xt, const float* __restrict__ off,
                                                                 const dbf16x8* __restrict__ wx, const float* __restrict__ bias,
                                                                 float* __restrict__ y, float* __restrict__ yt, int N, int H, int W,
-                                                                long offsn, int act, float slope, int tilesX, int tilesY, int abl) {
-  // (abl: libdbm_measure.so only, DBM_X3W_ABL, results wrong: 1 no step loop, 2 no window staging, 4 no geometry, 8 no stores)
+                                                                long offsn, int act, float slope, int tilesX, int tilesY, int abl_arg) {
+#ifdef DBM_MEASURE
+  const int abl = abl_arg;   // (a run-time value costs a dozen branches per step: libdbm_measure.so's times are ~5 % above the product's)
+#else
+  constexpr int abl = 0;
+  (void)abl_arg;
+#endif
+  // (abl: libdbm_measure.so only, DBM_X3W_ABL, results wrong: 1 no step loop, 2 no window staging, 4 no geometry, 8 no stores,
+  //  16 every step's weight fragments are step 0's, 32 no weight loads, 64 no corner reads, 128 no blend arithmetic, 256 no MFMAs)
   extern __shared__ __attribute__((aligned(16))) unsigned char win[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // workgroup -> tile: every XCD (workgroups are dealt to the eight XCDs round robin) takes one contiguous run of tiles -- neighbouring
@@ -651,16 +658,26 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
   } else if (!wave_far) {
     // ---- every sample of this wavefront inside the window: 36 pipelined steps ----
     // The reads are inline asm with hand-placed wait counts: left to hipcc every read ends up right in front of its first use (its IR
-    // passes sink loads through __builtin_amdgcn_sched_barrier; volatile loads turn into flat loads with a wait each).  A step requests
-    // the eight corner pieces and four weight fragments of step s + 1, waits for step s's (vmcnt / lgkmcnt count in order: "all but the
-    // twelve just issued"; the values pass through the wait as "+v" operands, so that nothing using them can move above it), blends,
-    // splits, multiplies.
+    // passes sink loads through __builtin_amdgcn_sched_barrier; volatile loads turn into flat loads with a wait each); the values pass
+    // through the wait as "+v" operands, so that nothing using them can move above it.  Step s:
+    //   corner pieces of step s + 1 requested (LDS, their own double buffer);
+    //   wait: corners of s (lgkmcnt: all but the eight just issued), weight fragments of s - 1 (vmcnt: all but step s's four);
+    //   blend + split of step s as four channel PAIRS in lock step, the six MFMAs of step s - 1 dealt between its stages -- a wavefront's
+    //     matrix instructions run under its own vector arithmetic (left to hipcc: one pair after the other through the same two
+    //     registers, eight dependent packed operations deep with a wait state between each, then six MFMAs back to back; the loop
+    //     without any load was 259 of the kernel's 511 us).  The empty asm statements are ordering fences: every pair's operation k
+    //     before any pair's operation k + 1, MFMA k between stage k and stage k + 1 (its B operands pass through both fences);
+    //   weight fragments of step s + 1 requested into the registers the MFMAs just read.
+    // Same expression trees as blend4 / the older kernel's split, same MFMA order per accumulator: the same bits.
     typedef float f4t __attribute__((ext_vector_type(4)));
+    typedef float f2t __attribute__((ext_vector_type(2)));
     f4t C[2][8], A[2][4];
+    dbf16x8 pbh, pbl;   // B operands of the step before
     const unsigned lbase = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)win;
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(wl);   // + 4096 per step; hi ct 0 / hi ct 1 / lo ct 0 / lo ct 1: + 0 / 1024 / 2048 / 3072
-    auto request = [&](int st, f4t (&c)[8], f4t (&aw)[4]) {
+    auto request_corners = [&](int st, f4t (&c)[8]) {
       const unsigned ad = lbase + (unsigned)pc[st >> 2] + (st & 3) * 64;
+      if (abl & 64) return;   // (64: no corner reads)
       asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\t"
                    "ds_read_b128 %2, %8 offset:%9\n\tds_read_b128 %3, %8 offset:%10\n\t"
                    "ds_read_b128 %4, %8 offset:%11\n\tds_read_b128 %5, %8 offset:%12\n\t"
@@ -668,38 +685,99 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
                    : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
                    : "v"(ad), "n"(DW_PIX), "n"(DW_PIX + 16), "n"(DW_WIN * DW_PIX), "n"(DW_WIN * DW_PIX + 16), "n"((DW_WIN + 1) * DW_PIX),
                      "n"((DW_WIN + 1) * DW_PIX + 16));
-      const unsigned char* q = wp + (long)st * 4096;
+    };
+    auto request_weights = [&](int st, f4t (&aw)[4]) {
+      const unsigned char* q = wp + (long)((abl & 16) ? 0 : st) * 4096;   // (16: every step multiplies by step 0's fragments)
+      if (abl & 32) return;                                                  // (32: no weight loads at all)
       asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"
                    "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"
                    : "=&v"(aw[0]), "=&v"(aw[1]), "=&v"(aw[2]), "=&v"(aw[3])
                    : "v"(q));
     };
-    auto arrived = [&](f4t (&c)[8], f4t (&aw)[4], bool last) {
-      if (last)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(aw[0]), "+v"(aw[1]),
-                       "+v"(aw[2]), "+v"(aw[3]));
-      else
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(8)"
-                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(aw[0]), "+v"(aw[1]),
-                       "+v"(aw[2]), "+v"(aw[3]));
+#define DW_THROUGH(c, aw) "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(aw[0]), "+v"(aw[1]), \
+                          "+v"(aw[2]), "+v"(aw[3])
+    request_corners(0, C[0]);
+    request_weights(0, A[0]);
+    request_weights(1, A[1]);
+    // MFMA k of the step whose fragments are aw (per accumulator: hi * lo, lo * hi, hi * hi -- small terms first)
+    auto mfma_k = [&](int k, const f4t (&aw)[4]) {
+      const int ct = k & 1;
+      const dbf16x8 a = __builtin_bit_cast(dbf16x8, aw[k < 2 ? ct : k < 4 ? 2 + ct : ct]);   // hi ct 0, hi ct 1, lo ct 0, lo ct 1
+      if (abl & 256) return;   // (256: no MFMAs)
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, k < 2 ? pbl : pbh, acc[ct], 0, 0, 0);
     };
-    auto f4 = [](const f4t& v) { return make_float4(v[0], v[1], v[2], v[3]); };
-    request(0, C[0], A[0]);
 #pragma unroll
     for (int st = 0; st < 36; ++st) {
       f4t (&c)[8] = C[st & 1];
-      f4t (&aw)[4] = A[st & 1];
-      if (st + 1 < 36) request(st + 1, C[(st + 1) & 1], A[(st + 1) & 1]);
-      arrived(c, aw, st + 1 >= 36);
-      const float4 v0 = blend4(cw[st >> 2], f4(c[0]), f4(c[2]), f4(c[4]), f4(c[6]));
-      const float4 v1 = blend4(cw[st >> 2], f4(c[1]), f4(c[3]), f4(c[5]), f4(c[7]));
+      f4t (&aw)[4] = A[(st + 1) & 1];    // the fragments of step st - 1
+      if (st + 1 < 36) request_corners(st + 1, C[(st + 1) & 1]);
+      if (st == 0) asm volatile("s_waitcnt lgkmcnt(8)" : DW_THROUGH(c, aw));
+      else if (st + 1 < 36) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(8)" : DW_THROUGH(c, aw));
+      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : DW_THROUGH(c, aw));
+      auto mfma = [&](int k) {
+        if (st > 0) mfma_k(k, aw);
+      };
+      const float4 w = cw[st >> 2];
+      f2t m[4], hf[4];
       dbf16x8 bh, bl;
-      split(v0, v1, bh, bl);
-      const dbf16x8 Aw[4] = {__builtin_bit_cast(dbf16x8, aw[0]), __builtin_bit_cast(dbf16x8, aw[1]), __builtin_bit_cast(dbf16x8, aw[2]),
-                             __builtin_bit_cast(dbf16x8, aw[3])};
-      mfmas(Aw, bh, bl);
+      if (abl & 128) {   // (128: no blend / split arithmetic -- the MFMAs' B operands are raw corner bytes)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) mfma(k);
+        pbh = __builtin_bit_cast(dbf16x8, c[0]);
+        pbl = __builtin_bit_cast(dbf16x8, c[1]);
+        if (st >= 1 && st + 1 < 36) request_weights(st + 1, A[(st + 1) & 1]);
+        continue;
+      }
+#define DW_FENCE asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(pbh), "+v"(pbl))
+#define DW_PAIR(q, k) ((f2t){c[q + (k >> 1)][2 * (k & 1)], c[q + (k >> 1)][2 * (k & 1) + 1]})   /* corner q / 2, channel pair k of the eight */
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = w.y * DW_PAIR(2, k);
+      DW_FENCE;
+      mfma(0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = __builtin_elementwise_fma((f2t){w.x, w.x}, DW_PAIR(0, k), m[k]);
+      DW_FENCE;
+      mfma(1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = __builtin_elementwise_fma((f2t){w.z, w.z}, DW_PAIR(4, k), m[k]);
+      DW_FENCE;
+      mfma(2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = __builtin_elementwise_fma((f2t){w.w, w.w}, DW_PAIR(6, k), m[k]);
+      DW_FENCE;
+      mfma(3);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bh[2 * k] = (__bf16)m[k][0];
+        bh[2 * k + 1] = (__bf16)m[k][1];
+      }
+      asm volatile("" : "+v"(bh), "+v"(pbh), "+v"(pbl));
+      mfma(4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hf[k] = (f2t){(float)bh[2 * k], (float)bh[2 * k + 1]};
+      asm volatile("" : "+v"(hf[0]), "+v"(hf[1]), "+v"(hf[2]), "+v"(hf[3]), "+v"(pbh), "+v"(pbl));
+      mfma(5);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = m[k] - hf[k];
+      DW_FENCE;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        bl[2 * k] = (__bf16)m[k][0];
+        bl[2 * k + 1] = (__bf16)m[k][1];
+      }
+#undef DW_FENCE
+#undef DW_PAIR
+      pbh = bh;
+      pbl = bl;
+      if (st >= 1 && st + 1 < 36) request_weights(st + 1, A[(st + 1) & 1]);   // (into the registers step st - 1's MFMAs have just read)
     }
+    {  // step 35's MFMAs
+      f4t (&aw)[4] = A[1];
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(aw[0]), "+v"(aw[1]), "+v"(aw[2]), "+v"(aw[3]));
+#pragma unroll
+      for (int k = 0; k < 6; ++k) mfma_k(k, aw);
+    }
+#undef DW_THROUGH
   } else {
     // ---- the generic loop: per tap the window, or global memory when a lane's sample leaves it ----
 #pragma unroll   // (a run-time tap index would send pc[] and cw[] to scratch -- for the pipelined side as well)
