@@ -918,6 +918,65 @@ __global__ __launch_bounds__(256) void deform1_premul_kernel(const float* __rest
   }
 }
 
+// The same premultiplication on the matrix pipes (round 6; nz <= 16, i.e. the model's own 64 -> 1 layer): the kernel above spends four
+// FMAs, four cross-lane adds and an LDS write per (position, tap) on sixteen lanes -- 180 of the 220 us of the layer on a 1144 x 1144
+// plane, against 42 us for reading the plane once.  Here z (16 rows, nz live) x 16 positions = W (16 x 64) . x (64 x 16 positions) is
+// sixteen v_mfma_f32_16x16x4f32 per wavefront and 16 positions: lane (j, kq) holds row j of W for the channels kq * 16 .. + 15 (registers,
+// loaded once) and reads those sixteen channels of position j as ONE 64-byte run; step s multiplies the channels {kq * 16 + s}.  fp32
+// operands, fp32 accumulation; the channels are summed in another order than above (equal to fp32 rounding).
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void deform1_premul_mfma_kernel(const float* __restrict__ xt, const float* __restrict__ w,
+                                                                  float* __restrict__ z, int total, int plane, int nz) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, kq = lane >> 4;
+  float a[16];
+  {
+    const int co = j / 9, t = j - 9 * co;   // row j of z = (output channel co, tap t); w in its canonical OIHW order (co, c, t)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a[s] = j < nz ? w[((long)co * 64 + kq * 16 + s) * 9 + t] : 0.f;
+  }
+  const int ntile = (total + 15) >> 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+    const int P = tile * 16 + j;
+    const float* src = xt + (long)(P < total ? P : total - 1) * 64 + kq * 16;
+    float4 b[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) b[m] = *reinterpret_cast<const float4*>(src + 4 * m);
+    f32x4m acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + 0], b[m].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + 1], b[m].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + 2], b[m].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * m + 3], b[m].w, acc, 0, 0, 0);
+    }
+    if (P < total) {   // lane (j, kq) holds rows 4 kq .. 4 kq + 3 of column j
+      const int n = P / plane, p = P - n * plane;
+      float* dst = z + ((long)n * nz + 4 * kq) * plane + p;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * kq + r < nz) dst[(long)r * plane] = acc[r];
+    }
+  }
+}
+
+static void launch_premul(const float* xt, const float* w, float* z, long total, int plane, int nz, hipStream_t s) {
+  static const int mfma_env = DBM_TUNE_GETENV("DEFORM1_PREMUL_MFMA") ? atoi(DBM_TUNE_GETENV("DEFORM1_PREMUL_MFMA")) : 1;   // (0: the vector-ALU kernel -- A/B)
+  if (nz <= 16 && mfma_env && total < (1L << 31)) {
+    const long ntile = (total + 15) / 16;
+    const unsigned blocks = (unsigned)std::min<long>((ntile + 3) / 4, 4096);
+    hipLaunchKernelGGL(deform1_premul_mfma_kernel, dim3(blocks), dim3(256), 0, s, xt, w, z, (int)total, plane, nz);
+    return;
+  }
+  static bool attr = false;   // (O >= 15: 2 * 9 * O * 64 floats exceed the 64 KB default of dynamic LDS)
+  if (!attr) {
+    DBM_HIP(hipFuncSetAttribute((const void*)deform1_premul_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 9 * 16 * 64 * (int)sizeof(float)));
+    attr = true;
+  }
+  const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
+  hipLaunchKernelGGL(deform1_premul_kernel, dim3(blocks), dim3(256), (size_t)2 * nz * 64 * sizeof(float), s, xt, w, z, total, plane, nz);
+}
+
 // y[(n * oc + co) * plane + p] = bias[co] + sum_t bilinear(z[n][co * 9 + t], p + tap_t + offset_t(p));  blockIdx.y = co
 __global__ __launch_bounds__(256) void deform1_sample_kernel(const float* __restrict__ z, const float* __restrict__ off,
                                                              const float* __restrict__ bias, float* __restrict__ y, long total, int H, int W,
@@ -1394,12 +1453,7 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
                        DBM_MEASURE_ENV("DEFORM_ABL"));
   else if (z) {
     const int nz = 9 * O;
-    static bool attr = false;   // (O >= 15: 2 * 9 * O * 64 floats exceed the 64 KB default of dynamic LDS)
-    if (!attr) {
-      DBM_HIP(hipFuncSetAttribute((const void*)deform1_premul_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 9 * 16 * 64 * (int)sizeof(float)));
-      attr = true;
-    }
-    hipLaunchKernelGGL(deform1_premul_kernel, dim3(blocks), dim3(256), (size_t)2 * nz * 64 * sizeof(float), s, xt, w, z, total, H * W, nz);
+    launch_premul(xt, w, z, total, H * W, nz, s);
     hipLaunchKernelGGL(deform1_sample_kernel, dim3((unsigned)((total + 255) / 256), (unsigned)O), dim3(256), 0, s, z, off, bias, y, total, H, W,
                        offsn, O);
   } else
@@ -1534,9 +1588,7 @@ void launch_deform_bwd1_premul(const float* xt, const float* off, const float* w
 // z[n][t][p] = sum_c w[c][t] x_c(p) for the O == 1 layer (the forward's premultiplication alone: the op-level backward entry point)
 void launch_deform1_premul(const float* xt, const float* w, float* z, int N, int H, int W, int O, hipStream_t s) {
   const long total = (long)N * H * W;
-  const unsigned blocks = (unsigned)((total + DF_POS - 1) / DF_POS);
-  const int nz = 9 * O;
-  DBM_CHECK(O >= 1 && O <= 7, "launch_deform1_premul: the default 64 KB of dynamic LDS serve up to seven output channels");
-  hipLaunchKernelGGL(deform1_premul_kernel, dim3(blocks), dim3(256), (size_t)2 * nz * 64 * sizeof(float), s, xt, w, z, total, H * W, nz);
+  DBM_CHECK(O >= 1 && O <= 16, "launch_deform1_premul: up to sixteen output channels");
+  launch_premul(xt, w, z, total, H * W, 9 * O, s);
   DBM_HIP(hipGetLastError());
 }
