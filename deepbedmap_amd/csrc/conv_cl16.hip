@@ -368,6 +368,9 @@ struct ClX3Args {
   float* yp; long ysn; int ypc;      // channel-plane output yp[n * ysn + co * H * W + pixel], co < ypc (may be null)
   int act; float slope;
   int N, H, W, nslots, tilesX, tilesY;
+#ifdef DBM_MEASURE
+  int abl;                           // libdbm_measure.so only (DBM_CL16X3_ABL, results wrong): 1 no MFMA loop, 2 no epilogue, 4 no staging after chunk 0
+#endif
 };
 
 __device__ __forceinline__ void split_bf16(const f4v v, bf16x4& hi, bf16x4& lo) {
@@ -379,12 +382,16 @@ __device__ __forceinline__ void split_bf16(const f4v v, bf16x4& hi, bf16x4& lo) 
   }
 }
 
-template <int MT>
-__global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
+// TSLOTS: the largest tile height (in 2-row patches) the LDS layout is sized for.  12: one workgroup per CU.  8 (one output-channel
+// tile only: 78 KB, <= 128 registers): TWO workgroups per CU -- the full-resolution planes are 13 rounds of tiles, and a tile's fixed
+// part (index arithmetic, first chunk through registers, the barrier: 7 of its 16 us by DBM_CL16X3_ABL=7) then runs under the other
+// workgroup's MFMAs.
+template <int MT, int TSLOTS = CL_MAXSLOTS>
+__global__ __launch_bounds__(CL_NT, TSLOTS <= 8 ? 2 : 1) void conv_cl16x3_kernel(ClX3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int TH = 2 * a.nslots, HR = TH + 2, NPIX = HR * CL_HW;
-  constexpr int ACT_BYTES = CL_ACT_BYTES;
+  constexpr int ACT_BYTES = cl_act_bytes(TSLOTS);
   constexpr int WINS = 9 * MT * 2;               // LDS-DMA instructions (1 KB) of a 16-channel chunk's weights
   constexpr int W_BYTES = WINS * 1024;
   constexpr int WGT0 = 2 * ACT_BYTES;
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
   const long simg = (long)n * Hs * Ws;
 
   // ---- activations: 16-byte pieces (4 channels) through registers; piece idx = (pixel q, quarter p) ----
-  constexpr int ASTEPS = (26 * CL_HW * 4 + CL_NT - 1) / CL_NT;
+  constexpr int ASTEPS = ((2 * TSLOTS + 2) * CL_HW * 4 + CL_NT - 1) / CL_NT;
   constexpr int WSTEPS = (WINS + 7) / 8;
   const float* asrc[ASTEPS];
   int ahi[ASTEPS];   // LDS byte of the piece's hi half (-1: no piece); lo half = the same ^ 32
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
 
   int g, i;
   patch_of(lane & 31, g, i);
-  const bool has0 = wave < a.nslots, has1 = wave + 8 < a.nslots;
+  const bool has0 = wave < a.nslots, has1 = TSLOTS > 8 && wave + 8 < a.nslots;   // (tiles of <= 8 patches: one per wavefront)
   const int prow0 = 2 * wave + g, prow1 = 2 * (wave + 8) + g;
   int bad0[9], bad1[9];   // hi fragment of tap t (K half = lane >> 5); lo fragment = the same ^ 32
 #pragma unroll
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
 
   auto compute = [&](auto BUF) {
     constexpr int buf = decltype(BUF)::value;
-    if (!has0) return;
+    if (!has0 || DBM_ABL_BIT(a, 1)) return;
     const unsigned char* ab = smem + buf * ACT_BYTES;
     const unsigned char* wb = smem + WGT0 + buf * W_BYTES + lane * 16;
 #pragma unroll
@@ -497,7 +504,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
   commit(B0{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int c = 0; c < nchunk; c += 2) {
+  for (int c = 0; c < (DBM_ABL_BIT(a, 4) ? 1 : nchunk); c += 2) {
     if (c + 1 < nchunk) issue(c + 1, B1{});
     compute(B0{});
     if (c + 1 < nchunk) commit(B1{});
@@ -514,6 +521,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16x3_kernel(ClX3Args a) {
   // ---- epilogue ----
   // (round 5: the bias quads are loaded ONCE, before the first store -- a load behind a store is awaited by draining the store,
   //  vmcnt being in order over both: the per-(patch, tile, quad) loads of the first version cost a write round trip each)
+  if (DBM_ABL_BIT(a, 2)) return;
   const long plane = (long)a.H * a.W;
   f4v bq[MT][4];
 #pragma unroll
@@ -778,15 +786,22 @@ void launch_conv_cl16x3(const ClX3Launch& L, hipStream_t s) {
   a.y32 = L.y32; a.yc = L.yc; a.r1 = L.r1; a.r1c = L.r1c; a.y16 = (__bf16*)L.y16; a.y16c = L.y16c; a.yp = L.yp; a.ysn = L.ysn; a.ypc = L.ypc; a.act = L.act; a.slope = L.slope;
   DBM_CHECK(!L.r1 || (L.r1c % 4 == 0 && L.Cout % 32 == 0), "cl16x3 conv: the residual needs whole 32-channel tiles and 16-byte alignment");
   a.N = L.N; a.H = L.H; a.W = L.W;
-  a.nslots = cl16_choose_slots(L.N, L.H, L.W, n_cus);
-  a.tilesX = (L.W + CL_TW - 1) / CL_TW;
-  a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
+#ifdef DBM_MEASURE
+  a.abl = DBM_MEASURE_ENV("CL16X3_ABL");
+#endif
   const int MT = (L.Cout + 31) / 32;
-  const size_t lds = 2 * (size_t)CL_ACT_BYTES + 2 * (size_t)9 * MT * 2 * 1024;
+  a.tilesX = (L.W + CL_TW - 1) / CL_TW;
+  // two workgroups per CU (tiles of <= 8 patches, one output-channel tile) once the plane is several rounds of tiles anyway
+  static const int pair_env = DBM_TUNE_GETENV("CL16X3_PAIR") ? atoi(DBM_TUNE_GETENV("CL16X3_PAIR")) : 1;   // (0: one workgroup per CU -- A/B)
+  const bool pair = pair_env && MT == 1 && (long)L.N * a.tilesX * ((L.H + 15) / 16) >= 4L * n_cus;
+  a.nslots = pair ? cl16_choose_slots(L.N, L.H, L.W, n_cus, 8, 2) : cl16_choose_slots(L.N, L.H, L.W, n_cus);
+  a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
+  const size_t lds = 2 * (size_t)cl_act_bytes(pair ? 8 : CL_MAXSLOTS) + 2 * (size_t)9 * MT * 2 * 1024;
   static bool attr = false;
   if (!attr) {
     DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16x3_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     attr = true;
   }
   const unsigned grid = (unsigned)((long)L.N * a.tilesX * a.tilesY);
@@ -799,7 +814,9 @@ void launch_conv_cl16x3(const ClX3Launch& L, hipStream_t s) {
     snprintf(tag, sizeof(tag), "x3_c%d>%d_%dx%d_n%d%s", L.Cin, L.Cout, L.H, L.W, L.N, L.ups ? "u" : "");
     g_profiler.begin(s, 0, 2.0 * px * L.Cout * L.Cin * 9, bytes, tag, grid);
   }
-  if (MT == 1)
+  if (pair)
+    hipLaunchKernelGGL((conv_cl16x3_kernel<1, 8>), dim3(grid), dim3(CL_NT), lds, s, a);
+  else if (MT == 1)
     hipLaunchKernelGGL(conv_cl16x3_kernel<1>, dim3(grid), dim3(CL_NT), lds, s, a);
   else
     hipLaunchKernelGGL(conv_cl16x3_kernel<2>, dim3(grid), dim3(CL_NT), lds, s, a);

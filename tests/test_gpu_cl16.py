@@ -110,6 +110,7 @@ X3_CASES = [
     (2, 36, 52, 64, 1, 1, 0),      # post_upsample: nearest x2 folded into the staging, two images
     (1, 33, 35, 18, 0, 0, 1),      # offset convolution: 18 channel planes
     (1, 572, 572, 64, 1, 1, 0),    # the sweep's first upsampling layer: 286 -> 572
+    (1, 520, 530, 18, 0, 0, 1),    # 1 122 tiles of one output-channel tile: the form with two workgroups per CU (tiles of <= 8 patches)
 ]
 
 
