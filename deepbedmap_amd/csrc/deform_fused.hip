@@ -516,12 +516,15 @@ __global__ __launch_bounds__(256) void deform_conv64_x3_kernel(const float* __re
 //   * no sample tile, no geometry table, no barrier inside the tap loop: a wavefront owns two rows of the tile (32 positions, dealt to
 //     the lanes by the ds_read_b128 groups as in conv_cl16.hip) and BOTH output-channel tiles; lane (j, kg) samples the eight channels
 //     16 ks + 8 kg .. + 7 of its position straight into the B operand of the k step (blend in fp32, split hi / lo in registers).
-//   * 36 steps (tap, k step), software-pipelined by hand: the corner reads and weight fragments of step s + 1 are requested before the
-//     blend of step s, whose MFMAs run under the blend of step s + 1 (hipcc left to itself waits for every read right behind its issue).
+//   * 36 steps (tap, k step), software-pipelined by hand (see the loop): corner pieces and weight fragments requested a step ahead, the
+//     blend as four channel pairs in lock step, the previous step's MFMAs dealt between its stages.
 //   * arithmetic and summation order are deform_conv64_x3_kernel's (same blend expression, same split, taps outer, k steps inner, the
 //     three products small terms first): the results are the same bits.
-//   * a wavefront one of whose samples leaves the window (offsets beyond DW_R: rare) takes the generic loop instead: per tap either the
-//     window or, like the older kernel, global memory -- any offset is served, the window is an accelerator.
+//   * a sample that leaves the window (offsets beyond DW_R) is served INSIDE the same loop: per tap the lanes whose four corners lie in
+//     the window read LDS, the others read the same bytes from global memory under the complementary EXEC mask, one step ahead like
+//     everything else -- any offset is served, the window is an accelerator.  (A first version sent the whole wavefront to an
+//     unpipelined loop as soon as one of its 288 samples left the window: with offsets of about a pixel -- tools/dem_model.py --
+//     that is every wavefront, and the continent sweep was SLOWER than with the gathering kernel: 1.86 against 1.76 s; now 1.60.)
 constexpr int DW_T = 16;                          // tile edge (positions)
 constexpr int DW_R = 2;                           // offsets in [-DW_R, DW_R + 1) stay inside the window
 constexpr int DW_WIN = DW_T + 2 * DW_R + 3;       // 23
@@ -591,12 +594,11 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
   const int a = ty * DW_T + 2 * wave + g, bcol = tx * DW_T + i;
   const bool valid = a < H && bcol < W;
   const int p = a * W + bcol;
-  int pc[9];        // LDS byte address of the top-left corner's pixel (+ this lane's k group), if every corner is inside the window
+  int pg[9];        // the top-left corner of tap t in image coordinates, packed (y0 + 2) << 16 | (x0 + 2)  (y0, x0 >= -2)
   float4 cw[9];     // bilinear weights (build_geometry's: a corner outside the image has weight 0)
-  bool far = false;
   if (abl & 4) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) { pc[t] = kg * 32; cw[t] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int t = 0; t < 9; ++t) { pg[t] = ((wy0 + 2 + 2) << 16) | (wx0 + 2 + 2); cw[t] = make_float4(0.f, 0.f, 0.f, 0.f); }
   } else {
     const float* on = off + (long)n * offsn + (valid ? p : 0);
     float ox[9], oy[9];
@@ -615,13 +617,9 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
       cw[t].y = (valid && iy0 && ix1) ? q.wu0 * q.wv1 : 0.f;
       cw[t].z = (valid && iy1 && ix0) ? q.wu1 * q.wv0 : 0.f;
       cw[t].w = (valid && iy1 && ix1) ? q.wu0 * q.wv0 : 0.f;
-      const int ry = y0 - wy0, rx = x0 - wx0;
-      const bool near = (unsigned)ry < (unsigned)(DW_WIN - 1) && (unsigned)rx < (unsigned)(DW_WIN - 1);
-      far |= valid && !near;
-      pc[t] = near ? (ry * DW_WIN + rx) * DW_PIX + kg * 32 : valid ? -1 : kg * 32;   // (-1: this tap of this lane leaves the window)
+      pg[t] = ((y0 + 2) << 16) | (x0 + 2);
     }
   }
-  const bool wave_far = __builtin_amdgcn_ballot_w64(far) != 0;   // wave-uniform
   const dbf16x8* wl = wx + lane;   // + ((t * 4 + ks) * 2 + hl) * 128 + ct * 64
   f32x16 acc[2];
 #pragma unroll
@@ -630,61 +628,88 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
   __syncthreads();
 
-  auto split = [](const float4& v0, const float4& v1, dbf16x8& bh, dbf16x8& bl) {
-    const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const __bf16 hi = (__bf16)f[u];
-      bh[u] = hi;
-      bl[u] = (__bf16)(f[u] - (float)hi);
-    }
-  };
-  auto mfmas = [&](const dbf16x8 (&A)[4], const dbf16x8& bh, const dbf16x8& bl) {   // A: hi ct 0, hi ct 1, lo ct 0, lo ct 1
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ct], bl, acc[ct], 0, 0, 0);   // small terms first
-      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2 + ct], bh, acc[ct], 0, 0, 0);
-      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ct], bh, acc[ct], 0, 0, 0);
-    }
-  };
-  auto weights = [&](int st, dbf16x8 (&A)[4]) {
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      A[ct] = wl[(st * 2 + 0) * 128 + ct * 64];
-      A[2 + ct] = wl[(st * 2 + 1) * 128 + ct * 64];
-    }
-  };
-  if (abl & 1) {
-  } else if (!wave_far) {
-    // ---- every sample of this wavefront inside the window: 36 pipelined steps ----
+  if (!(abl & 1)) {
+    // ---- 36 pipelined steps (tap, k step) ----
     // The reads are inline asm with hand-placed wait counts: left to hipcc every read ends up right in front of its first use (its IR
     // passes sink loads through __builtin_amdgcn_sched_barrier; volatile loads turn into flat loads with a wait each); the values pass
     // through the wait as "+v" operands, so that nothing using them can move above it.  Step s:
-    //   corner pieces of step s + 1 requested (LDS, their own double buffer);
-    //   wait: corners of s (lgkmcnt: all but the eight just issued), weight fragments of s - 1 (vmcnt: all but step s's four);
+    //   wait: the corner pieces of step s and the weight fragments of step s - 1 (vmcnt / lgkmcnt count in order: everything but the
+    //     four fragment loads of step s, the youngest requests);
+    //   the corner pieces of step s + 1 requested (their own double buffer): lanes whose four corners lie inside the window read LDS,
+    //     the others -- offsets beyond DW_R -- read the same bytes from global memory, in the same instruction slot under the
+    //     complementary EXEC mask (wave-uniform: a tap without such lanes issues the LDS reads only).  Any offset is served, at the
+    //     speed of its locality;
     //   blend + split of step s as four channel PAIRS in lock step, the six MFMAs of step s - 1 dealt between its stages -- a wavefront's
     //     matrix instructions run under its own vector arithmetic (left to hipcc: one pair after the other through the same two
-    //     registers, eight dependent packed operations deep with a wait state between each, then six MFMAs back to back; the loop
-    //     without any load was 259 of the kernel's 511 us).  The empty asm statements are ordering fences: every pair's operation k
-    //     before any pair's operation k + 1, MFMA k between stage k and stage k + 1 (its B operands pass through both fences);
-    //   weight fragments of step s + 1 requested into the registers the MFMAs just read.
-    // Same expression trees as blend4 / the older kernel's split, same MFMA order per accumulator: the same bits.
+    //     registers, eight dependent packed operations deep with a wait state between each, then six MFMAs back to back).  The empty
+    //     asm statements are ordering fences: every pair's operation k before any pair's operation k + 1, MFMA k between stage k and
+    //     stage k + 1 (its B operands pass through both fences);
+    //   the weight fragments of step s + 1 requested into the registers the MFMAs just read.
+    // Same expression trees as blend4 / the gathering kernel's split, same MFMA order per accumulator: the same bits.
     typedef float f4t __attribute__((ext_vector_type(4)));
     typedef float f2t __attribute__((ext_vector_type(2)));
     f4t C[2][8], A[2][4];
     dbf16x8 pbh, pbl;   // B operands of the step before
     const unsigned lbase = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)win;
     const unsigned char* wp = reinterpret_cast<const unsigned char*>(wl);   // + 4096 per step; hi ct 0 / hi ct 1 / lo ct 0 / lo ct 1: + 0 / 1024 / 2048 / 3072
-    auto request_corners = [&](int st, f4t (&c)[8]) {
-      const unsigned ad = lbase + (unsigned)pc[st >> 2] + (st & 3) * 64;
+    // the tap whose corners are being requested: LDS address (lanes inside the window), byte offsets of the four corners from the
+    // image's first pixel (the others; a corner outside the image is clamped onto it: its weight is 0), the lanes inside
+    unsigned t_lds = 0, t_g1 = 0, t_g2 = 0, t_g3 = 0, t_g4 = 0;
+    unsigned long t_near = ~0ul;
+    auto open_tap = [&](int t) {
+      const int y0 = (pg[t] >> 16) - 2, x0 = (pg[t] & 0xffff) - 2;
+      const int ry = y0 - wy0, rx = x0 - wx0;
+      const bool near = (unsigned)ry < (unsigned)(DW_WIN - 1) && (unsigned)rx < (unsigned)(DW_WIN - 1);
+      t_lds = lbase + (near ? (ry * DW_WIN + rx) * DW_PIX : 0) + kg * 32;
+      t_near = __builtin_amdgcn_ballot_w64(near);
+      if (t_near != ~0ul) {   // (wave-uniform)
+        const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1), xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
+        t_g1 = (unsigned)(ya * W + xa) * 256u + kg * 32;
+        t_g2 = (unsigned)(ya * W + xb) * 256u + kg * 32;
+        t_g3 = (unsigned)(yb * W + xa) * 256u + kg * 32;
+        t_g4 = (unsigned)(yb * W + xb) * 256u + kg * 32;
+      }
+    };
+#define DW_LDS_READS "ds_read_b128 %0, %[ad] offset:%[k0]\n\tds_read_b128 %1, %[ad] offset:%[k1]\n\t" \
+                     "ds_read_b128 %2, %[ad] offset:%[k2]\n\tds_read_b128 %3, %[ad] offset:%[k3]\n\t" \
+                     "ds_read_b128 %4, %[ad] offset:%[k4]\n\tds_read_b128 %5, %[ad] offset:%[k5]\n\t" \
+                     "ds_read_b128 %6, %[ad] offset:%[k6]\n\tds_read_b128 %7, %[ad] offset:%[k7]"
+#define DW_LDS_OFFS(KS) [k0] "n"(KS * 64), [k1] "n"(KS * 64 + 16), [k2] "n"(KS * 64 + DW_PIX), [k3] "n"(KS * 64 + DW_PIX + 16), \
+                        [k4] "n"(KS * 64 + DW_WIN * DW_PIX), [k5] "n"(KS * 64 + DW_WIN * DW_PIX + 16), \
+                        [k6] "n"(KS * 64 + (DW_WIN + 1) * DW_PIX), [k7] "n"(KS * 64 + (DW_WIN + 1) * DW_PIX + 16)
+    auto corners_ks = [&](auto KS, f4t (&c)[8]) {   // c[2 corner + e]
+      constexpr int ks = decltype(KS)::value;
       if (abl & 64) return;   // (64: no corner reads)
-      asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\t"
-                   "ds_read_b128 %2, %8 offset:%9\n\tds_read_b128 %3, %8 offset:%10\n\t"
-                   "ds_read_b128 %4, %8 offset:%11\n\tds_read_b128 %5, %8 offset:%12\n\t"
-                   "ds_read_b128 %6, %8 offset:%13\n\tds_read_b128 %7, %8 offset:%14"
-                   : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
-                   : "v"(ad), "n"(DW_PIX), "n"(DW_PIX + 16), "n"(DW_WIN * DW_PIX), "n"(DW_WIN * DW_PIX + 16), "n"((DW_WIN + 1) * DW_PIX),
-                     "n"((DW_WIN + 1) * DW_PIX + 16));
+      // (copies: clang does not capture a variable a generic lambda names in asm operands only)
+      const unsigned ad_ = t_lds, g1_ = t_g1, g2_ = t_g2, g3_ = t_g3, g4_ = t_g4;
+      const unsigned long nm_ = t_near;
+      const float* xb_ = xn;
+      if (nm_ == ~0ul) {
+        asm volatile(DW_LDS_READS
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+                     : [ad] "v"(ad_), DW_LDS_OFFS(ks));
+      } else {
+        unsigned long sv;
+        asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, %[sv], %[nm]\n\t" DW_LDS_READS "\n\t"
+                     "s_andn2_b64 exec, %[sv], %[nm]\n\t"
+                     "global_load_dwordx4 %0, %[g1], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %1, %[g1], %[xb] offset:%[o1]\n\t"
+                     "global_load_dwordx4 %2, %[g2], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %3, %[g2], %[xb] offset:%[o1]\n\t"
+                     "global_load_dwordx4 %4, %[g3], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %5, %[g3], %[xb] offset:%[o1]\n\t"
+                     "global_load_dwordx4 %6, %[g4], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %7, %[g4], %[xb] offset:%[o1]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]), [sv] "=&s"(sv)
+                     : [ad] "v"(ad_), DW_LDS_OFFS(ks), [nm] "s"(nm_), [g1] "v"(g1_), [g2] "v"(g2_), [g3] "v"(g3_), [g4] "v"(g4_),
+                       [xb] "s"(xb_), [o0] "n"(ks * 64), [o1] "n"(ks * 64 + 16));
+      }
+    };
+    auto request_corners = [&](int st, f4t (&c)[8]) {
+      if ((st & 3) == 0) open_tap(st >> 2);
+      switch (st & 3) {
+        case 0: corners_ks(std::integral_constant<int, 0>{}, c); break;
+        case 1: corners_ks(std::integral_constant<int, 1>{}, c); break;
+        case 2: corners_ks(std::integral_constant<int, 2>{}, c); break;
+        default: corners_ks(std::integral_constant<int, 3>{}, c); break;
+      }
     };
     auto request_weights = [&](int st, f4t (&aw)[4]) {
       const unsigned char* q = wp + (long)((abl & 16) ? 0 : st) * 4096;   // (16: every step multiplies by step 0's fragments)
@@ -696,24 +721,26 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
     };
 #define DW_THROUGH(c, aw) "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(aw[0]), "+v"(aw[1]), \
                           "+v"(aw[2]), "+v"(aw[3])
-    request_corners(0, C[0]);
-    request_weights(0, A[0]);
-    request_weights(1, A[1]);
     // MFMA k of the step whose fragments are aw (per accumulator: hi * lo, lo * hi, hi * hi -- small terms first)
     auto mfma_k = [&](int k, const f4t (&aw)[4]) {
       const int ct = k & 1;
-      const dbf16x8 a = __builtin_bit_cast(dbf16x8, aw[k < 2 ? ct : k < 4 ? 2 + ct : ct]);   // hi ct 0, hi ct 1, lo ct 0, lo ct 1
+      const dbf16x8 av = __builtin_bit_cast(dbf16x8, aw[k < 2 ? ct : k < 4 ? 2 + ct : ct]);   // hi ct 0, hi ct 1, lo ct 0, lo ct 1
       if (abl & 256) return;   // (256: no MFMAs)
-      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, k < 2 ? pbl : pbh, acc[ct], 0, 0, 0);
+      acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, k < 2 ? pbl : pbh, acc[ct], 0, 0, 0);
     };
+    request_corners(0, C[0]);
+    request_weights(0, A[0]);
+    request_weights(1, A[1]);
 #pragma unroll
     for (int st = 0; st < 36; ++st) {
       f4t (&c)[8] = C[st & 1];
       f4t (&aw)[4] = A[(st + 1) & 1];    // the fragments of step st - 1
-      if (st + 1 < 36) request_corners(st + 1, C[(st + 1) & 1]);
-      if (st == 0) asm volatile("s_waitcnt lgkmcnt(8)" : DW_THROUGH(c, aw));
-      else if (st + 1 < 36) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(8)" : DW_THROUGH(c, aw));
+      // (in order: ... corners(st) [global part, if any], weights(st); both weight requests of the prologue are younger than corners(0),
+      //  corners(1) is the youngest request at step 1)
+      if (st == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : DW_THROUGH(c, aw));
+      else if (st == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : DW_THROUGH(c, aw));
       else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : DW_THROUGH(c, aw));
+      if (st + 1 < 36) request_corners(st + 1, C[(st + 1) & 1]);
       auto mfma = [&](int k) {
         if (st > 0) mfma_k(k, aw);
       };
@@ -778,56 +805,8 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
       for (int k = 0; k < 6; ++k) mfma_k(k, aw);
     }
 #undef DW_THROUGH
-  } else {
-    // ---- the generic loop: per tap the window, or global memory when a lane's sample leaves it ----
-#pragma unroll   // (a run-time tap index would send pc[] and cw[] to scratch -- for the pipelined side as well)
-    for (int t = 0; t < 9; ++t) {
-      const bool tap_far = __builtin_amdgcn_ballot_w64(valid && pc[t] < 0) != 0;   // wave-uniform
-      // a far lane's corners: image offsets from the encoded top-left corner; a corner outside the image: offset 0 (its weight is 0)
-      long go[4] = {0, 0, 0, 0};
-      if (tap_far) {
-        const DeformGeom q = deform_geom(off[(long)n * offsn + (long)t * plane + (valid ? p : 0)],
-                                         off[(long)n * offsn + (long)(9 + t) * plane + (valid ? p : 0)], a, bcol, t / 3, t % 3, H, W, 1);
-        const int y0 = q.v0 - 2, x0 = q.u0 - 2;
-        const bool iy0 = (unsigned)y0 < (unsigned)H, iy1 = (unsigned)(y0 + 1) < (unsigned)H;
-        const bool ix0 = (unsigned)x0 < (unsigned)W, ix1 = (unsigned)(x0 + 1) < (unsigned)W;
-        go[0] = (iy0 && ix0) ? ((long)y0 * W + x0) * 64 : 0;
-        go[1] = (iy0 && ix1) ? ((long)y0 * W + x0 + 1) * 64 : 0;
-        go[2] = (iy1 && ix0) ? ((long)(y0 + 1) * W + x0) * 64 : 0;
-        go[3] = (iy1 && ix1) ? ((long)(y0 + 1) * W + x0 + 1) * 64 : 0;
-      }
-      const int pb = pc[t] >= 0 ? pc[t] : kg * 32;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        float4 c[8];
-        if (!tap_far) {
-          const unsigned char* bp = win + pb + ks * 64;
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            c[0 + e] = *reinterpret_cast<const float4*>(bp + 16 * e);
-            c[2 + e] = *reinterpret_cast<const float4*>(bp + DW_PIX + 16 * e);
-            c[4 + e] = *reinterpret_cast<const float4*>(bp + DW_WIN * DW_PIX + 16 * e);
-            c[6 + e] = *reinterpret_cast<const float4*>(bp + (DW_WIN + 1) * DW_PIX + 16 * e);
-          }
-        } else {
-          const float* gp = xn + 16 * ks + 8 * kg;
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            c[0 + e] = *reinterpret_cast<const float4*>(gp + go[0] + 4 * e);
-            c[2 + e] = *reinterpret_cast<const float4*>(gp + go[1] + 4 * e);
-            c[4 + e] = *reinterpret_cast<const float4*>(gp + go[2] + 4 * e);
-            c[6 + e] = *reinterpret_cast<const float4*>(gp + go[3] + 4 * e);
-          }
-        }
-        dbf16x8 A[4];
-        weights(t * 4 + ks, A);
-        const float4 v0 = blend4(cw[t], c[0], c[2], c[4], c[6]);
-        const float4 v1 = blend4(cw[t], c[1], c[3], c[5], c[7]);
-        dbf16x8 bh, bl;
-        split(v0, v1, bh, bl);
-        mfmas(A, bh, bl);
-      }
-    }
+#undef DW_LDS_READS
+#undef DW_LDS_OFFS
   }
   if (!valid || (abl & 8)) return;
   const long Pm = (long)n * plane + p;
@@ -962,7 +941,10 @@ __global__ __launch_bounds__(256) void deform1_premul_mfma_kernel(const float* _
 
 static void launch_premul(const float* xt, const float* w, float* z, long total, int plane, int nz, hipStream_t s) {
   static const int mfma_env = DBM_TUNE_GETENV("DEFORM1_PREMUL_MFMA") ? atoi(DBM_TUNE_GETENV("DEFORM1_PREMUL_MFMA")) : 1;   // (0: the vector-ALU kernel -- A/B)
-  if (nz <= 16 && mfma_env && total < (1L << 31)) {
+  // (planes of the sweep only: on the training tile's 83 k positions the two kernels take the same time inside the iteration, and the
+  //  discriminator's theoretically-zero linear_2/b gradient -- rounding noise of 128 cancelling terms, held to 3.2e-7 by
+  //  tests/test_gpu_dem.py -- moves with the last bit of any fake: the training path keeps the summation order it was pinned with)
+  if (nz <= 16 && mfma_env && total >= (1L << 18) && total < (1L << 31)) {
     const long ntile = (total + 15) / 16;
     const unsigned blocks = (unsigned)std::min<long>((ntile + 3) / 4, 4096);
     hipLaunchKernelGGL(deform1_premul_mfma_kernel, dim3(blocks), dim3(256), 0, s, xt, w, z, (int)total, plane, nz);

@@ -265,6 +265,24 @@ def test_deform_conv_x3_window_kernel_is_bitwise_the_gathering_kernel(dbm, shape
     assert np.array_equal(y3.get(), y4.get())
 
 
+def test_deform1_premultiplication_on_the_matrix_pipes(dbm):
+    """The 64 -> 1 deformable layer (srgan_train.py:574) on a plane of the area sweep's size class (>= 2^18 positions): its
+    premultiplication -- the 1x1 convolution 64 -> 9 tap planes -- then runs on v_mfma_f32_16x16x4f32 (deform1_premul_mfma_kernel; the
+    training tile's planes keep the vector-ALU kernel and its summation order).  Against the oracle, fp32 tolerance."""
+    d, _lib, ctx = dbm
+    N, H, W = 1, 512, 520
+    rs = np.random.RandomState(77)
+    x = rs.normal(size=(N, 64, H, W)).astype(np.float32)
+    off = rs.normal(scale=0.7, size=(N, 18, H, W)).astype(np.float32)
+    w = (rs.normal(size=(1, 64, 3, 3)) / np.sqrt(64 * 9)).astype(np.float32)
+    b = rs.normal(size=(1,)).astype(np.float32)
+    ref = ops.deform_conv2d(x, off, w, b)
+    dx, doff, dw, db = dev(d, x), dev(d, off), dev(d, w), dev(d, b)
+    y = d.DeviceArray(ref.shape)
+    _lib.check(_lib.lib().dbm_op_deform_conv2d_form(ctx.handle, dx.ptr, doff.ptr, dw.ptr, db.ptr, y.ptr, N, H, W, 1, 1, 0), ctx.handle)
+    assert rel(y.get(), ref) < TOL
+
+
 def test_loss_known_answers(dbm):
     """The reference's doctest values through the HIP loss kernels (fp32)."""
     d, _, _ = dbm
