@@ -79,7 +79,7 @@ __host__ __device__ constexpr int cl_act_bytes(int maxs) { return (((2 * maxs + 
 // single crop wants (234 tiles of eleven patches on 256 CUs); 8: 78 KB with one output-channel tile -- two workgroups per CU, so
 // that one's staging and epilogue run under the other's MFMAs when a launch has several rounds of tiles (crops batched per forward).
 template <int MT, int TSLOTS>
-__global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
+__global__ __launch_bounds__(CL_NT, TSLOTS <= 8 ? 2 : 1) void conv_cl16_kernel(ClConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int TH = 2 * a.nslots, HR = TH + 2, NPIX = HR * CL_HW;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(CL_NT) void conv_cl16_kernel(ClConvArgs a) {
   // ---- this lane's patches ----
   int g, i;
   patch_of(lane & 31, g, i);
-  const bool has0 = wave < a.nslots, has1 = wave + 8 < a.nslots;   // wave-uniform
+  const bool has0 = wave < a.nslots, has1 = TSLOTS > 8 && wave + 8 < a.nslots;   // wave-uniform (tiles of <= 8 patches: one per wavefront)
   const int prow0 = 2 * wave + g, prow1 = 2 * (wave + 8) + g;
   // B operand addresses (K half 0; K half 1 = the same ^ 32): pixel q = (prow + ky) * 18 + i + kx, part = lane >> 5
   int bad0[9], bad1[9];
@@ -723,11 +723,14 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   a.N = L.N; a.H = L.H; a.W = L.W;
   const int MT = L.Cout / 32;
   a.tilesX = (L.W + CL_TW - 1) / CL_TW;
-  // (Tiles of at most eight patches with two workgroups per CU were measured in round 3 and bought nothing: the LDS fragment
-  //  reads of the CU, not one workgroup's latencies, are what a layer waits for.)
-  a.nslots = cl16_choose_slots(L.N, L.H, L.W, n_cus);
+  // (Tiles of at most eight patches with two workgroups per CU were measured in round 3, on that round's kernel, and bought nothing.)
+  // (round 6, again: tiles of <= 8 patches with one output-channel tile -- 78 KB, two workgroups per CU -- for launches of several
+  //  rounds of tiles: crops batched per forward.  DBM_CL16_PAIR, libdbm_measure.so: 0 never)
+  static const int pair_env = DBM_TUNE_GETENV("CL16_PAIR") ? atoi(DBM_TUNE_GETENV("CL16_PAIR")) : 1;
+  const bool pair = pair_env && MT == 1 && (long)L.N * a.tilesX * ((L.H + 15) / 16) >= 4L * n_cus;
+  a.nslots = pair ? cl16_choose_slots(L.N, L.H, L.W, n_cus, 8, 2) : cl16_choose_slots(L.N, L.H, L.W, n_cus);
   a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
-  size_t lds = 2 * (size_t)cl_act_bytes(CL_MAXSLOTS) + 2 * (size_t)18 * MT * 1024;
+  size_t lds = 2 * (size_t)cl_act_bytes(pair ? 8 : CL_MAXSLOTS) + 2 * (size_t)18 * MT * 1024;
   a.zeros = L.zeros;
 #ifdef DBM_MEASURE
   static const int abl = DBM_MEASURE_ENV("CL16_ABL");
@@ -738,6 +741,7 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   if (!attr) {
     DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1, CL_MAXSLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<2, CL_MAXSLOTS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    DBM_HIP(hipFuncSetAttribute((const void*)conv_cl16_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     attr = true;
   }
   const unsigned grid = (unsigned)((long)L.N * a.tilesX * a.tilesY);
@@ -751,7 +755,9 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
     snprintf(tag, sizeof(tag), "cl16_c%d>%d_%dx%d_n%d", L.Cin, L.Cout, L.H, L.W, L.N);
     g_profiler.begin(s, 0, 2.0 * px * L.Cout * L.Cin * 9, bytes, tag, grid);
   }
-  if (MT == 1)
+  if (pair)
+    hipLaunchKernelGGL((conv_cl16_kernel<1, 8>), dim3(grid), dim3(CL_NT), lds, s, a);
+  else if (MT == 1)
     hipLaunchKernelGGL((conv_cl16_kernel<1, CL_MAXSLOTS>), dim3(grid), dim3(CL_NT), lds, s, a);
   else
     hipLaunchKernelGGL((conv_cl16_kernel<2, CL_MAXSLOTS>), dim3(grid), dim3(CL_NT), lds, s, a);
