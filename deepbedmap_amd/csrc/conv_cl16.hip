@@ -727,7 +727,11 @@ void launch_conv_cl16(const ClConvLaunch& L, hipStream_t s) {
   // (round 6, again: tiles of <= 8 patches with one output-channel tile -- 78 KB, two workgroups per CU -- for launches of several
   //  rounds of tiles: crops batched per forward.  DBM_CL16_PAIR, libdbm_measure.so: 0 never)
   static const int pair_env = DBM_TUNE_GETENV("CL16_PAIR") ? atoi(DBM_TUNE_GETENV("CL16_PAIR")) : 1;
-  const bool pair = pair_env && MT == 1 && (long)L.N * a.tilesX * ((L.H + 15) / 16) >= 4L * n_cus;
+  // (DBM_CL16_PAIR_MIN: smallest number of 16-row tiles that takes the form.  A single crop -- 324 such tiles -- is slower with it:
+  //  4.51 against 4.47 ms; conv_layer5's 64 output channels as two workgroups of 32 per tile lost as well: continent 1.669 against 1.683 s
+  //  without any pairing, where the 32-channel layers alone gain 3 %: round6_calls/40_conv_cl16_halves.patch)
+  static const long pair_min = DBM_TUNE_GETENV("CL16_PAIR_MIN") ? atol(DBM_TUNE_GETENV("CL16_PAIR_MIN")) : 4L * n_cus;
+  const bool pair = pair_env && MT == 1 && (long)L.N * a.tilesX * ((L.H + 15) / 16) >= pair_min;
   a.nslots = pair ? cl16_choose_slots(L.N, L.H, L.W, n_cus, 8, 2) : cl16_choose_slots(L.N, L.H, L.W, n_cus);
   a.tilesY = (L.H + 2 * a.nslots - 1) / (2 * a.nslots);
   size_t lds = 2 * (size_t)cl_act_bytes(pair ? 8 : CL_MAXSLOTS) + 2 * (size_t)18 * MT * 1024;

@@ -173,6 +173,32 @@ def test_cl16_conv_random_shapes(dbm, case):
     assert np.abs(y.get() - ref).max() / max(np.abs(ref).max(), 1e-30) < 2e-5
 
 
+@pytest.mark.parametrize("O", [32, 64])
+def test_cl16_conv_two_workgroups_per_cu_form(dbm, O):
+    """conv_cl16_kernel on a launch of several rounds of tiles (four 272 x 272 planes = 1 156 tiles of 16 rows: crops batched per forward):
+    the 32-output-channel layers then run as tiles of <= 8 patches with two workgroups per CU; the 64-channel layer (conv_layer5, with
+    its residual epilogue) keeps its one-workgroup form -- both on four planes at once."""
+    d, _lib, ctx = dbm
+    N, Cc, H, W = 4, 32, 272, 272
+    rs = np.random.RandomState(O)
+    x = rs.normal(size=(N, Cc, H, W)).astype(np.float32)
+    w = (rs.normal(size=(O, Cc, 3, 3)) / np.sqrt(9 * Cc)).astype(np.float32)
+    b = rs.normal(size=(O,)).astype(np.float32)
+    resid = O == 64
+    r1 = rs.normal(size=(N, 64, H, W)).astype(np.float32) if resid else None
+    s1 = 0.1 if resid else 1.0
+    ref = ops.conv2d(bf16_round(x).astype(np.float64), bf16_round(w).astype(np.float64), b.astype(np.float64), 1, 1)
+    if resid:
+        ref = s1 * ref + r1
+    ref = np.where(ref >= 0, ref, 0.2 * ref)
+    y = d.DeviceArray((N, O, H, W))
+    dx, dw, db = d.to_device(x), d.to_device(w), d.to_device(b)
+    dr = d.to_device(r1) if resid else None
+    _lib.check(_lib.lib().dbm_op_conv2d_cl16(ctx.handle, dx.ptr, dw.ptr, db.ptr, dr.ptr if resid else None, s1, y.ptr, N, Cc, H, W, O, 1),
+               ctx.handle)
+    assert np.abs(y.get() - ref).max() / np.abs(ref).max() < 2e-5
+
+
 @pytest.mark.parametrize("case", _random_cases(202, 10, lambda r: (int(r.randint(1, 3)), int(r.randint(1, 40)), int(r.randint(1, 40)),
                                                                    int(r.randint(1, 65)), int(r.randint(0, 2)), int(r.randint(0, 2)), int(r.randint(0, 2)))))
 def test_split_bf16_conv_random_shapes(dbm, case):
