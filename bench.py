@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 def _traffic_json():  # tools/pmc_traffic.sh (separate --pmc passes); the newest round's file
-    for r in ("r5", "r4", "r3", "r2", "r1"):
+    for r in ("r6", "r5", "r4", "r3", "r2", "r1"):
         p = os.path.join(ROOT, "profiles", r, "traffic_pmc.json")
         if os.path.exists(p):
             return p
