@@ -205,6 +205,270 @@ __global__ __launch_bounds__(256) void deform_conv64_fused_kernel(const float* _
   }
 }
 
+// ---- the 64 -> 64 layer's forward with the sampler on an LDS window, fp32 (round 6; the training tile's narrow planes) ----
+// deform_conv64_fused_kernel above runs at 0.35 of the fp32 MFMA roof (111 us for 64 x 36 x 36 positions, 39 us of MFMAs): per tap it
+// gathers 64 KB from global memory, blends them into an LDS tile behind a barrier and feeds the MFMAs one ds_read_b32 each.  Here (the
+// idea of deform_conv64_x3w_kernel below, for planes narrow enough that a window of FULL rows fits) a workgroup of four wavefronts owns
+// 128 consecutive positions of one image and stages every input row a sample with a vertical offset in [-2, 3) can touch -- <= 12 rows
+// x (W + 7) pixels x 272 bytes (256 + padding: conflict-free corner reads) -- once; a wavefront owns 32 positions and BOTH
+// output-channel tiles, lane (position j, k half kh) blends its position's channels of parity kh straight into the B operand: no sample
+// tile, no barrier in the tap loop.  A sample whose rows leave the window (vertical offsets beyond the window; horizontally the window
+// spans the whole padded row) reads global memory through the same generic pointer -- any offset is served.
+// Blend expression, channel pairing per MFMA (2 cp, 2 cp + 1) and summation order (taps outer, channel pairs inner) are
+// deform_conv64_fused_kernel's: the same bits.  No sample-matrix output (colout): the launcher keeps the older kernel for that.
+constexpr int DWF_R = 2;
+constexpr int DWF_POS = 128;
+constexpr int DWF_MAXPIX = 528;               // window pixels the LDS layout is sized for (36-wide planes: 12 rows x 43 = 516)
+constexpr int DWF_PIX = 272;                  // bytes between window pixels
+constexpr int DWF_LDS = DWF_MAXPIX * DWF_PIX; // 143 616 bytes
+
+__global__ __launch_bounds__(256) void deform_conv64_fusedw_kernel(const float* __restrict__ xt, const float* __restrict__ off,
+                                                                   const float* __restrict__ wf, const float* __restrict__ bias,
+                                                                   float* __restrict__ y, float* __restrict__ yt, int N, int H, int W,
+                                                                   long offsn, int act, float slope, int tiles_per_image) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fwin[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int plane = H * W;
+  const int n = blockIdx.x / tiles_per_image, tile = blockIdx.x - n * tiles_per_image;
+  const int p0 = tile * DWF_POS, p1 = min(p0 + DWF_POS, plane) - 1;   // positions [p0, p1] of image n
+  const int a0 = p0 / W, a1 = p1 / W;
+  const int wy0 = a0 - 1 - DWF_R, NR = a1 - a0 + 1 + 2 * DWF_R + 3;   // window rows wy0 .. wy0 + NR - 1
+  const int NC = W + 2 * DWF_R + 3, wx0 = -1 - DWF_R;                 // window columns: the whole padded row
+  const int npix = NR * NC;
+  const float* xn = xt + (long)n * plane * 64;
+  // ---- the window: sixteen lanes per pixel (256 contiguous bytes), zeros outside the image.  ALL of a thread's pieces (<= 33) are
+  // requested before the first is written: one workgroup per CU at one wavefront per SIMD has 512 registers per lane and nothing else to
+  // hide a memory round trip behind (batches of eight: five round trips, 10 of a tile's 41 us) ----
+  {
+    constexpr int NP = DWF_MAXPIX * 16 / 256;
+    float4 st[NP];
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int u = it * 256 + tid, px = u >> 4, part = u & 15;
+      const int hy = px / NC, hx = px - hy * NC;
+      const int gy = wy0 + hy, gx = wx0 + hx;
+      const bool inside = px < npix && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      st[it] = inside ? *reinterpret_cast<const float4*>(xn + ((long)gy * W + gx) * 64 + 4 * part) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int u = it * 256 + tid, px = u >> 4, part = u & 15;
+      if (px < npix) *reinterpret_cast<float4*>(fwin + px * DWF_PIX + part * 16) = st[it];
+    }
+  }
+  // ---- this lane's position, its eighteen offsets, the nine taps' geometry ----
+  const int j = lane & 31, kh = lane >> 5;
+  const int p = p0 + 32 * wave + j;
+  const bool valid = p <= p1;
+  const int a = (valid ? p : p0) / W, b = (valid ? p : p0) - a * W;
+  int pg[9];        // the top-left corner of tap t in image coordinates, packed (y0 + 2) << 16 | (x0 + 2)
+  float4 cw[9];     // bilinear weights (build_geometry's: a corner outside the image has weight 0)
+  {
+    const float* on = off + (long)n * offsn + (valid ? p : p0);
+    float ox[9], oy[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      ox[t] = on[(long)t * plane];
+      oy[t] = on[(long)(9 + t) * plane];
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const DeformGeom q = deform_geom(ox[t], oy[t], a, b, t / 3, t % 3, H, W, 1);
+      const int y0 = q.v0 - 2, x0 = q.u0 - 2;   // image coordinates of the top-left corner (deform_corner: - pad - 1)
+      const bool iy0 = (unsigned)y0 < (unsigned)H, iy1 = (unsigned)(y0 + 1) < (unsigned)H;
+      const bool ix0 = (unsigned)x0 < (unsigned)W, ix1 = (unsigned)(x0 + 1) < (unsigned)W;
+      cw[t].x = (valid && iy0 && ix0) ? q.wu1 * q.wv1 : 0.f;
+      cw[t].y = (valid && iy0 && ix1) ? q.wu0 * q.wv1 : 0.f;
+      cw[t].z = (valid && iy1 && ix0) ? q.wu1 * q.wv0 : 0.f;
+      cw[t].w = (valid && iy1 && ix1) ? q.wu0 * q.wv0 : 0.f;
+      pg[t] = ((y0 + 2) << 16) | (x0 + 2);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  __syncthreads();
+
+  {
+    // ---- 72 pipelined steps (tap, eight channels): deform_conv64_x3w_kernel's loop (see there) with fp32 MFMAs.  Step s: wait for the
+    // corner pieces of step s and the weights of step s - 1; request the corner pieces of step s + 1 (lanes inside the window: LDS, the
+    // others: global memory under the complementary EXEC mask); blend the eight channels as four pairs in lock step, the eight MFMAs of
+    // step s - 1 (four channel pairs (2 cp, 2 cp + 1) x two output-channel tiles) dealt between the stages; request the sixteen weights
+    // of step s + 1.  A lane multiplies the channels of its parity: element kh of each blended pair.
+    typedef float f4t __attribute__((ext_vector_type(4)));
+    typedef float f2t __attribute__((ext_vector_type(2)));
+    f4t C[2][8];
+    float A[2][8];          // weights of a step: [channel pair i][output-channel tile ct] = A[.][2 i + ct]
+    float pb[4];            // B operands of the step before (this lane's parity of its four channel pairs)
+    const unsigned lbase = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)fwin;
+    const unsigned wvo = (unsigned)(kh * 9 * 64 + j) * 4u;   // this lane's byte offset into wf: + (((2 cp) * 9 + t) * 64 + ct * 32) * 4
+    unsigned t_lds = 0, t_g1 = 0, t_g2 = 0, t_g3 = 0, t_g4 = 0;
+    unsigned long t_near = ~0ul;
+    auto open_tap = [&](int t) {
+      const int y0 = (pg[t] >> 16) - 2, x0 = (pg[t] & 0xffff) - 2;
+      const int ry = y0 - wy0, rx = x0 - wx0;
+      const bool near = (unsigned)ry < (unsigned)(NR - 1);   // (0 <= rx, rx + 1 < NC always: x0 in [-2, W])
+      t_lds = lbase + (near ? (ry * NC + rx) * DWF_PIX : 0);
+      t_near = __builtin_amdgcn_ballot_w64(near);
+      if (t_near != ~0ul) {   // (wave-uniform)
+        const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1), xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
+        t_g1 = (unsigned)(ya * W + xa) * 256u;
+        t_g2 = (unsigned)(ya * W + xb) * 256u;
+        t_g3 = (unsigned)(yb * W + xa) * 256u;
+        t_g4 = (unsigned)(yb * W + xb) * 256u;
+      }
+    };
+#define DWF_LDS_READS "ds_read_b128 %0, %[ad] offset:%[k0]\n\tds_read_b128 %1, %[ad] offset:%[k1]\n\t" \
+                      "ds_read_b128 %2, %[ad]\n\tds_read_b128 %3, %[ad]\n\t" \
+                      "ds_read_b128 %4, %[ad]\n\tds_read_b128 %5, %[ad]\n\t" \
+                      "ds_read_b128 %6, %[ad]\n\tds_read_b128 %7, %[ad]"
+    // (the second / third / fourth corner's pixel lies NC - dependent bytes further: run-time distances, folded into the address registers)
+    auto corners_ks = [&](auto KS, f4t (&c)[8]) {   // c[2 corner + e]
+      constexpr int ks = decltype(KS)::value;   // channels 8 ks .. 8 ks + 7: bytes ks * 32 (+ 16)
+      const unsigned ad1 = t_lds, ad2 = t_lds + DWF_PIX, ad3 = t_lds + (unsigned)NC * DWF_PIX, ad4 = ad3 + DWF_PIX;
+      const unsigned g1_ = t_g1, g2_ = t_g2, g3_ = t_g3, g4_ = t_g4;
+      const unsigned long nm_ = t_near;
+      const float* xb_ = xn;
+      if (nm_ == ~0ul) {
+        asm volatile("ds_read_b128 %0, %[a1] offset:%[o0]\n\tds_read_b128 %1, %[a1] offset:%[o1]\n\t"
+                     "ds_read_b128 %2, %[a2] offset:%[o0]\n\tds_read_b128 %3, %[a2] offset:%[o1]\n\t"
+                     "ds_read_b128 %4, %[a3] offset:%[o0]\n\tds_read_b128 %5, %[a3] offset:%[o1]\n\t"
+                     "ds_read_b128 %6, %[a4] offset:%[o0]\n\tds_read_b128 %7, %[a4] offset:%[o1]"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
+                     : [a1] "v"(ad1), [a2] "v"(ad2), [a3] "v"(ad3), [a4] "v"(ad4), [o0] "n"(ks * 32), [o1] "n"(ks * 32 + 16));
+      } else {
+        unsigned long sv;
+        asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, %[sv], %[nm]\n\t"
+                     "ds_read_b128 %0, %[a1] offset:%[o0]\n\tds_read_b128 %1, %[a1] offset:%[o1]\n\t"
+                     "ds_read_b128 %2, %[a2] offset:%[o0]\n\tds_read_b128 %3, %[a2] offset:%[o1]\n\t"
+                     "ds_read_b128 %4, %[a3] offset:%[o0]\n\tds_read_b128 %5, %[a3] offset:%[o1]\n\t"
+                     "ds_read_b128 %6, %[a4] offset:%[o0]\n\tds_read_b128 %7, %[a4] offset:%[o1]\n\t"
+                     "s_andn2_b64 exec, %[sv], %[nm]\n\t"
+                     "global_load_dwordx4 %0, %[g1], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %1, %[g1], %[xb] offset:%[o1]\n\t"
+                     "global_load_dwordx4 %2, %[g2], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %3, %[g2], %[xb] offset:%[o1]\n\t"
+                     "global_load_dwordx4 %4, %[g3], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %5, %[g3], %[xb] offset:%[o1]\n\t"
+                     "global_load_dwordx4 %6, %[g4], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %7, %[g4], %[xb] offset:%[o1]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]), [sv] "=&s"(sv)
+                     : [a1] "v"(ad1), [a2] "v"(ad2), [a3] "v"(ad3), [a4] "v"(ad4), [nm] "s"(nm_), [g1] "v"(g1_), [g2] "v"(g2_), [g3] "v"(g3_),
+                       [g4] "v"(g4_), [xb] "s"(xb_), [o0] "n"(ks * 32), [o1] "n"(ks * 32 + 16));
+      }
+    };
+#undef DWF_LDS_READS
+    auto request_corners = [&](int st, f4t (&c)[8]) {
+      if ((st & 7) == 0) open_tap(st >> 3);
+      switch (st & 7) {
+        case 0: corners_ks(std::integral_constant<int, 0>{}, c); break;
+        case 1: corners_ks(std::integral_constant<int, 1>{}, c); break;
+        case 2: corners_ks(std::integral_constant<int, 2>{}, c); break;
+        case 3: corners_ks(std::integral_constant<int, 3>{}, c); break;
+        case 4: corners_ks(std::integral_constant<int, 4>{}, c); break;
+        case 5: corners_ks(std::integral_constant<int, 5>{}, c); break;
+        case 6: corners_ks(std::integral_constant<int, 6>{}, c); break;
+        default: corners_ks(std::integral_constant<int, 7>{}, c); break;
+      }
+    };
+    // the sixteen weights of step st = (tap t, channels 8 ks ..): channel pairs cp = 4 ks + i, rows ((2 cp) * 9 + t) of wf (+ kh * 9: wvo)
+    auto request_weights = [&](int st, float (&aw)[8]) {
+      const int t = st >> 3, ks = st & 7;
+      const float* b0 = wf + ((long)(2 * (4 * ks + 0)) * 9 + t) * 64;
+      const float* b1 = wf + ((long)(2 * (4 * ks + 1)) * 9 + t) * 64;
+      const float* b2 = wf + ((long)(2 * (4 * ks + 2)) * 9 + t) * 64;
+      const float* b3 = wf + ((long)(2 * (4 * ks + 3)) * 9 + t) * 64;
+      const unsigned vo = wvo;
+      asm volatile("global_load_dword %0, %[vo], %[b0]\n\tglobal_load_dword %1, %[vo], %[b0] offset:128\n\t"
+                   "global_load_dword %2, %[vo], %[b1]\n\tglobal_load_dword %3, %[vo], %[b1] offset:128\n\t"
+                   "global_load_dword %4, %[vo], %[b2]\n\tglobal_load_dword %5, %[vo], %[b2] offset:128\n\t"
+                   "global_load_dword %6, %[vo], %[b3]\n\tglobal_load_dword %7, %[vo], %[b3] offset:128"
+                   : "=&v"(aw[0]), "=&v"(aw[1]), "=&v"(aw[2]), "=&v"(aw[3]), "=&v"(aw[4]), "=&v"(aw[5]), "=&v"(aw[6]), "=&v"(aw[7])
+                   : [vo] "v"(vo), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [b3] "s"(b3));
+    };
+#define DWF_THROUGH(c, aw) "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(aw[0]), "+v"(aw[1]), \
+                           "+v"(aw[2]), "+v"(aw[3]), "+v"(aw[4]), "+v"(aw[5]), "+v"(aw[6]), "+v"(aw[7])
+    // MFMA k (0..7) of the step whose weights are aw: channel pair i = k >> 1, output-channel tile ct = k & 1
+    auto mfma_k = [&](int k, const float (&aw)[8]) {
+      acc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[k], pb[k >> 1], acc[k & 1], 0, 0, 0);
+    };
+    constexpr int NST = 72;
+    request_corners(0, C[0]);
+    request_weights(0, A[0]);
+    request_weights(1, A[1]);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      f4t (&c)[8] = C[st & 1];
+      float (&aw)[8] = A[(st + 1) & 1];    // the weights of step st - 1
+      // (in order: ... corners(st) [global part, if any], weights(st); both weight requests of the prologue are younger than corners(0),
+      //  corners(1) is the youngest request at step 1)
+      if (st == 0) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" : DWF_THROUGH(c, aw));
+      else if (st == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : DWF_THROUGH(c, aw));
+      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : DWF_THROUGH(c, aw));
+      if (st + 1 < NST) request_corners(st + 1, C[(st + 1) & 1]);
+      auto mfma = [&](int k) {
+        if (st > 0) mfma_k(k, aw);
+      };
+      const float4 w = cw[st >> 3];
+      f2t m[4];
+#define DWF_FENCE asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]))
+#define DWF_PAIR(q, k) ((f2t){c[q + (k >> 1)][2 * (k & 1)], c[q + (k >> 1)][2 * (k & 1) + 1]})   /* corner q / 2, channel pair k of the eight */
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = w.y * DWF_PAIR(2, k);
+      DWF_FENCE;
+      mfma(0); mfma(1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = __builtin_elementwise_fma((f2t){w.x, w.x}, DWF_PAIR(0, k), m[k]);
+      DWF_FENCE;
+      mfma(2); mfma(3);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = __builtin_elementwise_fma((f2t){w.z, w.z}, DWF_PAIR(4, k), m[k]);
+      DWF_FENCE;
+      mfma(4); mfma(5);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m[k] = __builtin_elementwise_fma((f2t){w.w, w.w}, DWF_PAIR(6, k), m[k]);
+      DWF_FENCE;
+      mfma(6); mfma(7);
+#undef DWF_FENCE
+#undef DWF_PAIR
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pb[k] = kh ? m[k][1] : m[k][0];
+      if (st >= 1 && st + 1 < NST) request_weights(st + 1, A[(st + 1) & 1]);   // (into the registers step st - 1's MFMAs have just read)
+    }
+    {  // the last step's MFMAs
+      float (&aw)[8] = A[(NST - 1) & 1];
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(aw[0]), "+v"(aw[1]), "+v"(aw[2]), "+v"(aw[3]), "+v"(aw[4]), "+v"(aw[5]), "+v"(aw[6]), "+v"(aw[7]));
+#pragma unroll
+      for (int k = 0; k < 8; ++k) mfma_k(k, aw);
+    }
+#undef DWF_THROUGH
+  }
+  if (!valid) return;
+  const long Pm = (long)n * plane + p;
+  float v[2][16];   // (all bias loads before the first store: see deform_conv64_fused_kernel)
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      v[ct][r] = acc[ct][r] + (bias ? bias[c] : 0.f);
+      if (act) v[ct][r] = v[ct][r] >= 0.f ? v[ct][r] : slope * v[ct][r];
+    }
+  if (y) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[(long)n * 64 * plane + p + (long)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * plane] = v[ct][r];
+  }
+  if (yt) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *reinterpret_cast<float4*>(yt + Pm * 64 + ct * 32 + 8 * gq + 4 * kh) =
+            make_float4(v[ct][4 * gq], v[ct][4 * gq + 1], v[ct][4 * gq + 2], v[ct][4 * gq + 3]);
+  }
+}
+
 // ---- weight gradient of the 64 -> 64 layer with the sampler fused in (round 6) ----
 // gW[o][c][t] += sum_{n,p} gy[n][o][p] * sample(c, t, n, p);  gb[o] += sum gy.
 // Until round 5 the retained forward wrote Chainer's sample matrix x_st (N, 576, plane): 191 MB at batch 64, written from the forward
@@ -1430,7 +1694,23 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
     snprintf(tag, sizeof(tag), "deform%d_%dx%d_n%d%s", O, H, W, N, colout ? "_keep" : "");
     g_profiler.begin(s, 0, 2.0 * (double)total * O * C * 9, bytes, tag, blocks);
   }
-  if (O == 64)
+  // (the window form, DBM_DEFORM_FWD_WINDOW=1: planes narrow enough that <= 128 consecutive positions + their vertical reach fit the LDS
+  //  layout, no sample matrix wanted -- the same bits as the gathering kernel.  OFF by default: 119 against 111 us standalone on the
+  //  training tile (one workgroup of four wavefronts per CU; 704 tiles = three rounds of 40 us where the MFMAs alone are 15), 7.55-7.58
+  //  against 7.57-7.61 ms per step in two A/B series: inside the noise -- profiles/r6/ab_deform_fwd_fp32_window.txt)
+  static const int fwin_env = getenv("DBM_DEFORM_FWD_WINDOW") ? atoi(getenv("DBM_DEFORM_FWD_WINDOW")) : 0;
+  const int span_rows = std::min(H, (DWF_POS - 1 + W - 1) / W + 1);   // most rows 128 consecutive positions can span
+  const bool fwin_ok = O == 64 && !colout && fwin_env && (span_rows + 2 * DWF_R + 3) * (W + 2 * DWF_R + 3) <= DWF_MAXPIX;
+  if (fwin_ok) {
+    static bool attr = false;
+    if (!attr) {
+      DBM_HIP(hipFuncSetAttribute((const void*)deform_conv64_fusedw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = true;
+    }
+    const int tpi = (H * W + DWF_POS - 1) / DWF_POS;
+    hipLaunchKernelGGL(deform_conv64_fusedw_kernel, dim3((unsigned)(N * tpi)), dim3(256), DWF_LDS, s, xt, off, w, bias, y, yt, N, H, W, offsn, act,
+                       slope, tpi);
+  } else if (O == 64)
     hipLaunchKernelGGL(deform_conv64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, bias, y, yt, colout, N, H, W, offsn, act, slope,
                        DBM_MEASURE_ENV("DEFORM_ABL"));
   else if (z) {
