@@ -225,7 +225,13 @@ constexpr int DWF_LDS = DWF_MAXPIX * DWF_PIX; // 143 616 bytes
 __global__ __launch_bounds__(256) void deform_conv64_fusedw_kernel(const float* __restrict__ xt, const float* __restrict__ off,
                                                                    const float* __restrict__ wf, const float* __restrict__ bias,
                                                                    float* __restrict__ y, float* __restrict__ yt, int N, int H, int W,
-                                                                   long offsn, int act, float slope, int tiles_per_image) {
+                                                                   long offsn, int act, float slope, int tiles_per_image, int abl_arg) {
+#ifdef DBM_MEASURE
+  const int abl = abl_arg;   // (libdbm_measure.so, DBM_FUSEDW_ABL, results wrong: 1 no step loop, 2 no window staging, 8 no stores, 256 no MFMAs)
+#else
+  constexpr int abl = 0;
+  (void)abl_arg;
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char fwin[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int plane = H * W;
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(256) void deform_conv64_fusedw_kernel(const float* 
   // ---- the window: sixteen lanes per pixel (256 contiguous bytes), zeros outside the image.  ALL of a thread's pieces (<= 33) are
   // requested before the first is written: one workgroup per CU at one wavefront per SIMD has 512 registers per lane and nothing else to
   // hide a memory round trip behind (batches of eight: five round trips, 10 of a tile's 41 us) ----
-  {
+  if (!(abl & 2)) {
     constexpr int NP = DWF_MAXPIX * 16 / 256;
     float4 st[NP];
 #pragma unroll
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(256) void deform_conv64_fusedw_kernel(const float* 
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
   __syncthreads();
 
-  {
+  if (!(abl & 1)) {
     // ---- 72 pipelined steps (tap, eight channels): deform_conv64_x3w_kernel's loop (see there) with fp32 MFMAs.  Step s: wait for the
     // corner pieces of step s and the weights of step s - 1; request the corner pieces of step s + 1 (lanes inside the window: LDS, the
     // others: global memory under the complementary EXEC mask); blend the eight channels as four pairs in lock step, the eight MFMAs of
@@ -300,7 +306,11 @@ __global__ __launch_bounds__(256) void deform_conv64_fusedw_kernel(const float* 
     typedef float f4t __attribute__((ext_vector_type(4)));
     typedef float f2t __attribute__((ext_vector_type(2)));
     f4t C[2][8];
-    float A[2][8];          // weights of a step: [channel pair i][output-channel tile ct] = A[.][2 i + ct]
+    float A[4][8];          // weights of a step: [channel pair i][output-channel tile ct] = A[.][2 i + ct]; requested TWO steps ahead (one
+                            // wavefront per SIMD: nobody else hides an L2 round trip -- with one step the loop took 830 cycles per
+                            // step even without its MFMAs), right behind the corner pieces: ONE wait count serves taps with and
+                            // without far lanes (a branch between a request and its wait makes hipcc copy registers whose loads are
+                            // still in flight: wrong results, measured)
     float pb[4];            // B operands of the step before (this lane's parity of its four channel pairs)
     const unsigned lbase = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char*)fwin;
     const unsigned wvo = (unsigned)(kh * 9 * 64 + j) * 4u;   // this lane's byte offset into wf: + (((2 cp) * 9 + t) * 64 + ct * 32) * 4
@@ -331,30 +341,27 @@ __global__ __launch_bounds__(256) void deform_conv64_fusedw_kernel(const float* 
       const unsigned g1_ = t_g1, g2_ = t_g2, g3_ = t_g3, g4_ = t_g4;
       const unsigned long nm_ = t_near;
       const float* xb_ = xn;
-      if (nm_ == ~0ul) {
-        asm volatile("ds_read_b128 %0, %[a1] offset:%[o0]\n\tds_read_b128 %1, %[a1] offset:%[o1]\n\t"
-                     "ds_read_b128 %2, %[a2] offset:%[o0]\n\tds_read_b128 %3, %[a2] offset:%[o1]\n\t"
-                     "ds_read_b128 %4, %[a3] offset:%[o0]\n\tds_read_b128 %5, %[a3] offset:%[o1]\n\t"
-                     "ds_read_b128 %6, %[a4] offset:%[o0]\n\tds_read_b128 %7, %[a4] offset:%[o1]"
-                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
-                     : [a1] "v"(ad1), [a2] "v"(ad2), [a3] "v"(ad3), [a4] "v"(ad4), [o0] "n"(ks * 32), [o1] "n"(ks * 32 + 16));
-      } else {
-        unsigned long sv;
-        asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, %[sv], %[nm]\n\t"
-                     "ds_read_b128 %0, %[a1] offset:%[o0]\n\tds_read_b128 %1, %[a1] offset:%[o1]\n\t"
-                     "ds_read_b128 %2, %[a2] offset:%[o0]\n\tds_read_b128 %3, %[a2] offset:%[o1]\n\t"
-                     "ds_read_b128 %4, %[a3] offset:%[o0]\n\tds_read_b128 %5, %[a3] offset:%[o1]\n\t"
-                     "ds_read_b128 %6, %[a4] offset:%[o0]\n\tds_read_b128 %7, %[a4] offset:%[o1]\n\t"
-                     "s_andn2_b64 exec, %[sv], %[nm]\n\t"
-                     "global_load_dwordx4 %0, %[g1], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %1, %[g1], %[xb] offset:%[o1]\n\t"
-                     "global_load_dwordx4 %2, %[g2], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %3, %[g2], %[xb] offset:%[o1]\n\t"
-                     "global_load_dwordx4 %4, %[g3], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %5, %[g3], %[xb] offset:%[o1]\n\t"
-                     "global_load_dwordx4 %6, %[g4], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %7, %[g4], %[xb] offset:%[o1]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]), [sv] "=&s"(sv)
-                     : [a1] "v"(ad1), [a2] "v"(ad2), [a3] "v"(ad3), [a4] "v"(ad4), [nm] "s"(nm_), [g1] "v"(g1_), [g2] "v"(g2_), [g3] "v"(g3_),
-                       [g4] "v"(g4_), [xb] "s"(xb_), [o0] "n"(ks * 32), [o1] "n"(ks * 32 + 16));
-      }
+      // ONE asm statement for both kinds of lanes (the far lanes' loads skipped by a branch INSIDE it when there are none): two
+      // statements in the arms of an if would define the same registers twice, and hipcc may then copy them at the join -- before the
+      // wait, while the loads are still in flight
+      unsigned long sv;
+      asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, %[sv], %[nm]\n\ts_cbranch_execz .Lfw_nolds%=\n\t"
+                   "ds_read_b128 %0, %[a1] offset:%[o0]\n\tds_read_b128 %1, %[a1] offset:%[o1]\n\t"
+                   "ds_read_b128 %2, %[a2] offset:%[o0]\n\tds_read_b128 %3, %[a2] offset:%[o1]\n\t"
+                   "ds_read_b128 %4, %[a3] offset:%[o0]\n\tds_read_b128 %5, %[a3] offset:%[o1]\n\t"
+                   "ds_read_b128 %6, %[a4] offset:%[o0]\n\tds_read_b128 %7, %[a4] offset:%[o1]\n"
+                   ".Lfw_nolds%=:\n\t"
+                   "s_andn2_b64 exec, %[sv], %[nm]\n\ts_cbranch_execz .Lfw_nofar%=\n\t"
+                   "global_load_dwordx4 %0, %[g1], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %1, %[g1], %[xb] offset:%[o1]\n\t"
+                   "global_load_dwordx4 %2, %[g2], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %3, %[g2], %[xb] offset:%[o1]\n\t"
+                   "global_load_dwordx4 %4, %[g3], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %5, %[g3], %[xb] offset:%[o1]\n\t"
+                   "global_load_dwordx4 %6, %[g4], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %7, %[g4], %[xb] offset:%[o1]\n"
+                   ".Lfw_nofar%=:\n\t"
+                   "s_mov_b64 exec, %[sv]"
+                   : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]), [sv] "=&s"(sv)
+                   : [a1] "v"(ad1), [a2] "v"(ad2), [a3] "v"(ad3), [a4] "v"(ad4), [nm] "s"(nm_), [g1] "v"(g1_), [g2] "v"(g2_), [g3] "v"(g3_),
+                     [g4] "v"(g4_), [xb] "s"(xb_), [o0] "n"(ks * 32), [o1] "n"(ks * 32 + 16)
+                   : "scc");
     };
 #undef DWF_LDS_READS
     auto request_corners = [&](int st, f4t (&c)[8]) {
@@ -389,6 +396,7 @@ __global__ __launch_bounds__(256) void deform_conv64_fusedw_kernel(const float* 
                            "+v"(aw[2]), "+v"(aw[3]), "+v"(aw[4]), "+v"(aw[5]), "+v"(aw[6]), "+v"(aw[7])
     // MFMA k (0..7) of the step whose weights are aw: channel pair i = k >> 1, output-channel tile ct = k & 1
     auto mfma_k = [&](int k, const float (&aw)[8]) {
+      if (abl & 256) return;
       acc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[k], pb[k >> 1], acc[k & 1], 0, 0, 0);
     };
     constexpr int NST = 72;
@@ -398,13 +406,15 @@ __global__ __launch_bounds__(256) void deform_conv64_fusedw_kernel(const float* 
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
       f4t (&c)[8] = C[st & 1];
-      float (&aw)[8] = A[(st + 1) & 1];    // the weights of step st - 1
-      // (in order: ... corners(st) [global part, if any], weights(st); both weight requests of the prologue are younger than corners(0),
-      //  corners(1) is the youngest request at step 1)
+      float (&aw)[8] = A[(st + 3) & 3];    // the weights of step st - 1
+      // Needed now: the corner pieces of step st (LDS: lgkmcnt(0); the global pieces of its far lanes, if the tap has any) and the weights
+      // of step st - 1.  In issue order: ... corner pieces(st) [step st - 1], weights(st + 1) [step st - 1, right behind them]: the
+      // youngest eight loads stay in flight (step 0: both weight requests of the prologue; the last step: nothing is younger).
       if (st == 0) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" : DWF_THROUGH(c, aw));
-      else if (st == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : DWF_THROUGH(c, aw));
-      else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : DWF_THROUGH(c, aw));
+      else if (st + 1 < NST) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" : DWF_THROUGH(c, aw));
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : DWF_THROUGH(c, aw));
       if (st + 1 < NST) request_corners(st + 1, C[(st + 1) & 1]);
+      if (st + 2 < NST) request_weights(st + 2, A[(st + 2) & 3]);
       auto mfma = [&](int k) {
         if (st > 0) mfma_k(k, aw);
       };
@@ -432,17 +442,16 @@ __global__ __launch_bounds__(256) void deform_conv64_fusedw_kernel(const float* 
 #undef DWF_PAIR
 #pragma unroll
       for (int k = 0; k < 4; ++k) pb[k] = kh ? m[k][1] : m[k][0];
-      if (st >= 1 && st + 1 < NST) request_weights(st + 1, A[(st + 1) & 1]);   // (into the registers step st - 1's MFMAs have just read)
     }
     {  // the last step's MFMAs
-      float (&aw)[8] = A[(NST - 1) & 1];
+      float (&aw)[8] = A[(NST - 1) & 3];
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(aw[0]), "+v"(aw[1]), "+v"(aw[2]), "+v"(aw[3]), "+v"(aw[4]), "+v"(aw[5]), "+v"(aw[6]), "+v"(aw[7]));
 #pragma unroll
       for (int k = 0; k < 8; ++k) mfma_k(k, aw);
     }
 #undef DWF_THROUGH
   }
-  if (!valid) return;
+  if (!valid || (abl & 8)) return;
   const long Pm = (long)n * plane + p;
   float v[2][16];   // (all bias loads before the first store: see deform_conv64_fused_kernel)
 #pragma unroll
@@ -948,23 +957,23 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
       const unsigned ad_ = t_lds, g1_ = t_g1, g2_ = t_g2, g3_ = t_g3, g4_ = t_g4;
       const unsigned long nm_ = t_near;
       const float* xb_ = xn;
-      if (nm_ == ~0ul) {
-        asm volatile(DW_LDS_READS
-                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7])
-                     : [ad] "v"(ad_), DW_LDS_OFFS(ks));
-      } else {
-        unsigned long sv;
-        asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, %[sv], %[nm]\n\t" DW_LDS_READS "\n\t"
-                     "s_andn2_b64 exec, %[sv], %[nm]\n\t"
-                     "global_load_dwordx4 %0, %[g1], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %1, %[g1], %[xb] offset:%[o1]\n\t"
-                     "global_load_dwordx4 %2, %[g2], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %3, %[g2], %[xb] offset:%[o1]\n\t"
-                     "global_load_dwordx4 %4, %[g3], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %5, %[g3], %[xb] offset:%[o1]\n\t"
-                     "global_load_dwordx4 %6, %[g4], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %7, %[g4], %[xb] offset:%[o1]\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]), [sv] "=&s"(sv)
-                     : [ad] "v"(ad_), DW_LDS_OFFS(ks), [nm] "s"(nm_), [g1] "v"(g1_), [g2] "v"(g2_), [g3] "v"(g3_), [g4] "v"(g4_),
-                       [xb] "s"(xb_), [o0] "n"(ks * 64), [o1] "n"(ks * 64 + 16));
-      }
+      // ONE asm statement for both kinds of lanes (the far lanes' loads skipped by a branch INSIDE it when there are none): two
+      // statements in the arms of an if would define the same registers twice, and hipcc may then copy them at the join -- before the
+      // wait, while the loads are still in flight (it did, in deform_conv64_fusedw_kernel's first two-armed wait)
+      unsigned long sv;
+      asm volatile("s_mov_b64 %[sv], exec\n\ts_and_b64 exec, %[sv], %[nm]\n\ts_cbranch_execz .Lxw_nolds%=\n\t" DW_LDS_READS "\n"
+                   ".Lxw_nolds%=:\n\t"
+                   "s_andn2_b64 exec, %[sv], %[nm]\n\ts_cbranch_execz .Lxw_nofar%=\n\t"
+                   "global_load_dwordx4 %0, %[g1], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %1, %[g1], %[xb] offset:%[o1]\n\t"
+                   "global_load_dwordx4 %2, %[g2], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %3, %[g2], %[xb] offset:%[o1]\n\t"
+                   "global_load_dwordx4 %4, %[g3], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %5, %[g3], %[xb] offset:%[o1]\n\t"
+                   "global_load_dwordx4 %6, %[g4], %[xb] offset:%[o0]\n\tglobal_load_dwordx4 %7, %[g4], %[xb] offset:%[o1]\n"
+                   ".Lxw_nofar%=:\n\t"
+                   "s_mov_b64 exec, %[sv]"
+                   : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "=&v"(c[4]), "=&v"(c[5]), "=&v"(c[6]), "=&v"(c[7]), [sv] "=&s"(sv)
+                   : [ad] "v"(ad_), DW_LDS_OFFS(ks), [nm] "s"(nm_), [g1] "v"(g1_), [g2] "v"(g2_), [g3] "v"(g3_), [g4] "v"(g4_),
+                     [xb] "s"(xb_), [o0] "n"(ks * 64), [o1] "n"(ks * 64 + 16)
+                   : "scc");
     };
     auto request_corners = [&](int st, f4t (&c)[8]) {
       if ((st & 3) == 0) open_tap(st >> 2);
@@ -1694,11 +1703,11 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
     snprintf(tag, sizeof(tag), "deform%d_%dx%d_n%d%s", O, H, W, N, colout ? "_keep" : "");
     g_profiler.begin(s, 0, 2.0 * (double)total * O * C * 9, bytes, tag, blocks);
   }
-  // (the window form, DBM_DEFORM_FWD_WINDOW=1: planes narrow enough that <= 128 consecutive positions + their vertical reach fit the LDS
-  //  layout, no sample matrix wanted -- the same bits as the gathering kernel.  OFF by default: 119 against 111 us standalone on the
-  //  training tile (one workgroup of four wavefronts per CU; 704 tiles = three rounds of 40 us where the MFMAs alone are 15), 7.55-7.58
-  //  against 7.57-7.61 ms per step in two A/B series: inside the noise -- profiles/r6/ab_deform_fwd_fp32_window.txt)
-  static const int fwin_env = getenv("DBM_DEFORM_FWD_WINDOW") ? atoi(getenv("DBM_DEFORM_FWD_WINDOW")) : 0;
+  // (the window form: planes narrow enough that <= 128 consecutive positions + their vertical reach fit the LDS layout, no sample matrix
+  //  wanted -- the same bits as the gathering kernel.  119-125 against 111 us standalone on the training tile (one workgroup of four
+  //  wavefronts per CU; 704 tiles = three rounds), but 7.56-7.58 against 7.59-7.61 ms per step in three A/B series: it leaves the CUs to
+  //  the kernels of the other streams.  DBM_DEFORM_FWD_WINDOW=0: the gathering kernel.  profiles/r6/ab_deform_fwd_fp32_window.txt)
+  static const int fwin_env = getenv("DBM_DEFORM_FWD_WINDOW") ? atoi(getenv("DBM_DEFORM_FWD_WINDOW")) : 1;
   const int span_rows = std::min(H, (DWF_POS - 1 + W - 1) / W + 1);   // most rows 128 consecutive positions can span
   const bool fwin_ok = O == 64 && !colout && fwin_env && (span_rows + 2 * DWF_R + 3) * (W + 2 * DWF_R + 3) <= DWF_MAXPIX;
   if (fwin_ok) {
@@ -1709,7 +1718,7 @@ void launch_deform_conv_fused(const float* xt, const float* off, const float* w,
     }
     const int tpi = (H * W + DWF_POS - 1) / DWF_POS;
     hipLaunchKernelGGL(deform_conv64_fusedw_kernel, dim3((unsigned)(N * tpi)), dim3(256), DWF_LDS, s, xt, off, w, bias, y, yt, N, H, W, offsn, act,
-                       slope, tpi);
+                       slope, tpi, DBM_MEASURE_ENV("FUSEDW_ABL"));
   } else if (O == 64)
     hipLaunchKernelGGL(deform_conv64_fused_kernel, dim3(blocks), dim3(256), 0, s, xt, off, w, bias, y, yt, colout, N, H, W, offsn, act, slope,
                        DBM_MEASURE_ENV("DEFORM_ABL"));

@@ -132,7 +132,7 @@ np.savez(sys.argv[2], m=np.array(m), **{"g|" + k.replace("/", "|"): v for k, v i
 @pytest.mark.parametrize("env", [{"DBM_ITER_DEFER_EVAL": "1"}, {"DBM_ITER_EARLY_TWIN": "1"}, {"DBM_ITER_EARLY_TWIN": "2"}, {"DBM_ITER_CSR_EARLY": "0", "DBM_PACK_SPLIT": "0"}, {"DBM_CONV_TILE": "0", "DBM_BN_REG": "0"},
                                  {"DBM_CONV_TILE_K4": "0", "DBM_CONV_TILE_9": "1"}, {"DBM_INPUT_FUSED": "0", "DBM_CONV_TILE_YT": "0"},
                                  {"DBM_CIN_LIVE": "0", "DBM_DEFORM1_PREMUL_BWD": "0"}, {"DBM_DEFORM1_PREMUL": "0", "DBM_BWD_GROUPS": "3"},
-                                 {"DBM_TRUNK_FUSED_BWD": "0"}, {"DBM_DEFORM_WGRAD_FUSED": "0"}, {"DBM_DEFORM_FWD_WINDOW": "1"}])
+                                 {"DBM_TRUNK_FUSED_BWD": "0"}, {"DBM_DEFORM_WGRAD_FUSED": "0"}, {"DBM_DEFORM_FWD_WINDOW": "0"}])
 def test_schedule_switches_of_round5_change_no_number(tmp_path, env):
     """DBM_ITER_EARLY_TWIN (where the G-step's own forward is released; 2 also moves the generator's weight gradients to its own
     stream) and DBM_ITER_CSR_EARLY=0 (the deformable layers' sampling lists built inside the backward pass instead of beside the
@@ -149,8 +149,8 @@ def test_schedule_switches_of_round5_change_no_number(tmp_path, env):
     layer's gathering backward kernels / forward without the premultiplied tap planes), DBM_BWD_GROUPS=3 (three chain launches, the
     data-parallel schedule's grouping), DBM_TRUNK_FUSED_BWD=0 (the layer-by-layer data-gradient chain behind the persistent forward) and
     DBM_DEFORM_WGRAD_FUSED=0 (final_conv_layer1's weight gradient from the retained sample matrix through the 1x1 form instead of the
-    sampler-fused kernel of round 6).  DBM_DEFORM_FWD_WINDOW=1 (final_conv_layer1's fp32 forward reading an LDS window of full rows -- deform_conv64_fusedw_kernel, opt-in --
-    instead of gathering every corner from memory; same blend, same channel pairing per MFMA, same summation order): BITWISE."""
+    sampler-fused kernel of round 6).  DBM_DEFORM_FWD_WINDOW=0 (final_conv_layer1's fp32 forward gathering every corner from memory instead of reading an LDS window of full
+    rows -- deform_conv64_fusedw_kernel --; same blend, same channel pairing per MFMA, same summation order): BITWISE."""
     script = tmp_path / "sched.py"
     script.write_text(_SCHEDULE_SCRIPT)
     outs = []
