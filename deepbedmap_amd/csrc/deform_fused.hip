@@ -1018,7 +1018,6 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
         if (st > 0) mfma_k(k, aw);
       };
       const float4 w = cw[st >> 2];
-      f2t m[4], hf[4];
       dbf16x8 bh, bl;
       if (abl & 128) {   // (128: no blend / split arithmetic -- the MFMAs' B operands are raw corner bytes)
 #pragma unroll
@@ -1028,45 +1027,57 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
         if (st >= 1 && st + 1 < 36) request_weights(st + 1, A[(st + 1) & 1]);
         continue;
       }
-#define DW_FENCE asm volatile("" : "+v"(m[0]), "+v"(m[1]), "+v"(m[2]), "+v"(m[3]), "+v"(pbh), "+v"(pbl))
-#define DW_PAIR(q, k) ((f2t){c[q + (k >> 1)][2 * (k & 1)], c[q + (k >> 1)][2 * (k & 1) + 1]})   /* corner q / 2, channel pair k of the eight */
+      // SCALAR fp32 instructions, written as asm: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 -- what hipcc makes of this arithmetic,
+      // two channels per instruction -- do NOT run under a wavefront's own MFMAs: 8 MFMAs + 64 packed FMAs take 256 + 336 cycles, with
+      // v_fma_f32 (or conversions, integer instructions) 256 + 64 (tools/experiments/ubench/mfma_valu_overlap.hip).  Volatile asm keeps
+      // its order: every channel's operation k before any channel's operation k + 1; the fences pin MFMA k between two stages.
+      float e[8];   // the eight channels of the step: channel 4 (k >> 2) .. of piece (k >> 2), element k & 3
+#define DW_FENCE asm volatile("" : "+v"(pbh), "+v"(pbl))
+#define DW_CH(q, k) c[q + (k >> 2)][k & 3]   /* corner q / 2, channel k of the eight */
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = w.y * DW_PAIR(2, k);
+      for (int k = 0; k < 8; ++k) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(e[k]) : "v"(w.y), "v"(DW_CH(2, k)));
       DW_FENCE;
       mfma(0);
+      DW_FENCE;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = __builtin_elementwise_fma((f2t){w.x, w.x}, DW_PAIR(0, k), m[k]);
+      for (int k = 0; k < 8; ++k) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(e[k]) : "v"(w.x), "v"(DW_CH(0, k)));
       DW_FENCE;
       mfma(1);
+      DW_FENCE;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = __builtin_elementwise_fma((f2t){w.z, w.z}, DW_PAIR(4, k), m[k]);
+      for (int k = 0; k < 8; ++k) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(e[k]) : "v"(w.z), "v"(DW_CH(4, k)));
       DW_FENCE;
       mfma(2);
+      DW_FENCE;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = __builtin_elementwise_fma((f2t){w.w, w.w}, DW_PAIR(6, k), m[k]);
+      for (int k = 0; k < 8; ++k) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(e[k]) : "v"(w.w), "v"(DW_CH(6, k)));
       DW_FENCE;
       mfma(3);
+      DW_FENCE;
+      unsigned hp[4], lp[4];   // hi / lo halves, two channels per register
+#pragma unroll
+      for (int k = 0; k < 4; ++k) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hp[k]) : "v"(e[2 * k]), "v"(e[2 * k + 1]));
+      DW_FENCE;
+      mfma(4);
+      DW_FENCE;
+      float hf[8];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        bh[2 * k] = (__bf16)m[k][0];
-        bh[2 * k + 1] = (__bf16)m[k][1];
+        asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(hf[2 * k]) : "v"(hp[k]));
+        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(hf[2 * k + 1]) : "v"(hp[k]));
       }
-      asm volatile("" : "+v"(bh), "+v"(pbh), "+v"(pbl));
-      mfma(4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) hf[k] = (f2t){(float)bh[2 * k], (float)bh[2 * k + 1]};
-      asm volatile("" : "+v"(hf[0]), "+v"(hf[1]), "+v"(hf[2]), "+v"(hf[3]), "+v"(pbh), "+v"(pbl));
+      DW_FENCE;
       mfma(5);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) m[k] = m[k] - hf[k];
       DW_FENCE;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        bl[2 * k] = (__bf16)m[k][0];
-        bl[2 * k + 1] = (__bf16)m[k][1];
-      }
+      for (int k = 0; k < 8; ++k) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(e[k]) : "v"(hf[k]));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lp[k]) : "v"(e[2 * k]), "v"(e[2 * k + 1]));
 #undef DW_FENCE
-#undef DW_PAIR
+#undef DW_CH
+      typedef unsigned u4t __attribute__((ext_vector_type(4)));
+      bh = __builtin_bit_cast(dbf16x8, (u4t){hp[0], hp[1], hp[2], hp[3]});
+      bl = __builtin_bit_cast(dbf16x8, (u4t){lp[0], lp[1], lp[2], lp[3]});
       pbh = bh;
       pbl = bl;
       if (st >= 1 && st + 1 < 36) request_weights(st + 1, A[(st + 1) & 1]);   // (into the registers step st - 1's MFMAs have just read)
