@@ -1198,13 +1198,27 @@ __global__ __launch_bounds__(256) void deform1_premul_mfma_kernel(const float* _
 #pragma unroll
     for (int s = 0; s < 16; ++s) a[s] = j < nz ? w[((long)co * 64 + kq * 16 + s) * 9 + t] : 0.f;
   }
+  // A tile's 16 positions x 64 channels = 4 KB, contiguous in memory: four coalesced 1 KB loads per wavefront (lane -> 16 consecutive
+  // bytes), transposed into the MFMA's B layout through a private LDS tile (rows of 272 bytes: conflict-free both ways).  Reading the
+  // B layout straight from memory -- lane (j, kq) = 64 bytes at position j, sixteen such lanes 256 bytes apart -- touched 64 cache
+  // lines per load instruction.
+  __shared__ __attribute__((aligned(16))) float tl[4][16 * 68];
+  float* mine = tl[wave];
+  const long nfl = (long)total * 64;
   const int ntile = (total + 15) >> 4;
   for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
     const int P = tile * 16 + j;
-    const float* src = xt + (long)(P < total ? P : total - 1) * 64 + kq * 16;
+    float4 g[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const long idx = (long)tile * 1024 + m * 256 + lane * 4;
+      g[m] = idx < nfl ? *reinterpret_cast<const float4*>(xt + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) *reinterpret_cast<float4*>(mine + (4 * m + (lane >> 4)) * 68 + (lane & 15) * 4) = g[m];
     float4 b[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) b[m] = *reinterpret_cast<const float4*>(src + 4 * m);
+    for (int m = 0; m < 4; ++m) b[m] = *reinterpret_cast<const float4*>(mine + j * 68 + kq * 16 + 4 * m);
     f32x4m acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
