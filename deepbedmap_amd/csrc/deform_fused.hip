@@ -1092,8 +1092,10 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
 #undef DW_LDS_READS
 #undef DW_LDS_OFFS
   }
-  if (!valid || (abl & 8)) return;
-  const long Pm = (long)n * plane + p;
+  // ---- epilogue: bias, LeakyReLU; the channels-last output leaves through LDS (round 6): from its accumulator layout a lane holds
+  // 16-byte runs of a pixel's 256 bytes -- eight store instructions each touching 32 pixels with 32 bytes; a wavefront's 32 x 64 tile,
+  // transposed through the (now free) window, leaves as whole 256-byte pixels, four per instruction ----
+  if (abl & 8) return;
   float v[2][16];   // (all bias loads before the first store: see deform_conv64_fused_kernel)
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
@@ -1103,19 +1105,32 @@ __global__ __launch_bounds__(512) void deform_conv64_x3w_kernel(const float* __r
       v[ct][r] = acc[ct][r] + (bias ? bias[c] : 0.f);
       if (act) v[ct][r] = v[ct][r] >= 0.f ? v[ct][r] : slope * v[ct][r];
     }
-  if (y) {
+  if (y && valid) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int r = 0; r < 16; ++r) y[(long)n * 64 * plane + p + (long)(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg) * plane] = v[ct][r];
   }
   if (yt) {
+    __syncthreads();   // every wavefront has finished reading the window
+    float* T = reinterpret_cast<float*>(win) + wave * (32 * 68);   // [pixel j][64 channels (+ 4: rows 272 bytes apart)]
+    const int jj = lane & 31;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq)
-        *reinterpret_cast<float4*>(yt + Pm * 64 + ct * 32 + 8 * gq + 4 * kg) =
+        *reinterpret_cast<float4*>(T + jj * 68 + ct * 32 + 8 * gq + 4 * kg) =
             make_float4(v[ct][4 * gq], v[ct][4 * gq + 1], v[ct][4 * gq + 2], v[ct][4 * gq + 3]);
+    // (a wavefront reads back only what it wrote itself: no barrier)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int pj = 4 * it + (lane >> 4), part = lane & 15;
+      int pg_, pi_;
+      dw_patch_of(pj, pg_, pi_);
+      const int pa = ty * DW_T + 2 * wave + pg_, pb_ = tx * DW_T + pi_;
+      if (pa < H && pb_ < W)
+        *reinterpret_cast<float4*>(yt + ((long)n * plane + (long)pa * W + pb_) * 64 + 4 * part) = *reinterpret_cast<const float4*>(T + pj * 68 + 4 * part);
+    }
   }
 }
 
